@@ -1,0 +1,180 @@
+/* suhpe.h — C ABI of libsuhpe.so: the MI355X (gfx950) hot path of SemiUHPE's teacher-student training step.
+ *
+ * The reference (hnuzhy/SemiUHPE) has no FFI of its own: its hot path is Python calling torch ops
+ * (SURVEY.md §8b).  This header is the boundary a maintainer binds instead (ctypes stub in INTEGRATION.md);
+ * each entry point cites the reference code it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is DEVICE memory unless the name ends in _host
+ *  - every launch is asynchronous on `stream` (a hipStream_t passed as void*); no allocation, no sync inside
+ *  - return 0 on success, negative SUHPE_E* otherwise; suhpe_last_error() gives the message (thread-local)
+ *  - activations are NHWC fp32 ("pixel-major": [n][h][w][c]); conv weights are [cout][r][s][cin_per_group]
+ *    (what torch stores for a channels_last (cout,cin,r,s) tensor); matrices are row-major
+ */
+#ifndef SUHPE_H
+#define SUHPE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SUHPE_OK 0
+#define SUHPE_EINVAL (-1)   /* bad argument (shape, alignment, null)            -> ValueError in the binding */
+#define SUHPE_ELAUNCH (-2)  /* HIP launch failure                               -> RuntimeError              */
+#define SUHPE_EWORKSPACE (-3) /* workspace too small (see *_workspace_bytes)    -> RuntimeError              */
+
+typedef void* suhpe_stream_t;
+
+const char* suhpe_last_error(void);
+int suhpe_abi_version(void);
+
+/* activation codes used by the fused normalise+activate kernels */
+enum { SUHPE_ACT_NONE = 0, SUHPE_ACT_RELU = 1, SUHPE_ACT_RELU6 = 2, SUHPE_ACT_SILU = 3, SUHPE_ACT_GELU = 4,
+       SUHPE_ACT_SIGMOID = 5 };
+
+/* ------------------------------------------------------------------ matrix-Fisher rotation head ---------- */
+/* src/fisher/fisher_utils.py:14-36 (vmf_loss / KL_Fisher) + :39-48.  A,R: (n,9).  Writes loss (n), the
+ * gradient dloss_i/dA_i (n,9) and the mode rotation Rest (n,9).  Any output pointer may be NULL. */
+int suhpe_fisher_nll(const float* A, const float* R, int n, float overreg, float* loss, float* dA, float* Rest,
+                     suhpe_stream_t stream);
+/* src/fisher/fisher_utils.py:39-48 batch_torch_A_to_R */
+int suhpe_fisher_svd_project(const float* A, int n, float* R, suhpe_stream_t stream);
+/* src/fisher/fisher_utils.py:70-81 fisher_entropy */
+int suhpe_fisher_entropy(const float* A, int n, float* H, suhpe_stream_t stream);
+/* src/fisher/fisher_utils.py:84-99 fisher_CE (teacher A1, student A2) and dCE_i/dA2_i.
+ * mask (n floats, 0/1) may be NULL; where mask==0 the outputs are exactly 0 (replaces the boolean
+ * compaction of src/agent.py:155). */
+int suhpe_fisher_ce(const float* A1, const float* A2, const float* mask, int n, float* ce, float* dA2,
+                    suhpe_stream_t stream);
+/* src/fisher/fisher_utils.py:51-67 fisher_log_pdf */
+int suhpe_fisher_log_pdf(const float* A, const float* R, int n, float* logp, suhpe_stream_t stream);
+/* src/agent.py:110-122 rotation-consistency adjust.  mode 0: aug*A (DAD3DHeads); mode 1: 300WLP form. */
+int suhpe_rot_adjust(const float* A, const float* aug, int n, int mode, float* out, suhpe_stream_t stream);
+/* src/utils.py:232-260 -> radians [pitch,yaw,roll] */
+int suhpe_euler_from_rot(const float* R, int n, int full_range, float* euler, suhpe_stream_t stream);
+/* src/agent.py:447-455: gt_euler_deg NULL -> geodesic degrees; else mean |euler(pred) - gt| degrees */
+int suhpe_pose_err_deg(const float* pred, const float* gt, const float* gt_euler_deg, int n, float* err,
+                       suhpe_stream_t stream);
+/* src/agent.py:148-150: mask_i = H_i < *thres (thres read from device memory so that the dynamic threshold
+ * never needs a host round trip); count (1 float) receives sum(mask). */
+int suhpe_entropy_mask(const float* H, const float* thres, int n, float* mask, float* count,
+                       suhpe_stream_t stream);
+
+/* ------------------------------------------------------------------ tensor augmentations ----------------- */
+/* src/augments.py:12-35 + :67-94 in one out-of-place pass, fused with the NCHW->NHWC layout change at the API
+ * edge.  src/dst: (n,c,h,w) or (n,h,w,c) element order selected by src_nhwc/dst_nhwc; src != dst.
+ * boxes: int32 (n,holes,4) = x0,y0,x1,y1 with the reference's axis use (y slices dim h, x slices dim w).
+ * cutout_boxes and/or cutmix_boxes may be NULL.  perm: int32 (n), source image of the CutMix paste
+ * (reference: image[rand_index], taken after CutOut). */
+int suhpe_strong_aug(const float* src, float* dst, int n, int c, int h, int w, int src_nhwc, int dst_nhwc,
+                     const int32_t* cutout_boxes, const int32_t* cutmix_boxes, const int32_t* perm, int holes,
+                     suhpe_stream_t stream);
+/* plain layout change: (n,c,h,w) contiguous -> (n,h,w,c) */
+int suhpe_nchw_to_nhwc(const float* src, int n, int c, int h, int w, float* dst, suhpe_stream_t stream);
+
+/* ------------------------------------------------------------------ convolution / linear ----------------- */
+typedef struct {
+    int n, h, w, cin;        /* input  (n,h,w,cin)  */
+    int ho, wo, cout;        /* output (n,ho,wo,cout) */
+    int r, s;                /* filter */
+    int stride, pad;
+    int groups;              /* 1, or cin==cout==groups for depthwise, or 2 (RepVGG g2) */
+} suhpe_conv_t;
+
+/* nn.Conv2d / nn.Linear forward (torch ops dispatched by src/networks.py, src/repvgg.py:28-32,
+ * src/tiny_vit.py:28-50).  w: [cout][r][s][cin/groups]; bias NULL or [cout]. */
+int suhpe_conv2d_fwd(const suhpe_conv_t* d, const float* x, const float* w, const float* bias, float* y,
+                     suhpe_stream_t stream);
+/* input gradient; wt is the transposed+flipped filter made by suhpe_conv2d_transpose_filter */
+int suhpe_conv2d_dgrad(const suhpe_conv_t* d, const float* dy, const float* wt, float* dx, suhpe_stream_t stream);
+int suhpe_conv2d_transpose_filter(const suhpe_conv_t* d, const float* w, float* wt, suhpe_stream_t stream);
+/* filter gradient; dw += sum (accumulate != 0) or dw = sum.  workspace: device scratch */
+int64_t suhpe_conv2d_wgrad_workspace_bytes(const suhpe_conv_t* d);
+int suhpe_conv2d_wgrad(const suhpe_conv_t* d, const float* x, const float* dy, float* dw, int accumulate,
+                       void* workspace, int64_t workspace_bytes, suhpe_stream_t stream);
+/* depthwise 3x3 (groups == cin == cout, cin % 4 == 0); w in torch layout [c][r*s] */
+int suhpe_dwconv_fwd(const suhpe_conv_t* d, const float* x, const float* w, float* y, suhpe_stream_t stream);
+int suhpe_dwconv_dgrad(const suhpe_conv_t* d, const float* dy, const float* w, float* dx, suhpe_stream_t stream);
+int64_t suhpe_dwconv_wgrad_workspace_bytes(const suhpe_conv_t* d);
+int suhpe_dwconv_wgrad(const suhpe_conv_t* d, const float* x, const float* dy, float* dw, int accumulate,
+                       void* workspace, int64_t workspace_bytes, suhpe_stream_t stream);
+/* db[c] (+)= sum over rows of dy (rows, c) */
+int suhpe_bias_grad(const float* dy, int64_t rows, int c, float* db, int accumulate, void* workspace,
+                    suhpe_stream_t stream);   /* workspace >= suhpe_bn_workspace_bytes(c) */
+
+/* ------------------------------------------------------------------ normalisation + activation ----------- */
+/* BatchNorm (train): per-channel statistics of x (rows, c).  Writes mean/rstd (c each) and updates
+ * running_mean / running_var (unbiased) / num_batches_tracked (int64, +1) when running_mean != NULL.
+ * workspace >= suhpe_bn_workspace_bytes(c). */
+int64_t suhpe_bn_workspace_bytes(int c);
+int suhpe_bn_stats(const float* x, int64_t rows, int c, float eps, float momentum, float* mean, float* rstd,
+                   float* running_mean, float* running_var, int64_t* num_batches_tracked, void* workspace,
+                   suhpe_stream_t stream);
+/* eval: mean/rstd from running stats */
+int suhpe_bn_eval_stats(const float* running_mean, const float* running_var, int c, float eps, float* mean,
+                        float* rstd, suhpe_stream_t stream);
+/* y = act(gamma*(x-mean)*rstd + beta + residual) ; gamma/beta/residual may be NULL (=1/0/0) */
+int suhpe_bn_act_fwd(const float* x, int64_t rows, int c, const float* mean, const float* rstd, const float* gamma,
+                     const float* beta, int act, const float* residual, float* y, suhpe_stream_t stream);
+/* backward of the above in train mode: given dy (grad of the activated output), recomputes the activation
+ * derivative from x and returns dx, dgamma (+)=, dbeta (+)=.  train_stats=0 treats mean/rstd as constants
+ * (eval mode).  y_out: the forward output, needed only when a residual was added before a ReLU (then the mask is
+ * y_out > 0); NULL otherwise.  workspace as suhpe_bn_stats. */
+int suhpe_bn_act_bwd(const float* x, const float* dy, const float* y_out, int64_t rows, int c, const float* mean,
+                     const float* rstd, const float* gamma, const float* beta, int act, int train_stats, float* dx,
+                     float* dgamma, float* dbeta, int accumulate, void* workspace, suhpe_stream_t stream);
+/* LayerNorm over the last dim (rows, c) (src/tiny_vit.py nn.LayerNorm) */
+int suhpe_layernorm_fwd(const float* x, int64_t rows, int c, float eps, const float* gamma, const float* beta,
+                        float* y, float* mean, float* rstd, suhpe_stream_t stream);
+int suhpe_layernorm_bwd(const float* x, const float* dy, int64_t rows, int c, const float* mean, const float* rstd,
+                        const float* gamma, float* dx, float* dgamma, float* dbeta, int accumulate,
+                        void* workspace, suhpe_stream_t stream);
+/* plain activation y = act(x + bias[c]) and its backward dx = dy * act'(x + bias) */
+int suhpe_act_fwd(const float* x, int64_t rows, int c, const float* bias, int act, float* y, suhpe_stream_t stream);
+int suhpe_act_bwd(const float* x, const float* dy, int64_t rows, int c, const float* bias, int act, float* dx,
+                  suhpe_stream_t stream);
+
+/* ------------------------------------------------------------------ pooling, SE, residual, dropout ------- */
+/* mean over the hw axis: x (n,hw,c) -> y (n,c) */
+int suhpe_avgpool_fwd(const float* x, int n, int hw, int c, float* y, suhpe_stream_t stream);
+int suhpe_avgpool_bwd(const float* dy, int n, int hw, int c, float* dx, suhpe_stream_t stream);
+/* squeeze-excite scale y[n,p,c] = x[n,p,c]*s[n,c] */
+int suhpe_se_scale_fwd(const float* x, const float* s, int n, int hw, int c, float* y, suhpe_stream_t stream);
+/* ds[n,c] = sum_p dy*x */
+int suhpe_se_scale_bwd_s(const float* dy, const float* x, int n, int hw, int c, float* ds, suhpe_stream_t stream);
+/* dx = dy*s + dpool/hw (dpool may be NULL) */
+int suhpe_se_scale_bwd_x(const float* dy, const float* s, const float* dpool, int n, int hw, int c, float* dx,
+                         suhpe_stream_t stream);
+/* y = a + b*rowscale[n]  (residual + stochastic depth 'row' mode; rowscale NULL = 1); per = elements per sample */
+int suhpe_add_rowscale(const float* a, const float* b, const float* rowscale, int n, int64_t per, float* y,
+                       suhpe_stream_t stream);
+/* y = x*rowscale[n] */
+int suhpe_mul_rowscale(const float* x, const float* rowscale, int n, int64_t per, float* y, suhpe_stream_t stream);
+/* y = x * mask (elementwise, mask already holds 0 or 1/keep) */
+int suhpe_mul(const float* x, const float* m, int64_t count, float* y, suhpe_stream_t stream);
+/* out[i] = a[i] + b[i] */
+int suhpe_add(const float* a, const float* b, int64_t count, float* y, suhpe_stream_t stream);
+/* Bernoulli(keep)/keep mask from a counter-based generator; *counter (device, 2 x uint64: seed, offset) is
+ * advanced by the kernel so that graph replays draw fresh numbers */
+int suhpe_dropout_mask(uint64_t* counter, float keep, int64_t count, float* mask, suhpe_stream_t stream);
+
+/* ------------------------------------------------------------------ reductions for the loss ------------- */
+/* out[0] = scale * sum_i x[i]*(w ? w[i] : 1) */
+int suhpe_weighted_sum(const float* x, const float* w, int64_t count, float scale, float* out, suhpe_stream_t stream);
+/* y[i,:] = x[i,:] * g[i] * scale (rows, c) */
+int suhpe_scale_rows(const float* x, const float* g, int64_t rows, int c, float scale, float* y, suhpe_stream_t stream);
+
+/* ------------------------------------------------------------------ optimiser and EMA teacher ----------- */
+/* torch.optim.Adam step (src/agent.py:37,210), flat buffers: p,g,m,v (count); *step_host is the 1-based
+ * step number for bias correction. */
+int suhpe_adam_step(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int64_t step, suhpe_stream_t stream);
+/* src/agent.py:277-299: ema = alpha*ema + (1-alpha)*p */
+int suhpe_ema_update(float* ema, const float* p, int64_t count, float alpha, suhpe_stream_t stream);
+int suhpe_fill(float* p, int64_t count, float value, suhpe_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUHPE_H */

@@ -1,0 +1,16 @@
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace suhpe {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace suhpe
+
+extern "C" const char* suhpe_last_error(void) { return suhpe::g_err; }
+extern "C" int suhpe_abi_version(void) { return 1; }

@@ -1,0 +1,543 @@
+// Dense / grouped convolution and Linear on gfx950 as implicit GEMM on the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD — gfx950 has no TF32/xf32).
+//
+//   igemm_nt : out[m][j] = sum_k G[m][k] * F[j][k]      forward (G = gathered input pixels, F = filter rows)
+//                                                      and dgrad (G = gathered dy, F = transposed filter)
+//   igemm_tn : dW[i][k'] = sum_m dY[m][i] * G[m][k']    wgrad, split over m into slabs + fixed-order reduce
+//
+// Data layout: activations pixel-major NHWC, so the reduction index k = (r,s,ci) is contiguous per pixel for
+// the gathered operand and per output channel for the filter [cout][r][s][ci]: both tiles are staged through
+// registers into LDS as [row][32+4 floats] (16-byte vectors, padded rows -> conflict-free ds_read_b128), and a
+// lane feeds 4 consecutive MFMAs from one 16-byte LDS read (lane half h takes k = 8g+4h+{0..3}).
+// Workgroup = 256 threads = 4 wavefronts; each wave owns a (TM x TN) grid of 32x32 accumulator tiles.
+//
+// Replaces the cuDNN / cuBLAS calls behind nn.Conv2d / nn.Linear in src/networks.py:229-332,407-441,
+// src/repvgg.py:28-32,67-76 and src/tiny_vit.py:28-50,84-151 (forward, input gradient, filter gradient).
+#include "common.h"
+
+namespace suhpe {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;          // reduction chunk staged per LDS tile
+constexpr int LDK = BK + 4;     // padded LDS row (floats): 144 B keeps 16-B alignment and spreads banks
+
+struct GatherGeom {
+    int N, GH, GW;       // gathered tensor spatial dims
+    int OH, OW;          // GEMM-row enumeration: m = (n, oh, ow)
+    int ldg;             // gathered tensor pixel stride (elements)
+    int Cg;              // channels per group in the gathered tensor (k = tap*Cg + c)
+    int R, S;
+    int stride, pad;
+    int mode;            // 0: gh = oh*stride - pad + r      (forward / wgrad gather of x)
+                         // 1: gh = (oh + pad - r)/stride     (dgrad gather of dy; only exact multiples)
+    int K;               // R*S*Cg
+    int64_t M;           // N*OH*OW
+};
+
+__device__ __forceinline__ bool gather_coord(const GatherGeom& g, int o, int tap, int extent, int* out) {
+    if (g.mode == 0) {
+        const int v = o * g.stride - g.pad + tap;
+        *out = v;
+        return v >= 0 && v < extent;
+    }
+    const int t = o + g.pad - tap;
+    if (t < 0) return false;
+    if (g.stride == 1) { *out = t; return t < extent; }
+    const int q = t / g.stride;
+    *out = q;
+    return (q * g.stride == t) && q < extent;
+}
+
+struct NtParams {
+    GatherGeom g;
+    const float* x;      // gathered tensor
+    const float* f;      // filter rows [Ng_total][K]
+    const float* bias;   // per output column or null
+    float* y;            // [M][ldy]
+    int Ng;              // output columns per group
+    int ldy;
+};
+
+// ---------------------------------------------------------------------------------------------- igemm_nt
+template <int BM, int BN, int WM, int WN, int VEC>
+__global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
+    constexpr int WAVES_N = BN / WN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+    __shared__ __attribute__((aligned(16))) float As[BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
+
+    const GatherGeom& g = p.g;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int grp = blockIdx.z;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const float* __restrict__ x = p.x + (int64_t)grp * g.Cg;
+    const float* __restrict__ f = p.f + (int64_t)grp * p.Ng * g.K;
+
+    // ---- loader geometry.  VEC=4: thread -> (vector column j = t&7, rows (t>>3)+32i).  VEC=1: (k = t&31, rows (t>>5)+8i)
+    constexpr int A_ROWS = VEC == 4 ? BM / 32 : BM / 8;
+    constexpr int B_ROWS = VEC == 4 ? BN / 32 : BN / 8;
+    constexpr int ROW_STEP = VEC == 4 ? 32 : 8;
+    const int lcol = VEC == 4 ? (t & 7) * 4 : (t & 31);
+    const int lrow = VEC == 4 ? (t >> 3) : (t >> 5);
+
+    int a_nbase[A_ROWS], a_oh[A_ROWS], a_ow[A_ROWS];
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {
+        const int64_t m = m0 + lrow + i * ROW_STEP;
+        if (m < g.M) {
+            const int n = (int)(m / ((int64_t)g.OH * g.OW));
+            const int rem = (int)(m - (int64_t)n * g.OH * g.OW);
+            a_oh[i] = rem / g.OW;
+            a_ow[i] = rem - a_oh[i] * g.OW;
+            a_nbase[i] = n * g.GH * g.GW;
+        } else {
+            a_nbase[i] = -1;
+            a_oh[i] = 0;
+            a_ow[i] = 0;
+        }
+    }
+
+    float a_reg[A_ROWS][VEC], b_reg[B_ROWS][VEC];
+
+    auto load_tiles = [&](int kt) {
+        const int k = kt * BK + lcol;
+        const bool kvalid = k < g.K;
+        int tap = 0, ci = k, r = 0, s = 0;
+        if (g.R * g.S > 1) { tap = k / g.Cg; ci = k - tap * g.Cg; r = tap / g.S; s = tap - r * g.S; }
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+            int gh = 0, gw = 0;
+            bool ok = kvalid && a_nbase[i] >= 0;
+            ok = ok && gather_coord(g, a_oh[i], r, g.GH, &gh);
+            ok = ok && gather_coord(g, a_ow[i], s, g.GW, &gw);
+            if (ok) {
+                const float* src = x + ((int64_t)(a_nbase[i] + gh * g.GW + gw)) * g.ldg + ci;
+                if (VEC == 4) { const float4 v = *reinterpret_cast<const float4*>(src); a_reg[i][0] = v.x; a_reg[i][1] = v.y; a_reg[i][2] = v.z; a_reg[i][3] = v.w; }
+                else a_reg[i][0] = src[0];
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) a_reg[i][v] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_ROWS; ++i) {
+            const int col = n0 + lrow + i * ROW_STEP;
+            if (kvalid && col < p.Ng) {
+                const float* src = f + (int64_t)col * g.K + k;
+                if (VEC == 4) { const float4 v = *reinterpret_cast<const float4*>(src); b_reg[i][0] = v.x; b_reg[i][1] = v.y; b_reg[i][2] = v.z; b_reg[i][3] = v.w; }
+                else b_reg[i][0] = src[0];
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) b_reg[i][v] = 0.f;
+            }
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+            float* dst = &As[(lrow + i * ROW_STEP) * LDK + lcol];
+            if (VEC == 4) *reinterpret_cast<float4*>(dst) = make_float4(a_reg[i][0], a_reg[i][1], a_reg[i][2], a_reg[i][3]);
+            else dst[0] = a_reg[i][0];
+        }
+#pragma unroll
+        for (int i = 0; i < B_ROWS; ++i) {
+            float* dst = &Bs[(lrow + i * ROW_STEP) * LDK + lcol];
+            if (VEC == 4) *reinterpret_cast<float4*>(dst) = make_float4(b_reg[i][0], b_reg[i][1], b_reg[i][2], b_reg[i][3]);
+            else dst[0] = b_reg[i][0];
+        }
+    };
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int r32 = lane & 31, h = lane >> 5;
+    const int nk = (g.K + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_tiles(kt + 1);          // global loads in flight under the MFMAs below
+#pragma unroll
+        for (int kg = 0; kg < BK / 8; ++kg) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(&As[(wm * WM + i * 32 + r32) * LDK + kg * 8 + h * 4]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(&Bs[(wn * WN + j * 32 + r32) * LDK + kg * 8 + h * 4]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            store_tiles();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    float* __restrict__ y = p.y + (int64_t)grp * p.Ng;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * WN + j * 32 + r32;
+        if (col >= p.Ng) continue;
+        const float bv = p.bias ? p.bias[grp * p.Ng + col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t row = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row < g.M) y[row * p.ldy + col] = acc[i][j][e] + bv;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- igemm_tn (wgrad)
+struct TnParams {
+    GatherGeom g;        // gather of x (mode 0); rows m = (n, oh, ow) of dy
+    const float* dy;     // [M][lddy]
+    const float* x;
+    float* slab;         // [splits][groups*Ng][K]
+    int Ng;              // output channels per group (rows of dW per group)
+    int lddy;
+    int64_t m_per_split; // multiple of BK
+    int tiles_n;         // tiles along k'
+};
+
+template <int BM, int BN, int WM, int WN, int VECA, int VECB>
+__global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams p) {
+    constexpr int WAVES_N = BN / WN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+    __shared__ __attribute__((aligned(16))) float As[BK * BM];   // [m][cout]
+    __shared__ __attribute__((aligned(16))) float Bs[BK * BN];   // [m][k']
+
+    const GatherGeom& g = p.g;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int grp = blockIdx.z;
+    const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x % p.tiles_n;
+    const int i0 = tile_m * BM;          // cout offset inside the group
+    const int k0 = tile_n * BN;          // k' offset
+    const int64_t mbeg = (int64_t)blockIdx.y * p.m_per_split;
+    int64_t mend = mbeg + p.m_per_split;
+    if (mend > g.M) mend = g.M;
+    const float* __restrict__ dy = p.dy + (int64_t)grp * p.Ng;
+    const float* __restrict__ x = p.x + (int64_t)grp * g.Cg;
+
+    // A loader: dy rows.  VECA=4: col group = t % (BM/4), row = t / (BM/4) + RA*i ; VECA=1: col = t % BM
+    constexpr int A_CG = BM / VECA;                 // column groups per row
+    constexpr int RA = 256 / A_CG;                  // rows covered per pass
+    constexpr int A_IT = BK / RA;
+    static_assert(A_IT >= 1, "tile too wide for the A loader");
+    const int a_col = (t % A_CG) * VECA, a_row = t / A_CG;
+    constexpr int B_CG = BN / VECB;
+    constexpr int RB = 256 / B_CG;
+    constexpr int B_IT = BK / RB;
+    static_assert(B_IT >= 1, "tile too wide for the B loader");
+    const int b_col = (t % B_CG) * VECB, b_row = t / B_CG;
+
+    // this thread's k' is fixed for the whole reduction: decode its filter tap once
+    const int kq = k0 + b_col;
+    const bool kq_valid = kq < g.K;
+    int r = 0, s = 0, ci = kq;
+    if (g.R * g.S > 1) { const int tap = kq / g.Cg; ci = kq - tap * g.Cg; r = tap / g.S; s = tap - r * g.S; }
+    const bool a_valid_col = i0 + a_col < p.Ng;
+
+    float a_reg[A_IT][VECA], b_reg[B_IT][VECB];
+    auto load_tiles = [&](int64_t mb) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int64_t m = mb + a_row + i * RA;
+            if (a_valid_col && m < mend) {
+                const float* src = dy + m * p.lddy + i0 + a_col;
+                if (VECA == 4) { const float4 v = *reinterpret_cast<const float4*>(src); a_reg[i][0] = v.x; a_reg[i][1] = v.y; a_reg[i][2] = v.z; a_reg[i][3] = v.w; }
+                else a_reg[i][0] = src[0];
+            } else {
+#pragma unroll
+                for (int v = 0; v < VECA; ++v) a_reg[i][v] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int64_t m = mb + b_row + i * RB;
+            bool ok = kq_valid && m < mend;
+            int gh = 0, gw = 0, n = 0;
+            if (ok) {
+                n = (int)(m / ((int64_t)g.OH * g.OW));
+                const int rem = (int)(m - (int64_t)n * g.OH * g.OW);
+                const int oh = rem / g.OW, ow = rem - oh * g.OW;
+                ok = gather_coord(g, oh, r, g.GH, &gh) && gather_coord(g, ow, s, g.GW, &gw);
+            }
+            if (ok) {
+                const float* src = x + ((int64_t)n * g.GH * g.GW + gh * g.GW + gw) * g.ldg + ci;
+                if (VECB == 4) { const float4 v = *reinterpret_cast<const float4*>(src); b_reg[i][0] = v.x; b_reg[i][1] = v.y; b_reg[i][2] = v.z; b_reg[i][3] = v.w; }
+                else b_reg[i][0] = src[0];
+            } else {
+#pragma unroll
+                for (int v = 0; v < VECB; ++v) b_reg[i][v] = 0.f;
+            }
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            float* dst = &As[(a_row + i * RA) * BM + a_col];
+            if (VECA == 4) *reinterpret_cast<float4*>(dst) = make_float4(a_reg[i][0], a_reg[i][1], a_reg[i][2], a_reg[i][3]);
+            else dst[0] = a_reg[i][0];
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            float* dst = &Bs[(b_row + i * RB) * BN + b_col];
+            if (VECB == 4) *reinterpret_cast<float4*>(dst) = make_float4(b_reg[i][0], b_reg[i][1], b_reg[i][2], b_reg[i][3]);
+            else dst[0] = b_reg[i][0];
+        }
+    };
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int r32 = lane & 31, h = lane >> 5;
+    if (mbeg < mend) {
+        load_tiles(mbeg);
+        store_tiles();
+        __syncthreads();
+        for (int64_t mb = mbeg; mb < mend; mb += BK) {
+            const bool more = mb + BK < mend;
+            if (more) load_tiles(mb + BK);
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                float af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = As[(kk * 2 + h) * BM + wm * WM + i * 32 + r32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = Bs[(kk * 2 + h) * BN + wn * WN + j * 32 + r32];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+            if (more) {
+                store_tiles();
+                __syncthreads();
+            }
+        }
+    }
+    // slab[split][grp*Ng + row][k']
+    float* __restrict__ out = p.slab + ((int64_t)blockIdx.y * gridDim.z * p.Ng + (int64_t)grp * p.Ng) * g.K;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = k0 + wn * WN + j * 32 + r32;
+        if (col >= g.K) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = i0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row < p.Ng) out[(int64_t)row * g.K + col] = acc[i][j][e];
+            }
+    }
+}
+
+// dw[i] (+)= sum_z slab[z][i], fixed order
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int splits, int64_t count, float* __restrict__ dw,
+                                                          int accumulate) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < splits; ++z) s += slab[(int64_t)z * count + i];
+        dw[i] = accumulate ? dw[i] + s : s;
+    }
+}
+
+// wt[g][ci][r][s][co] = w[g][co][r][s][ci]  (per group)
+__global__ __launch_bounds__(256) void transpose_filter_kernel(const float* __restrict__ w, float* __restrict__ wt, int groups, int Ng,
+                                                               int Cg, int RS) {
+    const int64_t total = (int64_t)groups * Ng * RS * Cg;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        // i enumerates the destination: (g, ci, tap, co)
+        const int co = (int)(i % Ng);
+        const int tap = (int)((i / Ng) % RS);
+        const int ci = (int)((i / ((int64_t)Ng * RS)) % Cg);
+        const int gq = (int)(i / ((int64_t)Ng * RS * Cg));
+        wt[i] = w[(((int64_t)gq * Ng + co) * RS + tap) * Cg + ci];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static int check_desc(const suhpe_conv_t* d, const char* who) {
+    if (!d) { set_error("%s: null descriptor", who); return SUHPE_EINVAL; }
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cin <= 0 || d->cout <= 0 || d->r <= 0 || d->s <= 0 || d->stride <= 0 || d->pad < 0 ||
+        d->groups <= 0 || d->cin % d->groups || d->cout % d->groups) {
+        set_error("%s: bad conv descriptor", who);
+        return SUHPE_EINVAL;
+    }
+    const int ho = (d->h + 2 * d->pad - d->r) / d->stride + 1, wo = (d->w + 2 * d->pad - d->s) / d->stride + 1;
+    if (ho != d->ho || wo != d->wo) { set_error("%s: ho/wo (%d,%d) do not match the geometry (%d,%d)", who, d->ho, d->wo, ho, wo); return SUHPE_EINVAL; }
+    return SUHPE_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int VEC>
+static void launch_nt(const NtParams& p, int groups, hipStream_t st) {
+    dim3 grid((unsigned)ceil_div(p.g.M, BM), (unsigned)ceil_div(p.Ng, BN), groups);
+    hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC>), grid, dim3(256), 0, st, p);
+}
+
+static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st) {
+    if (!vec4) { launch_nt<64, 64, 32, 32, 1>(p, groups, st); return; }
+    const int ng = p.Ng;
+    // pick the column tile with the least padding waste, preferring wide tiles
+    int bn = 32;
+    auto waste = [&](int b) { return (double)(ceil_div(ng, b) * b) / ng; };
+    if (waste(128) <= waste(64) + 1e-9 && waste(128) <= waste(32) + 1e-9) bn = 128;
+    else if (waste(64) <= waste(32) + 1e-9) bn = 64;
+    if (p.g.M < 2048) {          // small row counts (Linear layers, SE): favour more, smaller tiles
+        if (bn >= 64) launch_nt<64, 64, 32, 32, 4>(p, groups, st); else launch_nt<128, 32, 32, 32, 4>(p, groups, st);
+        return;
+    }
+    if (bn == 128) launch_nt<128, 128, 64, 64, 4>(p, groups, st);
+    else if (bn == 64) launch_nt<128, 64, 64, 32, 4>(p, groups, st);
+    else launch_nt<256, 32, 64, 32, 4>(p, groups, st);
+}
+
+}  // namespace suhpe
+
+using namespace suhpe;
+
+extern "C" {
+
+int suhpe_conv2d_fwd(const suhpe_conv_t* d, const float* x, const float* w, const float* bias, float* y, suhpe_stream_t stream) {
+    int rc = check_desc(d, "suhpe_conv2d_fwd");
+    if (rc) return rc;
+    SUHPE_REQUIRE(x && w && y, "suhpe_conv2d_fwd: null pointer");
+    NtParams p;
+    const int cg = d->cin / d->groups;
+    p.g = GatherGeom{d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0, d->r * d->s * cg,
+                     (int64_t)d->n * d->ho * d->wo};
+    p.x = x; p.f = w; p.bias = bias; p.y = y; p.Ng = d->cout / d->groups; p.ldy = d->cout;
+    const bool vec4 = (cg % 4 == 0) && (d->cin % 4 == 0) && aligned16(x) && aligned16(w);
+    dispatch_nt(p, d->groups, vec4, as_stream(stream));
+    return check_launch("suhpe_conv2d_fwd");
+}
+
+int suhpe_conv2d_transpose_filter(const suhpe_conv_t* d, const float* w, float* wt, suhpe_stream_t stream) {
+    int rc = check_desc(d, "suhpe_conv2d_transpose_filter");
+    if (rc) return rc;
+    SUHPE_REQUIRE(w && wt && w != wt, "suhpe_conv2d_transpose_filter: null or aliased pointers");
+    const int64_t total = (int64_t)d->cout * d->r * d->s * (d->cin / d->groups);
+    hipLaunchKernelGGL(transpose_filter_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), w, wt, d->groups,
+                       d->cout / d->groups, d->cin / d->groups, d->r * d->s);
+    return check_launch("suhpe_conv2d_transpose_filter");
+}
+
+int suhpe_conv2d_dgrad(const suhpe_conv_t* d, const float* dy, const float* wt, float* dx, suhpe_stream_t stream) {
+    int rc = check_desc(d, "suhpe_conv2d_dgrad");
+    if (rc) return rc;
+    SUHPE_REQUIRE(dy && wt && dx, "suhpe_conv2d_dgrad: null pointer");
+    NtParams p;
+    const int ng = d->cout / d->groups, cg = d->cin / d->groups;
+    // rows = input pixels (n,h,w); gathered tensor = dy (n,ho,wo,cout); filter rows = wt [cin][r][s][cout/groups]
+    p.g = GatherGeom{d->n, d->ho, d->wo, d->h, d->w, d->cout, ng, d->r, d->s, d->stride, d->pad, 1, d->r * d->s * ng,
+                     (int64_t)d->n * d->h * d->w};
+    p.x = dy; p.f = wt; p.bias = nullptr; p.y = dx; p.Ng = cg; p.ldy = d->cin;
+    const bool vec4 = (ng % 4 == 0) && (d->cout % 4 == 0) && aligned16(dy) && aligned16(wt);
+    dispatch_nt(p, d->groups, vec4, as_stream(stream));
+    return check_launch("suhpe_conv2d_dgrad");
+}
+
+static int wgrad_splits(const suhpe_conv_t* d, int bm, int bn) {
+    const int ng = d->cout / d->groups, K = d->r * d->s * (d->cin / d->groups);
+    const int64_t M = (int64_t)d->n * d->ho * d->wo;
+    const int64_t tiles = ceil_div(ng, bm) * ceil_div(K, bn) * d->groups;
+    int64_t splits = ceil_div(1536, tiles);
+    const int64_t max_by_m = ceil_div(M, 8 * BK);           // at least 256 rows per split
+    if (splits > max_by_m) splits = max_by_m;
+    const int64_t slab = (int64_t)d->cout * K * 4;
+    const int64_t cap = (int64_t)384 << 20;                  // keep slabs under 384 MiB
+    if (splits * slab > cap) splits = cap / slab;
+    if (splits < 1) splits = 1;
+    return (int)splits;
+}
+
+static void wgrad_tile(const suhpe_conv_t* d, int* bm, int* bn) {
+    const int ng = d->cout / d->groups, K = d->r * d->s * (d->cin / d->groups);
+    *bm = ng > 64 ? 128 : 64;
+    *bn = (K > 64) ? 128 : 64;
+    if (*bm == 64 && *bn == 128) { *bm = 64; *bn = 128; }
+}
+
+int64_t suhpe_conv2d_wgrad_workspace_bytes(const suhpe_conv_t* d) {
+    if (!d || d->groups <= 0) return 0;
+    int bm, bn;
+    wgrad_tile(d, &bm, &bn);
+    const int K = d->r * d->s * (d->cin / d->groups);
+    return (int64_t)wgrad_splits(d, bm, bn) * d->cout * K * 4;
+}
+
+int suhpe_conv2d_wgrad(const suhpe_conv_t* d, const float* x, const float* dy, float* dw, int accumulate, void* workspace,
+                       int64_t workspace_bytes, suhpe_stream_t stream) {
+    int rc = check_desc(d, "suhpe_conv2d_wgrad");
+    if (rc) return rc;
+    SUHPE_REQUIRE(x && dy && dw && workspace, "suhpe_conv2d_wgrad: null pointer");
+    if (workspace_bytes < suhpe_conv2d_wgrad_workspace_bytes(d)) {
+        set_error("suhpe_conv2d_wgrad: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)suhpe_conv2d_wgrad_workspace_bytes(d));
+        return SUHPE_EWORKSPACE;
+    }
+    int bm, bn;
+    wgrad_tile(d, &bm, &bn);
+    const int splits = wgrad_splits(d, bm, bn);
+    const int ng = d->cout / d->groups, cg = d->cin / d->groups;
+    TnParams p;
+    p.g = GatherGeom{d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0, d->r * d->s * cg,
+                     (int64_t)d->n * d->ho * d->wo};
+    p.dy = dy; p.x = x; p.slab = static_cast<float*>(workspace); p.Ng = ng; p.lddy = d->cout;
+    p.m_per_split = ceil_div(ceil_div(p.g.M, splits), BK) * BK;
+    p.tiles_n = (int)ceil_div(p.g.K, bn);
+    const int tiles_m = (int)ceil_div(ng, bm);
+    const bool va = (ng % 4 == 0) && (d->cout % 4 == 0) && aligned16(dy);
+    const bool vb = (cg % 4 == 0) && (d->cin % 4 == 0) && aligned16(x);
+    dim3 grid(tiles_m * p.tiles_n, splits, d->groups);
+    hipStream_t st = as_stream(stream);
+#define TN_LAUNCH(BM_, BN_, WM_, WN_, VA_, VB_) hipLaunchKernelGGL((igemm_tn_kernel<BM_, BN_, WM_, WN_, VA_, VB_>), grid, dim3(256), 0, st, p)
+    if (va && vb) {
+        if (bm == 128 && bn == 128) TN_LAUNCH(128, 128, 64, 64, 4, 4);
+        else if (bm == 128 && bn == 64) TN_LAUNCH(128, 64, 64, 32, 4, 4);
+        else if (bm == 64 && bn == 128) TN_LAUNCH(64, 128, 32, 64, 4, 4);
+        else TN_LAUNCH(64, 64, 32, 32, 4, 4);
+    } else {
+        // odd channel counts (RGB stem, 9-D head): scalar loaders, generic 64x64 tile
+        p.tiles_n = (int)ceil_div(p.g.K, 64);
+        grid = dim3((unsigned)(ceil_div(ng, 64) * p.tiles_n), splits, d->groups);
+        if (va) TN_LAUNCH(64, 64, 32, 32, 4, 1);
+        else if (vb) TN_LAUNCH(64, 64, 32, 32, 1, 4);
+        else TN_LAUNCH(64, 64, 32, 32, 1, 1);
+    }
+#undef TN_LAUNCH
+    const int64_t count = (int64_t)d->cout * p.g.K;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(count, 256)), dim3(256), 0, st, p.slab, splits, count, dw, accumulate);
+    return check_launch("suhpe_conv2d_wgrad");
+}
+
+}  // extern "C"

@@ -1,0 +1,206 @@
+// Depthwise 3x3 convolution (groups == channels) on gfx950: forward, input gradient, filter gradient.
+// HBM-bound VALU work (0.03 of EfficientNetV2-S's 2.85 GMAC but 28% of its conv activation bytes), so the
+// kernels are organised around 16-byte channel vectors of pixel-major NHWC tensors: a workgroup owns a chunk of
+// channels (filter taps staged once in LDS as [tap][channel]) and a slab of output pixels; a lane handles 4
+// channels of one pixel per step.  Replaces nn.Conv2d(groups=C) of torchvision MBConv (src/networks.py:303) and
+// src/tiny_vit.py:91-93,130-131,323-324.
+#include "common.h"
+
+namespace suhpe {
+
+constexpr int kMaxTaps = 9;
+constexpr int kDwMaxRowBlocks = 256;
+
+struct DwGeom {
+    int N, GH, GW;       // gathered tensor dims (x for fwd/wgrad, dy for dgrad)
+    int OH, OW;          // enumerated output pixels
+    int C;
+    int R, S, stride, pad;
+    int mode;            // 0: g = o*stride - pad + r ; 1: g = (o + pad - r)/stride (exact multiples only)
+    int cw, rp;          // columns (float4) per block, pixel rows per pass
+    int64_t P;           // N*OH*OW
+    int64_t pix_per_block;
+};
+
+__device__ __forceinline__ bool dw_coord(const DwGeom& g, int o, int tap, int extent, int* out) {
+    if (g.mode == 0) {
+        const int v = o * g.stride - g.pad + tap;
+        *out = v;
+        return v >= 0 && v < extent;
+    }
+    const int t = o + g.pad - tap;
+    if (t < 0) return false;
+    if (g.stride == 1) { *out = t; return t < extent; }
+    const int q = t / g.stride;
+    *out = q;
+    return q * g.stride == t && q < extent;
+}
+
+// y[p][c] = sum_taps G[gather(p,tap)][c] * w[c][tap]
+__global__ __launch_bounds__(256) void dw_conv_kernel(const DwGeom g, const float* __restrict__ src, const float* __restrict__ w,
+                                                      float* __restrict__ dst) {
+    __shared__ __attribute__((aligned(16))) float wl[kMaxTaps * 256 * 4];
+    const int t = threadIdx.x, col = t % g.cw, rsub = t / g.cw;
+    const int cv = g.C / 4, col0 = blockIdx.y * g.cw;
+    const int taps = g.R * g.S;
+    // stage the filter chunk: wl[tap][cw*4]
+    for (int i = t; i < taps * g.cw * 4; i += 256) {
+        const int tap = i / (g.cw * 4), cc = i - tap * g.cw * 4;
+        const int ch = col0 * 4 + cc;
+        wl[i] = ch < g.C ? w[(int64_t)ch * taps + tap] : 0.f;
+    }
+    __syncthreads();
+    if (rsub >= g.rp || col0 + col >= cv) return;
+    const int64_t p0 = (int64_t)blockIdx.x * g.pix_per_block;
+    int64_t p1 = p0 + g.pix_per_block;
+    if (p1 > g.P) p1 = g.P;
+    for (int64_t p = p0 + rsub; p < p1; p += g.rp) {
+        const int n = (int)(p / ((int64_t)g.OH * g.OW));
+        const int rem = (int)(p - (int64_t)n * g.OH * g.OW);
+        const int oh = rem / g.OW, ow = rem - oh * g.OW;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = 0; r < g.R; ++r) {
+            int gh;
+            if (!dw_coord(g, oh, r, g.GH, &gh)) continue;
+            for (int s = 0; s < g.S; ++s) {
+                int gw;
+                if (!dw_coord(g, ow, s, g.GW, &gw)) continue;
+                const float4 xv = *reinterpret_cast<const float4*>(src + (((int64_t)n * g.GH + gh) * g.GW + gw) * g.C + (col0 + col) * 4);
+                const float4 wv = *reinterpret_cast<const float4*>(&wl[((r * g.S + s) * g.cw + col) * 4]);
+                acc.x += xv.x * wv.x; acc.y += xv.y * wv.y; acc.z += xv.z * wv.z; acc.w += xv.w * wv.w;
+            }
+        }
+        *reinterpret_cast<float4*>(dst + p * g.C + (col0 + col) * 4) = acc;
+    }
+}
+
+// partial filter gradient: part[bx][tap][c] = sum over the block's pixels of dy[p][c] * x[gather(p,tap)][c]
+__global__ __launch_bounds__(256) void dw_wgrad_partial(const DwGeom g, const float* __restrict__ x, const float* __restrict__ dy,
+                                                        float* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float red[kMaxTaps * 256 * 4];
+    const int t = threadIdx.x, col = t % g.cw, rsub = t / g.cw;
+    const int cv = g.C / 4, col0 = blockIdx.y * g.cw;
+    const int taps = g.R * g.S;
+    float4 acc[kMaxTaps];
+#pragma unroll
+    for (int i = 0; i < kMaxTaps; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rsub < g.rp && col0 + col < cv) {
+        const int64_t p0 = (int64_t)blockIdx.x * g.pix_per_block;
+        int64_t p1 = p0 + g.pix_per_block;
+        if (p1 > g.P) p1 = g.P;
+        for (int64_t p = p0 + rsub; p < p1; p += g.rp) {
+            const int n = (int)(p / ((int64_t)g.OH * g.OW));
+            const int rem = (int)(p - (int64_t)n * g.OH * g.OW);
+            const int oh = rem / g.OW, ow = rem - oh * g.OW;
+            const float4 dv = *reinterpret_cast<const float4*>(dy + p * g.C + (col0 + col) * 4);
+#pragma unroll
+            for (int tap = 0; tap < kMaxTaps; ++tap) {
+                const int r = tap / g.S, s = tap - r * g.S;
+                int gh = 0, gw = 0;
+                const bool ok = tap < taps && dw_coord(g, oh, r, g.GH, &gh) && dw_coord(g, ow, s, g.GW, &gw);
+                if (ok) {
+                    const float4 xv = *reinterpret_cast<const float4*>(x + (((int64_t)n * g.GH + gh) * g.GW + gw) * g.C + (col0 + col) * 4);
+                    acc[tap].x += dv.x * xv.x; acc[tap].y += dv.y * xv.y; acc[tap].z += dv.z * xv.z; acc[tap].w += dv.w * xv.w;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int tap = 0; tap < kMaxTaps; ++tap) *reinterpret_cast<float4*>(&red[(tap * 256 + t) * 4]) = acc[tap];
+    __syncthreads();
+    if (t < g.cw && col0 + t < cv) {
+        for (int tap = 0; tap < taps; ++tap) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int rr = 0; rr < g.rp; ++rr) {
+                const float4 v = *reinterpret_cast<const float4*>(&red[(tap * 256 + rr * g.cw + t) * 4]);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            *reinterpret_cast<float4*>(&part[((int64_t)blockIdx.x * taps + tap) * g.C + (col0 + t) * 4]) = a;
+        }
+    }
+}
+
+// dw[c][tap] (+)= sum_bx part[bx][tap][c]
+__global__ void dw_wgrad_finalize(const float* __restrict__ part, int gx, int taps, int C, float* __restrict__ dw, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;    // enumerates (tap, c) with c fastest
+    if (i >= taps * C) return;
+    const int tap = i / C, c = i - tap * C;
+    double s = 0.0;
+    for (int b = 0; b < gx; ++b) s += (double)part[((int64_t)b * taps + tap) * C + c];
+    float* o = dw + (int64_t)c * taps + tap;
+    *o = accumulate ? *o + (float)s : (float)s;
+}
+
+static int dw_check(const suhpe_conv_t* d, const char* who) {
+    if (!d || d->groups != d->cin || d->cin != d->cout || d->cin % 4 || d->r * d->s > kMaxTaps || d->r <= 0 || d->s <= 0 || d->stride <= 0) {
+        set_error("%s: needs groups == cin == cout, cin %% 4 == 0 and r*s <= %d", who, kMaxTaps);
+        return SUHPE_EINVAL;
+    }
+    const int ho = (d->h + 2 * d->pad - d->r) / d->stride + 1, wo = (d->w + 2 * d->pad - d->s) / d->stride + 1;
+    if (ho != d->ho || wo != d->wo) { set_error("%s: ho/wo do not match the geometry", who); return SUHPE_EINVAL; }
+    return SUHPE_OK;
+}
+
+static DwGeom dw_geom(const suhpe_conv_t* d, int mode, int max_blocks) {
+    DwGeom g;
+    g.N = d->n; g.C = d->cin; g.R = d->r; g.S = d->s; g.stride = d->stride; g.pad = d->pad; g.mode = mode;
+    if (mode == 0) { g.GH = d->h; g.GW = d->w; g.OH = d->ho; g.OW = d->wo; }
+    else { g.GH = d->ho; g.GW = d->wo; g.OH = d->h; g.OW = d->w; }
+    const int cv = g.C / 4;
+    g.cw = cv < 256 ? cv : 256;
+    g.rp = 256 / g.cw;
+    g.P = (int64_t)g.N * g.OH * g.OW;
+    int64_t gx = ceil_div(g.P, (int64_t)g.rp * 4);
+    if (gx > max_blocks) gx = max_blocks;
+    if (gx < 1) gx = 1;
+    g.pix_per_block = ceil_div(g.P, gx);
+    return g;
+}
+
+}  // namespace suhpe
+
+using namespace suhpe;
+
+extern "C" {
+
+int suhpe_dwconv_fwd(const suhpe_conv_t* d, const float* x, const float* w, float* y, suhpe_stream_t stream) {
+    int rc = dw_check(d, "suhpe_dwconv_fwd");
+    if (rc) return rc;
+    SUHPE_REQUIRE(x && w && y, "suhpe_dwconv_fwd: null pointer");
+    const DwGeom g = dw_geom(d, 0, 2048);
+    const int gx = (int)ceil_div(g.P, g.pix_per_block), ny = (int)ceil_div(g.C / 4, g.cw);
+    hipLaunchKernelGGL(dw_conv_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), g, x, w, y);
+    return check_launch("suhpe_dwconv_fwd");
+}
+
+int suhpe_dwconv_dgrad(const suhpe_conv_t* d, const float* dy, const float* w, float* dx, suhpe_stream_t stream) {
+    int rc = dw_check(d, "suhpe_dwconv_dgrad");
+    if (rc) return rc;
+    SUHPE_REQUIRE(dy && w && dx, "suhpe_dwconv_dgrad: null pointer");
+    const DwGeom g = dw_geom(d, 1, 2048);
+    const int gx = (int)ceil_div(g.P, g.pix_per_block), ny = (int)ceil_div(g.C / 4, g.cw);
+    hipLaunchKernelGGL(dw_conv_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), g, dy, w, dx);
+    return check_launch("suhpe_dwconv_dgrad");
+}
+
+int64_t suhpe_dwconv_wgrad_workspace_bytes(const suhpe_conv_t* d) {
+    if (!d) return 0;
+    return (int64_t)kDwMaxRowBlocks * d->r * d->s * d->cin * sizeof(float);
+}
+
+int suhpe_dwconv_wgrad(const suhpe_conv_t* d, const float* x, const float* dy, float* dw, int accumulate, void* workspace,
+                       int64_t workspace_bytes, suhpe_stream_t stream) {
+    int rc = dw_check(d, "suhpe_dwconv_wgrad");
+    if (rc) return rc;
+    SUHPE_REQUIRE(x && dy && dw && workspace, "suhpe_dwconv_wgrad: null pointer");
+    if (workspace_bytes < suhpe_dwconv_wgrad_workspace_bytes(d)) { set_error("suhpe_dwconv_wgrad: workspace too small"); return SUHPE_EWORKSPACE; }
+    const DwGeom g = dw_geom(d, 0, kDwMaxRowBlocks);
+    const int gx = (int)ceil_div(g.P, g.pix_per_block), ny = (int)ceil_div(g.C / 4, g.cw);
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(dw_wgrad_partial, dim3(gx, ny), dim3(256), 0, as_stream(stream), g, x, dy, part);
+    const int taps = d->r * d->s;
+    hipLaunchKernelGGL(dw_wgrad_finalize, dim3((taps * g.C + 255) / 256), dim3(256), 0, as_stream(stream), part, gx, taps, g.C, dw, accumulate);
+    return check_launch("suhpe_dwconv_wgrad");
+}
+
+}  // extern "C"

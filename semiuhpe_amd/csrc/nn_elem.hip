@@ -1,0 +1,824 @@
+// HBM-bound layer kernels of the backbone on gfx950: BatchNorm (train/eval) fused with the activation,
+// LayerNorm, pooling, squeeze-excite scaling, residual/stochastic-depth, dropout masks, loss reductions,
+// Adam and the EMA teacher update.  All tensors are fp32, activations are pixel-major (rows = n*h*w, c fastest),
+// every access is a 16-byte vector per lane when c % 4 == 0 (scalar fallback otherwise), reductions are
+// per-thread fp32 partials -> LDS -> fixed-order fp64 finalisation (deterministic, no atomics).
+//
+// Reference ops replaced: nn.BatchNorm2d/1d, nn.SiLU/ReLU/ReLU6/GELU/Sigmoid, nn.AdaptiveAvgPool2d,
+// torchvision SqueezeExcitation / StochasticDepth("row"), nn.Dropout, nn.LayerNorm, optim.Adam (src/agent.py:37),
+// the EMA loop (src/agent.py:298-299).
+#include "common.h"
+
+namespace suhpe {
+
+constexpr int kMaxRowBlocks = 512;   // partial-sum slabs per channel (workspace = kMaxRowBlocks*c*2 floats)
+
+// ------------------------------------------------------------------------------------------ activations
+__device__ __forceinline__ float act_apply(float u, int act) {
+    switch (act) {
+        case SUHPE_ACT_RELU: return u > 0.f ? u : 0.f;
+        case SUHPE_ACT_RELU6: return fminf(fmaxf(u, 0.f), 6.f);
+        case SUHPE_ACT_SILU: return u / (1.f + expf(-u));
+        case SUHPE_ACT_GELU: return 0.5f * u * (1.f + erff(u * 0.70710678118654752f));
+        case SUHPE_ACT_SIGMOID: return 1.f / (1.f + expf(-u));
+        default: return u;
+    }
+}
+// d act(u) / du
+__device__ __forceinline__ float act_grad(float u, int act) {
+    switch (act) {
+        case SUHPE_ACT_RELU: return u > 0.f ? 1.f : 0.f;
+        case SUHPE_ACT_RELU6: return (u > 0.f && u < 6.f) ? 1.f : 0.f;
+        case SUHPE_ACT_SILU: {
+            const float s = 1.f / (1.f + expf(-u));
+            return s * (1.f + u * (1.f - s));
+        }
+        case SUHPE_ACT_GELU: {
+            const float cdf = 0.5f * (1.f + erff(u * 0.70710678118654752f));
+            return cdf + u * 0.3989422804014327f * expf(-0.5f * u * u);
+        }
+        case SUHPE_ACT_SIGMOID: {
+            const float s = 1.f / (1.f + expf(-u));
+            return s * (1.f - s);
+        }
+        default: return 1.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ column reductions
+// Geometry shared by every per-channel reduction over a (rows, c) matrix.  A block owns `cw` consecutive
+// columns (vec-columns when VEC=4) and a contiguous slab of rows; thread t -> (col = t % cw, rsub = t / cw).
+struct ColGeom {
+    int cv;        // columns in vector units
+    int cw;        // columns per block (<=256)
+    int ny;        // column chunks
+    int rp;        // rows per pass = 256 / cw
+    int gx;        // row blocks
+    int64_t rows_per_block;
+};
+
+static ColGeom col_geom(int64_t rows, int c, int vec) {
+    ColGeom g;
+    g.cv = c / vec;
+    g.cw = g.cv < 256 ? g.cv : 256;
+    g.ny = (g.cv + g.cw - 1) / g.cw;
+    g.rp = 256 / g.cw;
+    int64_t want = ceil_div(rows, (int64_t)g.rp * 8);          // >= 8 passes per block
+    int64_t cap = kMaxRowBlocks;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    g.gx = (int)want;
+    g.rows_per_block = ceil_div(rows, g.gx);
+    return g;
+}
+
+template <int VEC> struct VecT;
+template <> struct VecT<4> { using type = float4; };
+template <> struct VecT<1> { using type = float; };
+
+template <int VEC> __device__ __forceinline__ void vload(const float* p, float* o) {
+    if (VEC == 4) { const float4 v = *reinterpret_cast<const float4*>(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+    else o[0] = p[0];
+}
+template <int VEC> __device__ __forceinline__ void vstore(float* p, const float* o) {
+    if (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+    else p[0] = o[0];
+}
+
+// Block-level combine of per-thread partial sums that share a column: LDS [256][2*VEC] then the first cw
+// threads add the rp partials of their column in fixed order and write part[(bx*c + ch)*2 + {0,1}].
+template <int VEC>
+__device__ __forceinline__ void block_combine(const float* s0, const float* s1, int cw, int rp, int col0, int c,
+                                              int bx, float* __restrict__ part, float* lds) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { lds[(t * 2 + 0) * VEC + v] = s0[v]; lds[(t * 2 + 1) * VEC + v] = s1[v]; }
+    __syncthreads();
+    if (t < cw && (col0 + t) * VEC < c) {
+        float a0[VEC], a1[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { a0[v] = 0.f; a1[v] = 0.f; }
+        for (int r = 0; r < rp; ++r) {
+            const int tt = r * cw + t;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) { a0[v] += lds[(tt * 2 + 0) * VEC + v]; a1[v] += lds[(tt * 2 + 1) * VEC + v]; }
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const int ch = (col0 + t) * VEC + v;
+            part[((int64_t)bx * c + ch) * 2 + 0] = a0[v];
+            part[((int64_t)bx * c + ch) * 2 + 1] = a1[v];
+        }
+    }
+}
+
+// BN statistics, pass 1: per-block partial sum and sum of squares.
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ x, int64_t rows, int c, int cw, int rp,
+                                                        int64_t rows_per_block, float* __restrict__ part) {
+    __shared__ float lds[256 * 2 * VEC];
+    const int t = threadIdx.x, col = t % cw, rsub = t / cw;
+    const int col0 = blockIdx.y * cw;
+    const int cv = c / VEC;
+    float s0[VEC], s1[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { s0[v] = 0.f; s1[v] = 0.f; }
+    if (rsub < rp && col0 + col < cv) {
+        const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+        int64_t r1 = r0 + rows_per_block;
+        if (r1 > rows) r1 = rows;
+        for (int64_t r = r0 + rsub; r < r1; r += rp) {
+            float xv[VEC];
+            vload<VEC>(x + (r * cv + col0 + col) * VEC, xv);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) { s0[v] += xv[v]; s1[v] += xv[v] * xv[v]; }
+        }
+    }
+    block_combine<VEC>(s0, s1, cw, rp, col0, c, blockIdx.x, part, lds);
+}
+
+// pass 2: one thread per channel, fixed-order fp64 combine; running-stat update as nn.BatchNorm does
+__global__ void bn_stats_finalize(const float* __restrict__ part, int gx, int c, int64_t rows, float eps, float momentum,
+                                  float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
+                                  float* __restrict__ running_var, int64_t* __restrict__ nbt) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch == 0 && nbt) nbt[0] += 1;
+    if (ch >= c) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < gx; ++b) { s += (double)part[((int64_t)b * c + ch) * 2]; q += (double)part[((int64_t)b * c + ch) * 2 + 1]; }
+    const double m = s / (double)rows;
+    double var = q / (double)rows - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[ch] = (float)m;
+    rstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unb = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
+        running_mean[ch] = (float)((1.0 - momentum) * (double)running_mean[ch] + momentum * m);
+        running_var[ch] = (float)((1.0 - momentum) * (double)running_var[ch] + momentum * unb);
+    }
+}
+
+__global__ void bn_eval_stats_kernel(const float* __restrict__ rm, const float* __restrict__ rv, int c, float eps,
+                                     float* __restrict__ mean, float* __restrict__ rstd) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    mean[ch] = rm[ch];
+    rstd[ch] = 1.f / sqrtf(rv[ch] + eps);
+}
+
+// y = act(gamma*(x-mean)*rstd + beta + residual)
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, int64_t nvec, int cv,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         int act, const float* __restrict__ residual,
+                                                         float* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cv) * VEC;
+        float xv[VEC], rv[VEC], o[VEC];
+        vload<VEC>(x + i * VEC, xv);
+        if (residual) vload<VEC>(residual + i * VEC, rv);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const float g = gamma ? gamma[ch + v] : 1.f, b = beta ? beta[ch + v] : 0.f;
+            float u = (xv[v] - mean[ch + v]) * rstd[ch + v] * g + b;
+            if (residual) u += rv[v];
+            o[v] = act_apply(u, act);
+        }
+        vstore<VEC>(y + i * VEC, o);
+    }
+}
+
+// backward pass 1: partial sums of g and g*xhat, g = dy * act'(u)
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ x, const float* __restrict__ dy,
+                                                      const float* __restrict__ yout, int64_t rows, int c, int cw, int rp,
+                                                      int64_t rows_per_block, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, int act, float* __restrict__ part) {
+    __shared__ float lds[256 * 2 * VEC];
+    const int t = threadIdx.x, col = t % cw, rsub = t / cw;
+    const int col0 = blockIdx.y * cw;
+    const int cv = c / VEC;
+    float s0[VEC], s1[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { s0[v] = 0.f; s1[v] = 0.f; }
+    if (rsub < rp && col0 + col < cv) {
+        const int ch = (col0 + col) * VEC;
+        float mu[VEC], rs[VEC], ga[VEC], be[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            mu[v] = mean[ch + v]; rs[v] = rstd[ch + v];
+            ga[v] = gamma ? gamma[ch + v] : 1.f; be[v] = beta ? beta[ch + v] : 0.f;
+        }
+        const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+        int64_t r1 = r0 + rows_per_block;
+        if (r1 > rows) r1 = rows;
+        for (int64_t r = r0 + rsub; r < r1; r += rp) {
+            float xv[VEC], dv[VEC], yv[VEC];
+            const int64_t off = (r * cv + col0 + col) * VEC;
+            vload<VEC>(x + off, xv);
+            vload<VEC>(dy + off, dv);
+            if (yout) vload<VEC>(yout + off, yv);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const float xh = (xv[v] - mu[v]) * rs[v];
+                float g;
+                if (yout) g = yv[v] > 0.f ? dv[v] : 0.f;       // ReLU applied after a pre-activation residual
+                else g = dv[v] * act_grad(xh * ga[v] + be[v], act);
+                s0[v] += g;
+                s1[v] += g * xh;
+            }
+        }
+    }
+    block_combine<VEC>(s0, s1, cw, rp, col0, c, blockIdx.x, part, lds);
+}
+
+// pass 2: dbeta = sum g, dgamma = sum g*xhat (fp64, fixed order); leaves them in sums[c][2] for pass 3
+__global__ void bn_bwd_finalize(const float* __restrict__ part, int gx, int c, float* __restrict__ sums,
+                                float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < gx; ++b) { s += (double)part[((int64_t)b * c + ch) * 2]; q += (double)part[((int64_t)b * c + ch) * 2 + 1]; }
+    sums[2 * ch] = (float)s;
+    sums[2 * ch + 1] = (float)q;
+    if (dbeta) dbeta[ch] = accumulate ? dbeta[ch] + (float)s : (float)s;
+    if (dgamma) dgamma[ch] = accumulate ? dgamma[ch] + (float)q : (float)q;
+}
+
+// pass 3: dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat))   [train]   or gamma*rstd*g [eval]
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ dy,
+                                                    const float* __restrict__ yout, int64_t nvec, int cv,
+                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                    const float* __restrict__ sums, float inv_rows, int train_stats,
+                                                    float* __restrict__ dx) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cv) * VEC;
+        float xv[VEC], dv[VEC], yv[VEC], o[VEC];
+        vload<VEC>(x + i * VEC, xv);
+        vload<VEC>(dy + i * VEC, dv);
+        if (yout) vload<VEC>(yout + i * VEC, yv);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const float ga = gamma ? gamma[ch + v] : 1.f, be = beta ? beta[ch + v] : 0.f;
+            const float xh = (xv[v] - mean[ch + v]) * rstd[ch + v];
+            float g;
+            if (yout) g = yv[v] > 0.f ? dv[v] : 0.f;
+            else g = dv[v] * act_grad(xh * ga + be, act);
+            if (train_stats) g = g - sums[2 * (ch + v)] * inv_rows - xh * sums[2 * (ch + v) + 1] * inv_rows;
+            o[v] = ga * rstd[ch + v] * g;
+        }
+        vstore<VEC>(dx + i * VEC, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ LayerNorm (one wave per row)
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int64_t rows, int c, float eps,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ y, float* __restrict__ mean,
+                                                            float* __restrict__ rstd) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * c;
+    float s = 0.f;
+    for (int j = lane; j < c; j += 64) s += xr[j];
+    const float m = wave_sum(s) / c;
+    float q = 0.f;
+    for (int j = lane; j < c; j += 64) { const float d = xr[j] - m; q += d * d; }
+    const float rs = 1.f / sqrtf(wave_sum(q) / c + eps);
+    for (int j = lane; j < c; j += 64) y[row * c + j] = (xr[j] - m) * rs * (gamma ? gamma[j] : 1.f) + (beta ? beta[j] : 0.f);
+    if (lane == 0) { mean[row] = m; rstd[row] = rs; }
+}
+
+// dx per row; dgamma/dbeta partials via the column-reduction machinery (VEC=1 form, g = dy, xhat from saved stats)
+__global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               int64_t rows, int c, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                               float* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float m = mean[row], rs = rstd[row];
+    float s0 = 0.f, s1 = 0.f;
+    for (int j = lane; j < c; j += 64) {
+        const float g = dy[row * c + j] * (gamma ? gamma[j] : 1.f);
+        const float xh = (x[row * c + j] - m) * rs;
+        s0 += g;
+        s1 += g * xh;
+    }
+    s0 = wave_sum(s0) / c;
+    s1 = wave_sum(s1) / c;
+    for (int j = lane; j < c; j += 64) {
+        const float g = dy[row * c + j] * (gamma ? gamma[j] : 1.f);
+        const float xh = (x[row * c + j] - m) * rs;
+        dx[row * c + j] = rs * (g - s0 - xh * s1);
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void layernorm_bwd_partial(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             int64_t rows, int c, int cw, int rp, int64_t rows_per_block,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             float* __restrict__ part) {
+    __shared__ float lds[256 * 2 * VEC];
+    const int t = threadIdx.x, col = t % cw, rsub = t / cw;
+    const int col0 = blockIdx.y * cw;
+    const int cv = c / VEC;
+    float s0[VEC], s1[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { s0[v] = 0.f; s1[v] = 0.f; }
+    if (rsub < rp && col0 + col < cv) {
+        const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+        int64_t r1 = r0 + rows_per_block;
+        if (r1 > rows) r1 = rows;
+        for (int64_t r = r0 + rsub; r < r1; r += rp) {
+            float xv[VEC], dv[VEC];
+            const int64_t off = (r * cv + col0 + col) * VEC;
+            vload<VEC>(x + off, xv);
+            vload<VEC>(dy + off, dv);
+            const float m = mean[r], rs = rstd[r];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) { s0[v] += dv[v]; s1[v] += dv[v] * (xv[v] - m) * rs; }
+        }
+    }
+    block_combine<VEC>(s0, s1, cw, rp, col0, c, blockIdx.x, part, lds);
+}
+
+// ------------------------------------------------------------------------------------------ plain activation (+bias)
+template <int VEC>
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, int64_t nvec, int cv,
+                                                      const float* __restrict__ bias, int act, float* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cv) * VEC;
+        float xv[VEC], o[VEC];
+        vload<VEC>(x + i * VEC, xv);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o[v] = act_apply(xv[v] + (bias ? bias[ch + v] : 0.f), act);
+        vstore<VEC>(y + i * VEC, o);
+    }
+}
+template <int VEC>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int64_t nvec,
+                                                      int cv, const float* __restrict__ bias, int act, float* __restrict__ dx) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cv) * VEC;
+        float xv[VEC], dv[VEC], o[VEC];
+        vload<VEC>(x + i * VEC, xv);
+        vload<VEC>(dy + i * VEC, dv);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o[v] = dv[v] * act_grad(xv[v] + (bias ? bias[ch + v] : 0.f), act);
+        vstore<VEC>(dx + i * VEC, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ pooling / SE
+// One block per (sample, column chunk): y[n,c] = scale * sum_p x[n,p,c] * (w ? w[n,p,c] : 1)
+template <int VEC>
+__global__ __launch_bounds__(256) void pool_sum_kernel(const float* __restrict__ x, const float* __restrict__ w, int hw, int c,
+                                                       int cw, int rp, float scale, float* __restrict__ y) {
+    __shared__ float lds[256 * VEC];
+    const int t = threadIdx.x, col = t % cw, rsub = t / cw;
+    const int col0 = blockIdx.y * cw, cv = c / VEC;
+    const int64_t n = blockIdx.x;
+    float s[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) s[v] = 0.f;
+    if (rsub < rp && col0 + col < cv) {
+        for (int p = rsub; p < hw; p += rp) {
+            float xv[VEC], wv[VEC];
+            const int64_t off = ((n * hw + p) * cv + col0 + col) * VEC;
+            vload<VEC>(x + off, xv);
+            if (w) { vload<VEC>(w + off, wv);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) s[v] += xv[v] * wv[v];
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) s[v] += xv[v];
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) lds[t * VEC + v] = s[v];
+    __syncthreads();
+    if (t < cw && col0 + t < cv) {
+        float a[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) a[v] = 0.f;
+        for (int r = 0; r < rp; ++r)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) a[v] += lds[(r * cw + t) * VEC + v];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) a[v] *= scale;
+        vstore<VEC>(y + (n * cv + col0 + t) * VEC, a);
+    }
+}
+
+// dx[n,p,c] = dy[n,c]*scale
+template <int VEC>
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dy, int64_t nvec, int hw, int cv, float scale,
+                                                       float* __restrict__ dx) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / ((int64_t)hw * cv);
+        const int col = (int)(i % cv);
+        float g[VEC];
+        vload<VEC>(dy + (n * cv + col) * VEC, g);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) g[v] *= scale;
+        vstore<VEC>(dx + i * VEC, g);
+    }
+}
+
+// y = x*s[n,c]   or   dx = dy*s[n,c] + dpool[n,c]*inv_hw
+template <int VEC>
+__global__ __launch_bounds__(256) void se_scale_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                       const float* __restrict__ dpool, int64_t nvec, int hw, int cv,
+                                                       float inv_hw, float* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / ((int64_t)hw * cv);
+        const int col = (int)(i % cv);
+        float xv[VEC], sv[VEC], pv[VEC], o[VEC];
+        vload<VEC>(x + i * VEC, xv);
+        vload<VEC>(s + (n * cv + col) * VEC, sv);
+        if (dpool) vload<VEC>(dpool + (n * cv + col) * VEC, pv);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o[v] = xv[v] * sv[v] + (dpool ? pv[v] * inv_hw : 0.f);
+        vstore<VEC>(y + i * VEC, o);
+    }
+}
+
+// y = a + b*rowscale[n]   (a may be NULL -> y = b*rowscale[n])
+__global__ __launch_bounds__(256) void add_rowscale_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           const float* __restrict__ rowscale, int64_t nvec, int64_t per_vec,
+                                                           float* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const float sc = rowscale ? rowscale[i / per_vec] : 1.f;
+        const float4 bv = reinterpret_cast<const float4*>(b)[i];
+        float4 o = make_float4(bv.x * sc, bv.y * sc, bv.z * sc, bv.w * sc);
+        if (a) { const float4 av = reinterpret_cast<const float4*>(a)[i]; o.x += av.x; o.y += av.y; o.z += av.z; o.w += av.w; }
+        reinterpret_cast<float4*>(y)[i] = o;
+    }
+}
+
+// binary elementwise: op 0 = add, 1 = mul
+__global__ __launch_bounds__(256) void binary_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t count,
+                                                     int op, float* __restrict__ y) {
+    const int64_t nvec = count / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 av = reinterpret_cast<const float4*>(a)[i], bv = reinterpret_cast<const float4*>(b)[i];
+        reinterpret_cast<float4*>(y)[i] = op == 0 ? make_float4(av.x + bv.x, av.y + bv.y, av.z + bv.z, av.w + bv.w)
+                                                  : make_float4(av.x * bv.x, av.y * bv.y, av.z * bv.z, av.w * bv.w);
+    }
+    for (int64_t i = nvec * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = op == 0 ? a[i] + b[i] : a[i] * b[i];
+}
+
+// ------------------------------------------------------------------------------------------ dropout mask (Philox4x32-10)
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+__global__ __launch_bounds__(256) void dropout_mask_kernel(const uint64_t* __restrict__ counter, float keep, int64_t count,
+                                                           float* __restrict__ mask) {
+    const uint64_t seed = counter[0], offset = counter[1];
+    const float inv = keep > 0.f ? 1.f / keep : 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i * 4 < count; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t ctr = offset + (uint64_t)i;
+        uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x5355u, c3 = 0x4850u;
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) { philox_round(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+        const uint32_t rr[4] = {c0, c1, c2, c3};
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            if (i * 4 + v < count) mask[i * 4 + v] = ((rr[v] >> 8) * (1.0f / 16777216.0f)) < keep ? inv : 0.f;
+    }
+}
+__global__ void advance_counter_kernel(uint64_t* counter, uint64_t by) { counter[1] += by; }
+
+// ------------------------------------------------------------------------------------------ loss reductions
+__global__ __launch_bounds__(256) void weighted_sum_kernel(const float* __restrict__ x, const float* __restrict__ w, int64_t count,
+                                                           float scale, float* __restrict__ out) {
+    __shared__ double part[4];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < count; i += blockDim.x) s += (double)x[i] * (w ? (double)w[i] : 1.0);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)((part[0] + part[1] + part[2] + part[3]) * (double)scale);
+}
+
+__global__ void scale_rows_kernel(const float* __restrict__ x, const float* __restrict__ g, int64_t rows, int c, float scale,
+                                  float* __restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * c) return;
+    y[i] = x[i] * (g ? g[i / c] : 1.f) * scale;
+}
+
+// column sums of dy (rows, c): partial + finalize (bias gradient)
+template <int VEC>
+__global__ __launch_bounds__(256) void colsum_partial(const float* __restrict__ x, int64_t rows, int c, int cw, int rp,
+                                                      int64_t rows_per_block, float* __restrict__ part) {
+    __shared__ float lds[256 * 2 * VEC];
+    const int t = threadIdx.x, col = t % cw, rsub = t / cw;
+    const int col0 = blockIdx.y * cw, cv = c / VEC;
+    float s0[VEC], s1[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { s0[v] = 0.f; s1[v] = 0.f; }
+    if (rsub < rp && col0 + col < cv) {
+        const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+        int64_t r1 = r0 + rows_per_block;
+        if (r1 > rows) r1 = rows;
+        for (int64_t r = r0 + rsub; r < r1; r += rp) {
+            float xv[VEC];
+            vload<VEC>(x + (r * cv + col0 + col) * VEC, xv);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) s0[v] += xv[v];
+        }
+    }
+    block_combine<VEC>(s0, s1, cw, rp, col0, c, blockIdx.x, part, lds);
+}
+__global__ void colsum_finalize(const float* __restrict__ part, int gx, int c, float* __restrict__ out, int accumulate) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double s = 0.0;
+    for (int b = 0; b < gx; ++b) s += (double)part[((int64_t)b * c + ch) * 2];
+    out[ch] = accumulate ? out[ch] + (float)s : (float)s;
+}
+
+// ------------------------------------------------------------------------------------------ optimiser / EMA
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t count, float lr, float b1, float b2, float eps,
+                                                   float wd, float bc1, float bc2_sqrt) {
+    const float step_size = lr / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        const float pi = p[i];
+        if (wd != 0.f) gi += wd * pi;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = pi - step_size * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    }
+}
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ e, const float* __restrict__ p, int64_t count, float alpha) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        e[i] = e[i] * alpha + (1.f - alpha) * p[i];
+}
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, int64_t count, float value) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) p[i] = value;
+}
+
+static inline bool vec4_ok(int c, const void* a, const void* b = nullptr, const void* d = nullptr) {
+    auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return (c % 4 == 0) && al(a) && al(b) && al(d);
+}
+
+}  // namespace suhpe
+
+using namespace suhpe;
+
+#define LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL(kern, grid, block, 0, as_stream(stream), __VA_ARGS__)
+
+extern "C" {
+
+int64_t suhpe_bn_workspace_bytes(int c) { return (int64_t)kMaxRowBlocks * c * 2 * sizeof(float) + (int64_t)c * 2 * sizeof(float); }
+
+int suhpe_bn_stats(const float* x, int64_t rows, int c, float eps, float momentum, float* mean, float* rstd,
+                   float* running_mean, float* running_var, int64_t* nbt, void* workspace, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(x && mean && rstd && workspace && rows > 0 && c > 0, "suhpe_bn_stats: bad arguments (rows=%lld c=%d)", (long long)rows, c);
+    float* part = static_cast<float*>(workspace);
+    if (vec4_ok(c, x)) {
+        const ColGeom g = col_geom(rows, c, 4);
+        LAUNCH(bn_stats_partial<4>, dim3(g.gx, g.ny), dim3(256), stream, x, rows, c, g.cw, g.rp, g.rows_per_block, part);
+        LAUNCH(bn_stats_finalize, dim3((c + 255) / 256), dim3(256), stream, part, g.gx, c, rows, eps, momentum, mean, rstd,
+               running_mean, running_var, nbt);
+    } else {
+        const ColGeom g = col_geom(rows, c, 1);
+        LAUNCH(bn_stats_partial<1>, dim3(g.gx, g.ny), dim3(256), stream, x, rows, c, g.cw, g.rp, g.rows_per_block, part);
+        LAUNCH(bn_stats_finalize, dim3((c + 255) / 256), dim3(256), stream, part, g.gx, c, rows, eps, momentum, mean, rstd,
+               running_mean, running_var, nbt);
+    }
+    return check_launch("suhpe_bn_stats");
+}
+
+int suhpe_bn_eval_stats(const float* rm, const float* rv, int c, float eps, float* mean, float* rstd, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(rm && rv && mean && rstd && c > 0, "suhpe_bn_eval_stats: bad arguments");
+    LAUNCH(bn_eval_stats_kernel, dim3((c + 255) / 256), dim3(256), stream, rm, rv, c, eps, mean, rstd);
+    return check_launch("suhpe_bn_eval_stats");
+}
+
+int suhpe_bn_act_fwd(const float* x, int64_t rows, int c, const float* mean, const float* rstd, const float* gamma,
+                     const float* beta, int act, const float* residual, float* y, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(x && y && mean && rstd && rows > 0 && c > 0, "suhpe_bn_act_fwd: bad arguments");
+    if (vec4_ok(c, x, y, residual)) {
+        const int64_t nvec = rows * (c / 4);
+        LAUNCH(bn_act_fwd_kernel<4>, dim3(grid_for(nvec, 256)), dim3(256), stream, x, nvec, c / 4, mean, rstd, gamma, beta, act,
+               residual, y);
+    } else {
+        const int64_t nvec = rows * c;
+        LAUNCH(bn_act_fwd_kernel<1>, dim3(grid_for(nvec, 256)), dim3(256), stream, x, nvec, c, mean, rstd, gamma, beta, act,
+               residual, y);
+    }
+    return check_launch("suhpe_bn_act_fwd");
+}
+
+int suhpe_bn_act_bwd(const float* x, const float* dy, const float* y_out, int64_t rows, int c, const float* mean,
+                     const float* rstd, const float* gamma, const float* beta, int act, int train_stats, float* dx,
+                     float* dgamma, float* dbeta, int accumulate, void* workspace, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(x && dy && dx && mean && rstd && workspace && rows > 0 && c > 0, "suhpe_bn_act_bwd: bad arguments");
+    SUHPE_REQUIRE(!y_out || act == SUHPE_ACT_RELU, "suhpe_bn_act_bwd: y_out (pre-activation residual) needs act=RELU");
+    float* part = static_cast<float*>(workspace);
+    float* sums = part + (int64_t)kMaxRowBlocks * c * 2;
+    const float inv_rows = 1.0f / (float)rows;
+    if (vec4_ok(c, x, dy, dx) && vec4_ok(c, y_out)) {
+        const ColGeom g = col_geom(rows, c, 4);
+        LAUNCH(bn_bwd_partial<4>, dim3(g.gx, g.ny), dim3(256), stream, x, dy, y_out, rows, c, g.cw, g.rp, g.rows_per_block, mean,
+               rstd, gamma, beta, act, part);
+        LAUNCH(bn_bwd_finalize, dim3((c + 255) / 256), dim3(256), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
+        const int64_t nvec = rows * (c / 4);
+        LAUNCH(bn_bwd_apply<4>, dim3(grid_for(nvec, 256)), dim3(256), stream, x, dy, y_out, nvec, c / 4, mean, rstd, gamma, beta,
+               act, sums, inv_rows, train_stats, dx);
+    } else {
+        const ColGeom g = col_geom(rows, c, 1);
+        LAUNCH(bn_bwd_partial<1>, dim3(g.gx, g.ny), dim3(256), stream, x, dy, y_out, rows, c, g.cw, g.rp, g.rows_per_block, mean,
+               rstd, gamma, beta, act, part);
+        LAUNCH(bn_bwd_finalize, dim3((c + 255) / 256), dim3(256), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
+        const int64_t nvec = rows * c;
+        LAUNCH(bn_bwd_apply<1>, dim3(grid_for(nvec, 256)), dim3(256), stream, x, dy, y_out, nvec, c, mean, rstd, gamma, beta, act,
+               sums, inv_rows, train_stats, dx);
+    }
+    return check_launch("suhpe_bn_act_bwd");
+}
+
+int suhpe_layernorm_fwd(const float* x, int64_t rows, int c, float eps, const float* gamma, const float* beta, float* y,
+                        float* mean, float* rstd, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(x && y && mean && rstd && rows > 0 && c > 0, "suhpe_layernorm_fwd: bad arguments");
+    LAUNCH(layernorm_fwd_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), stream, x, rows, c, eps, gamma, beta, y, mean, rstd);
+    return check_launch("suhpe_layernorm_fwd");
+}
+
+int suhpe_layernorm_bwd(const float* x, const float* dy, int64_t rows, int c, const float* mean, const float* rstd,
+                        const float* gamma, float* dx, float* dgamma, float* dbeta, int accumulate, void* workspace,
+                        suhpe_stream_t stream) {
+    SUHPE_REQUIRE(x && dy && dx && mean && rstd && workspace && rows > 0 && c > 0, "suhpe_layernorm_bwd: bad arguments");
+    LAUNCH(layernorm_bwd_dx_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), stream, x, dy, rows, c, mean, rstd, gamma, dx);
+    if (dgamma || dbeta) {
+        float* part = static_cast<float*>(workspace);
+        float* sums = part + (int64_t)kMaxRowBlocks * c * 2;
+        if (vec4_ok(c, x, dy)) {
+            const ColGeom g = col_geom(rows, c, 4);
+            LAUNCH(layernorm_bwd_partial<4>, dim3(g.gx, g.ny), dim3(256), stream, x, dy, rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, part);
+            LAUNCH(bn_bwd_finalize, dim3((c + 255) / 256), dim3(256), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
+        } else {
+            const ColGeom g = col_geom(rows, c, 1);
+            LAUNCH(layernorm_bwd_partial<1>, dim3(g.gx, g.ny), dim3(256), stream, x, dy, rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, part);
+            LAUNCH(bn_bwd_finalize, dim3((c + 255) / 256), dim3(256), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
+        }
+    }
+    return check_launch("suhpe_layernorm_bwd");
+}
+
+int suhpe_act_fwd(const float* x, int64_t rows, int c, const float* bias, int act, float* y, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(x && y && rows > 0 && c > 0, "suhpe_act_fwd: bad arguments");
+    if (vec4_ok(c, x, y)) { const int64_t nv = rows * (c / 4); LAUNCH(act_fwd_kernel<4>, dim3(grid_for(nv, 256)), dim3(256), stream, x, nv, c / 4, bias, act, y); }
+    else { const int64_t nv = rows * c; LAUNCH(act_fwd_kernel<1>, dim3(grid_for(nv, 256)), dim3(256), stream, x, nv, c, bias, act, y); }
+    return check_launch("suhpe_act_fwd");
+}
+
+int suhpe_act_bwd(const float* x, const float* dy, int64_t rows, int c, const float* bias, int act, float* dx, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(x && dy && dx && rows > 0 && c > 0, "suhpe_act_bwd: bad arguments");
+    if (vec4_ok(c, x, dy, dx)) { const int64_t nv = rows * (c / 4); LAUNCH(act_bwd_kernel<4>, dim3(grid_for(nv, 256)), dim3(256), stream, x, dy, nv, c / 4, bias, act, dx); }
+    else { const int64_t nv = rows * c; LAUNCH(act_bwd_kernel<1>, dim3(grid_for(nv, 256)), dim3(256), stream, x, dy, nv, c, bias, act, dx); }
+    return check_launch("suhpe_act_bwd");
+}
+
+static int pool_sum(const float* x, const float* w, int n, int hw, int c, float scale, float* y, suhpe_stream_t stream, const char* who) {
+    if (!(x && y && n > 0 && hw > 0 && c > 0)) { set_error("%s: bad arguments", who); return SUHPE_EINVAL; }
+    const int vec = vec4_ok(c, x, w, y) ? 4 : 1;
+    const int cv = c / vec, cw = cv < 256 ? cv : 256, ny = (cv + cw - 1) / cw, rp = 256 / cw;
+    if (vec == 4) LAUNCH(pool_sum_kernel<4>, dim3(n, ny), dim3(256), stream, x, w, hw, c, cw, rp, scale, y);
+    else LAUNCH(pool_sum_kernel<1>, dim3(n, ny), dim3(256), stream, x, w, hw, c, cw, rp, scale, y);
+    return check_launch(who);
+}
+
+int suhpe_avgpool_fwd(const float* x, int n, int hw, int c, float* y, suhpe_stream_t stream) {
+    return pool_sum(x, nullptr, n, hw, c, 1.0f / (float)hw, y, stream, "suhpe_avgpool_fwd");
+}
+
+int suhpe_avgpool_bwd(const float* dy, int n, int hw, int c, float* dx, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(dy && dx && n > 0 && hw > 0 && c > 0, "suhpe_avgpool_bwd: bad arguments");
+    if (vec4_ok(c, dy, dx)) { const int64_t nv = (int64_t)n * hw * (c / 4); LAUNCH(pool_bwd_kernel<4>, dim3(grid_for(nv, 256)), dim3(256), stream, dy, nv, hw, c / 4, 1.0f / hw, dx); }
+    else { const int64_t nv = (int64_t)n * hw * c; LAUNCH(pool_bwd_kernel<1>, dim3(grid_for(nv, 256)), dim3(256), stream, dy, nv, hw, c, 1.0f / hw, dx); }
+    return check_launch("suhpe_avgpool_bwd");
+}
+
+int suhpe_se_scale_fwd(const float* x, const float* s, int n, int hw, int c, float* y, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(x && s && y && n > 0 && hw > 0 && c > 0, "suhpe_se_scale_fwd: bad arguments");
+    if (vec4_ok(c, x, s, y)) { const int64_t nv = (int64_t)n * hw * (c / 4); LAUNCH(se_scale_kernel<4>, dim3(grid_for(nv, 256)), dim3(256), stream, x, s, nullptr, nv, hw, c / 4, 0.f, y); }
+    else { const int64_t nv = (int64_t)n * hw * c; LAUNCH(se_scale_kernel<1>, dim3(grid_for(nv, 256)), dim3(256), stream, x, s, nullptr, nv, hw, c, 0.f, y); }
+    return check_launch("suhpe_se_scale_fwd");
+}
+
+int suhpe_se_scale_bwd_s(const float* dy, const float* x, int n, int hw, int c, float* ds, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(dy && x && ds, "suhpe_se_scale_bwd_s: null pointer");
+    return pool_sum(dy, x, n, hw, c, 1.0f, ds, stream, "suhpe_se_scale_bwd_s");
+}
+
+int suhpe_se_scale_bwd_x(const float* dy, const float* s, const float* dpool, int n, int hw, int c, float* dx, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(dy && s && dx && n > 0 && hw > 0 && c > 0, "suhpe_se_scale_bwd_x: bad arguments");
+    if (vec4_ok(c, dy, s, dx) && vec4_ok(c, dpool)) { const int64_t nv = (int64_t)n * hw * (c / 4); LAUNCH(se_scale_kernel<4>, dim3(grid_for(nv, 256)), dim3(256), stream, dy, s, dpool, nv, hw, c / 4, 1.0f / hw, dx); }
+    else { const int64_t nv = (int64_t)n * hw * c; LAUNCH(se_scale_kernel<1>, dim3(grid_for(nv, 256)), dim3(256), stream, dy, s, dpool, nv, hw, c, 1.0f / hw, dx); }
+    return check_launch("suhpe_se_scale_bwd_x");
+}
+
+int suhpe_add_rowscale(const float* a, const float* b, const float* rowscale, int n, int64_t per, float* y, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(b && y && n > 0 && per > 0 && per % 4 == 0, "suhpe_add_rowscale: bad arguments (per must be a multiple of 4)");
+    SUHPE_REQUIRE(vec4_ok(4, a, b, y), "suhpe_add_rowscale: pointers must be 16-byte aligned");
+    const int64_t nv = (int64_t)n * per / 4;
+    LAUNCH(add_rowscale_kernel, dim3(grid_for(nv, 256)), dim3(256), stream, a, b, rowscale, nv, per / 4, y);
+    return check_launch("suhpe_add_rowscale");
+}
+
+int suhpe_mul_rowscale(const float* x, const float* rowscale, int n, int64_t per, float* y, suhpe_stream_t stream) {
+    return suhpe_add_rowscale(nullptr, x, rowscale, n, per, y, stream);
+}
+
+int suhpe_mul(const float* x, const float* m, int64_t count, float* y, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(x && m && y && count > 0 && vec4_ok(4, x, m, y), "suhpe_mul: bad arguments");
+    LAUNCH(binary_kernel, dim3(grid_for(count / 4 + 1, 256)), dim3(256), stream, x, m, count, 1, y);
+    return check_launch("suhpe_mul");
+}
+
+int suhpe_add(const float* a, const float* b, int64_t count, float* y, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(a && b && y && count > 0 && vec4_ok(4, a, b, y), "suhpe_add: bad arguments");
+    LAUNCH(binary_kernel, dim3(grid_for(count / 4 + 1, 256)), dim3(256), stream, a, b, count, 0, y);
+    return check_launch("suhpe_add");
+}
+
+int suhpe_dropout_mask(uint64_t* counter, float keep, int64_t count, float* mask, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(counter && mask && count > 0 && keep >= 0.f && keep <= 1.f, "suhpe_dropout_mask: bad arguments");
+    const int64_t n4 = ceil_div(count, 4);
+    LAUNCH(dropout_mask_kernel, dim3(grid_for(n4, 256)), dim3(256), stream, counter, keep, count, mask);
+    LAUNCH(advance_counter_kernel, dim3(1), dim3(1), stream, counter, (uint64_t)n4);
+    return check_launch("suhpe_dropout_mask");
+}
+
+int suhpe_weighted_sum(const float* x, const float* w, int64_t count, float scale, float* out, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(x && out && count >= 0, "suhpe_weighted_sum: bad arguments");
+    LAUNCH(weighted_sum_kernel, dim3(1), dim3(256), stream, x, w, count, scale, out);
+    return check_launch("suhpe_weighted_sum");
+}
+
+int suhpe_scale_rows(const float* x, const float* g, int64_t rows, int c, float scale, float* y, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(x && y && rows >= 0 && c > 0, "suhpe_scale_rows: bad arguments");
+    if (rows == 0) return SUHPE_OK;
+    LAUNCH(scale_rows_kernel, dim3((unsigned)ceil_div(rows * c, 256)), dim3(256), stream, x, g, rows, c, scale, y);
+    return check_launch("suhpe_scale_rows");
+}
+
+int suhpe_bias_grad(const float* dy, int64_t rows, int c, float* db, int accumulate, void* workspace, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(dy && db && workspace && rows > 0 && c > 0, "suhpe_bias_grad: bad arguments");
+    float* part = static_cast<float*>(workspace);
+    if (vec4_ok(c, dy)) {
+        const ColGeom g = col_geom(rows, c, 4);
+        LAUNCH(colsum_partial<4>, dim3(g.gx, g.ny), dim3(256), stream, dy, rows, c, g.cw, g.rp, g.rows_per_block, part);
+        LAUNCH(colsum_finalize, dim3((c + 255) / 256), dim3(256), stream, part, g.gx, c, db, accumulate);
+    } else {
+        const ColGeom g = col_geom(rows, c, 1);
+        LAUNCH(colsum_partial<1>, dim3(g.gx, g.ny), dim3(256), stream, dy, rows, c, g.cw, g.rp, g.rows_per_block, part);
+        LAUNCH(colsum_finalize, dim3((c + 255) / 256), dim3(256), stream, part, g.gx, c, db, accumulate);
+    }
+    return check_launch("suhpe_bias_grad");
+}
+
+int suhpe_adam_step(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int64_t step, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(p && g && m && v && count > 0 && step >= 1, "suhpe_adam_step: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    LAUNCH(adam_kernel, dim3(grid_for(count, 256)), dim3(256), stream, p, g, m, v, count, lr, beta1, beta2, eps, weight_decay,
+           (float)bc1, (float)sqrt(bc2));
+    return check_launch("suhpe_adam_step");
+}
+
+int suhpe_ema_update(float* ema, const float* p, int64_t count, float alpha, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(ema && p && count > 0, "suhpe_ema_update: bad arguments");
+    LAUNCH(ema_kernel, dim3(grid_for(count, 256)), dim3(256), stream, ema, p, count, alpha);
+    return check_launch("suhpe_ema_update");
+}
+
+int suhpe_fill(float* p, int64_t count, float value, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(p && count >= 0, "suhpe_fill: bad arguments");
+    if (count == 0) return SUHPE_OK;
+    LAUNCH(fill_kernel, dim3(grid_for(count, 256)), dim3(256), stream, p, count, value);
+    return check_launch("suhpe_fill");
+}
+
+}  // extern "C"

@@ -1,0 +1,396 @@
+"""Tensor-level wrappers over the C ABI (include/suhpe.h).
+
+Every function takes/returns torch CUDA tensors purely as device-memory handles: it checks dtype/contiguity,
+allocates outputs from torch's caching allocator, and launches the hand-written HIP kernel on the current stream.
+No arithmetic happens in torch here.  Activations are pixel-major: shape (N, H, W, C) contiguous fp32.
+Conv filters keep torch's logical shape (Cout, Cin/g, R, S) in channels_last memory, i.e. physically
+[Cout][R][S][Cin/g].
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, call, ptr, workspace
+
+ACT = {"none": 0, None: 0, "relu": 1, "relu6": 2, "silu": 3, "gelu": 4, "sigmoid": 5}
+
+
+def _chk(t, name="tensor"):
+    if t is None:
+        return
+    if not t.is_cuda:
+        _lib.require_gpu()
+        raise RuntimeError(f"semiuhpe_amd: {name} must live on the HIP device (got {t.device}); there is no CPU path")
+    if t.dtype != torch.float32:
+        raise ValueError(f"{name}: expected float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous tensor, got strides {t.stride()} for shape {tuple(t.shape)}")
+
+
+def filter_is_physical(w):
+    """True when a (Cout, Cg, R, S) filter is stored [Cout][R][S][Cg]."""
+    co, cg, r, s = w.shape
+    want = (r * s * cg, 1, s * cg, cg)
+    st = w.stride()
+    return all(w.shape[i] == 1 or st[i] == want[i] for i in range(4))
+
+
+def to_filter_layout(w):
+    """Return `w` (Cout,Cg,R,S) re-strided so that memory is [Cout][R][S][Cg] (a view-compatible new tensor)."""
+    co, cg, r, s = w.shape
+    out = torch.empty_strided((co, cg, r, s), (r * s * cg, 1, s * cg, cg), dtype=w.dtype, device=w.device)
+    out.copy_(w)
+    return out
+
+
+def conv_desc(x_shape, w_shape, stride, pad, groups):
+    n, h, w_, cin = x_shape
+    cout, cg, r, s = w_shape
+    if cg * groups != cin:
+        raise ValueError(f"conv: filter {tuple(w_shape)} does not match input channels {cin} with groups={groups}")
+    ho = (h + 2 * pad - r) // stride + 1
+    wo = (w_ + 2 * pad - s) // stride + 1
+    return ConvDesc(n, h, w_, cin, ho, wo, cout, r, s, stride, pad, groups)
+
+
+def _is_depthwise(d):
+    return d.groups == d.cin and d.cin == d.cout and d.groups > 1
+
+
+# ---------------------------------------------------------------------------------------------- convolution
+def conv2d_fwd(x, w, bias=None, stride=1, pad=0, groups=1):
+    _chk(x, "x"); _chk(bias, "bias")
+    assert filter_is_physical(w), "filter must be stored [Cout][R][S][Cin/g]"
+    d = conv_desc(x.shape, w.shape, stride, pad, groups)
+    y = torch.empty((d.n, d.ho, d.wo, d.cout), dtype=torch.float32, device=x.device)
+    if _is_depthwise(d) and d.cin % 4 == 0:
+        assert bias is None
+        call("suhpe_dwconv_fwd", ctypes.byref(d), ptr(x), ptr(w), ptr(y))
+    else:
+        call("suhpe_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(y))
+    return y
+
+
+def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, groups=1):
+    _chk(dy, "dy")
+    d = conv_desc(x_shape, w.shape, stride, pad, groups)
+    dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
+    if _is_depthwise(d) and d.cin % 4 == 0:
+        call("suhpe_dwconv_dgrad", ctypes.byref(d), ptr(dy), ptr(w), ptr(dx))
+    else:
+        wt = workspace("wt", w.numel() * 4, dy.device)
+        call("suhpe_conv2d_transpose_filter", ctypes.byref(d), ptr(w), ptr(wt))
+        call("suhpe_conv2d_dgrad", ctypes.byref(d), ptr(dy), ptr(wt), ptr(dx))
+    return dx
+
+
+def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, groups=1, out=None, accumulate=False):
+    """Filter gradient in the filter's physical layout.  out: tensor with the filter's shape/strides."""
+    _chk(x, "x"); _chk(dy, "dy")
+    d = conv_desc(x.shape, w_shape, stride, pad, groups)
+    if out is None:
+        co, cg, r, s = w_shape
+        out = torch.empty_strided(tuple(w_shape), (r * s * cg, 1, s * cg, cg), dtype=torch.float32, device=x.device)
+        accumulate = False
+    assert filter_is_physical(out)
+    lib = _lib.load()
+    if _is_depthwise(d) and d.cin % 4 == 0:
+        nbytes = lib.suhpe_dwconv_wgrad_workspace_bytes(ctypes.byref(d))
+        ws = workspace("wgrad", nbytes, x.device)
+        call("suhpe_dwconv_wgrad", ctypes.byref(d), ptr(x), ptr(dy), ptr(out), int(accumulate), ptr(ws), nbytes)
+    else:
+        nbytes = lib.suhpe_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
+        ws = workspace("wgrad", nbytes, x.device)
+        call("suhpe_conv2d_wgrad", ctypes.byref(d), ptr(x), ptr(dy), ptr(out), int(accumulate), ptr(ws), nbytes)
+    return out
+
+
+def bias_grad(dy, c, out=None, accumulate=False):
+    _chk(dy, "dy")
+    rows = dy.numel() // c
+    if out is None:
+        out = torch.empty(c, dtype=torch.float32, device=dy.device)
+        accumulate = False
+    nbytes = _lib.load().suhpe_bn_workspace_bytes(c)
+    ws = workspace("bn", nbytes, dy.device)
+    call("suhpe_bias_grad", ptr(dy), rows, c, ptr(out), int(accumulate), ptr(ws))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- normalisation
+def bn_stats(x, c, eps, momentum, running_mean=None, running_var=None, nbt=None):
+    _chk(x, "x")
+    rows = x.numel() // c
+    mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(c, dtype=torch.float32, device=x.device)
+    ws = workspace("bn", _lib.load().suhpe_bn_workspace_bytes(c), x.device)
+    call("suhpe_bn_stats", ptr(x), rows, c, float(eps), float(momentum), ptr(mean), ptr(rstd), ptr(running_mean),
+         ptr(running_var), ptr(nbt), ptr(ws))
+    return mean, rstd
+
+
+def bn_eval_stats(running_mean, running_var, eps):
+    c = running_mean.numel()
+    mean = torch.empty(c, dtype=torch.float32, device=running_mean.device)
+    rstd = torch.empty(c, dtype=torch.float32, device=running_mean.device)
+    call("suhpe_bn_eval_stats", ptr(running_mean), ptr(running_var), c, float(eps), ptr(mean), ptr(rstd))
+    return mean, rstd
+
+
+def bn_act_fwd(x, c, mean, rstd, gamma, beta, act, residual=None):
+    _chk(x, "x"); _chk(residual, "residual")
+    y = torch.empty_like(x)
+    call("suhpe_bn_act_fwd", ptr(x), x.numel() // c, c, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ACT[act],
+         ptr(residual), ptr(y))
+    return y
+
+
+def bn_act_bwd(x, dy, c, mean, rstd, gamma, beta, act, train_stats, dgamma=None, dbeta=None, accumulate=False, y_out=None):
+    _chk(x, "x"); _chk(dy, "dy")
+    dx = torch.empty_like(x)
+    ws = workspace("bn", _lib.load().suhpe_bn_workspace_bytes(c), x.device)
+    call("suhpe_bn_act_bwd", ptr(x), ptr(dy), ptr(y_out), x.numel() // c, c, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
+         ACT[act], int(train_stats), ptr(dx), ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws))
+    return dx
+
+
+def layernorm_fwd(x, c, eps, gamma, beta):
+    _chk(x, "x")
+    rows = x.numel() // c
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    call("suhpe_layernorm_fwd", ptr(x), rows, c, float(eps), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd))
+    return y, mean, rstd
+
+
+def layernorm_bwd(x, dy, c, mean, rstd, gamma, dgamma=None, dbeta=None, accumulate=False):
+    _chk(x, "x"); _chk(dy, "dy")
+    dx = torch.empty_like(x)
+    ws = workspace("bn", _lib.load().suhpe_bn_workspace_bytes(c), x.device)
+    call("suhpe_layernorm_bwd", ptr(x), ptr(dy), x.numel() // c, c, ptr(mean), ptr(rstd), ptr(gamma), ptr(dx), ptr(dgamma),
+         ptr(dbeta), int(accumulate), ptr(ws))
+    return dx
+
+
+def act_fwd(x, c, act, bias=None):
+    _chk(x, "x")
+    y = torch.empty_like(x)
+    call("suhpe_act_fwd", ptr(x), x.numel() // c, c, ptr(bias), ACT[act], ptr(y))
+    return y
+
+
+def act_bwd(x, dy, c, act, bias=None):
+    _chk(x, "x"); _chk(dy, "dy")
+    dx = torch.empty_like(x)
+    call("suhpe_act_bwd", ptr(x), ptr(dy), x.numel() // c, c, ptr(bias), ACT[act], ptr(dx))
+    return dx
+
+
+# ---------------------------------------------------------------------------------------------- pooling / SE / misc
+def avgpool_fwd(x):
+    """(N,H,W,C) or (N,L,C) -> (N,C)"""
+    _chk(x, "x")
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    y = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    call("suhpe_avgpool_fwd", ptr(x), n, hw, c, ptr(y))
+    return y
+
+
+def avgpool_bwd(dy, x_shape):
+    _chk(dy, "dy")
+    n, c = x_shape[0], x_shape[-1]
+    dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
+    call("suhpe_avgpool_bwd", ptr(dy), n, dx.numel() // (n * c), c, ptr(dx))
+    return dx
+
+
+def se_scale_fwd(x, s):
+    _chk(x, "x"); _chk(s, "s")
+    n, c = x.shape[0], x.shape[-1]
+    y = torch.empty_like(x)
+    call("suhpe_se_scale_fwd", ptr(x), ptr(s), n, x.numel() // (n * c), c, ptr(y))
+    return y
+
+
+def se_scale_bwd_s(dy, x):
+    n, c = x.shape[0], x.shape[-1]
+    ds = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    call("suhpe_se_scale_bwd_s", ptr(dy), ptr(x), n, x.numel() // (n * c), c, ptr(ds))
+    return ds
+
+
+def se_scale_bwd_x(dy, s, dpool):
+    n, c = dy.shape[0], dy.shape[-1]
+    dx = torch.empty_like(dy)
+    call("suhpe_se_scale_bwd_x", ptr(dy), ptr(s), ptr(dpool), n, dy.numel() // (n * c), c, ptr(dx))
+    return dx
+
+
+def add_rowscale(a, b, rowscale):
+    """a + b * rowscale[n]  (a or rowscale may be None)"""
+    _chk(b, "b"); _chk(a, "a")
+    n = b.shape[0]
+    y = torch.empty_like(b)
+    call("suhpe_add_rowscale", ptr(a), ptr(b), ptr(rowscale), n, b.numel() // n, ptr(y))
+    return y
+
+
+def add(a, b):
+    _chk(a, "a"); _chk(b, "b")
+    y = torch.empty_like(a)
+    call("suhpe_add", ptr(a), ptr(b), a.numel(), ptr(y))
+    return y
+
+
+def mul(a, b):
+    _chk(a, "a"); _chk(b, "b")
+    y = torch.empty_like(a)
+    call("suhpe_mul", ptr(a), ptr(b), a.numel(), ptr(y))
+    return y
+
+
+_counters = {}
+
+
+def rng_counter(device, seed=None):
+    """Device-resident (seed, offset) pair of the counter-based mask generator."""
+    key = torch.device(device)
+    if key not in _counters or seed is not None:
+        s = int(seed if seed is not None else torch.initial_seed()) & ((1 << 63) - 1)
+        _counters[key] = torch.tensor([s, 0], dtype=torch.int64).to(key)
+    return _counters[key]
+
+
+def dropout_mask(shape, keep, device):
+    m = torch.empty(shape, dtype=torch.float32, device=device)
+    call("suhpe_dropout_mask", ptr(rng_counter(device)), float(keep), m.numel(), ptr(m))
+    return m
+
+
+def weighted_sum(x, w=None, scale=1.0):
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    call("suhpe_weighted_sum", ptr(x), ptr(w), x.numel(), float(scale), ptr(out))
+    return out
+
+
+def scale_rows(x, g, scale=1.0):
+    c = x.shape[-1]
+    y = torch.empty_like(x)
+    call("suhpe_scale_rows", ptr(x), ptr(g), x.numel() // c, c, float(scale), ptr(y))
+    return y
+
+
+def fill_(t, value):
+    call("suhpe_fill", ptr(t), t.numel(), float(value))
+    return t
+
+
+def nchw_to_nhwc(img):
+    _chk(img, "img")
+    n, c, h, w = img.shape
+    out = torch.empty((n, h, w, c), dtype=torch.float32, device=img.device)
+    call("suhpe_nchw_to_nhwc", ptr(img), n, c, h, w, ptr(out))
+    return out
+
+
+def strong_aug(src, cutout_boxes, cutmix_boxes, perm, holes, src_nhwc=False, dst_nhwc=True):
+    """CutOut + CutMix (+ layout change) out of place.  src (N,C,H,W) or (N,H,W,C)."""
+    _chk(src, "src")
+    if src_nhwc:
+        n, h, w, c = src.shape
+    else:
+        n, c, h, w = src.shape
+    dst = torch.empty((n, h, w, c) if dst_nhwc else (n, c, h, w), dtype=torch.float32, device=src.device)
+    call("suhpe_strong_aug", ptr(src), ptr(dst), n, c, h, w, int(src_nhwc), int(dst_nhwc), ptr(cutout_boxes),
+         ptr(cutmix_boxes), ptr(perm), int(holes))
+    return dst
+
+
+# ---------------------------------------------------------------------------------------------- head
+def fisher_nll(A, R, overreg):
+    _chk(A, "A"); _chk(R, "R")
+    n = A.shape[0]
+    loss = torch.empty(n, dtype=torch.float32, device=A.device)
+    dA = torch.empty((n, 9), dtype=torch.float32, device=A.device)
+    Rest = torch.empty((n, 3, 3), dtype=torch.float32, device=A.device)
+    call("suhpe_fisher_nll", ptr(A), ptr(R), n, float(overreg), ptr(loss), ptr(dA), ptr(Rest))
+    return loss, dA, Rest
+
+
+def fisher_svd_project(A):
+    _chk(A, "A")
+    n = A.numel() // 9
+    R = torch.empty((n, 3, 3), dtype=torch.float32, device=A.device)
+    call("suhpe_fisher_svd_project", ptr(A), n, ptr(R))
+    return R
+
+
+def fisher_entropy(A):
+    _chk(A, "A")
+    n = A.numel() // 9
+    H = torch.empty(n, dtype=torch.float32, device=A.device)
+    call("suhpe_fisher_entropy", ptr(A), n, ptr(H))
+    return H
+
+
+def fisher_ce(A1, A2, mask=None):
+    _chk(A1, "A1"); _chk(A2, "A2"); _chk(mask, "mask")
+    n = A1.numel() // 9
+    ce = torch.empty(n, dtype=torch.float32, device=A1.device)
+    dA2 = torch.empty((n, 9), dtype=torch.float32, device=A1.device)
+    call("suhpe_fisher_ce", ptr(A1), ptr(A2), ptr(mask), n, ptr(ce), ptr(dA2))
+    return ce, dA2
+
+
+def fisher_log_pdf(A, R):
+    _chk(A, "A"); _chk(R, "R")
+    n = A.numel() // 9
+    out = torch.empty(n, dtype=torch.float32, device=A.device)
+    call("suhpe_fisher_log_pdf", ptr(A), ptr(R), n, ptr(out))
+    return out
+
+
+def rot_adjust(A, aug, mode):
+    _chk(A, "A"); _chk(aug, "aug")
+    n = A.numel() // 9
+    out = torch.empty((n, 9), dtype=torch.float32, device=A.device)
+    call("suhpe_rot_adjust", ptr(A), ptr(aug), n, int(mode), ptr(out))
+    return out
+
+
+def euler_from_rot(R, full_range=False):
+    _chk(R, "R")
+    n = R.numel() // 9
+    e = torch.empty((n, 3), dtype=torch.float32, device=R.device)
+    call("suhpe_euler_from_rot", ptr(R), n, int(full_range), ptr(e))
+    return e
+
+
+def pose_err_deg(pred, gt, gt_euler=None):
+    _chk(pred, "pred"); _chk(gt, "gt"); _chk(gt_euler, "gt_euler")
+    n = pred.numel() // 9
+    err = torch.empty(n, dtype=torch.float32, device=pred.device)
+    call("suhpe_pose_err_deg", ptr(pred), ptr(gt), ptr(gt_euler), n, ptr(err))
+    return err
+
+
+def entropy_mask(H, thres):
+    """thres: 1-element device tensor.  -> (mask float (n,), count (1,))"""
+    n = H.numel()
+    mask = torch.empty(n, dtype=torch.float32, device=H.device)
+    count = torch.empty(1, dtype=torch.float32, device=H.device)
+    call("suhpe_entropy_mask", ptr(H), ptr(thres), n, ptr(mask), ptr(count))
+    return mask, count
+
+
+# ---------------------------------------------------------------------------------------------- optimiser
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
+    call("suhpe_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+         float(weight_decay), int(step))
+
+
+def ema_update(ema, p, alpha):
+    call("suhpe_ema_update", ptr(ema), ptr(p), ema.numel(), float(alpha))
