@@ -1,0 +1,388 @@
+"""Layers with explicit forward/backward over the HIP kernels (no autograd inside the backbone).
+
+Why not torch.autograd per op: the backbone is ~500 kernels per pass; an explicit tape (what the layer needs for
+its own backward, pushed in forward order and popped in reverse) keeps the host cost per kernel at one ctypes call,
+lets parameter gradients accumulate in place into a flat, pre-zeroed buffer (one RCCL all-reduce, one Adam
+launch), and keeps every addition of gradients (residual fan-out) in our own kernels.  torch.autograd only sees
+ONE node per network call (`NetFunction`), so reference-style code (`loss.backward()`) keeps working.
+
+Layers are nn.Modules purely for parameter / buffer / state_dict bookkeeping: names and shapes equal the
+reference's modules so released checkpoints load.
+Activations are (N, H, W, C) contiguous fp32; filters are (Cout, Cin/g, R, S) stored [Cout][R][S][Cin/g].
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+
+# ------------------------------------------------------------------------------------------------ randomness hooks
+# Parity tests feed host-made masks so that the HIP path and the CPU oracle see identical Bernoulli draws.
+# hook(kind, shape, keep) -> float tensor of 0 / (1/keep) on the device, or None to use the device generator.
+_mask_hook = None
+
+
+def set_mask_hook(fn):
+    global _mask_hook
+    _mask_hook = fn
+
+
+def draw_mask(kind, shape, keep, device):
+    if _mask_hook is not None:
+        m = _mask_hook(kind, tuple(shape), keep)
+        if m is not None:
+            return m.to(device=device, dtype=torch.float32).contiguous()
+    return K.dropout_mask(tuple(shape), keep, device)
+
+
+def grad_of(p):
+    """The accumulation buffer of a parameter (a view of the flat gradient buffer once the optimiser has
+    flattened the model; allocated lazily otherwise)."""
+    if p.grad is None:
+        p.grad = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=p.device)
+        K.fill_(p.grad, 0.0)
+    return p.grad
+
+
+class Layer(nn.Module):
+    """fwd(x, tape) pushes what bwd needs; bwd(dy, tape) pops it, accumulates parameter gradients, returns dx."""
+
+    def fwd(self, x, tape):
+        raise NotImplementedError
+
+    def bwd(self, dy, tape):
+        raise NotImplementedError
+
+
+def _filter_param(cout, cg, r, s):
+    w = torch.empty_strided((cout, cg, r, s), (r * s * cg, 1, s * cg, cg), dtype=torch.float32)
+    return nn.Parameter(w)
+
+
+class Conv2d(Layer):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, groups=1, bias=False):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        self.stride, self.padding, self.groups = stride, padding, groups
+        self.weight = _filter_param(out_channels, in_channels // groups, kernel_size, kernel_size)
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.need_input_grad = True
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in = self.weight.shape[1] * self.kernel_size * self.kernel_size
+            bound = 1 / math.sqrt(fan_in)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def fwd(self, x, tape):
+        if not K.filter_is_physical(self.weight):
+            self.weight.data = K.to_filter_layout(self.weight.data)
+        y = K.conv2d_fwd(x, self.weight, self.bias, self.stride, self.padding, self.groups)
+        if tape is not None:
+            tape.append(x)
+        return y
+
+    def bwd(self, dy, tape):
+        x = tape.pop()
+        K.conv2d_wgrad(x, dy, self.weight.shape, self.stride, self.padding, self.groups, out=grad_of(self.weight), accumulate=True)
+        if self.bias is not None:
+            K.bias_grad(dy, self.out_channels, out=grad_of(self.bias), accumulate=True)
+        if not self.need_input_grad:
+            return None
+        return K.conv2d_dgrad(dy, self.weight, x.shape, self.stride, self.padding, self.groups)
+
+    def extra_repr(self):
+        return f"{self.in_channels}, {self.out_channels}, k={self.kernel_size}, s={self.stride}, p={self.padding}, g={self.groups}"
+
+
+class Linear(Layer):
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            nn.init.uniform_(self.bias, -1 / math.sqrt(in_features), 1 / math.sqrt(in_features))
+
+    def _w4(self):
+        return self.weight.view(self.out_features, self.in_features, 1, 1)
+
+    def fwd(self, x, tape):
+        shp = x.shape
+        x4 = x.reshape(-1, 1, 1, self.in_features)
+        y = K.conv2d_fwd(x4, self._w4(), self.bias, 1, 0, 1)
+        if tape is not None:
+            tape.append(x4)
+        return y.view(*shp[:-1], self.out_features)
+
+    def bwd(self, dy, tape):
+        x4 = tape.pop()
+        shp = dy.shape
+        dy4 = dy.reshape(-1, 1, 1, self.out_features)
+        gw = grad_of(self.weight).view(self.out_features, self.in_features, 1, 1)
+        K.conv2d_wgrad(x4, dy4, gw.shape, 1, 0, 1, out=gw, accumulate=True)
+        if self.bias is not None:
+            K.bias_grad(dy4, self.out_features, out=grad_of(self.bias), accumulate=True)
+        dx = K.conv2d_dgrad(dy4, self._w4(), x4.shape, 1, 0, 1)
+        return dx.view(*shp[:-1], self.in_features)
+
+
+class _BatchNorm(Layer):
+    """BatchNorm fused with the activation that follows it (and an optional pre-activation residual)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, act="none"):
+        super().__init__()
+        self.num_features, self.eps, self.momentum, self.act = num_features, eps, momentum, act
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def fwd(self, x, tape, residual=None):
+        c = self.num_features
+        if self.training:
+            mean, rstd = K.bn_stats(x, c, self.eps, self.momentum, self.running_mean, self.running_var, self.num_batches_tracked)
+        else:
+            mean, rstd = K.bn_eval_stats(self.running_mean, self.running_var, self.eps)
+        y = K.bn_act_fwd(x, c, mean, rstd, self.weight, self.bias, self.act, residual)
+        if tape is not None:
+            tape.append((x, mean, rstd, self.training, y if residual is not None and self.act == "relu" else None))
+        return y
+
+    def bwd(self, dy, tape):
+        x, mean, rstd, train_stats, y_out = tape.pop()
+        return K.bn_act_bwd(x, dy, self.num_features, mean, rstd, self.weight, self.bias, self.act, train_stats,
+                            grad_of(self.weight), grad_of(self.bias), True, y_out)
+
+    def extra_repr(self):
+        return f"{self.num_features}, eps={self.eps}, momentum={self.momentum}, act={self.act}"
+
+
+class BatchNorm2d(_BatchNorm):
+    pass
+
+
+class BatchNorm1d(_BatchNorm):
+    pass
+
+
+class LayerNorm(Layer):
+    def __init__(self, dim, eps=1e-5):
+        super().__init__()
+        self.dim, self.eps = dim, eps
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+    def fwd(self, x, tape):
+        y, mean, rstd = K.layernorm_fwd(x, self.dim, self.eps, self.weight, self.bias)
+        if tape is not None:
+            tape.append((x, mean, rstd))
+        return y
+
+    def bwd(self, dy, tape):
+        x, mean, rstd = tape.pop()
+        return K.layernorm_bwd(x, dy, self.dim, mean, rstd, self.weight, grad_of(self.weight), grad_of(self.bias), True)
+
+
+class Activation(Layer):
+    """Stand-alone activation (kept as a module so Sequential indices match the reference's)."""
+
+    def __init__(self, act):
+        super().__init__()
+        self.act = act
+
+    def fwd(self, x, tape):
+        y = K.act_fwd(x, x.shape[-1], self.act)
+        if tape is not None:
+            tape.append(x)
+        return y
+
+    def bwd(self, dy, tape):
+        x = tape.pop()
+        return K.act_bwd(x, dy, x.shape[-1], self.act)
+
+
+class Identity(Layer):
+    """Placeholder for an activation that has been fused into the preceding BatchNorm."""
+
+    def fwd(self, x, tape):
+        return x
+
+    def bwd(self, dy, tape):
+        return dy
+
+
+class Dropout(Layer):
+    def __init__(self, p=0.5):
+        super().__init__()
+        self.p = p
+
+    def fwd(self, x, tape):
+        if not self.training or self.p == 0.0:
+            if tape is not None:
+                tape.append(None)
+            return x
+        mask = draw_mask("dropout", x.shape, 1.0 - self.p, x.device)
+        if tape is not None:
+            tape.append(mask)
+        return K.mul(x, mask)
+
+    def bwd(self, dy, tape):
+        mask = tape.pop()
+        return dy if mask is None else K.mul(dy, mask)
+
+
+class StochasticDepth(Layer):
+    """torchvision.ops.StochasticDepth(p, 'row') fused with the residual add: y = skip + branch * keep_mask[n]/keep."""
+
+    def __init__(self, p, mode="row"):
+        super().__init__()
+        assert mode == "row"
+        self.p = p
+
+    def fwd2(self, branch, skip, tape):
+        rowscale = None
+        if self.training and self.p > 0.0:
+            rowscale = draw_mask("stochastic_depth", (branch.shape[0],), 1.0 - self.p, branch.device)
+        if tape is not None:
+            tape.append(rowscale)
+        return K.add_rowscale(skip, branch, rowscale)
+
+    def bwd2(self, dy, tape):
+        """-> (d_branch, d_skip)"""
+        rowscale = tape.pop()
+        return (dy if rowscale is None else K.add_rowscale(None, dy, rowscale)), dy
+
+
+class GlobalAvgPool(Layer):
+    def fwd(self, x, tape):
+        if tape is not None:
+            tape.append(x.shape)
+        return K.avgpool_fwd(x)
+
+    def bwd(self, dy, tape):
+        return K.avgpool_bwd(dy, tape.pop())
+
+
+class SqueezeExcitation(Layer):
+    """torchvision.ops.SqueezeExcitation (avgpool -> fc1 -> SiLU -> fc2 -> Sigmoid -> scale) as one layer so that the
+    two gradient paths into the input (scale and squeeze) are summed inside our own kernel."""
+
+    def __init__(self, input_channels, squeeze_channels, act="silu", scale_act="sigmoid"):
+        super().__init__()
+        self.fc1 = Conv2d(input_channels, squeeze_channels, 1, bias=True)
+        self.fc2 = Conv2d(squeeze_channels, input_channels, 1, bias=True)
+        self.act, self.scale_act = act, scale_act
+        self.c, self.csq = input_channels, squeeze_channels
+
+    def fwd(self, z, tape):
+        n = z.shape[0]
+        p = K.avgpool_fwd(z).view(n, 1, 1, self.c)
+        a1 = K.conv2d_fwd(p, self.fc1.weight, self.fc1.bias, 1, 0, 1)
+        h = K.act_fwd(a1, self.csq, self.act)
+        a2 = K.conv2d_fwd(h, self.fc2.weight, self.fc2.bias, 1, 0, 1)
+        s = K.act_fwd(a2, self.c, self.scale_act).view(n, self.c)
+        if tape is not None:
+            tape.append((z, p, a1, h, a2, s))
+        return K.se_scale_fwd(z, s)
+
+    def bwd(self, dy, tape):
+        z, p, a1, h, a2, s = tape.pop()
+        n = z.shape[0]
+        ds = K.se_scale_bwd_s(dy, z).view(n, 1, 1, self.c)
+        da2 = K.act_bwd(a2, ds, self.c, self.scale_act)
+        K.conv2d_wgrad(h, da2, self.fc2.weight.shape, 1, 0, 1, out=grad_of(self.fc2.weight), accumulate=True)
+        K.bias_grad(da2, self.c, out=grad_of(self.fc2.bias), accumulate=True)
+        dh = K.conv2d_dgrad(da2, self.fc2.weight, h.shape, 1, 0, 1)
+        da1 = K.act_bwd(a1, dh, self.csq, self.act)
+        K.conv2d_wgrad(p, da1, self.fc1.weight.shape, 1, 0, 1, out=grad_of(self.fc1.weight), accumulate=True)
+        K.bias_grad(da1, self.csq, out=grad_of(self.fc1.bias), accumulate=True)
+        dp = K.conv2d_dgrad(da1, self.fc1.weight, p.shape, 1, 0, 1).view(n, self.c)
+        return K.se_scale_bwd_x(dy, s, dp)
+
+
+class Sequential(Layer):
+    """Sequential container with numeric child names (state_dict keys '0.weight', ...)."""
+
+    def __init__(self, *mods):
+        super().__init__()
+        for i, m in enumerate(mods):
+            self.add_module(str(i), m)
+
+    def __iter__(self):
+        return iter(self._modules.values())
+
+    def __len__(self):
+        return len(self._modules)
+
+    def __getitem__(self, i):
+        return list(self._modules.values())[i]
+
+    def fwd(self, x, tape):
+        for m in self._modules.values():
+            x = m.fwd(x, tape)
+        return x
+
+    def bwd(self, dy, tape):
+        for m in reversed(list(self._modules.values())):
+            dy = m.bwd(dy, tape)
+        return dy
+
+
+class ConvNormActivation(Sequential):
+    """torchvision.ops.Conv2dNormActivation: children '0' (conv, no bias) and '1' (BatchNorm); the activation that
+    torchvision keeps as child '2' has no parameters and is fused into the BatchNorm kernel."""
+
+    def __init__(self, cin, cout, kernel_size=3, stride=1, groups=1, act="silu", bn_eps=1e-5, bn_momentum=0.1):
+        super().__init__(Conv2d(cin, cout, kernel_size, stride, (kernel_size - 1) // 2, groups, bias=False),
+                         BatchNorm2d(cout, bn_eps, bn_momentum, act))
+
+
+# ------------------------------------------------------------------------------------------------ autograd bridge
+class NetFunction(torch.autograd.Function):
+    """One autograd node for a whole backbone call: forward runs the explicit layer chain recording a tape, backward
+    replays it in reverse; parameter gradients are accumulated in place (grad_of), the node itself returns none."""
+
+    @staticmethod
+    def forward(ctx, net, x, anchor):
+        tape = []
+        ctx.net, ctx.tape = net, tape
+        return net.fwd(x, tape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        net, tape = ctx.net, ctx.tape
+        ctx.tape = None
+        net.bwd(dy.contiguous(), tape)
+        assert len(tape) == 0, "backward did not consume the whole tape"
+        return None, None, None
+
+
+class Network(Layer):
+    """Base of the backbones: forward(img NCHW) like the reference's nn.Modules; routes through NetFunction when
+    gradients are needed and straight through the kernels otherwise (teacher, validation)."""
+
+    def forward(self, img, nhwc=False):
+        K._chk(img, "img")
+        x = img if nhwc else K.nchw_to_nhwc(img)
+        anchor = next(self.parameters())
+        if torch.is_grad_enabled() and anchor.requires_grad:
+            return NetFunction.apply(self, x, anchor)
+        return self.fwd(x, None)
+
+    def init_like_reference_(self):
+        """conv: kaiming_normal(fan_out); BN: ones/zeros — the init torchvision / RepVGG apply before pretrained
+        weights overwrite them (pretrained blobs are not available offline)."""
+        for m in self.modules():
+            if isinstance(m, Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out")
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, _BatchNorm):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)

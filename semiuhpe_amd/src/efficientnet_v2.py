@@ -1,0 +1,138 @@
+"""EfficientNetV2-S backbone with the module tree (and therefore state_dict keys) of torchvision 0.14.1's
+`efficientnet_v2_s`, which the reference instantiates at src/networks.py:301-303 and whose `classifier` it replaces
+(:309-331).  torchvision itself is not part of the reference repo and is not installed here: the architecture is
+restated from its published definition — parity of this backbone body is UNPINNED
+(sanity-pinned by parameter count 20,177,488 and 2.849 GMAC @224 in tests/test_networks_cpu.py).
+
+Blocks are Layers with explicit forward/backward over the HIP kernels (semiuhpe_amd/layers.py).
+"""
+import torch
+import torch.nn as nn
+
+from .. import kernels as K
+from ..layers import (BatchNorm1d, Conv2d, ConvNormActivation, Dropout, GlobalAvgPool, Identity, Layer, Linear, Network,
+                      Sequential, SqueezeExcitation, StochasticDepth)
+
+# (block, expand_ratio, kernel, stride, in, out, layers) — torchvision `_efficientnet_conf("efficientnet_v2_s")`
+V2_S = [
+    ("fused", 1, 3, 1, 24, 24, 2),
+    ("fused", 4, 3, 2, 24, 48, 4),
+    ("fused", 4, 3, 2, 48, 64, 4),
+    ("mb", 4, 3, 2, 64, 128, 6),
+    ("mb", 6, 3, 1, 128, 160, 9),
+    ("mb", 6, 3, 2, 160, 256, 15),
+]
+LAST_CHANNEL = 1280
+BN_EPS = 1e-3           # torchvision: partial(nn.BatchNorm2d, eps=1e-03) for the V2 family
+STOCHASTIC_DEPTH_PROB = 0.2
+
+
+def _make_divisible(v, divisor=8):
+    new_v = max(divisor, int(v + divisor / 2) // divisor * divisor)
+    if new_v < 0.9 * v:
+        new_v += divisor
+    return new_v
+
+
+class _ResidualBlock(Layer):
+    """Shared tail: optional skip connection through StochasticDepth('row')."""
+
+    def _fwd_res(self, x, y, tape):
+        return self.stochastic_depth.fwd2(y, x, tape) if self.use_res_connect else y
+
+    def fwd(self, x, tape):
+        return self._fwd_res(x, self.block.fwd(x, tape), tape)
+
+    def bwd(self, dy, tape):
+        if not self.use_res_connect:
+            return self.block.bwd(dy, tape)
+        d_branch, d_skip = self.stochastic_depth.bwd2(dy, tape)
+        return K.add(self.block.bwd(d_branch, tape), d_skip)
+
+
+class FusedMBConv(_ResidualBlock):
+    def __init__(self, expand, kernel, stride, cin, cout, sd_prob):
+        super().__init__()
+        self.use_res_connect = stride == 1 and cin == cout
+        exp = _make_divisible(cin * expand)
+        if exp != cin:
+            layers = [ConvNormActivation(cin, exp, kernel, stride, act="silu", bn_eps=BN_EPS),
+                      ConvNormActivation(exp, cout, 1, 1, act="none", bn_eps=BN_EPS)]
+        else:
+            layers = [ConvNormActivation(cin, cout, kernel, stride, act="silu", bn_eps=BN_EPS)]
+        self.block = Sequential(*layers)
+        self.stochastic_depth = StochasticDepth(sd_prob, "row")
+
+
+class MBConv(_ResidualBlock):
+    def __init__(self, expand, kernel, stride, cin, cout, sd_prob):
+        super().__init__()
+        self.use_res_connect = stride == 1 and cin == cout
+        exp = _make_divisible(cin * expand)
+        layers = []
+        if exp != cin:
+            layers.append(ConvNormActivation(cin, exp, 1, 1, act="silu", bn_eps=BN_EPS))
+        layers.append(ConvNormActivation(exp, exp, kernel, stride, groups=exp, act="silu", bn_eps=BN_EPS))
+        layers.append(SqueezeExcitation(exp, max(1, cin // 4), act="silu", scale_act="sigmoid"))
+        layers.append(ConvNormActivation(exp, cout, 1, 1, act="none", bn_eps=BN_EPS))
+        self.block = Sequential(*layers)
+        self.stochastic_depth = StochasticDepth(sd_prob, "row")
+
+
+def regression_head(in_dim, hidden1, hidden2, num_classes):
+    """The 3-layer MLP the reference bolts on every backbone (src/networks.py:264-273, 309-319, 419-428):
+    Dropout(0.2) Linear BN1d ReLU6 Linear BN1d ReLU6 Linear; indices 0..7 so keys read '<name>.1.weight' ..."""
+    return Sequential(Dropout(0.2), Linear(in_dim, hidden1), BatchNorm1d(hidden1, act="relu6"), Identity(),
+                      Linear(hidden1, hidden2), BatchNorm1d(hidden2, act="relu6"), Identity(),
+                      Linear(hidden2, num_classes))
+
+
+def init_regression_head_(head):
+    """Linear ~ N(0, 0.01), bias 0; BN ones/zeros (src/networks.py:275-285, 321-331, 430-440)."""
+    for m in head:
+        if isinstance(m, Linear):
+            nn.init.normal_(m.weight, 0, 0.01)
+            nn.init.zeros_(m.bias)
+        elif isinstance(m, BatchNorm1d):
+            nn.init.ones_(m.weight)
+            nn.init.zeros_(m.bias)
+
+
+class EfficientNetV2S(Network):
+    def __init__(self, num_classes=9):
+        super().__init__()
+        feats = [ConvNormActivation(3, V2_S[0][4], 3, 2, act="silu", bn_eps=BN_EPS)]
+        feats[0][0].need_input_grad = False                     # nothing upstream of the image
+        total = sum(c[-1] for c in V2_S)
+        idx = 0
+        for kind, expand, kernel, stride, cin, cout, nlayers in V2_S:
+            stage = []
+            for i in range(nlayers):
+                sd = STOCHASTIC_DEPTH_PROB * float(idx) / total
+                cls = FusedMBConv if kind == "fused" else MBConv
+                stage.append(cls(expand, kernel, stride if i == 0 else 1, cin if i == 0 else cout, cout, sd))
+                idx += 1
+            feats.append(Sequential(*stage))
+        feats.append(ConvNormActivation(V2_S[-1][5], LAST_CHANNEL, 1, 1, act="silu", bn_eps=BN_EPS))
+        self.features = Sequential(*feats)
+        self.avgpool = GlobalAvgPool()
+        self.classifier = regression_head(LAST_CHANNEL, 512, 128, num_classes)
+        self.init_like_reference_()
+        init_regression_head_(self.classifier)
+
+    def fwd(self, x, tape):
+        x = self.features.fwd(x, tape)
+        x = self.avgpool.fwd(x, tape)
+        return self.classifier.fwd(x, tape)
+
+    def bwd(self, dy, tape):
+        dy = self.classifier.bwd(dy, tape)
+        dy = self.avgpool.bwd(dy, tape)
+        return self.features.bwd(dy, tape)
+
+
+def get_EfficientNet_V2(config, model_name="S"):
+    """src/networks.py:301-332 (pretrained ImageNet weights are not available offline: random init, same recipe)."""
+    if model_name != "S":
+        raise NotImplementedError("only EfficientNetV2-S is instantiated by the reference (src/networks.py:25)")
+    return EfficientNetV2S(num_classes=config.num_classes)
