@@ -162,6 +162,13 @@ int suhpe_dropout_mask(uint64_t* counter, float keep, int64_t count, float* mask
 /* ------------------------------------------------------------------ reductions for the loss ------------- */
 /* out[0] = scale * sum_i x[i]*(w ? w[i] : 1) */
 int suhpe_weighted_sum(const float* x, const float* w, int64_t count, float scale, float* out, suhpe_stream_t stream);
+/* out[0] = sum(mask*x)/sum(mask): masked diagnostics of src/agent.py:171-181 without boolean compaction */
+int suhpe_masked_mean(const float* x, const float* mask, int64_t count, float* out, suhpe_stream_t stream);
+/* out[i] = src[0]*scale  (gradient of a mean: broadcast of a device scalar) */
+int suhpe_broadcast_scale(const float* src, float scale, int64_t count, float* out, suhpe_stream_t stream);
+/* out = alpha*a + beta*b  (b may be NULL); used for loss_all = loss + lambda*unsup (src/agent.py:206) */
+int suhpe_axpby(const float* a, float alpha, const float* b, float beta, int64_t count, float* out,
+                suhpe_stream_t stream);
 /* y[i,:] = x[i,:] * g[i] * scale (rows, c) */
 int suhpe_scale_rows(const float* x, const float* g, int64_t rows, int c, float scale, float* y, suhpe_stream_t stream);
 

@@ -513,11 +513,35 @@ __global__ __launch_bounds__(256) void weighted_sum_kernel(const float* __restri
     if (threadIdx.x == 0) out[0] = (float)((part[0] + part[1] + part[2] + part[3]) * (double)scale);
 }
 
+// out[0] = sum(mask*x) / sum(mask)   (nan when nothing is selected, like the mean of an empty tensor)
+__global__ __launch_bounds__(256) void masked_mean_kernel(const float* __restrict__ x, const float* __restrict__ mask, int64_t count,
+                                                          float* __restrict__ out) {
+    __shared__ double part[8];
+    double s = 0.0, c = 0.0;
+    for (int64_t i = threadIdx.x; i < count; i += blockDim.x) { s += (double)x[i] * (double)mask[i]; c += (double)mask[i]; }
+    s = wave_sum(s);
+    c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = s; part[4 + (threadIdx.x >> 6)] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)((part[0] + part[1] + part[2] + part[3]) / (part[4] + part[5] + part[6] + part[7]));
+}
+
 __global__ void scale_rows_kernel(const float* __restrict__ x, const float* __restrict__ g, int64_t rows, int c, float scale,
                                   float* __restrict__ y) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * c) return;
     y[i] = x[i] * (g ? g[i / c] : 1.f) * scale;
+}
+
+// out[i] = src[0]*scale (broadcast of a device scalar, e.g. d(mean)/dx) ; out = alpha*a + beta*b on short vectors
+__global__ void broadcast_scale_kernel(const float* __restrict__ src, float scale, int64_t count, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = src[0] * scale;
+}
+__global__ void axpby_kernel(const float* __restrict__ a, float alpha, const float* __restrict__ b, float beta, int64_t count,
+                             float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
 }
 
 // column sums of dy (rows, c): partial + finalize (bias gradient)
@@ -776,11 +800,31 @@ int suhpe_weighted_sum(const float* x, const float* w, int64_t count, float scal
     return check_launch("suhpe_weighted_sum");
 }
 
+int suhpe_masked_mean(const float* x, const float* mask, int64_t count, float* out, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(x && mask && out && count >= 0, "suhpe_masked_mean: bad arguments");
+    LAUNCH(masked_mean_kernel, dim3(1), dim3(256), stream, x, mask, count, out);
+    return check_launch("suhpe_masked_mean");
+}
+
 int suhpe_scale_rows(const float* x, const float* g, int64_t rows, int c, float scale, float* y, suhpe_stream_t stream) {
     SUHPE_REQUIRE(x && y && rows >= 0 && c > 0, "suhpe_scale_rows: bad arguments");
     if (rows == 0) return SUHPE_OK;
     LAUNCH(scale_rows_kernel, dim3((unsigned)ceil_div(rows * c, 256)), dim3(256), stream, x, g, rows, c, scale, y);
     return check_launch("suhpe_scale_rows");
+}
+
+int suhpe_broadcast_scale(const float* src, float scale, int64_t count, float* out, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(src && out && count >= 0, "suhpe_broadcast_scale: bad arguments");
+    if (count == 0) return SUHPE_OK;
+    LAUNCH(broadcast_scale_kernel, dim3((unsigned)ceil_div(count, 256)), dim3(256), stream, src, scale, count, out);
+    return check_launch("suhpe_broadcast_scale");
+}
+
+int suhpe_axpby(const float* a, float alpha, const float* b, float beta, int64_t count, float* out, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(a && out && count >= 0, "suhpe_axpby: bad arguments");
+    if (count == 0) return SUHPE_OK;
+    LAUNCH(axpby_kernel, dim3((unsigned)ceil_div(count, 256)), dim3(256), stream, a, alpha, b, beta, count, out);
+    return check_launch("suhpe_axpby");
 }
 
 int suhpe_bias_grad(const float* dy, int64_t rows, int c, float* db, int accumulate, void* workspace, suhpe_stream_t stream) {

@@ -283,6 +283,24 @@ def scale_rows(x, g, scale=1.0):
     return y
 
 
+def masked_mean(x, mask):
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    call("suhpe_masked_mean", ptr(x), ptr(mask), x.numel(), ptr(out))
+    return out
+
+
+def broadcast_scale(src, scale, count):
+    out = torch.empty(count, dtype=torch.float32, device=src.device)
+    call("suhpe_broadcast_scale", ptr(src), float(scale), int(count), ptr(out))
+    return out
+
+
+def axpby(a, alpha, b=None, beta=0.0):
+    out = torch.empty_like(a)
+    call("suhpe_axpby", ptr(a), float(alpha), ptr(b), float(beta), a.numel(), ptr(out))
+    return out
+
+
 def fill_(t, value):
     call("suhpe_fill", ptr(t), t.numel(), float(value))
     return t

