@@ -29,3 +29,17 @@ def rel_err(x, ref):
     x = x.detach().cpu().double().reshape(-1)
     ref = ref.detach().cpu().double().reshape(-1)
     return float((x - ref).abs().max() / max(1e-12, float(ref.abs().max())))
+
+
+def grad_mismatches(named_ref, named_got, rtol, atol_frac=1e-5):
+    """Per-tensor max |got-ref| <= rtol*max|ref| + atol_frac*global_max|ref|.  The absolute term covers gradients
+    that are analytically zero (e.g. a bias feeding a train-mode BatchNorm) and hold only rounding noise."""
+    gmax = max(float(g.abs().max()) for g in named_ref.values())
+    bad = {}
+    for n, g in named_ref.items():
+        got = named_got[n].detach().cpu().double()
+        err = float((got - g.double()).abs().max())
+        lim = rtol * float(g.abs().max()) + atol_frac * gmax
+        if err > lim:
+            bad[n] = (err, lim)
+    return bad
