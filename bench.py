@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""bench.py — throughput of SemiUHPE's teacher-student training step on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1], "C2"): SemiUHPE 300WLP_AFLW2000, EfficientNetV2-S, per GPU B=32 labeled +
+muB=128 unlabeled 224x224 synthetic heads, dynamic threshold (left_ratio 0.95) + CutOut + CutMix, fp32.
+One "step" = SSLAgent.train_func: EMA update, student fwd (labeled), teacher fwd (weak), strong-aug, student fwd
+(strong), Fisher NLL + entropy filter + CE, backward over 160 images, gradient all-reduce (N>1), Adam.
+Inputs are resident in HBM before the timed region.  metric = counted train images/s = (B + muB) * N / step time.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, live HIP-event timing) and `cpu_baseline`
+(the CPU oracle timed on this host's cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_MFMA_F32_TFLOPS = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA peak (= fp32 vector peak)
+PEAK_HBM_GBS = 8000.0
+B_LABELED, MU = 32, 4
+
+
+def make_config(log_dir):
+    return SimpleNamespace(
+        lr=1e-4, log_dir=log_dir, model_dir=log_dir, distribution="matrixFisher", is_full_range=False, rotate_aug=False,
+        train_labeled="300WLP", train_unlabeled="300WLP", cutout_aug=True, cutmix_aug=True, conf_thres=-5.3,
+        type_unsuper="ce", SSL_lambda=1.0, is_ema=True, ema_decay=0.999, eman=False, stage1_iteration=0,
+        network="effinetv2", num_classes=9, exp_name="300WLP_AFLW2000", date="bench", left_ratio=0.95, save_feat=False,
+        dynamic_thres=True)
+
+
+def synthetic(rank, device, B, muB, size=224):
+    from semiuhpe_amd.synthetic import synthetic_batches
+    data, ulb = synthetic_batches(B, muB, size=size, seed=rank, rotate_aug=False)
+    to = lambda d: {k: v.to(device).contiguous() for k, v in d.items()}
+    return to(data), to(ulb)
+
+
+def gpu_leg(args, rank, world, device):
+    from semiuhpe_amd import kernels as K
+    from semiuhpe_amd.src.agent import SSLAgent
+    torch.manual_seed(1234)                                 # same init on every rank (also broadcast by the agent)
+    cfg = make_config(os.path.join("/tmp", f"suhpe_bench_{os.getpid()}"))
+    agent = SSLAgent(cfg)
+    data, ulb = synthetic(rank, device, B_LABELED, B_LABELED * MU)
+    # dynamic threshold at warm-up: the batch's left_ratio quantile of teacher entropies, so ~95% pass the filter
+    cfg.conf_thres = float(agent.compute_dynamic_entropy_threshold([ulb]))
+    torch.manual_seed(100 + rank)
+    for _ in range(args.warmup):
+        agent.train_func(data, ulb)
+        agent.clock.tick()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fd, fu, out = agent.train_func(data, ulb)
+        agent.clock.tick()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    agent.check_finite()
+    info = dict(mask_ratio=float(fu["mask_ratio"]), loss_all=float(out["loss_all"]), conf_thres=float(cfg.conf_thres))
+
+    # ---- roofline of the dominant kernel: same step, every dense-conv launch bracketed by HIP events on the
+    # launch stream (torch's current stream is the stream the C ABI launches on)
+    roof = None
+    if rank == 0:
+        K.PROFILE = []
+        nprof = 2
+        for _ in range(nprof):
+            agent.train_func(data, ulb)
+            agent.clock.tick()
+        torch.cuda.synchronize()
+        recs, K.PROFILE = K.PROFILE, None
+        agg = {}
+        for name, flops, nbytes, e0, e1 in recs:
+            a = agg.setdefault(name, [0.0, 0.0, 0.0, 0])
+            a[0] += e0.elapsed_time(e1) * 1e-3
+            a[1] += flops
+            a[2] += nbytes
+            a[3] += 1
+        total_gemm_s = sum(a[0] for a in agg.values())
+        name, (secs, flops, nbytes, launches) = max(agg.items(), key=lambda kv: kv[1][0])
+        tf = flops / secs / 1e12
+        roof = {"bound": "mfma", "kernel": name, "achieved": round(tf, 2), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tf / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+                "launches_per_step": launches // nprof, "avg_launch_us": round(secs / launches * 1e6, 2),
+                "avg_launch_gflop": round(flops / launches / 1e9, 3),
+                "kernel_share_of_step": round(secs / nprof / (dt / args.steps), 3),
+                "all_gemm_kernels": {k: {"ms_per_step": round(v[0] / nprof * 1e3, 3), "tflops": round(v[1] / v[0] / 1e12, 2),
+                                         "launches_per_step": v[3] // nprof} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])},
+                "gemm_ms_per_step": round(total_gemm_s / nprof * 1e3, 2)}
+    agent.logs_writer.close()
+    return dt, info, roof
+
+
+def cpu_leg():
+    """The CPU oracle (our torch-CPU restatement of the reference step, kind="port") on this host's cores:
+    one SSL step of the same shape (B=32 + muB=128, EfficientNetV2-S, 224x224), after a small warm-up step."""
+    from oracle import networks as ON
+    from oracle.agent import OracleAgent, synthetic_batches
+    torch.set_num_threads(os.cpu_count())
+    torch.manual_seed(1234)
+    cfg = make_config("/tmp")
+    cfg.conf_thres = 1e9
+    agent = OracleAgent(cfg, lambda: ON.EfficientNetV2S())
+    d0, u0 = synthetic_batches(2, 8, size=224, seed=0)
+    agent.train_func(d0, u0)                                   # warm-up (allocator, thread pool)
+    data, ulb = synthetic_batches(B_LABELED, B_LABELED * MU, size=224, seed=0)
+    t0 = time.perf_counter()
+    agent.train_func(data, ulb)
+    dt = time.perf_counter() - t0
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round((B_LABELED + B_LABELED * MU) / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"1 SSL step B=32+muB=128 EfficientNetV2-S 224x224 fp32 ({dt:.1f} s), torch-CPU oracle",
+            "cpu": model}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    dt, info, roof = gpu_leg(args, rank, world, device)
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        out = {
+            "metric": "train images/sec (labeled+unlabeled)", "value": round((B_LABELED + B_LABELED * MU) * world / (dt / args.steps), 2),
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2 SemiUHPE 300WLP_AFLW2000: EfficientNetV2-S, per-GPU bs=32 labeled + 128 unlabeled (ulb_ratio 4), "
+                                   "224x224 synthetic heads, dynamic_thres(left_ratio 0.95)+CutOut+CutMix, CE unsup loss, Adam lr 1e-4",
+                       "per_gpu_batch": "32+128", "parallelism": f"dp{world}", "global_batch": (B_LABELED + B_LABELED * MU) * world,
+                       **info},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_leg()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

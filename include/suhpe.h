@@ -89,6 +89,8 @@ int suhpe_conv2d_fwd(const suhpe_conv_t* d, const float* x, const float* w, cons
 /* input gradient; wt is the transposed+flipped filter made by suhpe_conv2d_transpose_filter */
 int suhpe_conv2d_dgrad(const suhpe_conv_t* d, const float* dy, const float* wt, float* dx, suhpe_stream_t stream);
 int suhpe_conv2d_transpose_filter(const suhpe_conv_t* d, const float* w, float* wt, suhpe_stream_t stream);
+/* name of the kernel instance a call dispatches to (pass 0 fwd, 1 dgrad, 2 wgrad) — for profiling/roofline reports */
+const char* suhpe_conv2d_kernel_name(const suhpe_conv_t* d, int pass);
 /* filter gradient; dw += sum (accumulate != 0) or dw = sum.  workspace: device scratch */
 int64_t suhpe_conv2d_wgrad_workspace_bytes(const suhpe_conv_t* d);
 int suhpe_conv2d_wgrad(const suhpe_conv_t* d, const float* x, const float* dy, float* dw, int accumulate,

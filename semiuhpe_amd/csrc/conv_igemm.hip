@@ -405,21 +405,31 @@ static void launch_nt(const NtParams& p, int groups, hipStream_t st) {
     hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC>), grid, dim3(256), 0, st, p);
 }
 
-static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st) {
-    if (!vec4) { launch_nt<64, 64, 32, 32, 1>(p, groups, st); return; }
-    const int ng = p.Ng;
+// tile selection for igemm_nt; returns the kernel's name (as rocprofv3 prints the template arguments)
+enum NtTile { NT_64x64_S = 0, NT_64x64, NT_128x32, NT_128x128, NT_128x64, NT_256x32 };
+static const char* kNtNames[] = {"igemm_nt_kernel<64,64,32,32,1>", "igemm_nt_kernel<64,64,32,32,4>", "igemm_nt_kernel<128,32,32,32,4>",
+                                 "igemm_nt_kernel<128,128,64,64,4>", "igemm_nt_kernel<128,64,64,32,4>", "igemm_nt_kernel<256,32,64,32,4>"};
+
+static NtTile choose_nt(int64_t M, int ng, bool vec4) {
+    if (!vec4) return NT_64x64_S;
     // pick the column tile with the least padding waste, preferring wide tiles
     int bn = 32;
     auto waste = [&](int b) { return (double)(ceil_div(ng, b) * b) / ng; };
     if (waste(128) <= waste(64) + 1e-9 && waste(128) <= waste(32) + 1e-9) bn = 128;
     else if (waste(64) <= waste(32) + 1e-9) bn = 64;
-    if (p.g.M < 2048) {          // small row counts (Linear layers, SE): favour more, smaller tiles
-        if (bn >= 64) launch_nt<64, 64, 32, 32, 4>(p, groups, st); else launch_nt<128, 32, 32, 32, 4>(p, groups, st);
-        return;
+    if (M < 2048) return bn >= 64 ? NT_64x64 : NT_128x32;     // small row counts (Linear, SE): more, smaller tiles
+    return bn == 128 ? NT_128x128 : (bn == 64 ? NT_128x64 : NT_256x32);
+}
+
+static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st) {
+    switch (choose_nt(p.g.M, p.Ng, vec4)) {
+        case NT_64x64_S: launch_nt<64, 64, 32, 32, 1>(p, groups, st); break;
+        case NT_64x64: launch_nt<64, 64, 32, 32, 4>(p, groups, st); break;
+        case NT_128x32: launch_nt<128, 32, 32, 32, 4>(p, groups, st); break;
+        case NT_128x128: launch_nt<128, 128, 64, 64, 4>(p, groups, st); break;
+        case NT_128x64: launch_nt<128, 64, 64, 32, 4>(p, groups, st); break;
+        case NT_256x32: launch_nt<256, 32, 64, 32, 4>(p, groups, st); break;
     }
-    if (bn == 128) launch_nt<128, 128, 64, 64, 4>(p, groups, st);
-    else if (bn == 64) launch_nt<128, 64, 64, 32, 4>(p, groups, st);
-    else launch_nt<256, 32, 64, 32, 4>(p, groups, st);
 }
 
 }  // namespace suhpe
@@ -486,6 +496,19 @@ static void wgrad_tile(const suhpe_conv_t* d, int* bm, int* bn) {
     *bm = ng > 64 ? 128 : 64;
     *bn = (K > 64) ? 128 : 64;
     if (*bm == 64 && *bn == 128) { *bm = 64; *bn = 128; }
+}
+
+const char* suhpe_conv2d_kernel_name(const suhpe_conv_t* d, int pass) {
+    if (!d || d->groups <= 0) return "";
+    const int ng = d->cout / d->groups, cg = d->cin / d->groups;
+    if (pass == 0) return kNtNames[choose_nt((int64_t)d->n * d->ho * d->wo, ng, cg % 4 == 0 && d->cin % 4 == 0)];
+    if (pass == 1) return kNtNames[choose_nt((int64_t)d->n * d->h * d->w, cg, ng % 4 == 0 && d->cout % 4 == 0)];
+    const bool va = ng % 4 == 0 && d->cout % 4 == 0, vb = cg % 4 == 0 && d->cin % 4 == 0;
+    if (!(va && vb)) return va ? "igemm_tn_kernel<64,64,32,32,4,1>" : (vb ? "igemm_tn_kernel<64,64,32,32,1,4>" : "igemm_tn_kernel<64,64,32,32,1,1>");
+    int bm, bn;
+    wgrad_tile(d, &bm, &bn);
+    if (bm == 128) return bn == 128 ? "igemm_tn_kernel<128,128,64,64,4,4>" : "igemm_tn_kernel<128,64,64,32,4,4>";
+    return bn == 128 ? "igemm_tn_kernel<64,128,32,64,4,4>" : "igemm_tn_kernel<64,64,32,32,4,4>";
 }
 
 int64_t suhpe_conv2d_wgrad_workspace_bytes(const suhpe_conv_t* d) {

@@ -59,6 +59,39 @@ def _is_depthwise(d):
 
 
 # ---------------------------------------------------------------------------------------------- convolution
+# Optional live profile of the GEMM-shaped launches (bench.py): when PROFILE is a list, every dense conv / linear
+# launch is bracketed by HIP events on the launch stream and recorded as
+# (kernel name, algorithmic FLOPs, algorithmic bytes, start event, end event).
+PROFILE = None
+
+
+def conv_flops(d):
+    """2 * MACs of one pass over the conv described by d (identical for fwd, dgrad and wgrad)."""
+    return 2.0 * d.n * d.ho * d.wo * d.cout * (d.cin // d.groups) * d.r * d.s
+
+
+def conv_bytes(d):
+    """algorithmic HBM bytes of one pass: input + output activations + filter, each touched once (fp32)."""
+    return 4.0 * (d.n * d.h * d.w * d.cin + d.n * d.ho * d.wo * d.cout + d.cout * (d.cin // d.groups) * d.r * d.s)
+
+
+class _Prof:
+    def __init__(self, d, pass_id):
+        self.on = PROFILE is not None
+        if self.on:
+            self.name = _lib.load().suhpe_conv2d_kernel_name(ctypes.byref(d), pass_id).decode()
+            self.rec = (self.name, conv_flops(d), conv_bytes(d), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+
+    def __enter__(self):
+        if self.on:
+            self.rec[3].record()
+
+    def __exit__(self, *a):
+        if self.on:
+            self.rec[4].record()
+            PROFILE.append(self.rec)
+
+
 def conv2d_fwd(x, w, bias=None, stride=1, pad=0, groups=1):
     _chk(x, "x"); _chk(bias, "bias")
     assert filter_is_physical(w), "filter must be stored [Cout][R][S][Cin/g]"
@@ -68,7 +101,8 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, groups=1):
         assert bias is None
         call("suhpe_dwconv_fwd", ctypes.byref(d), ptr(x), ptr(w), ptr(y))
     else:
-        call("suhpe_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(y))
+        with _Prof(d, 0):
+            call("suhpe_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(y))
     return y
 
 
@@ -81,7 +115,8 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, groups=1):
     else:
         wt = workspace("wt", w.numel() * 4, dy.device)
         call("suhpe_conv2d_transpose_filter", ctypes.byref(d), ptr(w), ptr(wt))
-        call("suhpe_conv2d_dgrad", ctypes.byref(d), ptr(dy), ptr(wt), ptr(dx))
+        with _Prof(d, 1):
+            call("suhpe_conv2d_dgrad", ctypes.byref(d), ptr(dy), ptr(wt), ptr(dx))
     return dx
 
 
@@ -102,7 +137,8 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, groups=1, out=None, accumulate
     else:
         nbytes = lib.suhpe_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
         ws = workspace("wgrad", nbytes, x.device)
-        call("suhpe_conv2d_wgrad", ctypes.byref(d), ptr(x), ptr(dy), ptr(out), int(accumulate), ptr(ws), nbytes)
+        with _Prof(d, 2):
+            call("suhpe_conv2d_wgrad", ctypes.byref(d), ptr(x), ptr(dy), ptr(out), int(accumulate), ptr(ws), nbytes)
     return out
 
 
