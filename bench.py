@@ -117,7 +117,8 @@ def cpu_leg():
     one SSL step of the same shape (B=32 + muB=128, EfficientNetV2-S, 224x224), after a small warm-up step."""
     from oracle import networks as ON
     from oracle.agent import OracleAgent, synthetic_batches
-    torch.set_num_threads(os.cpu_count())
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(ncores, 64)))
     torch.manual_seed(1234)
     cfg = make_config("/tmp")
     cfg.conf_thres = 1e9

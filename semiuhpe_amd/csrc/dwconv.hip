@@ -9,7 +9,7 @@
 namespace suhpe {
 
 constexpr int kMaxTaps = 9;
-constexpr int kDwMaxRowBlocks = 256;
+constexpr int kDwMaxRowBlocks = 128;
 
 struct DwGeom {
     int N, GH, GW;       // gathered tensor dims (x for fwd/wgrad, dy for dgrad)
@@ -120,15 +120,23 @@ __global__ __launch_bounds__(256) void dw_wgrad_partial(const DwGeom g, const fl
     }
 }
 
-// dw[c][tap] (+)= sum_bx part[bx][tap][c]
-__global__ void dw_wgrad_finalize(const float* __restrict__ part, int gx, int taps, int C, float* __restrict__ dw, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;    // enumerates (tap, c) with c fastest
-    if (i >= taps * C) return;
-    const int tap = i / C, c = i - tap * C;
+// dw[c][tap] (+)= sum_bx part[bx][tap][c]; a block owns 64 consecutive (tap,c) outputs, 4 threads share the row blocks
+__global__ __launch_bounds__(256) void dw_wgrad_finalize(const float* __restrict__ part, int gx, int taps, int C, float* __restrict__ dw,
+                                                         int accumulate) {
+    __shared__ double red[256];
+    const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + o;             // enumerates (tap, c) with c fastest
     double s = 0.0;
-    for (int b = 0; b < gx; ++b) s += (double)part[((int64_t)b * taps + tap) * C + c];
-    float* o = dw + (int64_t)c * taps + tap;
-    *o = accumulate ? *o + (float)s : (float)s;
+    if (i < taps * C)
+        for (int b = q; b < gx; b += 4) s += (double)part[(int64_t)b * taps * C + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (q == 0 && i < taps * C) {
+        const double tot = red[o] + red[64 + o] + red[128 + o] + red[192 + o];
+        const int tap = i / C, c = i - tap * C;
+        float* out = dw + (int64_t)c * taps + tap;
+        *out = accumulate ? *out + (float)tot : (float)tot;
+    }
 }
 
 static int dw_check(const suhpe_conv_t* d, const char* who) {
@@ -199,7 +207,7 @@ int suhpe_dwconv_wgrad(const suhpe_conv_t* d, const float* x, const float* dy, f
     float* part = static_cast<float*>(workspace);
     hipLaunchKernelGGL(dw_wgrad_partial, dim3(gx, ny), dim3(256), 0, as_stream(stream), g, x, dy, part);
     const int taps = d->r * d->s;
-    hipLaunchKernelGGL(dw_wgrad_finalize, dim3((taps * g.C + 255) / 256), dim3(256), 0, as_stream(stream), part, gx, taps, g.C, dw, accumulate);
+    hipLaunchKernelGGL(dw_wgrad_finalize, dim3((taps * g.C + 63) / 64), dim3(256), 0, as_stream(stream), part, gx, taps, g.C, dw, accumulate);
     return check_launch("suhpe_dwconv_wgrad");
 }
 

@@ -72,6 +72,32 @@ static ColGeom col_geom(int64_t rows, int c, int vec) {
     return g;
 }
 
+// Geometry of the row/column elementwise kernels: thread -> (fixed vector column, rows strided by rp); no per-element
+// integer division, per-channel constants live in registers.
+struct EwGeom { int cw, ny, rp, gx; int rows_per_block; };
+static EwGeom ew_geom(int64_t rows, int c, int vec) {
+    EwGeom g;
+    const int cv = c / vec;
+    g.cw = cv < 64 ? cv : 64;
+    g.ny = (cv + g.cw - 1) / g.cw;
+    g.rp = 256 / g.cw;
+    int64_t gx = ceil_div(rows, (int64_t)g.rp * 8);
+    const int64_t cap = 4096 / g.ny > 1 ? 4096 / g.ny : 1;
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    g.gx = (int)gx;
+    g.rows_per_block = (int)ceil_div(rows, gx);
+    return g;
+}
+#define EW_THREAD_SETUP(VEC)                                                              \
+    const int t = threadIdx.x, col = t % cw, rsub = t / cw;                               \
+    const int cv = c / VEC, vc = blockIdx.y * cw + col;                                   \
+    if (rsub >= rp || vc >= cv) return;                                                   \
+    const int ch = vc * VEC; (void)ch;                                                    \
+    const int r0 = blockIdx.x * rows_per_block;                                           \
+    int r1 = r0 + rows_per_block;                                                         \
+    if (r1 > rows) r1 = rows;
+
 template <int VEC> struct VecT;
 template <> struct VecT<4> { using type = float4; };
 template <> struct VecT<1> { using type = float; };
@@ -86,7 +112,16 @@ template <int VEC> __device__ __forceinline__ void vstore(float* p, const float*
 }
 
 // Block-level combine of per-thread partial sums that share a column: LDS [256][2*VEC] then the first cw
-// threads add the rp partials of their column in fixed order and write part[(bx*c + ch)*2 + {0,1}].
+// threads add the rp partials of their column in fixed order and write part[(ch*gridDim.x + bx)*2 + {0,1}].
+// The finalisers give one wavefront to each channel: lanes stride over the row blocks (contiguous reads),
+// fp64 wave reduction in a fixed order.
+__device__ __forceinline__ void wave_channel_sums(const float* __restrict__ part, int gx, int ch, int lane, double* s, double* q) {
+    double a = 0.0, b = 0.0;
+    const float2* p = reinterpret_cast<const float2*>(part) + (int64_t)ch * gx;
+    for (int i = lane; i < gx; i += 64) { const float2 v = p[i]; a += (double)v.x; b += (double)v.y; }
+    *s = wave_sum(a);
+    *q = wave_sum(b);
+}
 template <int VEC>
 __device__ __forceinline__ void block_combine(const float* s0, const float* s1, int cw, int rp, int col0, int c,
                                               int bx, float* __restrict__ part, float* lds) {
@@ -106,8 +141,8 @@ __device__ __forceinline__ void block_combine(const float* s0, const float* s1, 
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             const int ch = (col0 + t) * VEC + v;
-            part[((int64_t)bx * c + ch) * 2 + 0] = a0[v];
-            part[((int64_t)bx * c + ch) * 2 + 1] = a1[v];
+            part[((int64_t)ch * gridDim.x + bx) * 2 + 0] = a0[v];      // [channel][row block][2]
+            part[((int64_t)ch * gridDim.x + bx) * 2 + 1] = a1[v];
         }
     }
 }
@@ -137,15 +172,18 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
     block_combine<VEC>(s0, s1, cw, rp, col0, c, blockIdx.x, part, lds);
 }
 
-// pass 2: one thread per channel, fixed-order fp64 combine; running-stat update as nn.BatchNorm does
-__global__ void bn_stats_finalize(const float* __restrict__ part, int gx, int c, int64_t rows, float eps, float momentum,
-                                  float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
-                                  float* __restrict__ running_var, int64_t* __restrict__ nbt) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch == 0 && nbt) nbt[0] += 1;
+// pass 2: one wavefront per channel; running-stat update as nn.BatchNorm does
+__global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict__ part, int gx, int c, int64_t rows, float eps,
+                                                         float momentum, float* __restrict__ mean, float* __restrict__ rstd,
+                                                         float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                         int64_t* __restrict__ nbt) {
+    const int lane = threadIdx.x & 63;
+    const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ch == 0 && lane == 0 && nbt) nbt[0] += 1;
     if (ch >= c) return;
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < gx; ++b) { s += (double)part[((int64_t)b * c + ch) * 2]; q += (double)part[((int64_t)b * c + ch) * 2 + 1]; }
+    double s, q;
+    wave_channel_sums(part, gx, ch, lane, &s, &q);
+    if (lane != 0) return;
     const double m = s / (double)rows;
     double var = q / (double)rows - m * m;
     if (var < 0.0) var = 0.0;
@@ -168,24 +206,31 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ rm, const float* 
 
 // y = act(gamma*(x-mean)*rstd + beta + residual)
 template <int VEC>
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, int64_t nvec, int cv,
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, int rows, int c, int cw, int rp, int rows_per_block,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          int act, const float* __restrict__ residual,
                                                          float* __restrict__ y) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(i % cv) * VEC;
+    EW_THREAD_SETUP(VEC)
+    float sc[VEC], sh[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        const float g = gamma ? gamma[ch + v] : 1.f, b = beta ? beta[ch + v] : 0.f;
+        sc[v] = rstd[ch + v] * g;
+        sh[v] = b - mean[ch + v] * sc[v];
+    }
+    for (int r = r0 + rsub; r < r1; r += rp) {
+        const int64_t off = ((int64_t)r * cv + vc) * VEC;
         float xv[VEC], rv[VEC], o[VEC];
-        vload<VEC>(x + i * VEC, xv);
-        if (residual) vload<VEC>(residual + i * VEC, rv);
+        vload<VEC>(x + off, xv);
+        if (residual) vload<VEC>(residual + off, rv);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-            const float g = gamma ? gamma[ch + v] : 1.f, b = beta ? beta[ch + v] : 0.f;
-            float u = (xv[v] - mean[ch + v]) * rstd[ch + v] * g + b;
+            float u = xv[v] * sc[v] + sh[v];
             if (residual) u += rv[v];
             o[v] = act_apply(u, act);
         }
-        vstore<VEC>(y + i * VEC, o);
+        vstore<VEC>(y + off, o);
     }
 }
 
@@ -234,13 +279,15 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
     block_combine<VEC>(s0, s1, cw, rp, col0, c, blockIdx.x, part, lds);
 }
 
-// pass 2: dbeta = sum g, dgamma = sum g*xhat (fp64, fixed order); leaves them in sums[c][2] for pass 3
-__global__ void bn_bwd_finalize(const float* __restrict__ part, int gx, int c, float* __restrict__ sums,
-                                float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+// pass 2: dbeta = sum g, dgamma = sum g*xhat (one wavefront per channel); leaves them in sums[c][2] for pass 3
+__global__ __launch_bounds__(256) void bn_bwd_finalize(const float* __restrict__ part, int gx, int c, float* __restrict__ sums,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ch >= c) return;
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < gx; ++b) { s += (double)part[((int64_t)b * c + ch) * 2]; q += (double)part[((int64_t)b * c + ch) * 2 + 1]; }
+    double s, q;
+    wave_channel_sums(part, gx, ch, lane, &s, &q);
+    if (lane != 0) return;
     sums[2 * ch] = (float)s;
     sums[2 * ch + 1] = (float)q;
     if (dbeta) dbeta[ch] = accumulate ? dbeta[ch] + (float)s : (float)s;
@@ -250,28 +297,36 @@ __global__ void bn_bwd_finalize(const float* __restrict__ part, int gx, int c, f
 // pass 3: dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat))   [train]   or gamma*rstd*g [eval]
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ dy,
-                                                    const float* __restrict__ yout, int64_t nvec, int cv,
+                                                    const float* __restrict__ yout, int rows, int c, int cw, int rp, int rows_per_block,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta, int act,
                                                     const float* __restrict__ sums, float inv_rows, int train_stats,
                                                     float* __restrict__ dx) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(i % cv) * VEC;
+    EW_THREAD_SETUP(VEC)
+    float mu[VEC], rs[VEC], ga[VEC], be[VEC], m0[VEC], m1[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        mu[v] = mean[ch + v]; rs[v] = rstd[ch + v];
+        ga[v] = gamma ? gamma[ch + v] : 1.f; be[v] = beta ? beta[ch + v] : 0.f;
+        m0[v] = train_stats ? sums[2 * (ch + v)] * inv_rows : 0.f;
+        m1[v] = train_stats ? sums[2 * (ch + v) + 1] * inv_rows : 0.f;
+    }
+    for (int r = r0 + rsub; r < r1; r += rp) {
+        const int64_t off = ((int64_t)r * cv + vc) * VEC;
         float xv[VEC], dv[VEC], yv[VEC], o[VEC];
-        vload<VEC>(x + i * VEC, xv);
-        vload<VEC>(dy + i * VEC, dv);
-        if (yout) vload<VEC>(yout + i * VEC, yv);
+        vload<VEC>(x + off, xv);
+        vload<VEC>(dy + off, dv);
+        if (yout) vload<VEC>(yout + off, yv);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-            const float ga = gamma ? gamma[ch + v] : 1.f, be = beta ? beta[ch + v] : 0.f;
-            const float xh = (xv[v] - mean[ch + v]) * rstd[ch + v];
+            const float xh = (xv[v] - mu[v]) * rs[v];
             float g;
             if (yout) g = yv[v] > 0.f ? dv[v] : 0.f;
-            else g = dv[v] * act_grad(xh * ga + be, act);
-            if (train_stats) g = g - sums[2 * (ch + v)] * inv_rows - xh * sums[2 * (ch + v) + 1] * inv_rows;
-            o[v] = ga * rstd[ch + v] * g;
+            else g = dv[v] * act_grad(xh * ga[v] + be[v], act);
+            g = g - m0[v] - xh * m1[v];
+            o[v] = ga[v] * rs[v] * g;
         }
-        vstore<VEC>(dx + i * VEC, o);
+        vstore<VEC>(dx + off, o);
     }
 }
 
@@ -350,28 +405,37 @@ __global__ __launch_bounds__(256) void layernorm_bwd_partial(const float* __rest
 
 // ------------------------------------------------------------------------------------------ plain activation (+bias)
 template <int VEC>
-__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, int64_t nvec, int cv,
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, int rows, int c, int cw, int rp, int rows_per_block,
                                                       const float* __restrict__ bias, int act, float* __restrict__ y) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(i % cv) * VEC;
-        float xv[VEC], o[VEC];
-        vload<VEC>(x + i * VEC, xv);
+    EW_THREAD_SETUP(VEC)
+    float bv[VEC];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) o[v] = act_apply(xv[v] + (bias ? bias[ch + v] : 0.f), act);
-        vstore<VEC>(y + i * VEC, o);
+    for (int v = 0; v < VEC; ++v) bv[v] = bias ? bias[ch + v] : 0.f;
+    for (int r = r0 + rsub; r < r1; r += rp) {
+        const int64_t off = ((int64_t)r * cv + vc) * VEC;
+        float xv[VEC], o[VEC];
+        vload<VEC>(x + off, xv);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o[v] = act_apply(xv[v] + bv[v], act);
+        vstore<VEC>(y + off, o);
     }
 }
 template <int VEC>
-__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int64_t nvec,
-                                                      int cv, const float* __restrict__ bias, int act, float* __restrict__ dx) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(i % cv) * VEC;
-        float xv[VEC], dv[VEC], o[VEC];
-        vload<VEC>(x + i * VEC, xv);
-        vload<VEC>(dy + i * VEC, dv);
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int rows, int c, int cw,
+                                                      int rp, int rows_per_block, const float* __restrict__ bias, int act,
+                                                      float* __restrict__ dx) {
+    EW_THREAD_SETUP(VEC)
+    float bv[VEC];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) o[v] = dv[v] * act_grad(xv[v] + (bias ? bias[ch + v] : 0.f), act);
-        vstore<VEC>(dx + i * VEC, o);
+    for (int v = 0; v < VEC; ++v) bv[v] = bias ? bias[ch + v] : 0.f;
+    for (int r = r0 + rsub; r < r1; r += rp) {
+        const int64_t off = ((int64_t)r * cv + vc) * VEC;
+        float xv[VEC], dv[VEC], o[VEC];
+        vload<VEC>(x + off, xv);
+        vload<VEC>(dy + off, dv);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o[v] = dv[v] * act_grad(xv[v] + bv[v], act);
+        vstore<VEC>(dx + off, o);
     }
 }
 
@@ -417,49 +481,48 @@ __global__ __launch_bounds__(256) void pool_sum_kernel(const float* __restrict__
     }
 }
 
-// dx[n,p,c] = dy[n,c]*scale
+// mode 0: y[n,p,c] = x[n,p,c]*s[n,c] + dpool[n,c]*inv_hw   (SE scale fwd / bwd-x)
+// mode 1: y[n,p,c] = s[n,c]*inv_hw                          (average-pool backward; x unused)
+// grid (row blocks within a sample, column chunks, n)
 template <int VEC>
-__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dy, int64_t nvec, int hw, int cv, float scale,
-                                                       float* __restrict__ dx) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t n = i / ((int64_t)hw * cv);
-        const int col = (int)(i % cv);
-        float g[VEC];
-        vload<VEC>(dy + (n * cv + col) * VEC, g);
+__global__ __launch_bounds__(256) void per_sample_scale_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                               const float* __restrict__ dpool, int hw, int c, int cw, int rp,
+                                                               int rows_per_block, float inv_hw, int mode, float* __restrict__ y) {
+    const int rows = hw;
+    EW_THREAD_SETUP(VEC)
+    const int64_t n = blockIdx.z;
+    float sv[VEC], pv[VEC];
+    vload<VEC>(s + (n * cv + vc) * VEC, sv);
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) g[v] *= scale;
-        vstore<VEC>(dx + i * VEC, g);
+    for (int v = 0; v < VEC; ++v) pv[v] = 0.f;
+    if (dpool) vload<VEC>(dpool + (n * cv + vc) * VEC, pv);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { pv[v] *= inv_hw; if (mode == 1) sv[v] *= inv_hw; }
+    for (int r = r0 + rsub; r < r1; r += rp) {
+        const int64_t off = ((n * hw + r) * cv + vc) * VEC;
+        float xv[VEC], o[VEC];
+        if (mode == 0) {
+            vload<VEC>(x + off, xv);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) o[v] = xv[v] * sv[v] + pv[v];
+        } else {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) o[v] = sv[v];
+        }
+        vstore<VEC>(y + off, o);
     }
 }
 
-// y = x*s[n,c]   or   dx = dy*s[n,c] + dpool[n,c]*inv_hw
-template <int VEC>
-__global__ __launch_bounds__(256) void se_scale_kernel(const float* __restrict__ x, const float* __restrict__ s,
-                                                       const float* __restrict__ dpool, int64_t nvec, int hw, int cv,
-                                                       float inv_hw, float* __restrict__ y) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t n = i / ((int64_t)hw * cv);
-        const int col = (int)(i % cv);
-        float xv[VEC], sv[VEC], pv[VEC], o[VEC];
-        vload<VEC>(x + i * VEC, xv);
-        vload<VEC>(s + (n * cv + col) * VEC, sv);
-        if (dpool) vload<VEC>(dpool + (n * cv + col) * VEC, pv);
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) o[v] = xv[v] * sv[v] + (dpool ? pv[v] * inv_hw : 0.f);
-        vstore<VEC>(y + i * VEC, o);
-    }
-}
-
-// y = a + b*rowscale[n]   (a may be NULL -> y = b*rowscale[n])
+// y = a + b*rowscale[n]   (a may be NULL -> y = b*rowscale[n]); grid (chunks of a sample, n)
 __global__ __launch_bounds__(256) void add_rowscale_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                           const float* __restrict__ rowscale, int64_t nvec, int64_t per_vec,
-                                                           float* __restrict__ y) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-        const float sc = rowscale ? rowscale[i / per_vec] : 1.f;
-        const float4 bv = reinterpret_cast<const float4*>(b)[i];
+                                                           const float* __restrict__ rowscale, int per_vec, float* __restrict__ y) {
+    const int64_t base = (int64_t)blockIdx.y * per_vec;
+    const float sc = rowscale ? rowscale[blockIdx.y] : 1.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per_vec; i += gridDim.x * blockDim.x) {
+        const float4 bv = reinterpret_cast<const float4*>(b)[base + i];
         float4 o = make_float4(bv.x * sc, bv.y * sc, bv.z * sc, bv.w * sc);
-        if (a) { const float4 av = reinterpret_cast<const float4*>(a)[i]; o.x += av.x; o.y += av.y; o.z += av.z; o.w += av.w; }
-        reinterpret_cast<float4*>(y)[i] = o;
+        if (a) { const float4 av = reinterpret_cast<const float4*>(a)[base + i]; o.x += av.x; o.y += av.y; o.z += av.z; o.w += av.w; }
+        reinterpret_cast<float4*>(y)[base + i] = o;
     }
 }
 
@@ -567,12 +630,13 @@ __global__ __launch_bounds__(256) void colsum_partial(const float* __restrict__ 
     }
     block_combine<VEC>(s0, s1, cw, rp, col0, c, blockIdx.x, part, lds);
 }
-__global__ void colsum_finalize(const float* __restrict__ part, int gx, int c, float* __restrict__ out, int accumulate) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void colsum_finalize(const float* __restrict__ part, int gx, int c, float* __restrict__ out, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ch >= c) return;
-    double s = 0.0;
-    for (int b = 0; b < gx; ++b) s += (double)part[((int64_t)b * c + ch) * 2];
-    out[ch] = accumulate ? out[ch] + (float)s : (float)s;
+    double s, q;
+    wave_channel_sums(part, gx, ch, lane, &s, &q);
+    if (lane == 0) out[ch] = accumulate ? out[ch] + (float)s : (float)s;
 }
 
 // ------------------------------------------------------------------------------------------ optimiser / EMA
@@ -621,12 +685,12 @@ int suhpe_bn_stats(const float* x, int64_t rows, int c, float eps, float momentu
     if (vec4_ok(c, x)) {
         const ColGeom g = col_geom(rows, c, 4);
         LAUNCH(bn_stats_partial<4>, dim3(g.gx, g.ny), dim3(256), stream, x, rows, c, g.cw, g.rp, g.rows_per_block, part);
-        LAUNCH(bn_stats_finalize, dim3((c + 255) / 256), dim3(256), stream, part, g.gx, c, rows, eps, momentum, mean, rstd,
+        LAUNCH(bn_stats_finalize, dim3((c + 3) / 4), dim3(256), stream, part, g.gx, c, rows, eps, momentum, mean, rstd,
                running_mean, running_var, nbt);
     } else {
         const ColGeom g = col_geom(rows, c, 1);
         LAUNCH(bn_stats_partial<1>, dim3(g.gx, g.ny), dim3(256), stream, x, rows, c, g.cw, g.rp, g.rows_per_block, part);
-        LAUNCH(bn_stats_finalize, dim3((c + 255) / 256), dim3(256), stream, part, g.gx, c, rows, eps, momentum, mean, rstd,
+        LAUNCH(bn_stats_finalize, dim3((c + 3) / 4), dim3(256), stream, part, g.gx, c, rows, eps, momentum, mean, rstd,
                running_mean, running_var, nbt);
     }
     return check_launch("suhpe_bn_stats");
@@ -640,15 +704,15 @@ int suhpe_bn_eval_stats(const float* rm, const float* rv, int c, float eps, floa
 
 int suhpe_bn_act_fwd(const float* x, int64_t rows, int c, const float* mean, const float* rstd, const float* gamma,
                      const float* beta, int act, const float* residual, float* y, suhpe_stream_t stream) {
-    SUHPE_REQUIRE(x && y && mean && rstd && rows > 0 && c > 0, "suhpe_bn_act_fwd: bad arguments");
+    SUHPE_REQUIRE(x && y && mean && rstd && rows > 0 && rows < (1LL << 31) && c > 0, "suhpe_bn_act_fwd: bad arguments");
     if (vec4_ok(c, x, y, residual)) {
-        const int64_t nvec = rows * (c / 4);
-        LAUNCH(bn_act_fwd_kernel<4>, dim3(grid_for(nvec, 256)), dim3(256), stream, x, nvec, c / 4, mean, rstd, gamma, beta, act,
-               residual, y);
+        const EwGeom g = ew_geom(rows, c, 4);
+        LAUNCH(bn_act_fwd_kernel<4>, dim3(g.gx, g.ny), dim3(256), stream, x, (int)rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta,
+               act, residual, y);
     } else {
-        const int64_t nvec = rows * c;
-        LAUNCH(bn_act_fwd_kernel<1>, dim3(grid_for(nvec, 256)), dim3(256), stream, x, nvec, c, mean, rstd, gamma, beta, act,
-               residual, y);
+        const EwGeom g = ew_geom(rows, c, 1);
+        LAUNCH(bn_act_fwd_kernel<1>, dim3(g.gx, g.ny), dim3(256), stream, x, (int)rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta,
+               act, residual, y);
     }
     return check_launch("suhpe_bn_act_fwd");
 }
@@ -656,7 +720,7 @@ int suhpe_bn_act_fwd(const float* x, int64_t rows, int c, const float* mean, con
 int suhpe_bn_act_bwd(const float* x, const float* dy, const float* y_out, int64_t rows, int c, const float* mean,
                      const float* rstd, const float* gamma, const float* beta, int act, int train_stats, float* dx,
                      float* dgamma, float* dbeta, int accumulate, void* workspace, suhpe_stream_t stream) {
-    SUHPE_REQUIRE(x && dy && dx && mean && rstd && workspace && rows > 0 && c > 0, "suhpe_bn_act_bwd: bad arguments");
+    SUHPE_REQUIRE(x && dy && dx && mean && rstd && workspace && rows > 0 && rows < (1LL << 31) && c > 0, "suhpe_bn_act_bwd: bad arguments");
     SUHPE_REQUIRE(!y_out || act == SUHPE_ACT_RELU, "suhpe_bn_act_bwd: y_out (pre-activation residual) needs act=RELU");
     float* part = static_cast<float*>(workspace);
     float* sums = part + (int64_t)kMaxRowBlocks * c * 2;
@@ -665,18 +729,18 @@ int suhpe_bn_act_bwd(const float* x, const float* dy, const float* y_out, int64_
         const ColGeom g = col_geom(rows, c, 4);
         LAUNCH(bn_bwd_partial<4>, dim3(g.gx, g.ny), dim3(256), stream, x, dy, y_out, rows, c, g.cw, g.rp, g.rows_per_block, mean,
                rstd, gamma, beta, act, part);
-        LAUNCH(bn_bwd_finalize, dim3((c + 255) / 256), dim3(256), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
-        const int64_t nvec = rows * (c / 4);
-        LAUNCH(bn_bwd_apply<4>, dim3(grid_for(nvec, 256)), dim3(256), stream, x, dy, y_out, nvec, c / 4, mean, rstd, gamma, beta,
-               act, sums, inv_rows, train_stats, dx);
+        LAUNCH(bn_bwd_finalize, dim3((c + 3) / 4), dim3(256), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
+        const EwGeom e = ew_geom(rows, c, 4);
+        LAUNCH(bn_bwd_apply<4>, dim3(e.gx, e.ny), dim3(256), stream, x, dy, y_out, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd,
+               gamma, beta, act, sums, inv_rows, train_stats, dx);
     } else {
         const ColGeom g = col_geom(rows, c, 1);
         LAUNCH(bn_bwd_partial<1>, dim3(g.gx, g.ny), dim3(256), stream, x, dy, y_out, rows, c, g.cw, g.rp, g.rows_per_block, mean,
                rstd, gamma, beta, act, part);
-        LAUNCH(bn_bwd_finalize, dim3((c + 255) / 256), dim3(256), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
-        const int64_t nvec = rows * c;
-        LAUNCH(bn_bwd_apply<1>, dim3(grid_for(nvec, 256)), dim3(256), stream, x, dy, y_out, nvec, c, mean, rstd, gamma, beta, act,
-               sums, inv_rows, train_stats, dx);
+        LAUNCH(bn_bwd_finalize, dim3((c + 3) / 4), dim3(256), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
+        const EwGeom e = ew_geom(rows, c, 1);
+        LAUNCH(bn_bwd_apply<1>, dim3(e.gx, e.ny), dim3(256), stream, x, dy, y_out, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd,
+               gamma, beta, act, sums, inv_rows, train_stats, dx);
     }
     return check_launch("suhpe_bn_act_bwd");
 }
@@ -699,11 +763,11 @@ int suhpe_layernorm_bwd(const float* x, const float* dy, int64_t rows, int c, co
         if (vec4_ok(c, x, dy)) {
             const ColGeom g = col_geom(rows, c, 4);
             LAUNCH(layernorm_bwd_partial<4>, dim3(g.gx, g.ny), dim3(256), stream, x, dy, rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, part);
-            LAUNCH(bn_bwd_finalize, dim3((c + 255) / 256), dim3(256), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
+            LAUNCH(bn_bwd_finalize, dim3((c + 3) / 4), dim3(256), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
         } else {
             const ColGeom g = col_geom(rows, c, 1);
             LAUNCH(layernorm_bwd_partial<1>, dim3(g.gx, g.ny), dim3(256), stream, x, dy, rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, part);
-            LAUNCH(bn_bwd_finalize, dim3((c + 255) / 256), dim3(256), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
+            LAUNCH(bn_bwd_finalize, dim3((c + 3) / 4), dim3(256), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
         }
     }
     return check_launch("suhpe_layernorm_bwd");
@@ -711,24 +775,35 @@ int suhpe_layernorm_bwd(const float* x, const float* dy, int64_t rows, int c, co
 
 int suhpe_act_fwd(const float* x, int64_t rows, int c, const float* bias, int act, float* y, suhpe_stream_t stream) {
     SUHPE_REQUIRE(x && y && rows > 0 && c > 0, "suhpe_act_fwd: bad arguments");
-    if (vec4_ok(c, x, y)) { const int64_t nv = rows * (c / 4); LAUNCH(act_fwd_kernel<4>, dim3(grid_for(nv, 256)), dim3(256), stream, x, nv, c / 4, bias, act, y); }
-    else { const int64_t nv = rows * c; LAUNCH(act_fwd_kernel<1>, dim3(grid_for(nv, 256)), dim3(256), stream, x, nv, c, bias, act, y); }
+    SUHPE_REQUIRE(rows < (1LL << 31), "suhpe_act_fwd: too many rows");
+    if (vec4_ok(c, x, y)) { const EwGeom g = ew_geom(rows, c, 4); LAUNCH(act_fwd_kernel<4>, dim3(g.gx, g.ny), dim3(256), stream, x, (int)rows, c, g.cw, g.rp, g.rows_per_block, bias, act, y); }
+    else { const EwGeom g = ew_geom(rows, c, 1); LAUNCH(act_fwd_kernel<1>, dim3(g.gx, g.ny), dim3(256), stream, x, (int)rows, c, g.cw, g.rp, g.rows_per_block, bias, act, y); }
     return check_launch("suhpe_act_fwd");
 }
 
 int suhpe_act_bwd(const float* x, const float* dy, int64_t rows, int c, const float* bias, int act, float* dx, suhpe_stream_t stream) {
     SUHPE_REQUIRE(x && dy && dx && rows > 0 && c > 0, "suhpe_act_bwd: bad arguments");
-    if (vec4_ok(c, x, dy, dx)) { const int64_t nv = rows * (c / 4); LAUNCH(act_bwd_kernel<4>, dim3(grid_for(nv, 256)), dim3(256), stream, x, dy, nv, c / 4, bias, act, dx); }
-    else { const int64_t nv = rows * c; LAUNCH(act_bwd_kernel<1>, dim3(grid_for(nv, 256)), dim3(256), stream, x, dy, nv, c, bias, act, dx); }
+    SUHPE_REQUIRE(rows < (1LL << 31), "suhpe_act_bwd: too many rows");
+    if (vec4_ok(c, x, dy, dx)) { const EwGeom g = ew_geom(rows, c, 4); LAUNCH(act_bwd_kernel<4>, dim3(g.gx, g.ny), dim3(256), stream, x, dy, (int)rows, c, g.cw, g.rp, g.rows_per_block, bias, act, dx); }
+    else { const EwGeom g = ew_geom(rows, c, 1); LAUNCH(act_bwd_kernel<1>, dim3(g.gx, g.ny), dim3(256), stream, x, dy, (int)rows, c, g.cw, g.rp, g.rows_per_block, bias, act, dx); }
     return check_launch("suhpe_act_bwd");
 }
 
 static int pool_sum(const float* x, const float* w, int n, int hw, int c, float scale, float* y, suhpe_stream_t stream, const char* who) {
     if (!(x && y && n > 0 && hw > 0 && c > 0)) { set_error("%s: bad arguments", who); return SUHPE_EINVAL; }
     const int vec = vec4_ok(c, x, w, y) ? 4 : 1;
-    const int cv = c / vec, cw = cv < 256 ? cv : 256, ny = (cv + cw - 1) / cw, rp = 256 / cw;
+    const int cv = c / vec, cw = cv < 32 ? cv : 32, ny = (cv + cw - 1) / cw, rp = 256 / cw;
     if (vec == 4) LAUNCH(pool_sum_kernel<4>, dim3(n, ny), dim3(256), stream, x, w, hw, c, cw, rp, scale, y);
     else LAUNCH(pool_sum_kernel<1>, dim3(n, ny), dim3(256), stream, x, w, hw, c, cw, rp, scale, y);
+    return check_launch(who);
+}
+
+static int per_sample_scale(const float* x, const float* s, const float* dpool, int n, int hw, int c, float inv_hw, int mode, float* y,
+                            suhpe_stream_t stream, const char* who) {
+    const bool v4 = vec4_ok(c, x, s, y) && vec4_ok(c, dpool);
+    const EwGeom g = ew_geom(hw, c, v4 ? 4 : 1);
+    if (v4) LAUNCH(per_sample_scale_kernel<4>, dim3(g.gx, g.ny, n), dim3(256), stream, x, s, dpool, hw, c, g.cw, g.rp, g.rows_per_block, inv_hw, mode, y);
+    else LAUNCH(per_sample_scale_kernel<1>, dim3(g.gx, g.ny, n), dim3(256), stream, x, s, dpool, hw, c, g.cw, g.rp, g.rows_per_block, inv_hw, mode, y);
     return check_launch(who);
 }
 
@@ -738,16 +813,12 @@ int suhpe_avgpool_fwd(const float* x, int n, int hw, int c, float* y, suhpe_stre
 
 int suhpe_avgpool_bwd(const float* dy, int n, int hw, int c, float* dx, suhpe_stream_t stream) {
     SUHPE_REQUIRE(dy && dx && n > 0 && hw > 0 && c > 0, "suhpe_avgpool_bwd: bad arguments");
-    if (vec4_ok(c, dy, dx)) { const int64_t nv = (int64_t)n * hw * (c / 4); LAUNCH(pool_bwd_kernel<4>, dim3(grid_for(nv, 256)), dim3(256), stream, dy, nv, hw, c / 4, 1.0f / hw, dx); }
-    else { const int64_t nv = (int64_t)n * hw * c; LAUNCH(pool_bwd_kernel<1>, dim3(grid_for(nv, 256)), dim3(256), stream, dy, nv, hw, c, 1.0f / hw, dx); }
-    return check_launch("suhpe_avgpool_bwd");
+    return per_sample_scale(nullptr, dy, nullptr, n, hw, c, 1.0f / hw, 1, dx, stream, "suhpe_avgpool_bwd");
 }
 
 int suhpe_se_scale_fwd(const float* x, const float* s, int n, int hw, int c, float* y, suhpe_stream_t stream) {
     SUHPE_REQUIRE(x && s && y && n > 0 && hw > 0 && c > 0, "suhpe_se_scale_fwd: bad arguments");
-    if (vec4_ok(c, x, s, y)) { const int64_t nv = (int64_t)n * hw * (c / 4); LAUNCH(se_scale_kernel<4>, dim3(grid_for(nv, 256)), dim3(256), stream, x, s, nullptr, nv, hw, c / 4, 0.f, y); }
-    else { const int64_t nv = (int64_t)n * hw * c; LAUNCH(se_scale_kernel<1>, dim3(grid_for(nv, 256)), dim3(256), stream, x, s, nullptr, nv, hw, c, 0.f, y); }
-    return check_launch("suhpe_se_scale_fwd");
+    return per_sample_scale(x, s, nullptr, n, hw, c, 0.f, 0, y, stream, "suhpe_se_scale_fwd");
 }
 
 int suhpe_se_scale_bwd_s(const float* dy, const float* x, int n, int hw, int c, float* ds, suhpe_stream_t stream) {
@@ -757,16 +828,17 @@ int suhpe_se_scale_bwd_s(const float* dy, const float* x, int n, int hw, int c, 
 
 int suhpe_se_scale_bwd_x(const float* dy, const float* s, const float* dpool, int n, int hw, int c, float* dx, suhpe_stream_t stream) {
     SUHPE_REQUIRE(dy && s && dx && n > 0 && hw > 0 && c > 0, "suhpe_se_scale_bwd_x: bad arguments");
-    if (vec4_ok(c, dy, s, dx) && vec4_ok(c, dpool)) { const int64_t nv = (int64_t)n * hw * (c / 4); LAUNCH(se_scale_kernel<4>, dim3(grid_for(nv, 256)), dim3(256), stream, dy, s, dpool, nv, hw, c / 4, 1.0f / hw, dx); }
-    else { const int64_t nv = (int64_t)n * hw * c; LAUNCH(se_scale_kernel<1>, dim3(grid_for(nv, 256)), dim3(256), stream, dy, s, dpool, nv, hw, c, 1.0f / hw, dx); }
-    return check_launch("suhpe_se_scale_bwd_x");
+    return per_sample_scale(dy, s, dpool, n, hw, c, 1.0f / hw, 0, dx, stream, "suhpe_se_scale_bwd_x");
 }
 
 int suhpe_add_rowscale(const float* a, const float* b, const float* rowscale, int n, int64_t per, float* y, suhpe_stream_t stream) {
     SUHPE_REQUIRE(b && y && n > 0 && per > 0 && per % 4 == 0, "suhpe_add_rowscale: bad arguments (per must be a multiple of 4)");
     SUHPE_REQUIRE(vec4_ok(4, a, b, y), "suhpe_add_rowscale: pointers must be 16-byte aligned");
-    const int64_t nv = (int64_t)n * per / 4;
-    LAUNCH(add_rowscale_kernel, dim3(grid_for(nv, 256)), dim3(256), stream, a, b, rowscale, nv, per / 4, y);
+    SUHPE_REQUIRE(per / 4 < (1LL << 31), "suhpe_add_rowscale: sample too large");
+    const int per_vec = (int)(per / 4);
+    int gx = (per_vec + 256 * 4 - 1) / (256 * 4);
+    if (gx > 64) gx = 64;
+    LAUNCH(add_rowscale_kernel, dim3(gx, n), dim3(256), stream, a, b, rowscale, per_vec, y);
     return check_launch("suhpe_add_rowscale");
 }
 
@@ -833,11 +905,11 @@ int suhpe_bias_grad(const float* dy, int64_t rows, int c, float* db, int accumul
     if (vec4_ok(c, dy)) {
         const ColGeom g = col_geom(rows, c, 4);
         LAUNCH(colsum_partial<4>, dim3(g.gx, g.ny), dim3(256), stream, dy, rows, c, g.cw, g.rp, g.rows_per_block, part);
-        LAUNCH(colsum_finalize, dim3((c + 255) / 256), dim3(256), stream, part, g.gx, c, db, accumulate);
+        LAUNCH(colsum_finalize, dim3((c + 3) / 4), dim3(256), stream, part, g.gx, c, db, accumulate);
     } else {
         const ColGeom g = col_geom(rows, c, 1);
         LAUNCH(colsum_partial<1>, dim3(g.gx, g.ny), dim3(256), stream, dy, rows, c, g.cw, g.rp, g.rows_per_block, part);
-        LAUNCH(colsum_finalize, dim3((c + 255) / 256), dim3(256), stream, part, g.gx, c, db, accumulate);
+        LAUNCH(colsum_finalize, dim3((c + 3) / 4), dim3(256), stream, part, g.gx, c, db, accumulate);
     }
     return check_launch("suhpe_bias_grad");
 }
