@@ -33,7 +33,16 @@ struct GatherGeom {
                          // 1: gh = (oh + pad - r)/stride     (dgrad gather of dy; only exact multiples)
     int K;               // R*S*Cg
     int64_t M;           // N*OH*OW
+    // affine form used by the fast paths: coordinate = o*gm + sgn*tap + off
+    //   forward (any stride): gm = stride, sgn = +1, off = -pad ;  dgrad stride 1: gm = 1, sgn = -1, off = +pad
+    int gm, sgn, off;
+    // magic numbers for n / (OH*OW) and rem / OW on dividends < 2^31 (q = umulhi(n, mul) >> shr)
+    unsigned div_hw_mul, div_hw_shr, div_w_mul, div_w_shr;
 };
+
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned mul, unsigned shr) {
+    return mul ? (__umulhi(n, mul) >> shr) : n;       // mul == 0 encodes divisor 1
+}
 
 __device__ __forceinline__ bool gather_coord(const GatherGeom& g, int o, int tap, int extent, int* out) {
     if (g.mode == 0) {
@@ -60,7 +69,12 @@ struct NtParams {
 };
 
 // ---------------------------------------------------------------------------------------------- igemm_nt
-template <int BM, int BN, int WM, int WN, int VEC>
+// MODE 0: generic gather (any stride, dgrad with stride > 1: per-tap divisibility test)
+// MODE 1: pointwise (1x1, stride 1, no padding): the gathered row IS row m
+// MODE 2: affine taps, coordinate = o*gm + sgn*tap + off (forward with any stride, dgrad with stride 1)
+// In every mode the tap of a thread's k advances incrementally (no division in the k loop), addresses are 32-bit
+// element offsets from a uniform base, and out-of-range taps are predicated (offset 0, value zeroed): no branches.
+template <int BM, int BN, int WM, int WN, int VEC, int MODE>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -84,56 +98,90 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
     const int lcol = VEC == 4 ? (t & 7) * 4 : (t & 31);
     const int lrow = VEC == 4 ? (t >> 3) : (t >> 5);
 
-    int a_nbase[A_ROWS], a_oh[A_ROWS], a_ow[A_ROWS];
+    // per-row constants: a_pix = pixel index of tap (0,0) (MODE 2) / of the row itself (MODE 1) / n*GH*GW (MODE 0);
+    // a_h/a_w = o*gm (MODE 2) or o (MODE 0).  a_pix < 0 marks rows beyond M.
+    int a_pix[A_ROWS], a_h[A_ROWS], a_w[A_ROWS];
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
         const int64_t m = m0 + lrow + i * ROW_STEP;
+        a_h[i] = 0; a_w[i] = 0;
         if (m < g.M) {
-            const int n = (int)(m / ((int64_t)g.OH * g.OW));
-            const int rem = (int)(m - (int64_t)n * g.OH * g.OW);
-            a_oh[i] = rem / g.OW;
-            a_ow[i] = rem - a_oh[i] * g.OW;
-            a_nbase[i] = n * g.GH * g.GW;
+            if (MODE == 1) {
+                a_pix[i] = (int)m;
+            } else {
+                const unsigned n = fast_div((unsigned)m, g.div_hw_mul, g.div_hw_shr);
+                const unsigned rem = (unsigned)m - n * (unsigned)(g.OH * g.OW);
+                const unsigned oh = fast_div(rem, g.div_w_mul, g.div_w_shr);
+                const unsigned ow = rem - oh * (unsigned)g.OW;
+                if (MODE == 2) {
+                    a_h[i] = (int)oh * g.gm; a_w[i] = (int)ow * g.gm;
+                    a_pix[i] = (int)n * g.GH * g.GW + a_h[i] * g.GW + a_w[i];
+                } else {
+                    a_h[i] = (int)oh; a_w[i] = (int)ow;
+                    a_pix[i] = (int)n * g.GH * g.GW;
+                }
+            }
         } else {
-            a_nbase[i] = -1;
-            a_oh[i] = 0;
-            a_ow[i] = 0;
+            a_pix[i] = -1;
         }
+    }
+    // this thread's position in the reduction: k = tap*Cg + ci, tap = (r, s); advanced by BK per tile
+    int kk = lcol, ci = lcol, tr = 0, ts = 0;
+    if (MODE != 1 && g.R * g.S > 1) { const int tap = kk / g.Cg; ci = kk - tap * g.Cg; tr = tap / g.S; ts = tap - tr * g.S; }
+    int b_off[B_ROWS];
+#pragma unroll
+    for (int i = 0; i < B_ROWS; ++i) {
+        const int col = n0 + lrow + i * ROW_STEP;
+        b_off[i] = col < p.Ng ? col * g.K : -1;
     }
 
     float a_reg[A_ROWS][VEC], b_reg[B_ROWS][VEC];
 
-    auto load_tiles = [&](int kt) {
-        const int k = kt * BK + lcol;
-        const bool kvalid = k < g.K;
-        int tap = 0, ci = k, r = 0, s = 0;
-        if (g.R * g.S > 1) { tap = k / g.Cg; ci = k - tap * g.Cg; r = tap / g.S; s = tap - r * g.S; }
+    auto load_tiles = [&]() {
+        const bool kvalid = kk < g.K;
+        int dh = 0, dw = 0, dpix = 0;
+        if (MODE == 2) { dh = g.sgn * tr + g.off; dw = g.sgn * ts + g.off; dpix = dh * g.GW + dw; }
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
-            int gh = 0, gw = 0;
-            bool ok = kvalid && a_nbase[i] >= 0;
-            ok = ok && gather_coord(g, a_oh[i], r, g.GH, &gh);
-            ok = ok && gather_coord(g, a_ow[i], s, g.GW, &gw);
-            if (ok) {
-                const float* src = x + ((int64_t)(a_nbase[i] + gh * g.GW + gw)) * g.ldg + ci;
-                if (VEC == 4) { const float4 v = *reinterpret_cast<const float4*>(src); a_reg[i][0] = v.x; a_reg[i][1] = v.y; a_reg[i][2] = v.z; a_reg[i][3] = v.w; }
-                else a_reg[i][0] = src[0];
+            bool ok = kvalid && a_pix[i] >= 0;
+            int pix = a_pix[i];
+            if (MODE == 2) {
+                ok = ok && (unsigned)(a_h[i] + dh) < (unsigned)g.GH && (unsigned)(a_w[i] + dw) < (unsigned)g.GW;
+                pix += dpix;
+            } else if (MODE == 0) {
+                int gh = 0, gw = 0;
+                ok = ok && gather_coord(g, a_h[i], tr, g.GH, &gh);
+                ok = ok && gather_coord(g, a_w[i], ts, g.GW, &gw);
+                pix += gh * g.GW + gw;
+            }
+            const unsigned off = ok ? (unsigned)pix * (unsigned)g.ldg + (unsigned)ci : 0u;
+            if (VEC == 4) {
+                float4 v = *reinterpret_cast<const float4*>(x + off);
+                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                a_reg[i][0] = v.x; a_reg[i][1] = v.y; a_reg[i][2] = v.z; a_reg[i][3] = v.w;
             } else {
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) a_reg[i][v] = 0.f;
+                const float v = x[off];
+                a_reg[i][0] = ok ? v : 0.f;
             }
         }
 #pragma unroll
         for (int i = 0; i < B_ROWS; ++i) {
-            const int col = n0 + lrow + i * ROW_STEP;
-            if (kvalid && col < p.Ng) {
-                const float* src = f + (int64_t)col * g.K + k;
-                if (VEC == 4) { const float4 v = *reinterpret_cast<const float4*>(src); b_reg[i][0] = v.x; b_reg[i][1] = v.y; b_reg[i][2] = v.z; b_reg[i][3] = v.w; }
-                else b_reg[i][0] = src[0];
+            const bool ok = kvalid && b_off[i] >= 0;
+            const unsigned off = ok ? (unsigned)b_off[i] + (unsigned)kk : 0u;
+            if (VEC == 4) {
+                float4 v = *reinterpret_cast<const float4*>(f + off);
+                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                b_reg[i][0] = v.x; b_reg[i][1] = v.y; b_reg[i][2] = v.z; b_reg[i][3] = v.w;
             } else {
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) b_reg[i][v] = 0.f;
+                const float v = f[off];
+                b_reg[i][0] = ok ? v : 0.f;
             }
+        }
+        // advance to the next tile
+        kk += BK;
+        ci += BK;
+        if (MODE != 1) {
+            while (ci >= g.Cg && g.R * g.S > 1) { ci -= g.Cg; if (++ts == g.S) { ts = 0; ++tr; } }
         }
     };
     auto store_tiles = [&]() {
@@ -161,11 +209,11 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
 
     const int r32 = lane & 31, h = lane >> 5;
     const int nk = (g.K + BK - 1) / BK;
-    load_tiles(0);
+    load_tiles();
     store_tiles();
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_tiles(kt + 1);          // global loads in flight under the MFMAs below
+        if (kt + 1 < nk) load_tiles();                // global loads in flight under the MFMAs below
 #pragma unroll
         for (int kg = 0; kg < BK / 8; ++kg) {
             float4 af[TM], bf[TN];
@@ -258,39 +306,43 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams p) {
     int r = 0, s = 0, ci = kq;
     if (g.R * g.S > 1) { const int tap = kq / g.Cg; ci = kq - tap * g.Cg; r = tap / g.S; s = tap - r * g.S; }
     const bool a_valid_col = i0 + a_col < p.Ng;
+    const int dr = r - g.pad, ds = s - g.pad;          // wgrad always gathers x in forward form: g = o*stride - pad + tap
 
     float a_reg[A_IT][VECA], b_reg[B_IT][VECB];
     auto load_tiles = [&](int64_t mb) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int64_t m = mb + a_row + i * RA;
-            if (a_valid_col && m < mend) {
-                const float* src = dy + m * p.lddy + i0 + a_col;
-                if (VECA == 4) { const float4 v = *reinterpret_cast<const float4*>(src); a_reg[i][0] = v.x; a_reg[i][1] = v.y; a_reg[i][2] = v.z; a_reg[i][3] = v.w; }
-                else a_reg[i][0] = src[0];
+            const bool ok = a_valid_col && m < mend;
+            const float* src = dy + (ok ? m * p.lddy + i0 + a_col : 0);
+            if (VECA == 4) {
+                float4 v = *reinterpret_cast<const float4*>(src);
+                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                a_reg[i][0] = v.x; a_reg[i][1] = v.y; a_reg[i][2] = v.z; a_reg[i][3] = v.w;
             } else {
-#pragma unroll
-                for (int v = 0; v < VECA; ++v) a_reg[i][v] = 0.f;
+                const float v = src[0];
+                a_reg[i][0] = ok ? v : 0.f;
             }
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             const int64_t m = mb + b_row + i * RB;
             bool ok = kq_valid && m < mend;
-            int gh = 0, gw = 0, n = 0;
-            if (ok) {
-                n = (int)(m / ((int64_t)g.OH * g.OW));
-                const int rem = (int)(m - (int64_t)n * g.OH * g.OW);
-                const int oh = rem / g.OW, ow = rem - oh * g.OW;
-                ok = gather_coord(g, oh, r, g.GH, &gh) && gather_coord(g, ow, s, g.GW, &gw);
-            }
-            if (ok) {
-                const float* src = x + ((int64_t)n * g.GH * g.GW + gh * g.GW + gw) * g.ldg + ci;
-                if (VECB == 4) { const float4 v = *reinterpret_cast<const float4*>(src); b_reg[i][0] = v.x; b_reg[i][1] = v.y; b_reg[i][2] = v.z; b_reg[i][3] = v.w; }
-                else b_reg[i][0] = src[0];
+            const unsigned mu = ok ? (unsigned)m : 0u;
+            const unsigned n = fast_div(mu, g.div_hw_mul, g.div_hw_shr);
+            const unsigned rem = mu - n * (unsigned)(g.OH * g.OW);
+            const unsigned oh = fast_div(rem, g.div_w_mul, g.div_w_shr);
+            const unsigned ow = rem - oh * (unsigned)g.OW;
+            const int gh = (int)oh * g.stride + dr, gw = (int)ow * g.stride + ds;
+            ok = ok && (unsigned)gh < (unsigned)g.GH && (unsigned)gw < (unsigned)g.GW;
+            const unsigned off = ok ? ((unsigned)n * (unsigned)(g.GH * g.GW) + (unsigned)(gh * g.GW + gw)) * (unsigned)g.ldg + (unsigned)ci : 0u;
+            if (VECB == 4) {
+                float4 v = *reinterpret_cast<const float4*>(x + off);
+                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                b_reg[i][0] = v.x; b_reg[i][1] = v.y; b_reg[i][2] = v.z; b_reg[i][3] = v.w;
             } else {
-#pragma unroll
-                for (int v = 0; v < VECB; ++v) b_reg[i][v] = 0.f;
+                const float v = x[off];
+                b_reg[i][0] = ok ? v : 0.f;
             }
         }
     };
@@ -396,13 +448,50 @@ static int check_desc(const suhpe_conv_t* d, const char* who) {
     }
     const int ho = (d->h + 2 * d->pad - d->r) / d->stride + 1, wo = (d->w + 2 * d->pad - d->s) / d->stride + 1;
     if (ho != d->ho || wo != d->wo) { set_error("%s: ho/wo (%d,%d) do not match the geometry (%d,%d)", who, d->ho, d->wo, ho, wo); return SUHPE_EINVAL; }
+    const int64_t lim = (int64_t)1 << 31;      // kernels address tensors with 32-bit element offsets
+    if ((int64_t)d->n * d->h * d->w * d->cin >= lim || (int64_t)d->n * d->ho * d->wo * d->cout >= lim ||
+        (int64_t)d->cout * d->r * d->s * (d->cin / d->groups) >= lim) {
+        set_error("%s: tensor larger than 2^31 elements", who);
+        return SUHPE_EINVAL;
+    }
     return SUHPE_OK;
+}
+
+static void magic_div(unsigned d, unsigned* mul, unsigned* shr) {
+    if (d <= 1) { *mul = 0; *shr = 0; return; }
+    unsigned lg = 0;
+    while ((1ull << lg) < d) ++lg;
+    const unsigned pw = 31 + lg;
+    *mul = (unsigned)(((1ull << pw) + d - 1) / d);
+    *shr = pw - 32;
+}
+
+static GatherGeom make_geom(int N, int GH, int GW, int OH, int OW, int ldg, int Cg, int R, int S, int stride, int pad, int mode) {
+    GatherGeom g;
+    g.N = N; g.GH = GH; g.GW = GW; g.OH = OH; g.OW = OW; g.ldg = ldg; g.Cg = Cg; g.R = R; g.S = S; g.stride = stride; g.pad = pad;
+    g.mode = mode; g.K = R * S * Cg; g.M = (int64_t)N * OH * OW;
+    if (mode == 0) { g.gm = stride; g.sgn = 1; g.off = -pad; }
+    else { g.gm = 1; g.sgn = -1; g.off = pad; }
+    magic_div((unsigned)(OH * OW), &g.div_hw_mul, &g.div_hw_shr);
+    magic_div((unsigned)OW, &g.div_w_mul, &g.div_w_shr);
+    return g;
+}
+
+// fast-path selector: 1 = pointwise, 2 = affine taps, 0 = generic
+static int nt_mode(const GatherGeom& g) {
+    if (g.R == 1 && g.S == 1 && g.stride == 1 && g.pad == 0) return 1;
+    if (g.mode == 0 || g.stride == 1) return 2;
+    return 0;
 }
 
 template <int BM, int BN, int WM, int WN, int VEC>
 static void launch_nt(const NtParams& p, int groups, hipStream_t st) {
     dim3 grid((unsigned)ceil_div(p.g.M, BM), (unsigned)ceil_div(p.Ng, BN), groups);
-    hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC>), grid, dim3(256), 0, st, p);
+    switch (nt_mode(p.g)) {
+        case 1: hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1>), grid, dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 2>), grid, dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 0>), grid, dim3(256), 0, st, p); break;
+    }
 }
 
 // tile selection for igemm_nt; returns the kernel's name (as rocprofv3 prints the template arguments)
@@ -444,8 +533,7 @@ int suhpe_conv2d_fwd(const suhpe_conv_t* d, const float* x, const float* w, cons
     SUHPE_REQUIRE(x && w && y, "suhpe_conv2d_fwd: null pointer");
     NtParams p;
     const int cg = d->cin / d->groups;
-    p.g = GatherGeom{d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0, d->r * d->s * cg,
-                     (int64_t)d->n * d->ho * d->wo};
+    p.g = make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0);
     p.x = x; p.f = w; p.bias = bias; p.y = y; p.Ng = d->cout / d->groups; p.ldy = d->cout;
     const bool vec4 = (cg % 4 == 0) && (d->cin % 4 == 0) && aligned16(x) && aligned16(w);
     dispatch_nt(p, d->groups, vec4, as_stream(stream));
@@ -469,8 +557,7 @@ int suhpe_conv2d_dgrad(const suhpe_conv_t* d, const float* dy, const float* wt, 
     NtParams p;
     const int ng = d->cout / d->groups, cg = d->cin / d->groups;
     // rows = input pixels (n,h,w); gathered tensor = dy (n,ho,wo,cout); filter rows = wt [cin][r][s][cout/groups]
-    p.g = GatherGeom{d->n, d->ho, d->wo, d->h, d->w, d->cout, ng, d->r, d->s, d->stride, d->pad, 1, d->r * d->s * ng,
-                     (int64_t)d->n * d->h * d->w};
+    p.g = make_geom(d->n, d->ho, d->wo, d->h, d->w, d->cout, ng, d->r, d->s, d->stride, d->pad, 1);
     p.x = dy; p.f = wt; p.bias = nullptr; p.y = dx; p.Ng = cg; p.ldy = d->cin;
     const bool vec4 = (ng % 4 == 0) && (d->cout % 4 == 0) && aligned16(dy) && aligned16(wt);
     dispatch_nt(p, d->groups, vec4, as_stream(stream));
@@ -533,8 +620,7 @@ int suhpe_conv2d_wgrad(const suhpe_conv_t* d, const float* x, const float* dy, f
     const int splits = wgrad_splits(d, bm, bn);
     const int ng = d->cout / d->groups, cg = d->cin / d->groups;
     TnParams p;
-    p.g = GatherGeom{d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0, d->r * d->s * cg,
-                     (int64_t)d->n * d->ho * d->wo};
+    p.g = make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0);
     p.dy = dy; p.x = x; p.slab = static_cast<float*>(workspace); p.Ng = ng; p.lddy = d->cout;
     p.m_per_split = ceil_div(ceil_div(p.g.M, splits), BK) * BK;
     p.tiles_n = (int)ceil_div(p.g.K, bn);
