@@ -38,6 +38,11 @@ struct GatherGeom {
     int gm, sgn, off;
     // magic numbers for n / (OH*OW) and rem / OW on dividends < 2^31 (q = umulhi(n, mul) >> shr)
     unsigned div_hw_mul, div_hw_shr, div_w_mul, div_w_shr;
+    // MODE 3 (dgrad of a strided conv, one launch per output parity class (ph,pw)): rows enumerate the sub-grid
+    // (n, a, b) -> output pixel (a*om+ph, b*om+pw) of a (YH,YW) tensor; taps enumerate only the filter rows/cols
+    // r = r0 + om*th, s = s0 + om*tw that hit this parity (R,S hold the enumerated counts, Sfull the filter width);
+    // gathered coordinate = a - th + off_h, b - tw + off_w.
+    int om, ph, pw, YH, YW, r0, s0, Sfull, off_h, off_w;
 };
 
 __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned mul, unsigned shr) {
@@ -66,6 +71,8 @@ struct NtParams {
     float* y;            // [M][ldy]
     int Ng;              // output columns per group
     int ldy;
+    int col_tiles;       // ceil(Ng / BN), set by the launcher
+    int ldf;             // filter row length in elements (== g.K except in MODE 3)
 };
 
 // ---------------------------------------------------------------------------------------------- igemm_nt
@@ -86,10 +93,18 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int grp = blockIdx.z;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // XCD-aware tile order: workgroups b and b+8 share an XCD (round-robin dispatch, speed only).  Column tiles of one
+    // row tile reuse the same gathered rows, so they are made consecutive on ONE XCD: xcd = b%8, j = b/8,
+    // col tile = j % col_tiles, row tile = (j / col_tiles)*8 + xcd.  Row tiles are padded to a multiple of 8 by the host.
+    const int b = blockIdx.x;
+    const int jx = b >> 3;
+    const int col_tile = jx % p.col_tiles;
+    const int row_tile = (jx / p.col_tiles) * 8 + (b & 7);
+    const int64_t m0 = (int64_t)row_tile * BM;
+    if (m0 >= g.M) return;                               // padding workgroup (whole block exits before any barrier)
+    const int n0 = col_tile * BN;
     const float* __restrict__ x = p.x + (int64_t)grp * g.Cg;
-    const float* __restrict__ f = p.f + (int64_t)grp * p.Ng * g.K;
+    const float* __restrict__ f = p.f + (int64_t)grp * p.Ng * p.ldf;
 
     // ---- loader geometry.  VEC=4: thread -> (vector column j = t&7, rows (t>>3)+32i).  VEC=1: (k = t&31, rows (t>>5)+8i)
     constexpr int A_ROWS = VEC == 4 ? BM / 32 : BM / 8;
@@ -113,7 +128,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
                 const unsigned rem = (unsigned)m - n * (unsigned)(g.OH * g.OW);
                 const unsigned oh = fast_div(rem, g.div_w_mul, g.div_w_shr);
                 const unsigned ow = rem - oh * (unsigned)g.OW;
-                if (MODE == 2) {
+                if (MODE == 2 || MODE == 3) {
                     a_h[i] = (int)oh * g.gm; a_w[i] = (int)ow * g.gm;
                     a_pix[i] = (int)n * g.GH * g.GW + a_h[i] * g.GW + a_w[i];
                 } else {
@@ -132,7 +147,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
 #pragma unroll
     for (int i = 0; i < B_ROWS; ++i) {
         const int col = n0 + lrow + i * ROW_STEP;
-        b_off[i] = col < p.Ng ? col * g.K : -1;
+        b_off[i] = col < p.Ng ? col * p.ldf : -1;
     }
 
     float a_reg[A_ROWS][VEC], b_reg[B_ROWS][VEC];
@@ -141,11 +156,14 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
         const bool kvalid = kk < g.K;
         int dh = 0, dw = 0, dpix = 0;
         if (MODE == 2) { dh = g.sgn * tr + g.off; dw = g.sgn * ts + g.off; dpix = dh * g.GW + dw; }
+        if (MODE == 3) { dh = g.off_h - tr; dw = g.off_w - ts; dpix = dh * g.GW + dw; }
+        // position of this k inside a filter row (differs from kk only when the taps are a sub-lattice, MODE 3)
+        const int fk = MODE == 3 ? ((g.r0 + g.om * tr) * g.Sfull + g.s0 + g.om * ts) * g.Cg + ci : kk;
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
             bool ok = kvalid && a_pix[i] >= 0;
             int pix = a_pix[i];
-            if (MODE == 2) {
+            if (MODE == 2 || MODE == 3) {
                 ok = ok && (unsigned)(a_h[i] + dh) < (unsigned)g.GH && (unsigned)(a_w[i] + dw) < (unsigned)g.GW;
                 pix += dpix;
             } else if (MODE == 0) {
@@ -167,7 +185,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
 #pragma unroll
         for (int i = 0; i < B_ROWS; ++i) {
             const bool ok = kvalid && b_off[i] >= 0;
-            const unsigned off = ok ? (unsigned)b_off[i] + (unsigned)kk : 0u;
+            const unsigned off = ok ? (unsigned)b_off[i] + (unsigned)fk : 0u;
             if (VEC == 4) {
                 float4 v = *reinterpret_cast<const float4*>(f + off);
                 if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -250,7 +268,16 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int64_t row = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row < g.M) y[row * p.ldy + col] = acc[i][j][e] + bv;
+                if (row >= g.M) continue;
+                int64_t orow = row;
+                if (MODE == 3) {        // sub-grid row (n,a,b) -> pixel (n, a*om+ph, b*om+pw) of the full output
+                    const unsigned n = fast_div((unsigned)row, g.div_hw_mul, g.div_hw_shr);
+                    const unsigned rem = (unsigned)row - n * (unsigned)(g.OH * g.OW);
+                    const unsigned a = fast_div(rem, g.div_w_mul, g.div_w_shr);
+                    const unsigned bb = rem - a * (unsigned)g.OW;
+                    orow = ((int64_t)n * g.YH + a * g.om + g.ph) * g.YW + bb * g.om + g.pw;
+                }
+                y[orow * p.ldy + col] = acc[i][j][e] + bv;
             }
     }
 }
@@ -264,7 +291,7 @@ struct TnParams {
     int Ng;              // output channels per group (rows of dW per group)
     int lddy;
     int64_t m_per_split; // multiple of BK
-    int tiles_n;         // tiles along k'
+    int tiles_m, tiles_n; // output tiles along cout and along k'
 };
 
 template <int BM, int BN, int WM, int WN, int VECA, int VECB>
@@ -279,10 +306,15 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams p) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int grp = blockIdx.z;
-    const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x % p.tiles_n;
+    // XCD-aware order: all output tiles of one m-split run consecutively on one XCD (they stream the same dy / x rows)
+    const int tiles = p.tiles_m * p.tiles_n;
+    const int jx = blockIdx.x >> 3;
+    const int tile = jx % tiles;
+    const int split = (jx / tiles) * 8 + (blockIdx.x & 7);
+    const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
     const int i0 = tile_m * BM;          // cout offset inside the group
     const int k0 = tile_n * BN;          // k' offset
-    const int64_t mbeg = (int64_t)blockIdx.y * p.m_per_split;
+    const int64_t mbeg = (int64_t)split * p.m_per_split;
     int64_t mend = mbeg + p.m_per_split;
     if (mend > g.M) mend = g.M;
     const float* __restrict__ dy = p.dy + (int64_t)grp * p.Ng;
@@ -397,7 +429,7 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams p) {
         }
     }
     // slab[split][grp*Ng + row][k']
-    float* __restrict__ out = p.slab + ((int64_t)blockIdx.y * gridDim.z * p.Ng + (int64_t)grp * p.Ng) * g.K;
+    float* __restrict__ out = p.slab + ((int64_t)split * gridDim.z * p.Ng + (int64_t)grp * p.Ng) * g.K;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = k0 + wn * WN + j * 32 + r32;
@@ -474,22 +506,28 @@ static GatherGeom make_geom(int N, int GH, int GW, int OH, int OW, int ldg, int 
     else { g.gm = 1; g.sgn = -1; g.off = pad; }
     magic_div((unsigned)(OH * OW), &g.div_hw_mul, &g.div_hw_shr);
     magic_div((unsigned)OW, &g.div_w_mul, &g.div_w_shr);
+    g.om = 1; g.ph = g.pw = 0; g.YH = OH; g.YW = OW; g.r0 = g.s0 = 0; g.Sfull = S; g.off_h = g.off_w = 0;
     return g;
 }
 
-// fast-path selector: 1 = pointwise, 2 = affine taps, 0 = generic
+// fast-path selector: 1 = pointwise, 2 = affine taps, 3 = parity class of a strided dgrad, 0 = generic
 static int nt_mode(const GatherGeom& g) {
+    if (g.om > 1) return 3;
     if (g.R == 1 && g.S == 1 && g.stride == 1 && g.pad == 0) return 1;
     if (g.mode == 0 || g.stride == 1) return 2;
     return 0;
 }
 
 template <int BM, int BN, int WM, int WN, int VEC>
-static void launch_nt(const NtParams& p, int groups, hipStream_t st) {
-    dim3 grid((unsigned)ceil_div(p.g.M, BM), (unsigned)ceil_div(p.Ng, BN), groups);
+static void launch_nt(const NtParams& p_in, int groups, hipStream_t st) {
+    NtParams p = p_in;
+    p.col_tiles = (int)ceil_div(p.Ng, BN);
+    const int64_t row_tiles8 = ceil_div(ceil_div(p.g.M, BM), 8) * 8;
+    dim3 grid((unsigned)(row_tiles8 * p.col_tiles), 1, groups);
     switch (nt_mode(p.g)) {
         case 1: hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1>), grid, dim3(256), 0, st, p); break;
         case 2: hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 2>), grid, dim3(256), 0, st, p); break;
+        case 3: hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 3>), grid, dim3(256), 0, st, p); break;
         default: hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 0>), grid, dim3(256), 0, st, p); break;
     }
 }
@@ -501,13 +539,16 @@ static const char* kNtNames[] = {"igemm_nt_kernel<64,64,32,32,1>", "igemm_nt_ker
 
 static NtTile choose_nt(int64_t M, int ng, bool vec4) {
     if (!vec4) return NT_64x64_S;
-    // pick the column tile with the least padding waste, preferring wide tiles
-    int bn = 32;
-    auto waste = [&](int b) { return (double)(ceil_div(ng, b) * b) / ng; };
-    if (waste(128) <= waste(64) + 1e-9 && waste(128) <= waste(32) + 1e-9) bn = 128;
-    else if (waste(64) <= waste(32) + 1e-9) bn = 64;
-    if (M < 2048) return bn >= 64 ? NT_64x64 : NT_128x32;     // small row counts (Linear, SE): more, smaller tiles
-    return bn == 128 ? NT_128x128 : (bn == 64 ? NT_128x64 : NT_256x32);
+    if (M < 2048) return ng > 32 ? NT_64x64 : NT_128x32;     // small row counts (Linear, SE): more, smaller tiles
+    if (ng <= 32) return NT_256x32;                           // narrow outputs are operand-bandwidth bound anyway
+    // padded columns / relative efficiency of the tile (measured: 128-wide ~1.0, 64-wide ~0.85)
+    const double c128 = (double)(ceil_div(ng, 128) * 128), c64 = (double)(ceil_div(ng, 64) * 64) / 0.85;
+    NtTile tile = c128 <= c64 ? NT_128x128 : NT_128x64;
+    // keep >= ~1.5 workgroups per CU: shrink the tile when the grid would under-fill the 256 CUs
+    auto blocks = [&](int bm, int bn) { return ceil_div(M, bm) * ceil_div(ng, bn); };
+    if (tile == NT_128x128 && blocks(128, 128) < 384) tile = NT_128x64;
+    if (tile == NT_128x64 && blocks(128, 64) < 384) tile = NT_64x64;
+    return tile;
 }
 
 static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st) {
@@ -534,7 +575,7 @@ int suhpe_conv2d_fwd(const suhpe_conv_t* d, const float* x, const float* w, cons
     NtParams p;
     const int cg = d->cin / d->groups;
     p.g = make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0);
-    p.x = x; p.f = w; p.bias = bias; p.y = y; p.Ng = d->cout / d->groups; p.ldy = d->cout;
+    p.x = x; p.f = w; p.bias = bias; p.y = y; p.Ng = d->cout / d->groups; p.ldy = d->cout; p.ldf = p.g.K;
     const bool vec4 = (cg % 4 == 0) && (d->cin % 4 == 0) && aligned16(x) && aligned16(w);
     dispatch_nt(p, d->groups, vec4, as_stream(stream));
     return check_launch("suhpe_conv2d_fwd");
@@ -557,10 +598,30 @@ int suhpe_conv2d_dgrad(const suhpe_conv_t* d, const float* dy, const float* wt, 
     NtParams p;
     const int ng = d->cout / d->groups, cg = d->cin / d->groups;
     // rows = input pixels (n,h,w); gathered tensor = dy (n,ho,wo,cout); filter rows = wt [cin][r][s][cout/groups]
-    p.g = make_geom(d->n, d->ho, d->wo, d->h, d->w, d->cout, ng, d->r, d->s, d->stride, d->pad, 1);
-    p.x = dy; p.f = wt; p.bias = nullptr; p.y = dx; p.Ng = cg; p.ldy = d->cin;
     const bool vec4 = (ng % 4 == 0) && (d->cout % 4 == 0) && aligned16(dy) && aligned16(wt);
-    dispatch_nt(p, d->groups, vec4, as_stream(stream));
+    if (d->stride == 1) {
+        p.g = make_geom(d->n, d->ho, d->wo, d->h, d->w, d->cout, ng, d->r, d->s, d->stride, d->pad, 1);
+        p.x = dy; p.f = wt; p.bias = nullptr; p.y = dx; p.Ng = cg; p.ldy = d->cin; p.ldf = p.g.K;
+        dispatch_nt(p, d->groups, vec4, as_stream(stream));
+    } else {
+        // one launch per parity class of the input pixel: only the taps r = (ph+pad) mod stride (+ k*stride) reach it,
+        // so no MFMA work is spent on taps that are structurally zero (a masked gather would waste 1 - 1/stride^2).
+        const int st = d->stride;
+        for (int ph = 0; ph < st; ++ph)
+            for (int pw = 0; pw < st; ++pw) {
+                const int rh = (d->h - ph + st - 1) / st, rw = (d->w - pw + st - 1) / st;      // sub-grid extents
+                if (rh <= 0 || rw <= 0) continue;
+                const int r0 = (ph + d->pad) % st, s0 = (pw + d->pad) % st;
+                const int nth = r0 < d->r ? (d->r - r0 + st - 1) / st : 0, ntw = s0 < d->s ? (d->s - s0 + st - 1) / st : 0;
+                GatherGeom g = make_geom(d->n, d->ho, d->wo, rh, rw, d->cout, ng, nth, ntw, 1, 0, 1);
+                g.K = nth * ntw * ng;
+                g.om = st; g.ph = ph; g.pw = pw; g.YH = d->h; g.YW = d->w; g.r0 = r0; g.s0 = s0; g.Sfull = d->s;
+                g.off_h = (ph + d->pad - r0) / st; g.off_w = (pw + d->pad - s0) / st;
+                p.g = g;
+                p.x = dy; p.f = wt; p.bias = nullptr; p.y = dx; p.Ng = cg; p.ldy = d->cin; p.ldf = d->r * d->s * ng;
+                dispatch_nt(p, d->groups, vec4, as_stream(stream));
+            }
+    }
     return check_launch("suhpe_conv2d_dgrad");
 }
 
@@ -568,14 +629,14 @@ static int wgrad_splits(const suhpe_conv_t* d, int bm, int bn) {
     const int ng = d->cout / d->groups, K = d->r * d->s * (d->cin / d->groups);
     const int64_t M = (int64_t)d->n * d->ho * d->wo;
     const int64_t tiles = ceil_div(ng, bm) * ceil_div(K, bn) * d->groups;
-    int64_t splits = ceil_div(1536, tiles);
-    const int64_t max_by_m = ceil_div(M, 8 * BK);           // at least 256 rows per split
+    int64_t splits = ceil_div(768, tiles);
+    const int64_t max_by_m = ceil_div(M, 16 * BK);          // at least 512 rows per split
     if (splits > max_by_m) splits = max_by_m;
     const int64_t slab = (int64_t)d->cout * K * 4;
     const int64_t cap = (int64_t)384 << 20;                  // keep slabs under 384 MiB
     if (splits * slab > cap) splits = cap / slab;
     if (splits < 1) splits = 1;
-    return (int)splits;
+    return (int)(ceil_div(splits, 8) * 8);                   // multiple of 8: one XCD per split (see igemm_tn_kernel)
 }
 
 static void wgrad_tile(const suhpe_conv_t* d, int* bm, int* bn) {
@@ -589,7 +650,10 @@ const char* suhpe_conv2d_kernel_name(const suhpe_conv_t* d, int pass) {
     if (!d || d->groups <= 0) return "";
     const int ng = d->cout / d->groups, cg = d->cin / d->groups;
     if (pass == 0) return kNtNames[choose_nt((int64_t)d->n * d->ho * d->wo, ng, cg % 4 == 0 && d->cin % 4 == 0)];
-    if (pass == 1) return kNtNames[choose_nt((int64_t)d->n * d->h * d->w, cg, ng % 4 == 0 && d->cout % 4 == 0)];
+    if (pass == 1) {
+        const int st = d->stride;
+        return kNtNames[choose_nt((int64_t)d->n * ((d->h + st - 1) / st) * ((d->w + st - 1) / st), cg, ng % 4 == 0 && d->cout % 4 == 0)];
+    }
     const bool va = ng % 4 == 0 && d->cout % 4 == 0, vb = cg % 4 == 0 && d->cin % 4 == 0;
     if (!(va && vb)) return va ? "igemm_tn_kernel<64,64,32,32,4,1>" : (vb ? "igemm_tn_kernel<64,64,32,32,1,4>" : "igemm_tn_kernel<64,64,32,32,1,1>");
     int bm, bn;
@@ -624,10 +688,10 @@ int suhpe_conv2d_wgrad(const suhpe_conv_t* d, const float* x, const float* dy, f
     p.dy = dy; p.x = x; p.slab = static_cast<float*>(workspace); p.Ng = ng; p.lddy = d->cout;
     p.m_per_split = ceil_div(ceil_div(p.g.M, splits), BK) * BK;
     p.tiles_n = (int)ceil_div(p.g.K, bn);
-    const int tiles_m = (int)ceil_div(ng, bm);
+    p.tiles_m = (int)ceil_div(ng, bm);
     const bool va = (ng % 4 == 0) && (d->cout % 4 == 0) && aligned16(dy);
     const bool vb = (cg % 4 == 0) && (d->cin % 4 == 0) && aligned16(x);
-    dim3 grid(tiles_m * p.tiles_n, splits, d->groups);
+    dim3 grid(p.tiles_m * p.tiles_n * splits, 1, d->groups);
     hipStream_t st = as_stream(stream);
 #define TN_LAUNCH(BM_, BN_, WM_, WN_, VA_, VB_) hipLaunchKernelGGL((igemm_tn_kernel<BM_, BN_, WM_, WN_, VA_, VB_>), grid, dim3(256), 0, st, p)
     if (va && vb) {
@@ -638,7 +702,8 @@ int suhpe_conv2d_wgrad(const suhpe_conv_t* d, const float* x, const float* dy, f
     } else {
         // odd channel counts (RGB stem, 9-D head): scalar loaders, generic 64x64 tile
         p.tiles_n = (int)ceil_div(p.g.K, 64);
-        grid = dim3((unsigned)(ceil_div(ng, 64) * p.tiles_n), splits, d->groups);
+        p.tiles_m = (int)ceil_div(ng, 64);
+        grid = dim3((unsigned)(p.tiles_m * p.tiles_n * splits), 1, d->groups);
         if (va) TN_LAUNCH(64, 64, 32, 32, 4, 1);
         else if (vb) TN_LAUNCH(64, 64, 32, 32, 1, 4);
         else TN_LAUNCH(64, 64, 32, 32, 1, 1);

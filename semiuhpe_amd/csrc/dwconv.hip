@@ -149,13 +149,13 @@ static int dw_check(const suhpe_conv_t* d, const char* who) {
     return SUHPE_OK;
 }
 
-static DwGeom dw_geom(const suhpe_conv_t* d, int mode, int max_blocks) {
+static DwGeom dw_geom(const suhpe_conv_t* d, int mode, int max_blocks, int cw_cap = 256) {
     DwGeom g;
     g.N = d->n; g.C = d->cin; g.R = d->r; g.S = d->s; g.stride = d->stride; g.pad = d->pad; g.mode = mode;
     if (mode == 0) { g.GH = d->h; g.GW = d->w; g.OH = d->ho; g.OW = d->wo; }
     else { g.GH = d->ho; g.GW = d->wo; g.OH = d->h; g.OW = d->w; }
     const int cv = g.C / 4;
-    g.cw = cv < 256 ? cv : 256;
+    g.cw = cv < cw_cap ? cv : cw_cap;
     g.rp = 256 / g.cw;
     g.P = (int64_t)g.N * g.OH * g.OW;
     int64_t gx = ceil_div(g.P, (int64_t)g.rp * 4);
@@ -202,7 +202,7 @@ int suhpe_dwconv_wgrad(const suhpe_conv_t* d, const float* x, const float* dy, f
     if (rc) return rc;
     SUHPE_REQUIRE(x && dy && dw && workspace, "suhpe_dwconv_wgrad: null pointer");
     if (workspace_bytes < suhpe_dwconv_wgrad_workspace_bytes(d)) { set_error("suhpe_dwconv_wgrad: workspace too small"); return SUHPE_EWORKSPACE; }
-    const DwGeom g = dw_geom(d, 0, kDwMaxRowBlocks);
+    const DwGeom g = dw_geom(d, 0, kDwMaxRowBlocks, 32);      // narrow channel chunks: more workgroups per slab
     const int gx = (int)ceil_div(g.P, g.pix_per_block), ny = (int)ceil_div(g.C / 4, g.cw);
     float* part = static_cast<float*>(workspace);
     hipLaunchKernelGGL(dw_wgrad_partial, dim3(gx, ny), dim3(256), 0, as_stream(stream), g, x, dy, part);

@@ -77,5 +77,21 @@ def main():
     print("per-image-batch totals (s): fwd %.4f dgrad %.4f wgrad %.4f ; fwd TF/s overall %.2f" % (tot[0], tot[1], tot[2], totf / tot[0] / 1e12))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "gemm"):
     main()
+
+
+def gemm_main():
+    """asymptotic main-loop efficiency: plain GEMMs (1x1 conv) with large K"""
+    for (m, k, n) in ((32768, 4096, 1024), (32768, 1024, 1024), (32768, 256, 1024), (8192, 4096, 4096), (32768, 4096, 64), (32768, 4096, 32)):
+        x = torch.randn(m, 1, 1, k, device="cuda")
+        w = torch.randn(n, k, 1, 1, device="cuda")
+        fl = 2.0 * m * k * n
+        t = timeit(lambda: K.conv2d_fwd(x, w, None, 1, 0, 1), 5)
+        dy = torch.randn(m, 1, 1, n, device="cuda")
+        t2 = timeit(lambda: K.conv2d_wgrad(x, dy, w.shape, 1, 0, 1), 5)
+        print(f"M={m} K={k} N={n}: fwd {t*1e6:9.1f} us {fl/t/1e12:7.2f} TF/s | wgrad {t2*1e6:9.1f} us {fl/t2/1e12:7.2f} TF/s")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "gemm":
+    gemm_main()
