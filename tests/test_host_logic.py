@@ -1,0 +1,83 @@
+"""CPU tests of the host-side mirror of the reference interface: config surface, exp_detail naming, settings files,
+batch-dict contract of the synthetic loaders, EMA alpha schedule, TrainClock."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_settings_files_carry_the_reference_keys():
+    keys = {"gpu_ids", "exp_name", "is_full_range", "train_labeled", "train_unlabeled", "test_set", "ss_ratio", "network",
+            "SSL_lambda", "conf_thres", "is_ema", "ema_decay", "type_unsuper", "distribution", "lr", "batch_size", "num_workers",
+            "ulb_batch_ratio", "stage1_iteration", "max_iteration", "log_frequency", "val_frequency", "save_frequency"}
+    files = sorted(f for f in os.listdir(os.path.join(ROOT, "settings")) if f.endswith(".yml"))
+    assert len(files) == 13
+    for f in files:
+        y = yaml.safe_load(open(os.path.join(ROOT, "settings", f)))
+        assert keys <= set(y), (f, keys - set(y))
+        assert y["exp_name"] == f[:-4].replace("_RL", "") or y["exp_name"] == f[:-4]
+        assert float(y["lr"]) == 1e-4 and y["conf_thres"] == -5.3
+
+
+def test_config_cli_overrides_yaml_and_exp_detail(tmp_path):
+    from semiuhpe_amd.src.config import get_config
+    argv = ["--config", os.path.join(ROOT, "settings", "DAD3DHeads_WildHead.yml"), "--network", "effinetv2", "--batch_size", "64",
+            "--ulb_batch_ratio", "4", "--is_full_range", "--dynamic_thres", "--cutout_aug", "--cutmix_aug", "--rotate_aug",
+            "--left_ratio", "0.75", "--exp_root", str(tmp_path)]
+    cfg = get_config("train", argv)
+    # name of the released checkpoint's experiment in the reference README
+    assert cfg.exp_detail == "SSL1_r0.05_ce_effinetv2_tDyna0.75_b64_ema_RO_CO_CM_full" or \
+        cfg.exp_detail == "SSL1.0_r0.05_ce_effinetv2_tDyna0.75_b64_ema_RO_CO_CM_full"
+    assert cfg.num_classes == 9 and cfg.is_ema is True and cfg.lr == 1e-4 and cfg.train_labeled == "DAD3DHeads"
+    assert os.path.isdir(cfg.log_dir) and os.path.exists(os.path.join(cfg.log_dir, "log.txt"))
+    cfg2 = get_config("test", ["--config", os.path.join(ROOT, "settings", "DAD3DHeads_WildHead.yml"), "--exp_root", str(tmp_path),
+                               f"{cfg.exp_detail}/{cfg.date}/best"])
+    assert cfg2.ckpt == "best" and cfg2.log_dir == cfg.log_dir
+
+
+def test_synthetic_loader_batch_contract():
+    from types import SimpleNamespace
+
+    from semiuhpe_amd.src.datasets import build_loaders
+    os.environ["SUHPE_SYNTH_SIZE"] = "32"
+    os.environ["SUHPE_SYNTH_BATCHES"] = "2"
+    try:
+        cfg = SimpleNamespace(exp_name="300WLP_AFLW2000", is_full_range=False, synthetic=True, batch_size=8, ulb_batch_ratio=4,
+                              stage1_iteration=1, max_iteration=2, rotate_aug=True)
+        train, ulb, test = build_loaders(cfg)
+        d = next(iter(train))
+        assert set(d) == {"img", "rot_mat", "euler_angles"} and d["img"].shape == (8, 3, 32, 32) and d["rot_mat"].shape == (8, 3, 3)
+        R = d["rot_mat"].double()
+        assert torch.allclose(R @ R.transpose(1, 2), torch.eye(3, dtype=torch.float64).expand(8, 3, 3), atol=1e-6)
+        u = next(iter(ulb))
+        assert set(u) == {"img", "img_strong", "aug_rot_mat"} and u["img"].shape[0] == 32
+        ang = torch.rad2deg(torch.atan2(u["aug_rot_mat"][:, 0, 1], u["aug_rot_mat"][:, 0, 0]))
+        assert float(ang.abs().max()) <= 30.0 and float(ang.abs().max()) > 0
+        cfg.exp_name, cfg.is_full_range = "DAD3DHeads_WildHead", True
+        d = next(iter(build_loaders(cfg)[0]))
+        assert "euler_angles" not in d
+        # data-parallel sharding: per-rank batch = global / world, different seeds per rank
+        t0 = next(iter(build_loaders(cfg, rank=0, world=2)[0]))
+        t1 = next(iter(build_loaders(cfg, rank=1, world=2)[0]))
+        assert t0["img"].shape[0] == 4 and not torch.equal(t0["img"], t1["img"])
+    finally:
+        os.environ.pop("SUHPE_SYNTH_SIZE"); os.environ.pop("SUHPE_SYNTH_BATCHES")
+
+
+def test_clock_and_ema_schedule():
+    from semiuhpe_amd.src.utils import TrainClock
+    c = TrainClock()
+    for _ in range(3):
+        c.tick()
+    c.tock()
+    ck = c.make_checkpoint()
+    assert ck == {"epoch": 1, "minibatch": 0, "iteration": 3}
+    c2 = TrainClock(); c2.restore_checkpoint(ck)
+    assert c2.iteration == 3
+    # alpha = min(1 - 1/(t+1), decay): 0, 1/2, 2/3, ... then the decay (reference agent.py:277-283)
+    alphas = [min(1 - 1 / (t + 1), 0.999) for t in (0, 1, 2, 5000)]
+    assert alphas[0] == 0 and abs(alphas[1] - 0.5) < 1e-12 and abs(alphas[2] - 2 / 3) < 1e-12 and alphas[3] == 0.999
