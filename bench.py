@@ -157,8 +157,8 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        from semiuhpe_amd.src.distributed import init_from_env
+        init_from_env("nccl")
     dt, info, roof = gpu_leg(args, rank, world, device)
     if rank == 0:
         ms = dt / args.steps * 1e3

@@ -16,9 +16,9 @@ from datetime import datetime
 
 import numpy as np
 import torch
-import torch.distributed as dist
 
 from .. import kernels as K
+from . import distributed as D
 from . import utils
 from .augments import strong_view_nhwc
 from .fisher.fisher_utils import batch_torch_A_to_R, fisher_CE, fisher_entropy
@@ -76,15 +76,20 @@ class SSLAgent:
         self.optimizer = FusedAdam(self.net.parameters(), config.lr)
         self.optimizer.flatten()
         self._ema_flat = FlatBuffer(list(self.ema_net.parameters()), with_grad=False)
-        self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        self.rank = dist.get_rank() if self.world_size > 1 else 0
+        self.rank, self.world_size = D.world()
+        # BatchNorm running statistics of each network as one flat buffer (averaged across ranks once per step)
+        def bn_stats(net):
+            bufs = [b for n, b in net.named_buffers() if b.dtype == torch.float32]
+            return FlatBuffer(bufs, with_grad=False) if bufs else None
+        self._bn_flat, self._bn_flat_ema = bn_stats(self.net), bn_stats(self.ema_net)
         if self.world_size > 1:                       # identical replicas to start from (rank 0's init)
             for fb in self.optimizer.flat_buffers:
-                dist.broadcast(fb.data, 0)
-            dist.broadcast(self._ema_flat.data, 0)
-            for b0, b1 in zip(self.net.buffers(), self.ema_net.buffers()):
-                dist.broadcast(b0, 0)
-                dist.broadcast(b1, 0)
+                D.broadcast_(fb.data, 0)
+            D.broadcast_(self._ema_flat.data, 0)
+            for fb in (self._bn_flat, self._bn_flat_ema):
+                if fb is not None:
+                    D.broadcast_(fb.data, 0)
+        self._grad_seed = D.grad_seed(self.device)
         self._thres_host = None
         self._thres_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._finite_flag = None
@@ -178,11 +183,15 @@ class SSLAgent:
         return fisher_dict, fisher_dict_unsuper
 
     # ------------------------------------------------------------------------------------------------ steps
-    def _allreduce_grads(self):
+    def _exchange(self):
+        """The one exchange step of data-parallel training: SUM all-reduce of the flat (pre-scaled) gradient, AVG of the
+        BatchNorm running statistics of student and teacher."""
         if self.world_size > 1:
             for fb in self.optimizer.flat_buffers:
-                dist.all_reduce(fb.grad, op=dist.ReduceOp.SUM)
-                K.call("suhpe_axpby", K.ptr(fb.grad), 1.0 / self.world_size, None, 0.0, fb.grad.numel(), K.ptr(fb.grad))
+                D.allreduce_sum_(fb.grad)
+            for fb in (self._bn_flat, self._bn_flat_ema):
+                if fb is not None:
+                    D.allreduce_avg_(fb.data)
 
     def train_func(self, data, ulb_data):
         """one SSL step (reference :194-218)"""
@@ -195,8 +204,8 @@ class SSLAgent:
         SSL_lambda = self.config.SSL_lambda
         loss_all = _Axpby.apply(fisher_dict["loss"].reshape(1), fisher_dict_unsuper["unsuper_loss"].reshape(1),
                                 float(SSL_lambda)).squeeze(0)
-        loss_all.backward()
-        self._allreduce_grads()
+        loss_all.backward(self._grad_seed)
+        self._exchange()
         self.optimizer.step()
         return fisher_dict, fisher_dict_unsuper, dict(SSL_lambda=SSL_lambda, loss_all=loss_all.detach())
 
@@ -205,8 +214,8 @@ class SSLAgent:
         self.net.train()
         self.optimizer.zero_grad()
         fisher_dict, _ = self.forward(data, None)
-        fisher_dict["loss"].backward()
-        self._allreduce_grads()
+        fisher_dict["loss"].backward(self._grad_seed)
+        self._exchange()
         self.optimizer.step()
         return fisher_dict
 
@@ -299,15 +308,7 @@ class SSLAgent:
                 pred_weak = self.ema_net(_dev(ulb_data.get("img"), self.device))
                 chunks.append(fisher_entropy(pred_weak))
         ent = torch.cat(chunks) if chunks else torch.zeros(0, device=self.device)
-        if self.world_size > 1:
-            sizes = [torch.zeros(1, dtype=torch.long, device=self.device) for _ in range(self.world_size)]
-            dist.all_gather(sizes, torch.tensor([ent.numel()], dtype=torch.long, device=self.device))
-            mx = int(max(int(s.item()) for s in sizes))
-            pad = torch.zeros(mx, device=self.device)
-            pad[:ent.numel()] = ent
-            parts = [torch.zeros(mx, device=self.device) for _ in range(self.world_size)]
-            dist.all_gather(parts, pad)
-            ent = torch.cat([p[:int(s.item())] for p, s in zip(parts, sizes)])
+        ent = D.gather_varlen(ent)
         entropy_all = ent.cpu().numpy()
         entropy_all.sort()
         index = int(len(entropy_all) * self.config.left_ratio)

@@ -15,6 +15,7 @@ import torch.distributed as dist
 from semiuhpe_amd.src.agent import get_agent
 from semiuhpe_amd.src.config import get_config
 from semiuhpe_amd.src.datasets import build_loaders
+from semiuhpe_amd.src.distributed import init_from_env
 from semiuhpe_amd.src.utils import cycle, dict_get
 
 
@@ -49,11 +50,7 @@ def validate(agent, test_loader, s1, eval_ema, tag):
 
 
 def main():
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    if world > 1:
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+    rank, world = init_from_env("nccl")
     config = get_config("train")
     train_loader, ulb_train_loader, test_loader = build_loaders(config, rank, world)
     ssl = config.stage1_iteration < config.max_iteration
