@@ -201,3 +201,183 @@ class RepVggNet(nn.Module):
         for i in range(1, 5):
             x = getattr(self, f"layer{i}")(x)
         return self.linear_reg(torch.flatten(self.gap(x), 1))
+
+
+# ------------------------------------------------------------------------------------------------ TinyViT-21M
+class ConvBN(nn.Sequential):
+    """src/tiny_vit.py:28-50: children 'c' (conv, no bias) and 'bn'"""
+
+    def __init__(self, a, b, ks=1, stride=1, pad=0, groups=1):
+        super().__init__()
+        self.add_module("c", nn.Conv2d(a, b, ks, stride, pad, groups=groups, bias=False))
+        self.add_module("bn", nn.BatchNorm2d(b))
+
+
+class DropPath(nn.Module):
+    """timm DropPath: per-sample Bernoulli(keep)/keep in train mode"""
+
+    def __init__(self, p):
+        super().__init__()
+        self.p = p
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        m = _mask("drop_path", (x.shape[0],), 1.0 - self.p, x)
+        return x * m.view(-1, *([1] * (x.ndim - 1)))
+
+
+class TvMBConv(nn.Module):
+    """src/tiny_vit.py:84-122"""
+
+    def __init__(self, dim, expand, drop_path):
+        super().__init__()
+        hid = int(dim * expand)
+        self.conv1, self.conv2, self.conv3 = ConvBN(dim, hid, 1), ConvBN(hid, hid, 3, 1, 1, groups=hid), ConvBN(hid, dim, 1)
+        self.drop_path = DropPath(drop_path)
+
+    def forward(self, x):
+        y = F.gelu(self.conv1(x))
+        y = F.gelu(self.conv2(y))
+        y = self.drop_path(self.conv3(y))
+        return F.gelu(y + x)
+
+
+class TvPatchMerging(nn.Module):
+    """src/tiny_vit.py:125-151: 1x1 -> GELU -> dw3x3 s2 -> GELU -> 1x1, tokens out"""
+
+    def __init__(self, res, dim, out_dim):
+        super().__init__()
+        self.res = res
+        self.conv1, self.conv2, self.conv3 = ConvBN(dim, out_dim, 1), ConvBN(out_dim, out_dim, 3, 2, 1, groups=out_dim), ConvBN(out_dim, out_dim, 1)
+
+    def forward(self, x):
+        if x.ndim == 3:
+            B = x.shape[0]
+            x = x.view(B, self.res, self.res, -1).permute(0, 3, 1, 2)
+        x = self.conv3(F.gelu(self.conv2(F.gelu(self.conv1(x)))))
+        return x.flatten(2).transpose(1, 2)
+
+
+def attention_bias_index(ws):
+    """first-seen order of (|dy|,|dx|) offsets over points x points (src/tiny_vit.py:237-252) -> (N,N) long, count"""
+    pts = list(itertools.product(range(ws), range(ws)))
+    seen, idx = {}, []
+    for p1 in pts:
+        for p2 in pts:
+            off = (abs(p1[0] - p2[0]), abs(p1[1] - p2[1]))
+            if off not in seen:
+                seen[off] = len(seen)
+            idx.append(seen[off])
+    return torch.tensor(idx, dtype=torch.long).view(len(pts), len(pts)), len(seen)
+
+
+class TvAttention(nn.Module):
+    """src/tiny_vit.py:216-286 with attn_ratio = 1"""
+
+    def __init__(self, dim, key_dim, heads, ws):
+        super().__init__()
+        self.heads, self.kd, self.scale = heads, key_dim, key_dim ** -0.5
+        self.norm = nn.LayerNorm(dim)
+        self.qkv = nn.Linear(dim, 3 * key_dim * heads)
+        self.proj = nn.Linear(key_dim * heads, dim)
+        idx, n = attention_bias_index(ws)
+        self.attention_biases = nn.Parameter(torch.zeros(heads, n))
+        self.register_buffer("attention_bias_idxs", idx, persistent=False)
+
+    def forward(self, x):
+        B, N, _ = x.shape
+        qkv = self.qkv(self.norm(x)).view(B, N, self.heads, -1)
+        q, k, v = (t.permute(0, 2, 1, 3) for t in qkv.split([self.kd, self.kd, self.kd], dim=3))
+        attn = (q @ k.transpose(-2, -1)) * self.scale + self.attention_biases[:, self.attention_bias_idxs]
+        x = (attn.softmax(-1) @ v).transpose(1, 2).reshape(B, N, self.heads * self.kd)
+        return self.proj(x)
+
+
+class TvMlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.norm, self.fc1, self.fc2 = nn.LayerNorm(dim), nn.Linear(dim, hidden), nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(F.gelu(self.fc1(self.norm(x))))
+
+
+class TvBlock(nn.Module):
+    """src/tiny_vit.py:289-379"""
+
+    def __init__(self, dim, res, heads, ws, drop_path):
+        super().__init__()
+        self.dim, self.res, self.ws = dim, res, ws
+        self.attn = TvAttention(dim, dim // heads, heads, ws)
+        self.mlp = TvMlp(dim, dim * 4)
+        self.local_conv = ConvBN(dim, dim, 3, 1, 1, groups=dim)
+        self.drop_path = DropPath(drop_path)
+
+    def forward(self, x):
+        B, L, C = x.shape
+        H = W = self.res
+        res_x = x
+        if H == self.ws:
+            x = self.attn(x)
+        else:
+            assert H % self.ws == 0, "padding path not exercised at 224x224"
+            n = H // self.ws
+            x = x.view(B, n, self.ws, n, self.ws, C).transpose(2, 3).reshape(B * n * n, self.ws * self.ws, C)
+            x = self.attn(x)
+            x = x.view(B, n, n, self.ws, self.ws, C).transpose(2, 3).reshape(B, L, C)
+        x = res_x + self.drop_path(x)
+        x = self.local_conv(x.transpose(1, 2).reshape(B, C, H, W)).view(B, C, L).transpose(1, 2)
+        return x + self.drop_path(self.mlp(x))
+
+
+class _Stage(nn.Module):
+    def __init__(self, blocks, downsample):
+        super().__init__()
+        self.blocks = nn.ModuleList(blocks)
+        if downsample is not None:
+            self.downsample = downsample
+
+    def forward(self, x):
+        for b in self.blocks:
+            x = b(x)
+        return self.downsample(x) if hasattr(self, "downsample") else x
+
+
+class TinyViT21M(nn.Module):
+    """tiny_vit_21m_224 (src/tiny_vit.py:666-676) + the reference head (src/networks.py:419-428)"""
+    DIMS, DEPTHS, HEADS, WS = (96, 192, 384, 576), (2, 2, 6, 2), (3, 6, 12, 18), (7, 7, 14, 7)
+
+    def __init__(self, num_classes=9, drop_path_rate=0.2):
+        super().__init__()
+        d = self.DIMS
+        self.patch_embed = nn.Module()
+        self.patch_embed.seq = nn.Sequential(ConvBN(3, d[0] // 2, 3, 2, 1), nn.GELU(), ConvBN(d[0] // 2, d[0], 3, 2, 1))
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(self.DEPTHS))]
+        self.layers = nn.ModuleList()
+        res, k = 56, 0
+        for i in range(4):
+            out_dim = d[min(i + 1, 3)]
+            if i == 0:
+                blocks = [TvMBConv(d[0], 4.0, dpr[k + j]) for j in range(self.DEPTHS[0])]
+            else:
+                blocks = [TvBlock(d[i], res, self.HEADS[i], self.WS[i], dpr[k + j]) for j in range(self.DEPTHS[i])]
+            k += self.DEPTHS[i]
+            down = TvPatchMerging(res, d[i], out_dim) if i < 3 else None
+            self.layers.append(_Stage(blocks, down))
+            res //= 2 if i < 3 else 1
+        self.norm_head = nn.LayerNorm(d[3])
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                nn.init.zeros_(m.bias)
+        for m in self.modules():
+            if isinstance(m, TvMBConv):
+                nn.init.zeros_(m.conv3.bn.weight)           # bn_weight_init=0.0 (tiny_vit.py:100-101)
+        self.head = regression_head(d[3], 128, 64, num_classes)
+
+    def forward(self, x):
+        x = self.patch_embed.seq(x)
+        for layer in self.layers:
+            x = layer(x)
+        return self.head(self.norm_head(x.mean(1)))

@@ -1,0 +1,98 @@
+"""RepVGG-B1g2 backbone with the reference's module tree (src/repvgg.py:35-76,165-199; wrapper src/networks.py:229-290).
+
+The reference never re-parameterises during training or evaluation (`switch_to_deploy` is not called anywhere,
+SURVEY.md F11), so the block is the three-branch training form
+    out = ReLU( BN(conv3x3(x)) + BN(conv1x1(x)) + [BN(x) if cin == cout and stride == 1] )
+with per-branch batch statistics.  Blocks are Layers with explicit forward/backward over the HIP kernels.
+"""
+import torch.nn as nn
+
+from .. import kernels as K
+from ..layers import BatchNorm2d, Conv2d, GlobalAvgPool, Layer, Network, Sequential
+from .efficientnet_v2 import init_regression_head_, regression_head
+
+
+class _ConvBN(Layer):
+    """`conv_bn` of the reference (src/repvgg.py:28-32): children 'conv' and 'bn'"""
+
+    def __init__(self, cin, cout, k, stride, pad, groups):
+        super().__init__()
+        self.conv = Conv2d(cin, cout, k, stride, pad, groups, bias=False)
+        self.bn = BatchNorm2d(cout)
+
+
+class RepVGGBlock(Layer):
+    def __init__(self, in_channels, out_channels, stride=1, groups=1):
+        super().__init__()
+        self.rbr_identity = BatchNorm2d(in_channels) if out_channels == in_channels and stride == 1 else None
+        self.rbr_dense = _ConvBN(in_channels, out_channels, 3, stride, 1, groups)
+        self.rbr_1x1 = _ConvBN(in_channels, out_channels, 1, stride, 0, groups)
+        self.rbr_dense.bn.act = "relu"           # the block's ReLU is fused into the last kernel of the sum
+        self.need_input_grad = True
+
+    def fwd(self, x, tape):
+        t3 = self.rbr_dense.conv.fwd(x, tape)
+        t1 = self.rbr_1x1.conv.fwd(x, tape)
+        u = self.rbr_1x1.bn.fwd(t1, tape)
+        if self.rbr_identity is not None:
+            u = self.rbr_identity.fwd(x, tape, residual=u)
+        return self.rbr_dense.bn.fwd(t3, tape, residual=u)          # relu(bn(t3) + u)
+
+    def bwd(self, dout, tape):
+        out = tape[-1][4]                                           # forward output kept for the ReLU mask
+        d_t3 = self.rbr_dense.bn.bwd(dout, tape)
+        g = K.act_bwd(out, dout, out.shape[-1], "relu")             # dL/du = dout * (out > 0)
+        d_xid = self.rbr_identity.bwd(g, tape) if self.rbr_identity is not None else None
+        d_t1 = self.rbr_1x1.bn.bwd(g, tape)
+        self.rbr_1x1.conv.need_input_grad = self.rbr_dense.conv.need_input_grad = self.need_input_grad
+        dx1 = self.rbr_1x1.conv.bwd(d_t1, tape)
+        dx3 = self.rbr_dense.conv.bwd(d_t3, tape)
+        if not self.need_input_grad:
+            return None
+        dx = K.add(dx3, dx1)
+        return K.add(dx, d_xid) if d_xid is not None else dx
+
+
+def b1g2_stage_configs():
+    """(cin, cout, stride, groups): widths 64 | 128 256 512 2048, blocks 4/6/16/1, groups=2 on even layer indices 2..26
+    (src/repvgg.py:190-199, 213-214, 237-239)."""
+    stages = [[(3, 64, 2, 1)]]
+    in_planes, idx = 64, 1
+    for planes, n in ((128, 4), (256, 6), (512, 16), (2048, 1)):
+        blocks = []
+        for i in range(n):
+            blocks.append((in_planes, planes, 2 if i == 0 else 1, 2 if (idx % 2 == 0 and idx <= 26) else 1))
+            in_planes = planes
+            idx += 1
+        stages.append(blocks)
+    return stages
+
+
+class RepVggNet(Network):
+    def __init__(self, backbone_name="RepVGG-B1g2", num_classes=9):
+        super().__init__()
+        if backbone_name != "RepVGG-B1g2":
+            raise NotImplementedError("only RepVGG-B1g2 is instantiated by the reference (src/networks.py:231)")
+        st = b1g2_stage_configs()
+        self.layer0 = RepVGGBlock(*st[0][0])
+        self.layer0.need_input_grad = False
+        for i in range(1, 5):
+            setattr(self, f"layer{i}", Sequential(*[RepVGGBlock(*c) for c in st[i]]))
+        self.gap = GlobalAvgPool()
+        self.linear_reg = regression_head(2048, 512, 128, num_classes)
+        self.init_like_reference_()
+        init_regression_head_(self.linear_reg)
+
+    def _stages(self):
+        return [self.layer0, self.layer1, self.layer2, self.layer3, self.layer4]
+
+    def fwd(self, x, tape):
+        for s in self._stages():
+            x = s.fwd(x, tape)
+        return self.linear_reg.fwd(self.gap.fwd(x, tape), tape)
+
+    def bwd(self, dy, tape):
+        dy = self.gap.bwd(self.linear_reg.bwd(dy, tape), tape)
+        for s in reversed(self._stages()):
+            dy = s.bwd(dy, tape)
+        return dy

@@ -1,4 +1,5 @@
 """Helpers shared by the GPU parity tests: identical Bernoulli masks on both paths, gradient comparison."""
+import numpy as np
 import torch
 
 
@@ -43,3 +44,31 @@ def grad_mismatches(named_ref, named_got, rtol, atol_frac=1e-5):
         if err > lim:
             bad[n] = (err, lim)
     return bad
+
+
+def seeded_state_dict(template, seed):
+    """Deterministic weights for a module tree too large to commit: walk `template` (a state_dict) in key order with
+    one seeded generator.  Conv/Linear weights ~ N(0, 1/fan_in) * 1.5, BN/LN weight ~ U(0.6,1.4), biases ~ N(0,0.05),
+    running_mean ~ N(0,0.1), running_var ~ U(0.6,1.4), attention biases ~ N(0,0.5); integer buffers are kept."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, v in template.items():
+        if not torch.is_floating_point(v):
+            out[k] = v.clone()
+            continue
+        shape = tuple(v.shape)
+        if k.endswith("running_var"):
+            t = torch.rand(shape, generator=g) * 0.8 + 0.6
+        elif k.endswith("running_mean"):
+            t = torch.randn(shape, generator=g) * 0.1
+        elif k.endswith("attention_biases"):
+            t = torch.randn(shape, generator=g) * 0.5
+        elif v.ndim == 1 and k.endswith("weight"):
+            t = torch.rand(shape, generator=g) * 0.8 + 0.6
+        elif v.ndim == 1:
+            t = torch.randn(shape, generator=g) * 0.05
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            t = torch.randn(shape, generator=g) * (1.5 / fan_in ** 0.5)
+        out[k] = t.to(v.dtype)
+    return out

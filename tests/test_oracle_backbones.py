@@ -1,0 +1,123 @@
+"""Pins the oracle backbones (oracle/networks.py: RepVggNet, TinyViT21M and their blocks) against outputs of the
+reference's own modules (tests/golden/backbones.npz, made by tools/make_golden_backbones.py).  EfficientNetV2-S has no
+reference implementation to import (torchvision absent): parameter / MAC count sanity only (parity unpinned)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import networks as ON
+from parity_utils import seeded_state_dict
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "backbones.npz"))
+
+
+def check(store, key, got, rtol=2e-4):
+    got = got.detach().double().numpy() if torch.is_tensor(got) else np.asarray(got, np.float64)
+    if key in store.files:
+        ref = store[key].astype(np.float64)
+        assert np.abs(got - ref).max() <= rtol * max(1e-6, np.abs(ref).max()), key
+        return
+    stride = int(store[key + "@stride"])
+    ref = store[key + "@sample"].astype(np.float64)
+    smp = got.reshape(-1)[::stride][:4096]
+    assert np.abs(smp - ref).max() <= rtol * max(1e-6, np.abs(got).max()), key
+    sums = store[key + "@sums"]
+    assert abs(np.abs(got).sum() - sums[1]) <= 1e-3 * sums[1], key
+
+
+def run_net(model, tag, x, dy, keys):
+    model.eval()
+    with torch.no_grad():
+        check(G, tag + "/eval_out", model(x))
+    model.train()
+    for m in model.modules():
+        if isinstance(m, (ON.Dropout, ON.DropPath, ON.StochasticDepth)):
+            m.p = 0.0
+    out = model(x)
+    out.backward(dy)
+    check(G, tag + "/train_out", out)
+    params = dict(model.named_parameters())
+    for k in keys:
+        check(G, tag + "/grad/" + k, params[k].grad, rtol=1e-3)
+    sd = model.state_dict()
+    for k in G[tag + "/bn_keys"]:
+        check(G, tag + "/bn/" + str(k), sd[str(k)])
+
+
+def test_repvgg_b1g2_matches_reference():
+    m = ON.RepVggNet()
+    assert len(m.state_dict()) == int(G["repvgg/num_state_entries"]) == 467
+    m.load_state_dict(seeded_state_dict(m.state_dict(), 11))
+    keys = [k[len("repvgg/grad/"):].split("@")[0] for k in G.files if k.startswith("repvgg/grad/")]
+    run_net(m, "repvgg", torch.from_numpy(G["repvgg/x"]), torch.from_numpy(G["repvgg/dy"]), sorted(set(keys)))
+
+
+@pytest.mark.parametrize("tag,cfg", [("blockA", (64, 128, 2, 1)), ("blockB", (128, 128, 1, 2))])
+def test_repvgg_block(tag, cfg):
+    blk = ON.RepVGGBlock(*cfg)
+    blk.load_state_dict(seeded_state_dict(blk.state_dict(), 5))
+    blk.train()
+    x = torch.from_numpy(G[f"repvgg_{tag}/x"]).requires_grad_(True)
+    y = blk(x)
+    y.backward(torch.from_numpy(G[f"repvgg_{tag}/dy"]))
+    check(G, f"repvgg_{tag}/y", y)
+    check(G, f"repvgg_{tag}/dx", x.grad, 1e-3)
+    for k, p in blk.named_parameters():
+        check(G, f"repvgg_{tag}/grad/{k}", p.grad, 1e-3)
+
+
+def test_tinyvit_21m_matches_reference():
+    m = ON.TinyViT21M()
+    assert len(m.state_dict()) == int(G["tinyvit/num_state_entries"]) == 310
+    assert np.array_equal(m.layers[1].blocks[0].attn.attention_bias_idxs.numpy(), G["tinyvit/bias_idx_7"])
+    assert np.array_equal(m.layers[2].blocks[0].attn.attention_bias_idxs.numpy()[:2], G["tinyvit/bias_idx_14_row0"])
+    m.load_state_dict(seeded_state_dict(m.state_dict(), 13))
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(int(G["tinyvit/x_seed"]))) * 0.5
+    keys = [k[len("tinyvit/grad/"):].split("@")[0] for k in G.files if k.startswith("tinyvit/grad/")]
+    run_net(m, "tinyvit", x, torch.from_numpy(G["tinyvit/dy"]), sorted(set(keys)))
+
+
+def block_inputs(tag, yshape_fn):
+    meta = G[tag + "/meta"]
+    seed, wseed, shape = int(meta[0]), int(meta[1]), tuple(int(v) for v in meta[2:])
+    gb = torch.Generator().manual_seed(seed)
+    x = (torch.randn(*shape, generator=gb) * float(G[tag + "/scale"])).requires_grad_(True)
+    return x, gb, wseed
+
+
+@pytest.mark.parametrize("tag", ["tvblock", "attn", "mbconv", "patchmerge"])
+def test_tinyvit_blocks(tag):
+    mod = {"tvblock": lambda: ON.TvBlock(192, 28, 6, 7, 0.0), "attn": lambda: ON.TvAttention(384, 32, 12, 14),
+           "mbconv": lambda: ON.TvMBConv(96, 4.0, 0.0), "patchmerge": lambda: ON.TvPatchMerging(28, 192, 384)}[tag]()
+    x, gb, wseed = block_inputs(tag, None)
+    mod.load_state_dict(seeded_state_dict(mod.state_dict(), wseed))
+    mod.train()
+    y = mod(x)
+    y.backward(torch.randn(y.shape, generator=gb))
+    check(G, tag + "/y", y)
+    check(G, tag + "/dx", x.grad, 1e-3)
+    for k, p in mod.named_parameters():
+        check(G, tag + "/grad/" + k, p.grad, 1e-3)
+
+
+def test_efficientnet_v2_s_sanity_counts():
+    """torchvision's published numbers: 21,458,488 parameters with the ImageNet head (1,281,000) => 20,177,488 backbone."""
+    m = ON.EfficientNetV2S()
+    backbone = sum(p.numel() for n, p in m.named_parameters() if not n.startswith("classifier"))
+    assert backbone == 20177488 and backbone + 1281000 == 21458488
+    assert sum(p.numel() for p in m.parameters()) == 20901465
+    macs = 0
+
+    def hook(mod, inp, out):
+        nonlocal macs
+        macs += out.numel() * mod.weight.shape[1] * mod.weight.shape[2] * mod.weight.shape[3]
+
+    hs = [c.register_forward_hook(hook) for c in m.modules() if isinstance(c, torch.nn.Conv2d)]
+    m.eval()
+    with torch.no_grad():
+        m(torch.zeros(1, 3, 224, 224))
+    for h in hs:
+        h.remove()
+    assert abs(macs / 1e9 - 2.849) < 0.02
