@@ -440,6 +440,31 @@ def entropy_mask(H, thres):
     return mask, count
 
 
+# ---------------------------------------------------------------------------------------------- attention
+def window_attn_fwd(qkv, bias_table, bias_idx, B, H, W, ws, heads, scale, save_probs=True):
+    """qkv (B*H*W, heads*96) -> out (B*H*W, heads*32), probs (or None)"""
+    _chk(qkv, "qkv"); _chk(bias_table, "bias_table")
+    dh = qkv.shape[-1] // (3 * heads)
+    out = torch.empty((qkv.shape[0], heads * dh), dtype=torch.float32, device=qkv.device)
+    probs = None
+    if save_probs:
+        n = _lib.load().suhpe_window_attn_probs_elems(B, H, W, ws, heads)
+        probs = torch.empty(n, dtype=torch.float32, device=qkv.device)
+    call("suhpe_window_attn_fwd", ptr(qkv), ptr(bias_table), ptr(bias_idx), B, H, W, ws, heads, dh, bias_table.shape[1], float(scale),
+         ptr(out), ptr(probs))
+    return out, probs
+
+
+def window_attn_bwd(qkv, probs, dout, bias_idx, B, H, W, ws, heads, noff, scale, dbias):
+    _chk(qkv, "qkv"); _chk(dout, "dout")
+    dh = qkv.shape[-1] // (3 * heads)
+    dqkv = torch.empty_like(qkv)
+    ws_buf = workspace("attn", probs.numel() * 4, qkv.device)
+    call("suhpe_window_attn_bwd", ptr(qkv), ptr(probs), ptr(dout), ptr(bias_idx), B, H, W, ws, heads, dh, noff, float(scale), ptr(dqkv),
+         ptr(dbias), ptr(ws_buf))
+    return dqkv
+
+
 # ---------------------------------------------------------------------------------------------- optimiser
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
     call("suhpe_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),

@@ -1,0 +1,272 @@
+"""TinyViT-21M (224) backbone with the reference's module tree (src/tiny_vit.py:28-591, variant :666-676; head
+src/networks.py:407-441), as Layers with explicit forward/backward over the HIP kernels.
+
+Everything stays in the (B, H, W, C) pixel-major layout: the reference's NCHW <-> token transposes
+(tiny_vit.py:141-150, 370-374) and the window partition / reverse copies (:356-366) disappear — convolutions, LayerNorm,
+Linear and the windowed attention kernel all address the same tensor.
+"""
+import itertools
+
+import torch
+import torch.nn as nn
+
+from .. import kernels as K
+from ..layers import (BatchNorm2d, Conv2d, Dropout, Identity, Layer, LayerNorm, Linear, Network, Sequential, draw_mask, grad_of)
+from .efficientnet_v2 import init_regression_head_, regression_head
+
+
+class Conv2d_BN(Layer):
+    """src/tiny_vit.py:28-50: children 'c' (conv, no bias) and 'bn'; the activation that follows is fused into bn."""
+
+    def __init__(self, a, b, ks=1, stride=1, pad=0, groups=1, bn_weight_init=1.0, act="none"):
+        super().__init__()
+        self.c = Conv2d(a, b, ks, stride, pad, groups, bias=False)
+        self.bn = BatchNorm2d(b, act=act)
+        nn.init.constant_(self.bn.weight, bn_weight_init)
+
+    def fwd(self, x, tape):
+        return self.bn.fwd(self.c.fwd(x, tape), tape)
+
+    def bwd(self, dy, tape):
+        return self.c.bwd(self.bn.bwd(dy, tape), tape)
+
+
+class DropPath(Layer):
+    """timm DropPath fused with the residual add: y = skip + branch * mask[n]/keep"""
+
+    def __init__(self, drop_prob=0.0):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def fwd2(self, branch, skip, tape):
+        rs = None
+        if self.training and self.drop_prob > 0.0:
+            rs = draw_mask("drop_path", (branch.shape[0],), 1.0 - self.drop_prob, branch.device)
+        if tape is not None:
+            tape.append(rs)
+        return K.add_rowscale(skip, branch, rs)
+
+    def bwd2(self, dy, tape):
+        rs = tape.pop()
+        return (dy if rs is None else K.add_rowscale(None, dy, rs)), dy
+
+
+class PatchEmbed(Layer):
+    def __init__(self, in_chans, embed_dim):
+        super().__init__()
+        self.seq = Sequential(Conv2d_BN(in_chans, embed_dim // 2, 3, 2, 1, act="gelu"), Identity(), Conv2d_BN(embed_dim // 2, embed_dim, 3, 2, 1))
+        self.seq[0].c.need_input_grad = False
+
+    def fwd(self, x, tape):
+        return self.seq.fwd(x, tape)
+
+    def bwd(self, dy, tape):
+        return self.seq.bwd(dy, tape)
+
+
+class MBConv(Layer):
+    """src/tiny_vit.py:84-122: 1x1 -> GELU -> dw3x3 -> GELU -> 1x1 (BN weight init 0) -> drop_path -> + shortcut -> GELU"""
+
+    def __init__(self, in_chans, out_chans, expand_ratio, drop_path):
+        super().__init__()
+        hid = int(in_chans * expand_ratio)
+        self.conv1 = Conv2d_BN(in_chans, hid, 1, act="gelu")
+        self.conv2 = Conv2d_BN(hid, hid, 3, 1, 1, groups=hid, act="gelu")
+        self.conv3 = Conv2d_BN(hid, out_chans, 1, bn_weight_init=0.0)
+        self.drop_path = DropPath(drop_path)
+
+    def fwd(self, x, tape):
+        y = self.conv3.fwd(self.conv2.fwd(self.conv1.fwd(x, tape), tape), tape)
+        z = self.drop_path.fwd2(y, x, tape)
+        if tape is not None:
+            tape.append(z)
+        return K.act_fwd(z, z.shape[-1], "gelu")
+
+    def bwd(self, dy, tape):
+        z = tape.pop()
+        dz = K.act_bwd(z, dy, z.shape[-1], "gelu")
+        d_branch, d_skip = self.drop_path.bwd2(dz, tape)
+        dx = self.conv1.bwd(self.conv2.bwd(self.conv3.bwd(d_branch, tape), tape), tape)
+        return K.add(dx, d_skip)
+
+
+class PatchMerging(Layer):
+    """src/tiny_vit.py:125-151"""
+
+    def __init__(self, dim, out_dim):
+        super().__init__()
+        self.conv1 = Conv2d_BN(dim, out_dim, 1, act="gelu")
+        self.conv2 = Conv2d_BN(out_dim, out_dim, 3, 2, 1, groups=out_dim, act="gelu")
+        self.conv3 = Conv2d_BN(out_dim, out_dim, 1)
+
+    def fwd(self, x, tape):
+        return self.conv3.fwd(self.conv2.fwd(self.conv1.fwd(x, tape), tape), tape)
+
+    def bwd(self, dy, tape):
+        return self.conv1.bwd(self.conv2.bwd(self.conv3.bwd(dy, tape), tape), tape)
+
+
+def attention_bias_index(ws):
+    """offsets (|dy|,|dx|) numbered in first-seen order over points x points (src/tiny_vit.py:237-252)"""
+    pts = list(itertools.product(range(ws), range(ws)))
+    seen, idx = {}, []
+    for p1 in pts:
+        for p2 in pts:
+            off = (abs(p1[0] - p2[0]), abs(p1[1] - p2[1]))
+            if off not in seen:
+                seen[off] = len(seen)
+            idx.append(seen[off])
+    return torch.tensor(idx, dtype=torch.long).view(len(pts), len(pts)), len(seen)
+
+
+class Attention(Layer):
+    """src/tiny_vit.py:216-286 (attn_ratio = 1): LayerNorm -> qkv -> windowed softmax(q k^T s + bias) v -> proj"""
+
+    def __init__(self, dim, key_dim, num_heads, window):
+        super().__init__()
+        self.dim, self.key_dim, self.num_heads, self.window = dim, key_dim, num_heads, window
+        self.scale = key_dim ** -0.5
+        self.norm = LayerNorm(dim)
+        self.qkv = Linear(dim, 3 * key_dim * num_heads)
+        self.proj = Linear(key_dim * num_heads, dim)
+        idx, n = attention_bias_index(window)
+        self.attention_biases = nn.Parameter(torch.zeros(num_heads, n))
+        self.register_buffer("attention_bias_idxs", idx, persistent=False)
+        self._idx32 = None
+
+    def _index(self, device):
+        if self._idx32 is None or self._idx32.device != device:
+            self._idx32 = self.attention_bias_idxs.to(device=device, dtype=torch.int32).contiguous()
+        return self._idx32
+
+    def fwd(self, x, tape):
+        B, H, W, C = x.shape
+        xn = self.norm.fwd(x, tape)
+        qkv = self.qkv.fwd(xn.view(-1, C), tape)
+        out, probs = K.window_attn_fwd(qkv, self.attention_biases, self._index(x.device), B, H, W, self.window, self.num_heads,
+                                       self.scale, save_probs=tape is not None)
+        if tape is not None:
+            tape.append((qkv, probs, (B, H, W)))
+        return self.proj.fwd(out, tape).view(B, H, W, C)
+
+    def bwd(self, dy, tape):
+        B, H, W, C = dy.shape
+        d_out = self.proj.bwd(dy.view(-1, C), tape)
+        qkv, probs, _ = tape.pop()
+        dqkv = K.window_attn_bwd(qkv, probs, d_out, self._index(dy.device), B, H, W, self.window, self.num_heads,
+                                 self.attention_biases.shape[1], self.scale, grad_of(self.attention_biases))
+        d_xn = self.qkv.bwd(dqkv, tape)
+        return self.norm.bwd(d_xn.view(B, H, W, C), tape)
+
+
+class Mlp(Layer):
+    def __init__(self, in_features, hidden_features):
+        super().__init__()
+        self.norm = LayerNorm(in_features)
+        self.fc1 = Linear(in_features, hidden_features)
+        self.fc2 = Linear(hidden_features, in_features)
+        self.hidden = hidden_features
+
+    def fwd(self, x, tape):
+        shp = x.shape
+        h = self.fc1.fwd(self.norm.fwd(x, tape).view(-1, shp[-1]), tape)
+        if tape is not None:
+            tape.append(h)
+        return self.fc2.fwd(K.act_fwd(h, self.hidden, "gelu"), tape).view(shp)
+
+    def bwd(self, dy, tape):
+        shp = dy.shape
+        da = self.fc2.bwd(dy.view(-1, shp[-1]), tape)
+        h = tape.pop()
+        dh = K.act_bwd(h, da, self.hidden, "gelu")
+        return self.norm.bwd(self.fc1.bwd(dh, tape).view(shp), tape)
+
+
+class TinyViTBlock(Layer):
+    """src/tiny_vit.py:289-379"""
+
+    def __init__(self, dim, input_resolution, num_heads, window_size=7, mlp_ratio=4.0, drop_path=0.0):
+        super().__init__()
+        self.dim, self.input_resolution, self.window_size = dim, input_resolution, window_size
+        self.drop_path = DropPath(drop_path)
+        self.attn = Attention(dim, dim // num_heads, num_heads, window_size)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+        self.local_conv = Conv2d_BN(dim, dim, 3, 1, 1, groups=dim)
+
+    def fwd(self, x, tape):
+        a = self.attn.fwd(x, tape)
+        x1 = self.drop_path.fwd2(a, x, tape)
+        x2 = self.local_conv.fwd(x1, tape)
+        m = self.mlp.fwd(x2, tape)
+        return self.drop_path.fwd2(m, x2, tape)
+
+    def bwd(self, dy, tape):
+        d_m, d_x2 = self.drop_path.bwd2(dy, tape)
+        d_x2 = K.add(d_x2, self.mlp.bwd(d_m, tape))
+        d_x1 = self.local_conv.bwd(d_x2, tape)
+        d_a, d_x = self.drop_path.bwd2(d_x1, tape)
+        return K.add(d_x, self.attn.bwd(d_a, tape))
+
+
+class _Stage(Layer):
+    def __init__(self, blocks, downsample):
+        super().__init__()
+        self.blocks = Sequential(*blocks)
+        if downsample is not None:
+            self.downsample = downsample
+
+    def fwd(self, x, tape):
+        x = self.blocks.fwd(x, tape)
+        return self.downsample.fwd(x, tape) if hasattr(self, "downsample") else x
+
+    def bwd(self, dy, tape):
+        if hasattr(self, "downsample"):
+            dy = self.downsample.bwd(dy, tape)
+        return self.blocks.bwd(dy, tape)
+
+
+class TinyViT21M(Network):
+    """tiny_vit_21m_224: embed_dims 96/192/384/576, depths 2/2/6/2, heads 3/6/12/18, windows 7/7/14/7, drop_path 0.2"""
+    DIMS, DEPTHS, HEADS, WS = (96, 192, 384, 576), (2, 2, 6, 2), (3, 6, 12, 18), (7, 7, 14, 7)
+
+    def __init__(self, num_classes=9, drop_path_rate=0.2):
+        super().__init__()
+        d = self.DIMS
+        self.patch_embed = PatchEmbed(3, d[0])
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(self.DEPTHS))]
+        stages, res, k = [], 56, 0
+        for i in range(4):
+            if i == 0:
+                blocks = [MBConv(d[0], d[0], 4.0, dpr[k + j]) for j in range(self.DEPTHS[0])]
+            else:
+                blocks = [TinyViTBlock(d[i], (res, res), self.HEADS[i], self.WS[i], 4.0, dpr[k + j]) for j in range(self.DEPTHS[i])]
+            k += self.DEPTHS[i]
+            stages.append(_Stage(blocks, PatchMerging(d[i], d[min(i + 1, 3)]) if i < 3 else None))
+            if i < 3:
+                res //= 2
+        self.layers = Sequential(*stages)
+        self.norm_head = LayerNorm(d[3])
+        for m in self.modules():
+            if isinstance(m, Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                nn.init.zeros_(m.bias)
+        self.head = regression_head(d[3], 128, 64, num_classes)
+        init_regression_head_(self.head)
+
+    def fwd(self, x, tape):
+        x = self.layers.fwd(self.patch_embed.fwd(x, tape), tape)
+        if tape is not None:
+            tape.append(x.shape)
+        return self.head.fwd(self.norm_head.fwd(K.avgpool_fwd(x), tape), tape)
+
+    def bwd(self, dy, tape):
+        dy = self.norm_head.bwd(self.head.bwd(dy, tape), tape)
+        dy = K.avgpool_bwd(dy, tape.pop())
+        return self.patch_embed.bwd(self.layers.bwd(dy, tape), tape)
+
+
+def get_TinyViT(config, pretrain=True, model_name="21m"):
+    """src/networks.py:407-441 (pretrained blobs are not available offline; same init recipe)."""
+    if model_name != "21m":
+        raise NotImplementedError("the reference hard-codes the 21m variant (src/networks.py:29)")
+    return TinyViT21M(num_classes=config.num_classes)

@@ -34,7 +34,38 @@ def to_logical(t, like_shape):
     return t
 
 
-def run_net(model, tag, x, dy):
+def fp64_truth(oracle_model, x, dy):
+    """Gradients of the same step in float64 on the CPU oracle: the yardstick for fp32 rounding noise.  Through ~30
+    train-mode BatchNorm layers on a batch of 4 the reference's own fp32 gradients deviate from the exact ones at the
+    percent level in the first layers, so the HIP path is required to be as close to the exact values as the
+    reference's fp32 golden is (x4), not bit-close to the golden."""
+    from oracle import networks as ON
+    m = oracle_model.double().train()
+    for mod in m.modules():
+        if isinstance(mod, (ON.Dropout, ON.DropPath, ON.StochasticDepth)):
+            mod.p = 0.0
+    out = m(x.double())
+    out.backward(dy.double())
+    return {k: p.grad for k, p in m.named_parameters()}
+
+
+def check_grad(key, got, truth):
+    got = got.detach().cpu().double().numpy().reshape(-1)
+    t = truth.numpy().reshape(-1)
+    if key in G.files:
+        ref = G[key].astype(np.float64).reshape(-1)
+        tt, gg = t, got
+    else:
+        stride = int(G[key + "@stride"])
+        ref = G[key + "@sample"].astype(np.float64)
+        tt, gg = t[::stride][:4096], got[::stride][:4096]
+    scale = max(1e-6, np.abs(t).max())
+    noise = np.abs(ref - tt).max() / scale               # the reference's own fp32 error
+    err = np.abs(gg - tt).max() / scale
+    assert err <= max(2e-3, 4.0 * noise), (key, err, noise)
+
+
+def run_net(model, tag, x, dy, oracle_model=None):
     from semiuhpe_amd import layers as L
     model.eval()
     with torch.no_grad():
@@ -53,8 +84,9 @@ def run_net(model, tag, x, dy):
     check(tag + "/train_out", out)
     params = dict(model.named_parameters())
     keys = sorted({k[len(tag + "/grad/"):].split("@")[0] for k in G.files if k.startswith(tag + "/grad/")})
+    truth = fp64_truth(oracle_model, x, dy)
     for k in keys:
-        check(tag + "/grad/" + k, params[k].grad, 2e-3)
+        check_grad(tag + "/grad/" + k, params[k].grad, truth[k])
     sd = model.state_dict()
     for k in G[tag + "/bn_keys"]:
         check(tag + "/bn/" + str(k), sd[str(k)])
@@ -65,8 +97,11 @@ def test_repvgg_b1g2_vs_reference():
     m = RepVggNet()
     assert len(m.state_dict()) == 467
     m.load_state_dict(seeded_state_dict(m.state_dict(), 11))
+    from oracle import networks as ON
+    o = ON.RepVggNet()
+    o.load_state_dict(seeded_state_dict(o.state_dict(), 11))
     m.cuda()
-    run_net(m, "repvgg", torch.from_numpy(G["repvgg/x"]), torch.from_numpy(G["repvgg/dy"]))
+    run_net(m, "repvgg", torch.from_numpy(G["repvgg/x"]), torch.from_numpy(G["repvgg/dy"]), o)
 
 
 @pytest.mark.parametrize("tag,cfg", [("blockA", (64, 128, 2, 1)), ("blockB", (128, 128, 1, 2))])
@@ -92,6 +127,48 @@ def test_tinyvit_21m_vs_reference():
     m = tv.TinyViT21M()
     assert len(m.state_dict()) == 310
     m.load_state_dict(seeded_state_dict(m.state_dict(), 13))
+    from oracle import networks as ON
+    o = ON.TinyViT21M()
+    o.load_state_dict(seeded_state_dict(o.state_dict(), 13))
     m.cuda()
     x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(int(G["tinyvit/x_seed"]))) * 0.5
-    run_net(m, "tinyvit", x, torch.from_numpy(G["tinyvit/dy"]))
+    run_net(m, "tinyvit", x, torch.from_numpy(G["tinyvit/dy"]), o)
+
+
+def _block_case(tag):
+    meta = G[tag + "/meta"]
+    seed, wseed, shape = int(meta[0]), int(meta[1]), tuple(int(v) for v in meta[2:])
+    gb = torch.Generator().manual_seed(seed)
+    x = torch.randn(*shape, generator=gb) * float(G[tag + "/scale"])
+    return x, gb, wseed
+
+
+@pytest.mark.parametrize("tag", ["attn", "tvblock", "mbconv", "patchmerge"])
+def test_tinyvit_blocks_vs_reference(tag):
+    """One Attention (14x14 window, 12 heads), one TinyViTBlock (28x28, 7x7 windows addressed in place), one MBConv and
+    one PatchMerging against the reference modules' outputs, input gradients and parameter gradients."""
+    from semiuhpe_amd.src import tiny_vit as TV
+    x, gb, wseed = _block_case(tag)
+    if tag == "attn":
+        mod, x4 = TV.Attention(384, 32, 12, 14), x.view(2, 14, 14, 384)
+    elif tag == "tvblock":
+        mod, x4 = TV.TinyViTBlock(192, (28, 28), 6, 7, 4.0, 0.0), x.view(2, 28, 28, 192)
+    elif tag == "mbconv":
+        mod, x4 = TV.MBConv(96, 96, 4.0, 0.0), x.permute(0, 2, 3, 1).contiguous()
+    else:
+        mod, x4 = TV.PatchMerging(192, 384), x.view(2, 28, 28, 192)
+    mod.load_state_dict(seeded_state_dict(mod.state_dict(), wseed))
+    mod.cuda().train()
+    tape = []
+    y = mod.fwd(x4.contiguous().cuda(), tape)
+    # the reference's output layout: tokens (B, L, C) except MBConv which is NCHW
+    y_ref_layout = y.permute(0, 3, 1, 2) if tag == "mbconv" else y.reshape(y.shape[0], -1, y.shape[-1])
+    dy = torch.randn(tuple(y_ref_layout.shape), generator=gb)
+    dy4 = dy.permute(0, 2, 3, 1).contiguous() if tag == "mbconv" else dy.view(y.shape)
+    dx = mod.bwd(dy4.contiguous().cuda(), tape)
+    assert not tape
+    check(tag + "/y", y_ref_layout)
+    dx_ref_layout = dx.permute(0, 3, 1, 2) if tag == "mbconv" else dx.reshape(dx.shape[0], -1, dx.shape[-1])
+    check(tag + "/dx", dx_ref_layout, 2e-3)
+    for k, p in mod.named_parameters():
+        check(tag + "/grad/" + k, p.grad, 2e-3)
