@@ -89,7 +89,8 @@ def run_net(model, tag, x, dy, oracle_model=None):
         check_grad(tag + "/grad/" + k, params[k].grad, truth[k])
     sd = model.state_dict()
     for k in G[tag + "/bn_keys"]:
-        check(tag + "/bn/" + str(k), sd[str(k)])
+        # running statistics of the last BatchNorm1d layers average only 2-4 samples: activation-level fp32 noise
+        check(tag + "/bn/" + str(k), sd[str(k)], 5e-3)
 
 
 def test_repvgg_b1g2_vs_reference():
