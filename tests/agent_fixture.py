@@ -27,12 +27,13 @@ def sample(t):
     return flat[::stride][:512].double().numpy()
 
 
-def rel(a, ref):
+def rel(a, ref, floor=1e-6):
     a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
-    return np.abs(a - ref).max() / max(1e-6, np.abs(ref).max())
+    return np.abs(a - ref).max() / max(floor, np.abs(ref).max())
 
 
-def run_and_compare(agent, cfg, set_iteration, to_device, value_tol, grad_tol, param_tol=2e-5, steps=3, growth=(1.0, 40.0, 600.0)):
+def run_and_compare(agent, cfg, set_iteration, to_device, value_tol, grad_tol, param_tol=2e-5, steps=3, growth=(1.0, 40.0, 600.0),
+                    orth_tol=1e-4):
     """Step 0 is compared at the given tolerances.  Later steps start from parameters that already differ at the fp32
     rounding level and Adam's normalised update amplifies that (the reference's own trajectory is equally sensitive),
     so their tolerances grow by `growth`; what they pin is the schedule: EMA alpha 1/2, 2/3, strict-subset masks."""
@@ -46,14 +47,15 @@ def run_and_compare(agent, cfg, set_iteration, to_device, value_tol, grad_tol, p
         torch.manual_seed(100 + step)
         fd, fu, out = agent.train_func(to_device(data), to_device(ulb))
         t = lambda v: v.detach().cpu().double().numpy()
-        assert rel(t(fd["loss"]), G[f"s{step}/loss"]) < value_tol, ("loss", step)
+        # losses are differences of O(1) terms (-<A,R> + 1.025 logC): compare against an absolute floor of 1
+        assert rel(t(fd["loss"]), G[f"s{step}/loss"], 1.0) < value_tol, ("loss", step)
         assert rel(t(fd["pred"]), G[f"s{step}/pred"]) < value_tol, ("pred", step)
-        assert np.abs(t(fd["pred_orth"]).reshape(-1, 3, 3) - G[f"s{step}/pred_orth"]).max() < 1e-4, ("pred_orth", step)
+        assert np.abs(t(fd["pred_orth"]).reshape(-1, 3, 3) - G[f"s{step}/pred_orth"]).max() < orth_tol * growth[step], ("pred_orth", step)
         assert rel(t(fd["err_deg"]), G[f"s{step}/err_deg"]) < 10 * value_tol, ("err_deg", step)
         assert rel(t(fu["entropy"]), G[f"s{step}/entropy"]) < value_tol, ("entropy", step)
         assert abs(float(fu["mask_ratio"]) - float(G[f"s{step}/mask_ratio"])) < 1e-6, ("mask_ratio", step)
-        assert rel(t(fu["unsuper_loss"]), G[f"s{step}/unsuper_loss"]) < 5 * value_tol, ("unsuper_loss", step)
-        assert rel(t(out["loss_all"]), G[f"s{step}/loss_all"]) < 5 * value_tol, ("loss_all", step)
+        assert rel(t(fu["unsuper_loss"]), G[f"s{step}/unsuper_loss"], 1.0) < 5 * value_tol, ("unsuper_loss", step)
+        assert rel(t(out["loss_all"]), G[f"s{step}/loss_all"], 1.0) < 5 * value_tol, ("loss_all", step)
         assert rel(t(fu["err_weakAll_gt"]), G[f"s{step}/err_weakAll_gt"]) < 10 * value_tol, ("err_weakAll_gt", step)
         assert rel(float(t(fu["err_weakPseudo_gt"]).mean()), G[f"s{step}/err_weakPseudo_gt_mean"]) < 10 * value_tol
         assert rel(float(t(fu["err_strongSuper_pseudo"]).mean()), G[f"s{step}/err_strongSuper_pseudo_mean"]) < 50 * value_tol

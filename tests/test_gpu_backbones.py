@@ -69,7 +69,13 @@ def run_net(model, tag, x, dy, oracle_model=None):
     from semiuhpe_amd import layers as L
     model.eval()
     with torch.no_grad():
-        check(tag + "/eval_out", model(x.cuda()))
+        y_eval = model(x.cuda())
+        check(tag + "/eval_out", y_eval)
+        # north-star bound: rotation matrices within 1e-4 of the reference's (eval mode = what eval.py / AFLW2000 MAE uses)
+        from oracle import fisher as OF
+        from semiuhpe_amd import kernels as K
+        R_ref = OF.batch_torch_A_to_R(torch.from_numpy(G[tag + "/eval_out"]))
+        assert float((K.fisher_svd_project(y_eval).cpu() - R_ref).abs().max()) < 1e-4
     model.train()
     for m in model.modules():
         if isinstance(m, (L.Dropout, L.StochasticDepth)) or hasattr(m, "drop_prob"):
