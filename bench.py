@@ -118,7 +118,8 @@ def cpu_leg():
     from oracle import networks as ON
     from oracle.agent import OracleAgent, synthetic_batches
     ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    torch.set_num_threads(max(1, min(ncores, 64)))
+    # measured on the GPU box (256 hardware threads): 32 torch threads give the best CPU step time (64: 2.3x slower)
+    torch.set_num_threads(max(1, min(ncores, 32)))
     torch.manual_seed(1234)
     cfg = make_config("/tmp")
     cfg.conf_thres = 1e9

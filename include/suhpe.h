@@ -95,6 +95,11 @@ const char* suhpe_conv2d_kernel_name(const suhpe_conv_t* d, int pass);
 int64_t suhpe_conv2d_wgrad_workspace_bytes(const suhpe_conv_t* d);
 int suhpe_conv2d_wgrad(const suhpe_conv_t* d, const float* x, const float* dy, float* dw, int accumulate,
                        void* workspace, int64_t workspace_bytes, suhpe_stream_t stream);
+/* the two launches of suhpe_conv2d_wgrad separately: split-K partial slabs, then the fixed-order slab reduction */
+int suhpe_conv2d_wgrad_partial(const suhpe_conv_t* d, const float* x, const float* dy, void* workspace,
+                               int64_t workspace_bytes, suhpe_stream_t stream);
+int suhpe_conv2d_wgrad_reduce(const suhpe_conv_t* d, const void* workspace, float* dw, int accumulate,
+                              suhpe_stream_t stream);
 /* depthwise 3x3 (groups == cin == cout, cin % 4 == 0); w in torch layout [c][r*s] */
 int suhpe_dwconv_fwd(const suhpe_conv_t* d, const float* x, const float* w, float* y, suhpe_stream_t stream);
 int suhpe_dwconv_dgrad(const suhpe_conv_t* d, const float* dy, const float* w, float* dx, suhpe_stream_t stream);

@@ -670,11 +670,11 @@ int64_t suhpe_conv2d_wgrad_workspace_bytes(const suhpe_conv_t* d) {
     return (int64_t)wgrad_splits(d, bm, bn) * d->cout * K * 4;
 }
 
-int suhpe_conv2d_wgrad(const suhpe_conv_t* d, const float* x, const float* dy, float* dw, int accumulate, void* workspace,
-                       int64_t workspace_bytes, suhpe_stream_t stream) {
+int suhpe_conv2d_wgrad_partial(const suhpe_conv_t* d, const float* x, const float* dy, void* workspace, int64_t workspace_bytes,
+                               suhpe_stream_t stream) {
     int rc = check_desc(d, "suhpe_conv2d_wgrad");
     if (rc) return rc;
-    SUHPE_REQUIRE(x && dy && dw && workspace, "suhpe_conv2d_wgrad: null pointer");
+    SUHPE_REQUIRE(x && dy && workspace, "suhpe_conv2d_wgrad: null pointer");
     if (workspace_bytes < suhpe_conv2d_wgrad_workspace_bytes(d)) {
         set_error("suhpe_conv2d_wgrad: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)suhpe_conv2d_wgrad_workspace_bytes(d));
         return SUHPE_EWORKSPACE;
@@ -709,9 +709,28 @@ int suhpe_conv2d_wgrad(const suhpe_conv_t* d, const float* x, const float* dy, f
         else TN_LAUNCH(64, 64, 32, 32, 1, 1);
     }
 #undef TN_LAUNCH
-    const int64_t count = (int64_t)d->cout * p.g.K;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(count, 256)), dim3(256), 0, st, p.slab, splits, count, dw, accumulate);
-    return check_launch("suhpe_conv2d_wgrad");
+    return check_launch("suhpe_conv2d_wgrad_partial");
+}
+
+int suhpe_conv2d_wgrad_reduce(const suhpe_conv_t* d, const void* workspace, float* dw, int accumulate, suhpe_stream_t stream) {
+    int rc = check_desc(d, "suhpe_conv2d_wgrad");
+    if (rc) return rc;
+    SUHPE_REQUIRE(workspace && dw, "suhpe_conv2d_wgrad: null pointer");
+    int bm, bn;
+    wgrad_tile(d, &bm, &bn);
+    const int splits = wgrad_splits(d, bm, bn);
+    const int64_t count = (int64_t)d->cout * d->r * d->s * (d->cin / d->groups);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(count, 256)), dim3(256), 0, as_stream(stream), static_cast<const float*>(workspace),
+                       splits, count, dw, accumulate);
+    return check_launch("suhpe_conv2d_wgrad_reduce");
+}
+
+int suhpe_conv2d_wgrad(const suhpe_conv_t* d, const float* x, const float* dy, float* dw, int accumulate, void* workspace,
+                       int64_t workspace_bytes, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(dw, "suhpe_conv2d_wgrad: null pointer");
+    int rc = suhpe_conv2d_wgrad_partial(d, x, dy, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    return suhpe_conv2d_wgrad_reduce(d, workspace, dw, accumulate, stream);
 }
 
 }  // extern "C"
