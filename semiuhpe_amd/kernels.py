@@ -266,6 +266,26 @@ def se_scale_bwd_x(dy, s, dpool):
     return dx
 
 
+def se_mlp_fwd(p, w1, b1, w2, b2):
+    """p (n,c) -> a1 (n,csq), s (n,c)"""
+    n, c = p.shape
+    csq = w1.shape[0]
+    a1 = torch.empty((n, csq), dtype=torch.float32, device=p.device)
+    s = torch.empty((n, c), dtype=torch.float32, device=p.device)
+    call("suhpe_se_mlp_fwd", ptr(p), ptr(w1), ptr(b1), ptr(w2), ptr(b2), n, c, csq, ptr(a1), ptr(s))
+    return a1, s
+
+
+def se_mlp_bwd(ds, s, a1, p, w1, w2, dw1, db1, dw2, db2):
+    n, c = p.shape
+    csq = w1.shape[0]
+    dp = torch.empty((n, c), dtype=torch.float32, device=p.device)
+    ws = workspace("se", n * (c + csq) * 4, p.device)
+    call("suhpe_se_mlp_bwd", ptr(ds), ptr(s), ptr(a1), ptr(p), ptr(w1), ptr(w2), n, c, csq, ptr(dp), ptr(dw1), ptr(db1), ptr(dw2),
+         ptr(db2), ptr(ws))
+    return dp
+
+
 def add_rowscale(a, b, rowscale):
     """a + b * rowscale[n]  (a or rowscale may be None)"""
     _chk(b, "b"); _chk(a, "a")

@@ -280,8 +280,17 @@ class SqueezeExcitation(Layer):
         self.act, self.scale_act = act, scale_act
         self.c, self.csq = input_channels, squeeze_channels
 
+    def _fused(self):
+        return self.act == "silu" and self.scale_act == "sigmoid" and self.c % 4 == 0 and self.csq % 4 == 0 and self.csq <= 64
+
     def fwd(self, z, tape):
         n = z.shape[0]
+        if self._fused():                       # pool -> one micro-kernel for the whole MLP -> scale
+            p = K.avgpool_fwd(z)
+            a1, s = K.se_mlp_fwd(p, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+            if tape is not None:
+                tape.append((z, p, a1, None, None, s))
+            return K.se_scale_fwd(z, s)
         p = K.avgpool_fwd(z).view(n, 1, 1, self.c)
         a1 = K.conv2d_fwd(p, self.fc1.weight, self.fc1.bias, 1, 0, 1)
         h = K.act_fwd(a1, self.csq, self.act)
@@ -294,6 +303,11 @@ class SqueezeExcitation(Layer):
     def bwd(self, dy, tape):
         z, p, a1, h, a2, s = tape.pop()
         n = z.shape[0]
+        if h is None:
+            ds = K.se_scale_bwd_s(dy, z)
+            dp = K.se_mlp_bwd(ds, s, a1, p, self.fc1.weight, self.fc2.weight, grad_of(self.fc1.weight), grad_of(self.fc1.bias),
+                              grad_of(self.fc2.weight), grad_of(self.fc2.bias))
+            return K.se_scale_bwd_x(dy, s, dp)
         ds = K.se_scale_bwd_s(dy, z).view(n, 1, 1, self.c)
         da2 = K.act_bwd(a2, ds, self.c, self.scale_act)
         K.conv2d_wgrad(h, da2, self.fc2.weight.shape, 1, 0, 1, out=grad_of(self.fc2.weight), accumulate=True)

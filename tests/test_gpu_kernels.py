@@ -264,3 +264,22 @@ def test_strong_aug_matches_reference_fixture(K, seed):
     out = K.strong_aug(img.cuda(), co.cuda(), cm.cuda(), perm.cuda(), 3, dst_nhwc=True)
     assert np.array_equal(out.cpu().permute(0, 3, 1, 2).numpy(), D[tag + "/both"])
     assert np.array_equal(K.nchw_to_nhwc(img.cuda()).cpu().numpy(), img.permute(0, 2, 3, 1).numpy())
+
+
+@pytest.mark.parametrize("n,c,csq", [(7, 256, 16), (33, 960, 40), (5, 1536, 64)])
+def test_fused_se_mlp(K, n, c, csq):
+    g = torch.Generator().manual_seed(c)
+    p, ds = torch.randn(n, c, generator=g), torch.randn(n, c, generator=g)
+    w1, b1 = torch.randn(csq, c, generator=g) / c ** 0.5, torch.randn(csq, generator=g) * 0.1
+    w2, b2 = torch.randn(c, csq, generator=g) / csq ** 0.5, torch.randn(c, generator=g) * 0.1
+    P, W1, B1, W2, B2 = (t.double().requires_grad_(True) for t in (p, w1, b1, w2, b2))
+    a1_ref = P @ W1.t() + B1
+    s_ref = torch.sigmoid(F.silu(a1_ref) @ W2.t() + B2)
+    s_ref.backward(ds.double())
+    a1, s = K.se_mlp_fwd(p.cuda(), w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda())
+    assert rel(a1, a1_ref) < 1e-5 and rel(s, s_ref) < 1e-5
+    grads = [torch.ones(csq, c).cuda(), torch.ones(csq).cuda(), torch.ones(c, csq).cuda(), torch.ones(c).cuda()]   # accumulate onto ones
+    dp = K.se_mlp_bwd(ds.cuda(), s, a1, p.cuda(), w1.cuda(), w2.cuda(), *grads)
+    assert rel(dp, P.grad) < 2e-5
+    for got, ref in zip(grads, (W1.grad, B1.grad, W2.grad, B2.grad)):
+        assert rel(got, ref + 1.0) < 2e-5
