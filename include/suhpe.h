@@ -154,10 +154,10 @@ int suhpe_se_scale_bwd_s(const float* dy, const float* x, int n, int hw, int c, 
 int suhpe_se_scale_bwd_x(const float* dy, const float* s, const float* dpool, int n, int hw, int c, float* dx,
                          suhpe_stream_t stream);
 /* squeeze-excite MLP per sample: s = sigmoid(W2 silu(W1 p + b1) + b2); w1 [csq][c], w2 [c][csq]; a1 (n,csq) is kept for
- * backward.  c % 4 == 0, csq % 4 == 0, csq <= 64. */
+ * backward.  c % 4 == 0, c <= 2048, csq % 4 == 0, csq <= 64. */
 int suhpe_se_mlp_fwd(const float* p, const float* w1, const float* b1, const float* w2, const float* b2, int n, int c,
                      int csq, float* a1, float* s, suhpe_stream_t stream);
-/* backward: ds (n,c) -> dp (n,c); dw1/db1/dw2/db2 += gradients.  workspace >= n*(c+csq) floats */
+/* backward: ds (n,c) -> dp (n,c); dw1/db1/dw2/db2 += gradients.  workspace >= n*(c+2*csq) floats */
 int suhpe_se_mlp_bwd(const float* ds, const float* s, const float* a1, const float* p, const float* w1, const float* w2,
                      int n, int c, int csq, float* dp, float* dw1, float* db1, float* dw2, float* db2, void* workspace,
                      suhpe_stream_t stream);

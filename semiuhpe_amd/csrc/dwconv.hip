@@ -74,6 +74,136 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const DwGeom g, const floa
     }
 }
 
+// ---- 3x3, pad 1 fast path: a thread walks one output row with a sliding 3x3 window of float4 registers, so an
+// output pixel costs 3 (stride 1) or 6 (stride 2) new loads instead of 9.  `flip` reverses the taps: the input
+// gradient of a stride-1 depthwise conv is the same convolution with the filter rotated by 180 degrees.
+__device__ __forceinline__ float4 ld4_or_zero(const float* __restrict__ base, bool ok, int64_t off) {
+    float4 v = *reinterpret_cast<const float4*>(base + (ok ? off : 0));
+    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    return v;
+}
+__device__ __forceinline__ void fma4(float4& a, const float4& x, const float4& w) {
+    a.x += x.x * w.x; a.y += x.y * w.y; a.z += x.z * w.z; a.w += x.w * w.w;
+}
+
+__global__ __launch_bounds__(256) void dw3x3_row_kernel(const float* __restrict__ src, const float* __restrict__ w, float* __restrict__ dst,
+                                                        int N, int H, int W, int OH, int OW, int C, int stride, int flip, int cw, int rp) {
+    __shared__ __attribute__((aligned(16))) float wl[9 * 256 * 4];
+    const int t = threadIdx.x, col = t % cw, rsub = t / cw;
+    const int cv = C / 4, col0 = blockIdx.y * cw;
+    for (int i = t; i < 9 * cw * 4; i += 256) {
+        const int tap = i / (cw * 4), cc = i - tap * cw * 4;
+        const int ch = col0 * 4 + cc;
+        wl[i] = ch < C ? w[(int64_t)ch * 9 + (flip ? 8 - tap : tap)] : 0.f;
+    }
+    __syncthreads();
+    if (rsub >= rp || col0 + col >= cv) return;
+    float4 wv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wv[k] = *reinterpret_cast<const float4*>(&wl[(k * cw + col) * 4]);
+    const int coff = (col0 + col) * 4;
+    for (int row = blockIdx.x * rp + rsub; row < N * OH; row += gridDim.x * rp) {
+        const int n = row / OH, oh = row - n * OH;
+        const int ih0 = oh * stride - 1;
+        bool rok[3];
+        int64_t rbase[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { const int ih = ih0 + r; rok[r] = ih >= 0 && ih < H; rbase[r] = ((int64_t)n * H + ih) * W * C + coff; }
+        float4 x[3][3];
+        // prime the window: columns -1, 0 of the first output (column -1 is padding)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            x[r][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            x[r][2] = ld4_or_zero(src, rok[r], rbase[r]);                      // iw = 0
+        }
+        for (int ow = 0; ow < OW; ++ow) {
+            const int iw0 = ow * stride - 1;                                    // window columns iw0, iw0+1, iw0+2
+            if (stride == 1) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    x[r][0] = x[r][1]; x[r][1] = x[r][2];
+                    x[r][2] = ld4_or_zero(src, rok[r] && iw0 + 2 < W, rbase[r] + (int64_t)(iw0 + 2) * C);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    x[r][0] = ow == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : x[r][2];
+                    if (ow > 0) x[r][1] = ld4_or_zero(src, rok[r] && iw0 + 1 < W, rbase[r] + (int64_t)(iw0 + 1) * C);
+                    else x[r][1] = x[r][2];
+                    x[r][2] = ld4_or_zero(src, rok[r] && iw0 + 2 < W, rbase[r] + (int64_t)(iw0 + 2) * C);
+                }
+            }
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) fma4(acc, x[r][c], wv[r * 3 + c]);
+            *reinterpret_cast<float4*>(dst + ((int64_t)row * OW + ow) * C + coff) = acc;
+        }
+    }
+}
+
+// filter-gradient partials with the same sliding window: part[bx][tap][c]
+__global__ __launch_bounds__(256) void dw3x3_wgrad_row_kernel(const float* __restrict__ x_, const float* __restrict__ dy, float* __restrict__ part,
+                                                              int N, int H, int W, int OH, int OW, int C, int stride, int cw, int rp) {
+    __shared__ __attribute__((aligned(16))) float red[kMaxTaps * 256 * 4];
+    const int t = threadIdx.x, col = t % cw, rsub = t / cw;
+    const int cv = C / 4, col0 = blockIdx.y * cw;
+    float4 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rsub < rp && col0 + col < cv) {
+        const int coff = (col0 + col) * 4;
+        for (int row = blockIdx.x * rp + rsub; row < N * OH; row += gridDim.x * rp) {
+            const int n = row / OH, oh = row - n * OH;
+            const int ih0 = oh * stride - 1;
+            bool rok[3];
+            int64_t rbase[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { const int ih = ih0 + r; rok[r] = ih >= 0 && ih < H; rbase[r] = ((int64_t)n * H + ih) * W * C + coff; }
+            float4 x[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { x[r][1] = make_float4(0.f, 0.f, 0.f, 0.f); x[r][2] = ld4_or_zero(x_, rok[r], rbase[r]); }
+            for (int ow = 0; ow < OW; ++ow) {
+                const int iw0 = ow * stride - 1;
+                if (stride == 1) {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        x[r][0] = x[r][1]; x[r][1] = x[r][2];
+                        x[r][2] = ld4_or_zero(x_, rok[r] && iw0 + 2 < W, rbase[r] + (int64_t)(iw0 + 2) * C);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        x[r][0] = ow == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : x[r][2];
+                        if (ow > 0) x[r][1] = ld4_or_zero(x_, rok[r] && iw0 + 1 < W, rbase[r] + (int64_t)(iw0 + 1) * C);
+                        else x[r][1] = x[r][2];
+                        x[r][2] = ld4_or_zero(x_, rok[r] && iw0 + 2 < W, rbase[r] + (int64_t)(iw0 + 2) * C);
+                    }
+                }
+                const float4 dv = *reinterpret_cast<const float4*>(dy + ((int64_t)row * OW + ow) * C + coff);
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) fma4(acc[r * 3 + c], x[r][c], dv);
+            }
+        }
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) *reinterpret_cast<float4*>(&red[(tap * 256 + t) * 4]) = acc[tap];
+    __syncthreads();
+    if (t < cw && col0 + t < cv) {
+        for (int tap = 0; tap < 9; ++tap) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int rr = 0; rr < rp; ++rr) {
+                const float4 v = *reinterpret_cast<const float4*>(&red[(tap * 256 + rr * cw + t) * 4]);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            *reinterpret_cast<float4*>(&part[((int64_t)blockIdx.x * 9 + tap) * C + (col0 + t) * 4]) = a;
+        }
+    }
+}
+
 // partial filter gradient: part[bx][tap][c] = sum over the block's pixels of dy[p][c] * x[gather(p,tap)][c]
 __global__ __launch_bounds__(256) void dw_wgrad_partial(const DwGeom g, const float* __restrict__ x, const float* __restrict__ dy,
                                                         float* __restrict__ part) {
@@ -165,6 +295,20 @@ static DwGeom dw_geom(const suhpe_conv_t* d, int mode, int max_blocks, int cw_ca
     return g;
 }
 
+static bool dw_fast(const suhpe_conv_t* d) { return d->r == 3 && d->s == 3 && d->pad == 1; }
+
+// grid for the row-walking kernels: thread = (channel vector, output row); rows are strided over the grid
+static void dw_row_grid(int C, int rows, int max_gx, int* cw, int* rp, int* gx, int* ny, int cw_cap = 256) {
+    const int cv = C / 4;
+    *cw = cv < cw_cap ? cv : cw_cap;
+    *rp = 256 / *cw;
+    *ny = (cv + *cw - 1) / *cw;
+    int64_t g = ceil_div(rows, *rp);
+    if (g > max_gx) g = max_gx;
+    if (g < 1) g = 1;
+    *gx = (int)g;
+}
+
 }  // namespace suhpe
 
 using namespace suhpe;
@@ -175,6 +319,13 @@ int suhpe_dwconv_fwd(const suhpe_conv_t* d, const float* x, const float* w, floa
     int rc = dw_check(d, "suhpe_dwconv_fwd");
     if (rc) return rc;
     SUHPE_REQUIRE(x && w && y, "suhpe_dwconv_fwd: null pointer");
+    if (dw_fast(d) && (d->stride == 1 || d->stride == 2)) {
+        int cw, rp, gx, ny;
+        dw_row_grid(d->cin, d->n * d->ho, 4096, &cw, &rp, &gx, &ny);
+        hipLaunchKernelGGL(dw3x3_row_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), x, w, y, d->n, d->h, d->w, d->ho, d->wo, d->cin,
+                           d->stride, 0, cw, rp);
+        return check_launch("suhpe_dwconv_fwd");
+    }
     const DwGeom g = dw_geom(d, 0, 2048);
     const int gx = (int)ceil_div(g.P, g.pix_per_block), ny = (int)ceil_div(g.C / 4, g.cw);
     hipLaunchKernelGGL(dw_conv_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), g, x, w, y);
@@ -185,6 +336,13 @@ int suhpe_dwconv_dgrad(const suhpe_conv_t* d, const float* dy, const float* w, f
     int rc = dw_check(d, "suhpe_dwconv_dgrad");
     if (rc) return rc;
     SUHPE_REQUIRE(dy && w && dx, "suhpe_dwconv_dgrad: null pointer");
+    if (dw_fast(d) && d->stride == 1) {             // same conv on dy with the 180-degree rotated filter
+        int cw, rp, gx, ny;
+        dw_row_grid(d->cin, d->n * d->h, 4096, &cw, &rp, &gx, &ny);
+        hipLaunchKernelGGL(dw3x3_row_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), dy, w, dx, d->n, d->ho, d->wo, d->h, d->w, d->cin, 1, 1,
+                           cw, rp);
+        return check_launch("suhpe_dwconv_dgrad");
+    }
     const DwGeom g = dw_geom(d, 1, 2048);
     const int gx = (int)ceil_div(g.P, g.pix_per_block), ny = (int)ceil_div(g.C / 4, g.cw);
     hipLaunchKernelGGL(dw_conv_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), g, dy, w, dx);
@@ -202,11 +360,19 @@ int suhpe_dwconv_wgrad(const suhpe_conv_t* d, const float* x, const float* dy, f
     if (rc) return rc;
     SUHPE_REQUIRE(x && dy && dw && workspace, "suhpe_dwconv_wgrad: null pointer");
     if (workspace_bytes < suhpe_dwconv_wgrad_workspace_bytes(d)) { set_error("suhpe_dwconv_wgrad: workspace too small"); return SUHPE_EWORKSPACE; }
+    float* part = static_cast<float*>(workspace);
+    const int taps = d->r * d->s;
+    if (dw_fast(d) && (d->stride == 1 || d->stride == 2)) {
+        int cw, rp, gx, ny;
+        dw_row_grid(d->cin, d->n * d->ho, kDwMaxRowBlocks, &cw, &rp, &gx, &ny, 32);
+        hipLaunchKernelGGL(dw3x3_wgrad_row_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), x, dy, part, d->n, d->h, d->w, d->ho, d->wo,
+                           d->cin, d->stride, cw, rp);
+        hipLaunchKernelGGL(dw_wgrad_finalize, dim3((taps * d->cin + 63) / 64), dim3(256), 0, as_stream(stream), part, gx, taps, d->cin, dw, accumulate);
+        return check_launch("suhpe_dwconv_wgrad");
+    }
     const DwGeom g = dw_geom(d, 0, kDwMaxRowBlocks, 32);      // narrow channel chunks: more workgroups per slab
     const int gx = (int)ceil_div(g.P, g.pix_per_block), ny = (int)ceil_div(g.C / 4, g.cw);
-    float* part = static_cast<float*>(workspace);
     hipLaunchKernelGGL(dw_wgrad_partial, dim3(gx, ny), dim3(256), 0, as_stream(stream), g, x, dy, part);
-    const int taps = d->r * d->s;
     hipLaunchKernelGGL(dw_wgrad_finalize, dim3((taps * g.C + 63) / 64), dim3(256), 0, as_stream(stream), part, gx, taps, g.C, dw, accumulate);
     return check_launch("suhpe_dwconv_wgrad");
 }

@@ -280,7 +280,7 @@ def se_mlp_bwd(ds, s, a1, p, w1, w2, dw1, db1, dw2, db2):
     n, c = p.shape
     csq = w1.shape[0]
     dp = torch.empty((n, c), dtype=torch.float32, device=p.device)
-    ws = workspace("se", n * (c + csq) * 4, p.device)
+    ws = workspace("se", n * (c + 2 * csq) * 4, p.device)
     call("suhpe_se_mlp_bwd", ptr(ds), ptr(s), ptr(a1), ptr(p), ptr(w1), ptr(w2), n, c, csq, ptr(dp), ptr(dw1), ptr(db1), ptr(dw2),
          ptr(db2), ptr(ws))
     return dp

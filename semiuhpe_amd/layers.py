@@ -281,7 +281,8 @@ class SqueezeExcitation(Layer):
         self.c, self.csq = input_channels, squeeze_channels
 
     def _fused(self):
-        return self.act == "silu" and self.scale_act == "sigmoid" and self.c % 4 == 0 and self.csq % 4 == 0 and self.csq <= 64
+        return (self.act == "silu" and self.scale_act == "sigmoid" and self.c % 4 == 0 and self.c <= 2048 and self.csq % 4 == 0
+                and self.csq <= 64)
 
     def fwd(self, z, tape):
         n = z.shape[0]
