@@ -49,6 +49,10 @@ int suhpe_fisher_ce(const float* A1, const float* A2, const float* mask, int n, 
                     suhpe_stream_t stream);
 /* src/fisher/fisher_utils.py:51-67 fisher_log_pdf */
 int suhpe_fisher_log_pdf(const float* A, const float* R, int n, float* logp, suhpe_stream_t stream);
+/* src/laplace/rotation_laplace.py:24-34 NLL_loss("RLaplace", ...): discrete normalisation over `grids` (ngrid,9) SO(3)
+ * rotations; writes loss (n), dloss_i/dA_i (n,9) and the analytical mode (n,9).  Outputs may be NULL. */
+int suhpe_laplace_nll(const float* A, const float* R, const float* grids, int n, int ngrid, float* loss, float* dA,
+                      float* mode, suhpe_stream_t stream);
 /* src/agent.py:110-122 rotation-consistency adjust.  mode 0: aug*A (DAD3DHeads); mode 1: 300WLP form. */
 int suhpe_rot_adjust(const float* A, const float* aug, int n, int mode, float* out, suhpe_stream_t stream);
 /* src/utils.py:232-260 -> radians [pitch,yaw,roll] */

@@ -163,6 +163,75 @@ __global__ void entropy_mask_kernel(const float* __restrict__ H, const float* __
     if (threadIdx.x == 0 && count) count[0] = part[0] + part[1] + part[2] + part[3];
 }
 
+// Rotation-Laplace NLL (src/laplace/rotation_laplace.py:24-173): one workgroup per sample, the 4608 grid rotations
+// split over 256 threads in two passes (max, then the normaliser and the gradient sums), fp64 inside.
+//   p_g = -sqrt(max(S - <A,X_g>, 1e-8)),  S = s1+s2+s3 (s3 signed),  logF = c + log(mean_g e^{p_g-c}/(-p_g))
+//   nll = logF - p_x + log(-p_x);   dS/dA = U V^T (proper) =: Rhat,  dp/dA = (Rhat - X)/(2p) where not clamped
+__device__ __forceinline__ double block_reduce(double v, double* sh, int op) {   // op 0 sum, 1 max; result to all threads
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(v, o, 64); v = op ? fmax(v, t) : v + t; }
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    return op ? fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3])) : (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void laplace_nll_kernel(const float* __restrict__ A, const float* __restrict__ R, const float* __restrict__ grids,
+                                                          int ngrid, float* __restrict__ loss, float* __restrict__ dA, float* __restrict__ mode) {
+    __shared__ double sh[4];
+    const int b = blockIdx.x;
+    double a[9], x[9], rh[9];
+    load_mat(A + 9 * (int64_t)b, a);
+    load_mat(R + 9 * (int64_t)b, x);
+    Svd3 d;
+    svd3_proper(a, &d);
+    svd3_rotation(d, rh);
+    const double S = d.s[0] + d.s[1] + d.s[2];
+    const double eps = 1e-8;
+    double mx = -1e300;
+    for (int g = threadIdx.x; g < ngrid; g += 256) {
+        double tr = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) tr += a[i] * (double)grids[9 * (int64_t)g + i];
+        mx = fmax(mx, -sqrt(fmax(S - tr, eps)));
+    }
+    const double c = block_reduce(mx, sh, 1);
+    double sw = 0, sc = 0, sx[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int g = threadIdx.x; g < ngrid; g += 256) {
+        double xg[9], tr = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { xg[i] = (double)grids[9 * (int64_t)g + i]; tr += a[i] * xg[i]; }
+        const double q = S - tr;
+        const double p = -sqrt(fmax(q, eps));
+        const double w = exp(p - c) / (-p);
+        sw += w;
+        if (q > eps) {                                   // clamp_min passes no gradient below the floor
+            const double coef = w * (1.0 - 1.0 / p) / (2.0 * p);
+            sc += coef;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) sx[i] += coef * xg[i];
+        }
+    }
+    sw = block_reduce(sw, sh, 0);
+    sc = block_reduce(sc, sh, 0);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) sx[i] = block_reduce(sx[i], sh, 0);
+    if (threadIdx.x == 0) {
+        const double logF = c + log(sw / (double)ngrid);
+        double trx = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) trx += a[i] * x[i];
+        const double qx = S - trx, px = -sqrt(fmax(qx, eps));
+        if (loss) loss[b] = (float)(logF - px + log(-px));
+        const double cx = qx > eps ? (-1.0 + 1.0 / px) / (2.0 * px) : 0.0;
+        for (int i = 0; i < 9; ++i) {
+            if (dA) dA[9 * (int64_t)b + i] = (float)((rh[i] * sc - sx[i]) / sw + cx * (rh[i] - x[i]));
+            if (mode) mode[9 * (int64_t)b + i] = (float)rh[i];
+        }
+    }
+}
+
 }  // namespace suhpe
 
 using namespace suhpe;
@@ -208,6 +277,14 @@ int suhpe_fisher_ce(const float* A1, const float* A2, const float* mask, int n, 
     if (n == 0) return SUHPE_OK;
     hipLaunchKernelGGL(head_ce_kernel, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), A1, A2, mask, n, ce, dA2);
     return check_launch("suhpe_fisher_ce");
+}
+
+int suhpe_laplace_nll(const float* A, const float* R, const float* grids, int n, int ngrid, float* loss, float* dA, float* mode,
+                      suhpe_stream_t stream) {
+    SUHPE_REQUIRE(A && R && grids && n >= 0 && ngrid > 0, "suhpe_laplace_nll: null pointer or bad sizes");
+    if (n == 0) return SUHPE_OK;
+    hipLaunchKernelGGL(laplace_nll_kernel, dim3(n), dim3(256), 0, as_stream(stream), A, R, grids, ngrid, loss, dA, mode);
+    return check_launch("suhpe_laplace_nll");
 }
 
 int suhpe_rot_adjust(const float* A, const float* aug, int n, int mode, float* out, suhpe_stream_t stream) {

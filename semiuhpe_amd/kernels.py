@@ -428,6 +428,16 @@ def fisher_log_pdf(A, R):
     return out
 
 
+def laplace_nll(A, R, grids):
+    _chk(A, "A"); _chk(R, "R"); _chk(grids, "grids")
+    n = A.numel() // 9
+    loss = torch.empty(n, dtype=torch.float32, device=A.device)
+    dA = torch.empty((n, 9), dtype=torch.float32, device=A.device)
+    mode = torch.empty((n, 3, 3), dtype=torch.float32, device=A.device)
+    call("suhpe_laplace_nll", ptr(A), ptr(R), ptr(grids), n, grids.numel() // 9, ptr(loss), ptr(dA), ptr(mode))
+    return loss, dA, mode
+
+
 def rot_adjust(A, aug, mode):
     _chk(A, "A"); _chk(aug, "aug")
     n = A.numel() // 9

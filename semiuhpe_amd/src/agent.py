@@ -100,8 +100,10 @@ class SSLAgent:
             self.logs_writer = open(os.path.join(self.config.log_dir, "txt_" + nowstr + ".log"), "w")
         else:
             self.logs_writer = open(os.devnull, "w")
-        if getattr(config, "distribution", "matrixFisher") != "matrixFisher":
-            raise NotImplementedError("distribution='RotationLaplace' is not built yet (no BASELINE config selects it)")
+        self.grids = None
+        if getattr(config, "distribution", "matrixFisher") == "RotationLaplace":     # reference :43-58
+            from .laplace.rotation_laplace import default_grids
+            self.grids = default_grids(self.device)
 
     # ------------------------------------------------------------------------------------------------ helpers
     def _conf_thres(self):
@@ -126,7 +128,11 @@ class SSLAgent:
         gt_euler = _dev(data.get("euler_angles"), dev).contiguous() if "euler_angles" in data else None
         net = self.ema_net if eval_ema else self.net
         fisher_out = net(img)
-        losses, pred_orth = fisher_NLL(fisher_out, gt, overreg=1.025)
+        if cfg.distribution == "RotationLaplace":
+            from .laplace.rotation_laplace import NLL_loss as laplace_NLL
+            losses, pred_orth = laplace_NLL("RLaplace", fisher_out, gt, self.grids)
+        else:
+            losses, pred_orth = fisher_NLL(fisher_out, gt, overreg=1.025)
         loss = _Mean.apply(losses, losses.numel()).squeeze(0)
         err_deg = self.compute_err_deg_from_matrices(pred_orth, gt, gt_euler=gt_euler)
         fisher_dict = dict(loss=loss, pred=fisher_out, pred_orth=pred_orth, err_deg=err_deg)
@@ -161,7 +167,11 @@ class SSLAgent:
             unsuper_loss = _Mean.apply(unsuper_losses, mu_b).squeeze(0)       # == mean(CE[mask]) * mask_ratio
         else:  # 'nll' against the projected pseudo labels (reference :157)
             pseudo = batch_torch_A_to_R(pred_weak_adjusted).reshape(-1, 9)
-            nll, _ = fisher_NLL(pred_strong, pseudo, overreg=1.025)
+            if cfg.distribution == "RotationLaplace":
+                from .laplace.rotation_laplace import NLL_loss as laplace_NLL
+                nll, _ = laplace_NLL("RLaplace", pred_strong, pseudo, self.grids)
+            else:
+                nll, _ = fisher_NLL(pred_strong, pseudo, overreg=1.025)
             unsuper_loss = _MaskedSum.apply(nll, mask, 1.0 / mu_b).squeeze(0)
         self._finite_flag = unsuper_loss.detach()
 
