@@ -82,10 +82,11 @@ struct NtParams {
 // In every mode the tap of a thread's k advances incrementally (no division in the k loop), addresses are 32-bit
 // element offsets from a uniform base, and out-of-range taps are predicated (offset 0, value zeroed): no branches.
 template <int BM, int BN, int WM, int WN, int VEC, int MODE>
-__global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_nt_kernel(const NtParams p) {
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / 32, TN = WN / 32;
-    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;          // threads: 4 or 8 wavefronts
+    static_assert(NT == 256 || NT == 512, "4 or 8 waves per workgroup");
     __shared__ __attribute__((aligned(16))) float As[BM * LDK];
     __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
 
@@ -107,9 +108,10 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
     const float* __restrict__ f = p.f + (int64_t)grp * p.Ng * p.ldf;
 
     // ---- loader geometry.  VEC=4: thread -> (vector column j = t&7, rows (t>>3)+32i).  VEC=1: (k = t&31, rows (t>>5)+8i)
-    constexpr int A_ROWS = VEC == 4 ? BM / 32 : BM / 8;
-    constexpr int B_ROWS = VEC == 4 ? BN / 32 : BN / 8;
-    constexpr int ROW_STEP = VEC == 4 ? 32 : 8;
+    constexpr int ROW_STEP = VEC == 4 ? NT / 8 : NT / 32;
+    constexpr int A_ROWS = BM / ROW_STEP;
+    constexpr int B_ROWS = (BN + ROW_STEP - 1) / ROW_STEP;
+    static_assert(BM % ROW_STEP == 0, "tile rows must be a multiple of the loader pass");
     const int lcol = VEC == 4 ? (t & 7) * 4 : (t & 31);
     const int lrow = VEC == 4 ? (t >> 3) : (t >> 5);
 
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
 #pragma unroll
     for (int i = 0; i < B_ROWS; ++i) {
         const int col = n0 + lrow + i * ROW_STEP;
-        b_off[i] = col < p.Ng ? col * p.ldf : -1;
+        b_off[i] = (col < p.Ng && lrow + i * ROW_STEP < BN) ? col * p.ldf : -1;
     }
 
     float a_reg[A_ROWS][VEC], b_reg[B_ROWS][VEC];
@@ -211,6 +213,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
         }
 #pragma unroll
         for (int i = 0; i < B_ROWS; ++i) {
+            if (lrow + i * ROW_STEP >= BN) continue;
             float* dst = &Bs[(lrow + i * ROW_STEP) * LDK + lcol];
             if (VEC == 4) *reinterpret_cast<float4*>(dst) = make_float4(b_reg[i][0], b_reg[i][1], b_reg[i][2], b_reg[i][3]);
             else dst[0] = b_reg[i][0];
@@ -524,18 +527,19 @@ static void launch_nt(const NtParams& p_in, int groups, hipStream_t st) {
     p.col_tiles = (int)ceil_div(p.Ng, BN);
     const int64_t row_tiles8 = ceil_div(ceil_div(p.g.M, BM), 8) * 8;
     dim3 grid((unsigned)(row_tiles8 * p.col_tiles), 1, groups);
+    const dim3 block((BM / WM) * (BN / WN) * 64);
     switch (nt_mode(p.g)) {
-        case 1: hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1>), grid, dim3(256), 0, st, p); break;
-        case 2: hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 2>), grid, dim3(256), 0, st, p); break;
-        case 3: hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 3>), grid, dim3(256), 0, st, p); break;
-        default: hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 0>), grid, dim3(256), 0, st, p); break;
+        case 1: hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1>), grid, block, 0, st, p); break;
+        case 2: hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 2>), grid, block, 0, st, p); break;
+        case 3: hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 3>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 0>), grid, block, 0, st, p); break;
     }
 }
 
 // tile selection for igemm_nt; returns the kernel's name (as rocprofv3 prints the template arguments)
 enum NtTile { NT_64x64_S = 0, NT_64x64, NT_128x32, NT_128x128, NT_128x64, NT_256x32 };
 static const char* kNtNames[] = {"igemm_nt_kernel<64,64,32,32,1>", "igemm_nt_kernel<64,64,32,32,4>", "igemm_nt_kernel<128,32,32,32,4>",
-                                 "igemm_nt_kernel<128,128,64,64,4>", "igemm_nt_kernel<128,64,64,32,4>", "igemm_nt_kernel<256,32,64,32,4>"};
+                                 "igemm_nt_kernel<128,128,64,32,4>", "igemm_nt_kernel<128,64,64,32,4>", "igemm_nt_kernel<256,32,64,32,4>"};
 
 static NtTile choose_nt(int64_t M, int ng, bool vec4) {
     if (!vec4) return NT_64x64_S;
@@ -556,7 +560,7 @@ static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st
         case NT_64x64_S: launch_nt<64, 64, 32, 32, 1>(p, groups, st); break;
         case NT_64x64: launch_nt<64, 64, 32, 32, 4>(p, groups, st); break;
         case NT_128x32: launch_nt<128, 32, 32, 32, 4>(p, groups, st); break;
-        case NT_128x128: launch_nt<128, 128, 64, 64, 4>(p, groups, st); break;
+        case NT_128x128: launch_nt<128, 128, 64, 32, 4>(p, groups, st); break;      // 8 wavefronts of 64x32
         case NT_128x64: launch_nt<128, 64, 64, 32, 4>(p, groups, st); break;
         case NT_256x32: launch_nt<256, 32, 64, 32, 4>(p, groups, st); break;
     }
