@@ -11,7 +11,7 @@
 
 namespace suhpe {
 
-constexpr int kMaxRowBlocks = 512;   // partial-sum slabs per channel (workspace = kMaxRowBlocks*c*2 floats)
+constexpr int kMaxRowBlocks = 1024;   // partial-sum slabs per channel (workspace = kMaxRowBlocks*c*2 floats)
 
 // ------------------------------------------------------------------------------------------ activations
 __device__ __forceinline__ float act_apply(float u, int act) {
@@ -162,7 +162,21 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
         const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
         int64_t r1 = r0 + rows_per_block;
         if (r1 > rows) r1 = rows;
-        for (int64_t r = r0 + rsub; r < r1; r += rp) {
+        int64_t r = r0 + rsub;
+        // four independent row streams per thread keep 4 x 16 B loads in flight (the pass is pure HBM latency otherwise)
+        for (; r + 3 * (int64_t)rp < r1; r += 4 * (int64_t)rp) {
+            float xa[VEC], xb[VEC], xc[VEC], xd[VEC];
+            vload<VEC>(x + (r * cv + col0 + col) * VEC, xa);
+            vload<VEC>(x + ((r + rp) * cv + col0 + col) * VEC, xb);
+            vload<VEC>(x + ((r + 2 * (int64_t)rp) * cv + col0 + col) * VEC, xc);
+            vload<VEC>(x + ((r + 3 * (int64_t)rp) * cv + col0 + col) * VEC, xd);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                s0[v] += (xa[v] + xb[v]) + (xc[v] + xd[v]);
+                s1[v] += (xa[v] * xa[v] + xb[v] * xb[v]) + (xc[v] * xc[v] + xd[v] * xd[v]);
+            }
+        }
+        for (; r < r1; r += rp) {
             float xv[VEC];
             vload<VEC>(x + (r * cv + col0 + col) * VEC, xv);
 #pragma unroll
@@ -259,6 +273,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
         const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
         int64_t r1 = r0 + rows_per_block;
         if (r1 > rows) r1 = rows;
+#pragma unroll 4
         for (int64_t r = r0 + rsub; r < r1; r += rp) {
             float xv[VEC], dv[VEC], yv[VEC];
             const int64_t off = (r * cv + col0 + col) * VEC;
@@ -546,9 +561,9 @@ __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_
     const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
 }
-__global__ __launch_bounds__(256) void dropout_mask_kernel(const uint64_t* __restrict__ counter, float keep, int64_t count,
+__global__ __launch_bounds__(256) void dropout_mask_kernel(const uint64_t* __restrict__ counter, uint64_t extra, float keep, int64_t count,
                                                            float* __restrict__ mask) {
-    const uint64_t seed = counter[0], offset = counter[1];
+    const uint64_t seed = counter[0], offset = counter[1] + extra;
     const float inv = keep > 0.f ? 1.f / keep : 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i * 4 < count; i += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t ctr = offset + (uint64_t)i;
@@ -858,11 +873,11 @@ int suhpe_add(const float* a, const float* b, int64_t count, float* y, suhpe_str
     return check_launch("suhpe_add");
 }
 
-int suhpe_dropout_mask(uint64_t* counter, float keep, int64_t count, float* mask, suhpe_stream_t stream) {
+int suhpe_dropout_mask(uint64_t* counter, uint64_t host_offset, int advance, float keep, int64_t count, float* mask, suhpe_stream_t stream) {
     SUHPE_REQUIRE(counter && mask && count > 0 && keep >= 0.f && keep <= 1.f, "suhpe_dropout_mask: bad arguments");
     const int64_t n4 = ceil_div(count, 4);
-    LAUNCH(dropout_mask_kernel, dim3(grid_for(n4, 256)), dim3(256), stream, counter, keep, count, mask);
-    LAUNCH(advance_counter_kernel, dim3(1), dim3(1), stream, counter, (uint64_t)n4);
+    LAUNCH(dropout_mask_kernel, dim3(grid_for(n4, 256)), dim3(256), stream, counter, host_offset, keep, count, mask);
+    if (advance) LAUNCH(advance_counter_kernel, dim3(1), dim3(1), stream, counter, (uint64_t)n4);
     return check_launch("suhpe_dropout_mask");
 }
 

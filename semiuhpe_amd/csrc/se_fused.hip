@@ -25,6 +25,7 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* __restrict
     // fc1: a wavefront takes 4 squeeze outputs at a time (4 independent row streams)
     for (int j0 = wave * 4; j0 < csq; j0 += 16) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
         for (int i = lane * 4; i < c; i += 256) {
             const float4 pv = *reinterpret_cast<const float4*>(pl + i);
 #pragma unroll
@@ -46,7 +47,8 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* __restrict
     float acc[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { const int cc = t + 256 * k; acc[k] = cc < c ? b2[cc] : 0.f; }
-    for (int j = 0; j < csq; j += 4) {
+#pragma unroll 4
+    for (int j = 0; j < csq; j += 4) {              // unrolled: 32 independent 16-byte loads in flight per thread
         const float4 hv = *reinterpret_cast<const float4*>(hl + j);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -67,31 +69,27 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict
                                                          float* __restrict__ da2, float* __restrict__ da1, float* __restrict__ hbuf,
                                                          float* __restrict__ dp) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* dl = sm;                 // da1 [kMaxSq]
-    float* red = sm + kMaxSq;       // [4 waves][kMaxSq] partial dh
-    const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    // dh[j] = sum_c w2[c][j] * da2[c]: each thread folds its channels into csq register partials (rows of w2 are contiguous)
-    float part[kMaxSq];
-#pragma unroll
-    for (int j = 0; j < kMaxSq; ++j) part[j] = 0.f;
+    float* gl = sm;                     // da2 [c]
+    float* red = sm + c;                // [4][kMaxSq] partial dh
+    float* dl = red + 4 * kMaxSq;       // da1 [kMaxSq]
+    const int n = blockIdx.x, t = threadIdx.x;
     for (int cc = t; cc < c; cc += 256) {
         const float sv = s[(int64_t)n * c + cc];
         const float g = ds[(int64_t)n * c + cc] * sv * (1.f - sv);
+        gl[cc] = g;
         da2[(int64_t)n * c + cc] = g;
-#pragma unroll
-        for (int j = 0; j < kMaxSq; j += 4) {
-            if (j < csq) {
-                const float4 w = *reinterpret_cast<const float4*>(w2 + (int64_t)cc * csq + j);
-                part[j] += w.x * g; part[j + 1] += w.y * g; part[j + 2] += w.z * g; part[j + 3] += w.w * g;
-            }
-        }
     }
-#pragma unroll
-    for (int j = 0; j < kMaxSq; ++j) {
+    __syncthreads();
+    // dh[j] = sum_c w2[c][j] * da2[c]: thread = (j, quarter of the channels); rows of w2 are read coalesced across j
+    {
+        const int j = t & 63, q = t >> 6;
+        const int cq = (c + 3) / 4, c0 = q * cq, c1 = (c0 + cq < c) ? c0 + cq : c;
+        float acc = 0.f;
         if (j < csq) {
-            const float v = wave_sum(part[j]);
-            if (lane == 0) red[wave * kMaxSq + j] = v;
+#pragma unroll 16
+            for (int cc = c0; cc < c1; ++cc) acc += w2[(int64_t)cc * csq + j] * gl[cc];
         }
+        red[q * kMaxSq + j] = acc;
     }
     __syncthreads();
     if (t < csq) {
@@ -105,7 +103,8 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict
     float acc[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-    for (int j = 0; j < csq; ++j) {
+#pragma unroll 8
+    for (int j = 0; j < csq; ++j) {                 // unrolled: up to 64 independent loads in flight per thread
         const float g = dl[j];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -117,47 +116,29 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict
     for (int k = 0; k < 8; ++k) { const int cc = t + 256 * k; if (cc < c) dp[(int64_t)n * c + cc] = acc[k]; }
 }
 
-// Weight gradients.  A block owns 64 channels; thread = (channel, quarter of the squeeze outputs); one pass over n.
+// Weight gradients, one thread per (channel, squeeze output):
 //   dW2[c][j] += sum_n da2[n][c] h[n][j];  dW1[j][c] += sum_n da1[n][j] p[n][c];  db2[c] += sum_n da2[n][c];  db1[j] += sum_n da1[n][j]
+// block = 64 channels x 4 squeeze outputs; grid (c/64, csq/4).  All loads of the n-loop are independent (unrolled).
 __global__ __launch_bounds__(256) void se_wgrad_kernel(const float* __restrict__ p, const float* __restrict__ hbuf, const float* __restrict__ da1,
                                                        const float* __restrict__ da2, int n, int c, int csq, float* __restrict__ dw1,
                                                        float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2) {
-    constexpr int JQ = kMaxSq / 4;                               // up to 16 squeeze outputs per thread
-    __shared__ float hl[32 * kMaxSq], gl[32 * kMaxSq];           // h and da1 of a chunk of 32 samples
-    const int t = threadIdx.x, cl = t & 63, q = t >> 6;
-    const int cc = blockIdx.x * 64 + cl;
-    const bool ok = cc < c;
-    const int jn = (csq + 3) / 4;                                 // squeeze outputs per quarter
-    const int jbase = q * jn;
-    float acc1[JQ], acc2[JQ], sb2 = 0.f, sb1 = 0.f;
-#pragma unroll
-    for (int j = 0; j < JQ; ++j) { acc1[j] = 0.f; acc2[j] = 0.f; }
-    for (int n0 = 0; n0 < n; n0 += 32) {
-        const int nn = n - n0 < 32 ? n - n0 : 32;
-        __syncthreads();
-        for (int e = t; e < nn * csq; e += 256) { hl[e] = hbuf[(int64_t)n0 * csq + e]; gl[e] = da1[(int64_t)n0 * csq + e]; }
-        __syncthreads();
-        if (blockIdx.x == 0 && t < csq)
-            for (int i = 0; i < nn; ++i) sb1 += gl[i * csq + t];
-        if (ok) {
-            for (int i = 0; i < nn; ++i) {
-                const float g2 = da2[(int64_t)(n0 + i) * c + cc], pv = p[(int64_t)(n0 + i) * c + cc];
-                sb2 += g2;
-#pragma unroll
-                for (int j = 0; j < JQ; ++j) {
-                    if (j < jn && jbase + j < csq) { acc2[j] += g2 * hl[i * csq + jbase + j]; acc1[j] += gl[i * csq + jbase + j] * pv; }
-                }
-            }
-        }
+    const int cc = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (cc >= c || j >= csq) return;
+    float a2 = 0.f, a1v = 0.f, s2 = 0.f, s1 = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < n; ++i) {
+        const float g2 = da2[(int64_t)i * c + cc], pv = p[(int64_t)i * c + cc];
+        const float hv = hbuf[(int64_t)i * csq + j], g1 = da1[(int64_t)i * csq + j];
+        a2 += g2 * hv;
+        a1v += g1 * pv;
+        s2 += g2;
+        s1 += g1;
     }
-    if (ok) {
-#pragma unroll
-        for (int j = 0; j < JQ; ++j) {
-            if (j < jn && jbase + j < csq) { dw2[(int64_t)cc * csq + jbase + j] += acc2[j]; dw1[(int64_t)(jbase + j) * c + cc] += acc1[j]; }
-        }
-        if (q == 0) db2[cc] += sb2;
-    }
-    if (blockIdx.x == 0 && t < csq) db1[t] += sb1;
+    dw2[(int64_t)cc * csq + j] += a2;
+    dw1[(int64_t)j * c + cc] += a1v;
+    if (j == 0) db2[cc] += s2;
+    if (cc == 0) db1[j] += s1;
 }
 
 }  // namespace suhpe
@@ -182,9 +163,10 @@ int suhpe_se_mlp_bwd(const float* ds, const float* s, const float* a1, const flo
     float* da2 = static_cast<float*>(workspace);            // (n,c)
     float* da1 = da2 + (int64_t)n * c;                      // (n,csq)
     float* hb = da1 + (int64_t)n * csq;                     // (n,csq)
-    hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(n), dim3(256), (size_t)(5 * kMaxSq) * sizeof(float), as_stream(stream), ds, s, a1, w1, w2, c, csq,
+    hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(n), dim3(256), (size_t)(c + 5 * kMaxSq) * sizeof(float), as_stream(stream), ds, s, a1, w1, w2, c, csq,
                        da2, da1, hb, dp);
-    hipLaunchKernelGGL(se_wgrad_kernel, dim3((c + 63) / 64), dim3(256), 0, as_stream(stream), p, hb, da1, da2, n, c, csq, dw1, db1, dw2, db2);
+    hipLaunchKernelGGL(se_wgrad_kernel, dim3((c + 63) / 64, (csq + 3) / 4), dim3(256), 0, as_stream(stream), p, hb, da1, da2, n, c, csq, dw1, db1, dw2,
+                       db2);
     return check_launch("suhpe_se_mlp_bwd");
 }
 

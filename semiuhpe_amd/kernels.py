@@ -310,20 +310,26 @@ def mul(a, b):
 
 
 _counters = {}
+_host_offsets = {}
 
 
 def rng_counter(device, seed=None):
-    """Device-resident (seed, offset) pair of the counter-based mask generator."""
+    """Device-resident (seed, offset) pair of the counter-based mask generator; the running position is kept on the
+    host (one launch per draw)."""
     key = torch.device(device)
     if key not in _counters or seed is not None:
         s = int(seed if seed is not None else torch.initial_seed()) & ((1 << 63) - 1)
         _counters[key] = torch.tensor([s, 0], dtype=torch.int64).to(key)
+        _host_offsets[key] = 0
     return _counters[key]
 
 
 def dropout_mask(shape, keep, device):
     m = torch.empty(shape, dtype=torch.float32, device=device)
-    call("suhpe_dropout_mask", ptr(rng_counter(device)), float(keep), m.numel(), ptr(m))
+    ctr = rng_counter(device)
+    key = torch.device(device)
+    call("suhpe_dropout_mask", ptr(ctr), _host_offsets[key], 0, float(keep), m.numel(), ptr(m))
+    _host_offsets[key] += (m.numel() + 3) // 4
     return m
 
 
