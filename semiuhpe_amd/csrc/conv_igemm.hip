@@ -298,10 +298,11 @@ struct TnParams {
 };
 
 template <int BM, int BN, int WM, int WN, int VECA, int VECB>
-__global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams p) {
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_tn_kernel(const TnParams p) {
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / 32, TN = WN / 32;
-    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;
+    static_assert(NT == 256 || NT == 512, "4 or 8 waves per workgroup");
     __shared__ __attribute__((aligned(16))) float As[BK * BM];   // [m][cout]
     __shared__ __attribute__((aligned(16))) float Bs[BK * BN];   // [m][k']
 
@@ -325,12 +326,12 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams p) {
 
     // A loader: dy rows.  VECA=4: col group = t % (BM/4), row = t / (BM/4) + RA*i ; VECA=1: col = t % BM
     constexpr int A_CG = BM / VECA;                 // column groups per row
-    constexpr int RA = 256 / A_CG;                  // rows covered per pass
+    constexpr int RA = NT / A_CG;                   // rows covered per pass
     constexpr int A_IT = BK / RA;
     static_assert(A_IT >= 1, "tile too wide for the A loader");
     const int a_col = (t % A_CG) * VECA, a_row = t / A_CG;
     constexpr int B_CG = BN / VECB;
-    constexpr int RB = 256 / B_CG;
+    constexpr int RB = NT / B_CG;
     constexpr int B_IT = BK / RB;
     static_assert(B_IT >= 1, "tile too wide for the B loader");
     const int b_col = (t % B_CG) * VECB, b_row = t / B_CG;
@@ -662,7 +663,7 @@ const char* suhpe_conv2d_kernel_name(const suhpe_conv_t* d, int pass) {
     if (!(va && vb)) return va ? "igemm_tn_kernel<64,64,32,32,4,1>" : (vb ? "igemm_tn_kernel<64,64,32,32,1,4>" : "igemm_tn_kernel<64,64,32,32,1,1>");
     int bm, bn;
     wgrad_tile(d, &bm, &bn);
-    if (bm == 128) return bn == 128 ? "igemm_tn_kernel<128,128,64,64,4,4>" : "igemm_tn_kernel<128,64,64,32,4,4>";
+    if (bm == 128) return bn == 128 ? "igemm_tn_kernel<128,128,64,32,4,4>" : "igemm_tn_kernel<128,64,64,32,4,4>";
     return bn == 128 ? "igemm_tn_kernel<64,128,32,64,4,4>" : "igemm_tn_kernel<64,64,32,32,4,4>";
 }
 
@@ -697,9 +698,10 @@ int suhpe_conv2d_wgrad_partial(const suhpe_conv_t* d, const float* x, const floa
     const bool vb = (cg % 4 == 0) && (d->cin % 4 == 0) && aligned16(x);
     dim3 grid(p.tiles_m * p.tiles_n * splits, 1, d->groups);
     hipStream_t st = as_stream(stream);
-#define TN_LAUNCH(BM_, BN_, WM_, WN_, VA_, VB_) hipLaunchKernelGGL((igemm_tn_kernel<BM_, BN_, WM_, WN_, VA_, VB_>), grid, dim3(256), 0, st, p)
+#define TN_LAUNCH(BM_, BN_, WM_, WN_, VA_, VB_) \
+    hipLaunchKernelGGL((igemm_tn_kernel<BM_, BN_, WM_, WN_, VA_, VB_>), grid, dim3(((BM_) / (WM_)) * ((BN_) / (WN_)) * 64), 0, st, p)
     if (va && vb) {
-        if (bm == 128 && bn == 128) TN_LAUNCH(128, 128, 64, 64, 4, 4);
+        if (bm == 128 && bn == 128) TN_LAUNCH(128, 128, 64, 32, 4, 4);       // 8 wavefronts of 64x32
         else if (bm == 128 && bn == 64) TN_LAUNCH(128, 64, 64, 32, 4, 4);
         else if (bm == 64 && bn == 128) TN_LAUNCH(64, 128, 32, 64, 4, 4);
         else TN_LAUNCH(64, 64, 32, 32, 4, 4);
