@@ -540,7 +540,7 @@ static void launch_nt(const NtParams& p_in, int groups, hipStream_t st) {
 // tile selection for igemm_nt; returns the kernel's name (as rocprofv3 prints the template arguments)
 enum NtTile { NT_64x64_S = 0, NT_64x64, NT_128x32, NT_128x128, NT_128x64, NT_256x32 };
 static const char* kNtNames[] = {"igemm_nt_kernel<64,64,32,32,1>", "igemm_nt_kernel<64,64,32,32,4>", "igemm_nt_kernel<128,32,32,32,4>",
-                                 "igemm_nt_kernel<128,128,64,32,4>", "igemm_nt_kernel<128,64,64,32,4>", "igemm_nt_kernel<256,32,64,32,4>"};
+                                 "igemm_nt_kernel<128,128,64,32,4>", "igemm_nt_kernel<128,64,32,32,4>", "igemm_nt_kernel<256,32,64,32,4>"};
 
 static NtTile choose_nt(int64_t M, int ng, bool vec4) {
     if (!vec4) return NT_64x64_S;
@@ -562,7 +562,7 @@ static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st
         case NT_64x64: launch_nt<64, 64, 32, 32, 4>(p, groups, st); break;
         case NT_128x32: launch_nt<128, 32, 32, 32, 4>(p, groups, st); break;
         case NT_128x128: launch_nt<128, 128, 64, 32, 4>(p, groups, st); break;      // 8 wavefronts of 64x32
-        case NT_128x64: launch_nt<128, 64, 64, 32, 4>(p, groups, st); break;
+        case NT_128x64: launch_nt<128, 64, 32, 32, 4>(p, groups, st); break;        // 8 wavefronts of 32x32
         case NT_256x32: launch_nt<256, 32, 64, 32, 4>(p, groups, st); break;
     }
 }
