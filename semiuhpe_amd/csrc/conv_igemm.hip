@@ -73,6 +73,8 @@ struct NtParams {
     int ldy;
     int col_tiles;       // ceil(Ng / BN), set by the launcher
     int ldf;             // filter row length in elements (== g.K except in MODE 3)
+    float* stats;        // optional: per-(channel, row tile) partial sum / sum of squares of the output (BatchNorm statistics
+    int stat_gx;         // fused into the epilogue); layout [channel][stat_gx][4] = (S, Q, k, n), stat_gx = ceil(M / BM)
 };
 
 // ---------------------------------------------------------------------------------------------- igemm_nt
@@ -282,6 +284,52 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_nt_kernel(co
                 }
                 y[orow * p.ldy + col] = acc[i][j][e] + bv;
             }
+    }
+
+    // ---- fused BatchNorm statistics.  Each tile emits (S, Q, k, n) per column: sums of (y-k) and (y-k)^2 over its n valid
+    // rows, shifted by k = the tile's first-row value so the variance never forms from two large cancelling sums.
+    if (p.stats) {
+        __syncthreads();                                    // every wave is past its last LDS tile read
+        float* red = As;                                    // [BM/WM][BN][2]
+        float* kk = As + (BM / WM) * BN * 2;                // [BN]
+        if (wm == 0 && h == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) kk[wn * WN + j * 32 + r32] = acc[0][j][0];     // row m0 (always valid)
+        }
+        __syncthreads();
+        const int64_t rows_left = g.M - (m0 + wm * WM);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float k = kk[wn * WN + j * 32 + r32];
+            float a = 0.f, q = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int lr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const float v = lr < rows_left ? acc[i][j][e] - k : 0.f;
+                    a += v;
+                    q += v * v;
+                }
+            a += __shfl_xor(a, 32, 64);
+            q += __shfl_xor(q, 32, 64);
+            if (h == 0) {
+                const int idx = wm * BN + wn * WN + j * 32 + r32;
+                red[idx * 2] = a;
+                red[idx * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        const int64_t nrows = g.M - m0 < BM ? g.M - m0 : BM;
+        for (int idx = t; idx < BN; idx += NT) {
+            const int col = n0 + idx;
+            if (col >= p.Ng) continue;
+            float a = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < BM / WM; ++w) { a += red[(w * BN + idx) * 2]; q += red[(w * BN + idx) * 2 + 1]; }
+            float4* dst = reinterpret_cast<float4*>(p.stats) + ((int64_t)(grp * p.Ng + col)) * p.stat_gx + row_tile;
+            *dst = make_float4(a, q, kk[idx], (float)nrows);
+        }
     }
 }
 
@@ -556,6 +604,8 @@ static NtTile choose_nt(int64_t M, int ng, bool vec4) {
     return tile;
 }
 
+static int nt_tile_bm(NtTile t) { return (t == NT_64x64_S || t == NT_64x64) ? 64 : (t == NT_256x32 ? 256 : 128); }
+
 static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st) {
     switch (choose_nt(p.g.M, p.Ng, vec4)) {
         case NT_64x64_S: launch_nt<64, 64, 32, 32, 1>(p, groups, st); break;
@@ -581,9 +631,32 @@ int suhpe_conv2d_fwd(const suhpe_conv_t* d, const float* x, const float* w, cons
     const int cg = d->cin / d->groups;
     p.g = make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0);
     p.x = x; p.f = w; p.bias = bias; p.y = y; p.Ng = d->cout / d->groups; p.ldy = d->cout; p.ldf = p.g.K;
+    p.stats = nullptr; p.stat_gx = 0;
     const bool vec4 = (cg % 4 == 0) && (d->cin % 4 == 0) && aligned16(x) && aligned16(w);
     dispatch_nt(p, d->groups, vec4, as_stream(stream));
     return check_launch("suhpe_conv2d_fwd");
+}
+
+int suhpe_conv2d_fwd_stats_tiles(const suhpe_conv_t* d) {
+    if (!d || d->groups <= 0) return 0;
+    const int cg = d->cin / d->groups, ng = d->cout / d->groups;
+    const int64_t M = (int64_t)d->n * d->ho * d->wo;
+    return (int)ceil_div(M, nt_tile_bm(choose_nt(M, ng, cg % 4 == 0 && d->cin % 4 == 0)));
+}
+
+int suhpe_conv2d_fwd_stats(const suhpe_conv_t* d, const float* x, const float* w, float* y, float* stats, suhpe_stream_t stream) {
+    int rc = check_desc(d, "suhpe_conv2d_fwd_stats");
+    if (rc) return rc;
+    SUHPE_REQUIRE(x && w && y && stats, "suhpe_conv2d_fwd_stats: null pointer");
+    NtParams p;
+    const int cg = d->cin / d->groups;
+    p.g = make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0);
+    p.x = x; p.f = w; p.bias = nullptr; p.y = y; p.Ng = d->cout / d->groups; p.ldy = d->cout; p.ldf = p.g.K;
+    p.stats = stats; p.stat_gx = suhpe_conv2d_fwd_stats_tiles(d);
+    const bool vec4 = (cg % 4 == 0) && (d->cin % 4 == 0);
+    SUHPE_REQUIRE(!vec4 || (aligned16(x) && aligned16(w)), "suhpe_conv2d_fwd_stats: x / w must be 16-byte aligned");
+    dispatch_nt(p, d->groups, vec4, as_stream(stream));
+    return check_launch("suhpe_conv2d_fwd_stats");
 }
 
 int suhpe_conv2d_transpose_filter(const suhpe_conv_t* d, const float* w, float* wt, suhpe_stream_t stream) {
@@ -607,6 +680,7 @@ int suhpe_conv2d_dgrad(const suhpe_conv_t* d, const float* dy, const float* wt, 
     if (d->stride == 1) {
         p.g = make_geom(d->n, d->ho, d->wo, d->h, d->w, d->cout, ng, d->r, d->s, d->stride, d->pad, 1);
         p.x = dy; p.f = wt; p.bias = nullptr; p.y = dx; p.Ng = cg; p.ldy = d->cin; p.ldf = p.g.K;
+        p.stats = nullptr; p.stat_gx = 0;
         dispatch_nt(p, d->groups, vec4, as_stream(stream));
     } else {
         // one launch per parity class of the input pixel: only the taps r = (ph+pad) mod stride (+ k*stride) reach it,
@@ -624,6 +698,7 @@ int suhpe_conv2d_dgrad(const suhpe_conv_t* d, const float* dy, const float* wt, 
                 g.off_h = (ph + d->pad - r0) / st; g.off_w = (pw + d->pad - s0) / st;
                 p.g = g;
                 p.x = dy; p.f = wt; p.bias = nullptr; p.y = dx; p.Ng = cg; p.ldy = d->cin; p.ldf = d->r * d->s * ng;
+                p.stats = nullptr; p.stat_gx = 0;
                 dispatch_nt(p, d->groups, vec4, as_stream(stream));
             }
     }

@@ -11,7 +11,7 @@
 
 namespace suhpe {
 
-constexpr int kMaxRowBlocks = 1024;   // partial-sum slabs per channel (workspace = kMaxRowBlocks*c*2 floats)
+constexpr int kMaxRowBlocks = 1024;   // partial-sum slabs per channel (workspace = kMaxRowBlocks*c*4 floats)
 
 // ------------------------------------------------------------------------------------------ activations
 __device__ __forceinline__ float act_apply(float u, int act) {
@@ -122,9 +122,11 @@ __device__ __forceinline__ void wave_channel_sums(const float* __restrict__ part
     *s = wave_sum(a);
     *q = wave_sum(b);
 }
+// shift != nullptr selects the 4-float statistics record (S, Q, k, n) instead of the plain pair.
 template <int VEC>
 __device__ __forceinline__ void block_combine(const float* s0, const float* s1, int cw, int rp, int col0, int c,
-                                              int bx, float* __restrict__ part, float* lds) {
+                                              int bx, float* __restrict__ part, float* lds, const float* shift = nullptr,
+                                              float count = 0.f) {
     const int t = threadIdx.x;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) { lds[(t * 2 + 0) * VEC + v] = s0[v]; lds[(t * 2 + 1) * VEC + v] = s1[v]; }
@@ -141,13 +143,18 @@ __device__ __forceinline__ void block_combine(const float* s0, const float* s1, 
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             const int ch = (col0 + t) * VEC + v;
-            part[((int64_t)ch * gridDim.x + bx) * 2 + 0] = a0[v];      // [channel][row block][2]
-            part[((int64_t)ch * gridDim.x + bx) * 2 + 1] = a1[v];
+            if (shift) {
+                reinterpret_cast<float4*>(part)[(int64_t)ch * gridDim.x + bx] = make_float4(a0[v], a1[v], shift[v], count);
+            } else {
+                part[((int64_t)ch * gridDim.x + bx) * 2 + 0] = a0[v];      // [channel][row block][2]
+                part[((int64_t)ch * gridDim.x + bx) * 2 + 1] = a1[v];
+            }
         }
     }
 }
 
-// BN statistics, pass 1: per-block partial sum and sum of squares.
+// BN statistics, pass 1: per-block record (S, Q, k, n) per channel: sums of (x-k) and (x-k)^2 over the block's n rows,
+// shifted by k = the block's first-row value, so the variance is never the difference of two large sums.
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ x, int64_t rows, int c, int cw, int rp,
                                                         int64_t rows_per_block, float* __restrict__ part) {
@@ -155,13 +162,14 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
     const int t = threadIdx.x, col = t % cw, rsub = t / cw;
     const int col0 = blockIdx.y * cw;
     const int cv = c / VEC;
-    float s0[VEC], s1[VEC];
+    float s0[VEC], s1[VEC], k[VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) { s0[v] = 0.f; s1[v] = 0.f; }
-    if (rsub < rp && col0 + col < cv) {
-        const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-        int64_t r1 = r0 + rows_per_block;
-        if (r1 > rows) r1 = rows;
+    for (int v = 0; v < VEC; ++v) { s0[v] = 0.f; s1[v] = 0.f; k[v] = 0.f; }
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    if (rsub < rp && col0 + col < cv && r0 < rows) {
+        vload<VEC>(x + (r0 * cv + col0 + col) * VEC, k);
         int64_t r = r0 + rsub;
         // four independent row streams per thread keep 4 x 16 B loads in flight (the pass is pure HBM latency otherwise)
         for (; r + 3 * (int64_t)rp < r1; r += 4 * (int64_t)rp) {
@@ -172,18 +180,19 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
             vload<VEC>(x + ((r + 3 * (int64_t)rp) * cv + col0 + col) * VEC, xd);
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
-                s0[v] += (xa[v] + xb[v]) + (xc[v] + xd[v]);
-                s1[v] += (xa[v] * xa[v] + xb[v] * xb[v]) + (xc[v] * xc[v] + xd[v] * xd[v]);
+                const float a = xa[v] - k[v], b = xb[v] - k[v], cc = xc[v] - k[v], d = xd[v] - k[v];
+                s0[v] += (a + b) + (cc + d);
+                s1[v] += (a * a + b * b) + (cc * cc + d * d);
             }
         }
         for (; r < r1; r += rp) {
             float xv[VEC];
             vload<VEC>(x + (r * cv + col0 + col) * VEC, xv);
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) { s0[v] += xv[v]; s1[v] += xv[v] * xv[v]; }
+            for (int v = 0; v < VEC; ++v) { const float a = xv[v] - k[v]; s0[v] += a; s1[v] += a * a; }
         }
     }
-    block_combine<VEC>(s0, s1, cw, rp, col0, c, blockIdx.x, part, lds);
+    block_combine<VEC>(s0, s1, cw, rp, col0, c, blockIdx.x, part, lds, k, r1 > r0 ? (float)(r1 - r0) : 0.f);
 }
 
 // pass 2: one wavefront per channel; running-stat update as nn.BatchNorm does
@@ -195,11 +204,21 @@ __global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict
     const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ch == 0 && lane == 0 && nbt) nbt[0] += 1;
     if (ch >= c) return;
-    double s, q;
-    wave_channel_sums(part, gx, ch, lane, &s, &q);
+    // re-centre every record on zero in fp64 (exact to 1e-16) and add: sum x = S + n k, sum x^2 = Q + 2 k S + n k^2
+    double a = 0.0, b = 0.0;
+    const float4* pr = reinterpret_cast<const float4*>(part) + (int64_t)ch * gx;
+    for (int i = lane; i < gx; i += 64) {
+        const float4 v = pr[i];
+        const double S = v.x, Q = v.y, k = v.z, n = v.w;
+        a += S + n * k;
+        b += Q + 2.0 * k * S + n * k * k;
+    }
+    // centre on the first record's shift before the final subtraction: var = E[(x-k0)^2] - (E[x]-k0)^2
+    const double k0 = (double)pr[0].z;
+    const double s = wave_sum(a), q = wave_sum(b);
     if (lane != 0) return;
     const double m = s / (double)rows;
-    double var = q / (double)rows - m * m;
+    double var = (q - 2.0 * k0 * s + (double)rows * k0 * k0) / (double)rows - (m - k0) * (m - k0);
     if (var < 0.0) var = 0.0;
     mean[ch] = (float)m;
     rstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
@@ -691,7 +710,7 @@ using namespace suhpe;
 
 extern "C" {
 
-int64_t suhpe_bn_workspace_bytes(int c) { return (int64_t)kMaxRowBlocks * c * 2 * sizeof(float) + (int64_t)c * 2 * sizeof(float); }
+int64_t suhpe_bn_workspace_bytes(int c) { return (int64_t)kMaxRowBlocks * c * 4 * sizeof(float) + (int64_t)c * 2 * sizeof(float); }
 
 int suhpe_bn_stats(const float* x, int64_t rows, int c, float eps, float momentum, float* mean, float* rstd,
                    float* running_mean, float* running_var, int64_t* nbt, void* workspace, suhpe_stream_t stream) {
@@ -709,6 +728,13 @@ int suhpe_bn_stats(const float* x, int64_t rows, int c, float eps, float momentu
                running_mean, running_var, nbt);
     }
     return check_launch("suhpe_bn_stats");
+}
+
+int suhpe_bn_stats_from_partials(const float* part, int gx, int64_t rows, int c, float eps, float momentum, float* mean, float* rstd,
+                                 float* running_mean, float* running_var, int64_t* nbt, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(part && mean && rstd && gx > 0 && rows > 0 && c > 0, "suhpe_bn_stats_from_partials: bad arguments");
+    LAUNCH(bn_stats_finalize, dim3((c + 3) / 4), dim3(256), stream, part, gx, c, rows, eps, momentum, mean, rstd, running_mean, running_var, nbt);
+    return check_launch("suhpe_bn_stats_from_partials");
 }
 
 int suhpe_bn_eval_stats(const float* rm, const float* rv, int c, float eps, float* mean, float* rstd, suhpe_stream_t stream) {

@@ -106,6 +106,27 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, groups=1):
     return y
 
 
+def conv2d_fwd_stats(x, w, stride=1, pad=0, groups=1):
+    """Dense conv forward that also returns BatchNorm partial sums from its epilogue: (y, partials, tiles)."""
+    _chk(x, "x")
+    assert filter_is_physical(w)
+    d = conv_desc(x.shape, w.shape, stride, pad, groups)
+    tiles = _lib.load().suhpe_conv2d_fwd_stats_tiles(ctypes.byref(d))
+    y = torch.empty((d.n, d.ho, d.wo, d.cout), dtype=torch.float32, device=x.device)
+    part = torch.empty(d.cout * tiles * 4, dtype=torch.float32, device=x.device)
+    with _Prof(d, 0):
+        call("suhpe_conv2d_fwd_stats", ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(part))
+    return y, part, tiles
+
+
+def bn_stats_from_partials(part, tiles, rows, c, eps, momentum, running_mean=None, running_var=None, nbt=None):
+    mean = torch.empty(c, dtype=torch.float32, device=part.device)
+    rstd = torch.empty(c, dtype=torch.float32, device=part.device)
+    call("suhpe_bn_stats_from_partials", ptr(part), int(tiles), int(rows), c, float(eps), float(momentum), ptr(mean), ptr(rstd),
+         ptr(running_mean), ptr(running_var), ptr(nbt))
+    return mean, rstd
+
+
 def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, groups=1):
     _chk(dy, "dy")
     d = conv_desc(x_shape, w.shape, stride, pad, groups)

@@ -85,6 +85,19 @@ class Conv2d(Layer):
             tape.append(x)
         return y
 
+    def fwd_stats(self, x, tape):
+        """forward + BatchNorm partial statistics from the GEMM epilogue (dense, bias-free convs only) -> (y, (part, tiles))"""
+        if not K.filter_is_physical(self.weight):
+            self.weight.data = K.to_filter_layout(self.weight.data)
+        y, part, tiles = K.conv2d_fwd_stats(x, self.weight, self.stride, self.padding, self.groups)
+        if tape is not None:
+            tape.append(x)
+        return y, (part, tiles)
+
+    def fuses_stats(self):
+        depthwise = self.groups > 1 and self.groups == self.in_channels == self.out_channels
+        return self.bias is None and not depthwise
+
     def bwd(self, dy, tape):
         x = tape.pop()
         K.conv2d_wgrad(x, dy, self.weight.shape, self.stride, self.padding, self.groups, out=grad_of(self.weight), accumulate=True)
@@ -143,9 +156,12 @@ class _BatchNorm(Layer):
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
-    def fwd(self, x, tape, residual=None):
+    def fwd(self, x, tape, residual=None, partials=None):
         c = self.num_features
-        if self.training:
+        if self.training and partials is not None:          # statistics already accumulated by the producing conv's epilogue
+            mean, rstd = K.bn_stats_from_partials(partials[0], partials[1], x.numel() // c, c, self.eps, self.momentum,
+                                                  self.running_mean, self.running_var, self.num_batches_tracked)
+        elif self.training:
             mean, rstd = K.bn_stats(x, c, self.eps, self.momentum, self.running_mean, self.running_var, self.num_batches_tracked)
         else:
             mean, rstd = K.bn_eval_stats(self.running_mean, self.running_var, self.eps)
@@ -349,6 +365,14 @@ class Sequential(Layer):
         return dy
 
 
+def conv_bn_fwd(conv, bn, x, tape, residual=None):
+    """conv -> BatchNorm(+act): in training the statistics come out of the conv's epilogue when the conv is dense"""
+    if bn.training and conv.fuses_stats():
+        y, partials = conv.fwd_stats(x, tape)
+        return bn.fwd(y, tape, residual=residual, partials=partials)
+    return bn.fwd(conv.fwd(x, tape), tape, residual=residual)
+
+
 class ConvNormActivation(Sequential):
     """torchvision.ops.Conv2dNormActivation: children '0' (conv, no bias) and '1' (BatchNorm); the activation that
     torchvision keeps as child '2' has no parameters and is fused into the BatchNorm kernel."""
@@ -356,6 +380,9 @@ class ConvNormActivation(Sequential):
     def __init__(self, cin, cout, kernel_size=3, stride=1, groups=1, act="silu", bn_eps=1e-5, bn_momentum=0.1):
         super().__init__(Conv2d(cin, cout, kernel_size, stride, (kernel_size - 1) // 2, groups, bias=False),
                          BatchNorm2d(cout, bn_eps, bn_momentum, act))
+
+    def fwd(self, x, tape):
+        return conv_bn_fwd(self[0], self[1], x, tape)
 
 
 # ------------------------------------------------------------------------------------------------ autograd bridge

@@ -31,12 +31,13 @@ class RepVGGBlock(Layer):
         self.need_input_grad = True
 
     def fwd(self, x, tape):
-        t3 = self.rbr_dense.conv.fwd(x, tape)
-        t1 = self.rbr_1x1.conv.fwd(x, tape)
-        u = self.rbr_1x1.bn.fwd(t1, tape)
+        train = self.rbr_dense.bn.training
+        t3, p3 = self.rbr_dense.conv.fwd_stats(x, tape) if train else (self.rbr_dense.conv.fwd(x, tape), None)
+        t1, p1 = self.rbr_1x1.conv.fwd_stats(x, tape) if train else (self.rbr_1x1.conv.fwd(x, tape), None)
+        u = self.rbr_1x1.bn.fwd(t1, tape, partials=p1)
         if self.rbr_identity is not None:
             u = self.rbr_identity.fwd(x, tape, residual=u)
-        return self.rbr_dense.bn.fwd(t3, tape, residual=u)          # relu(bn(t3) + u)
+        return self.rbr_dense.bn.fwd(t3, tape, residual=u, partials=p3)          # relu(bn(t3) + u)
 
     def bwd(self, dout, tape):
         out = tape[-1][4]                                           # forward output kept for the ReLU mask

@@ -11,7 +11,8 @@ import torch
 import torch.nn as nn
 
 from .. import kernels as K
-from ..layers import (BatchNorm2d, Conv2d, Dropout, Identity, Layer, LayerNorm, Linear, Network, Sequential, draw_mask, grad_of)
+from ..layers import (BatchNorm2d, Conv2d, Dropout, Identity, Layer, LayerNorm, Linear, Network, Sequential, conv_bn_fwd, draw_mask,
+                      grad_of)
 from .efficientnet_v2 import init_regression_head_, regression_head
 
 
@@ -25,7 +26,7 @@ class Conv2d_BN(Layer):
         nn.init.constant_(self.bn.weight, bn_weight_init)
 
     def fwd(self, x, tape):
-        return self.bn.fwd(self.c.fwd(x, tape), tape)
+        return conv_bn_fwd(self.c, self.bn, x, tape)
 
     def bwd(self, dy, tape):
         return self.c.bwd(self.bn.bwd(dy, tape), tape)

@@ -89,13 +89,17 @@ def test_three_steps_match_oracle_with_resync():
         fd_o, fu_o, out_o = oracle.train_func({k: v.clone() for k, v in data.items()}, {k: v.clone() for k, v in ulb.items()})
         g_ref = {n: p.grad.clone() for n, p in oracle.net.named_parameters()}
         torch.manual_seed(100 + step)
-        truth.train_func(d64, u64)
+        fd_t, _, _ = truth.train_func(d64, u64)
         g_true = {n: p.grad.clone() for n, p in truth.net.named_parameters()}
         torch.manual_seed(100 + step)
         fd, fu, out = agent.train_func({k: v.cuda() for k, v in data.items()}, {k: v.cuda() for k, v in ulb.items()})
         assert rel_err(fd["loss"], fd_o["loss"]) < 3e-4 and rel_err(fd["err_deg"], fd_o["err_deg"]) < 2e-3      # geodesic metric
-        # train-mode BN on 4 images: the 1e-4 bound on rotation matrices is asserted in eval mode (test_gpu_backbones.py)
-        assert float((fd["pred_orth"].cpu() - fd_o["pred_orth"]).abs().max()) < 3e-4
+        # train-mode BN on 4 images amplifies fp32 rounding: the 1e-4 bound on rotation matrices is asserted in eval mode
+        # (test_gpu_backbones.py); here the HIP path must sit as close to the float64 result as the fp32 oracle does (x4)
+        orth_noise = float((fd_o["pred_orth"].double() - fd_t["pred_orth"]).abs().max())
+        orth_err = float((fd["pred_orth"].cpu().double() - fd_t["pred_orth"]).abs().max())
+        assert orth_err <= max(1e-4, 4.0 * orth_noise), (step, orth_err, orth_noise)
+        assert float((fd["pred_orth"].cpu() - fd_o["pred_orth"]).abs().max()) < 1e-3
         assert rel_err(fu["entropy"], fu_o["entropy"]) < 3e-4
         assert abs(float(fu["mask_ratio"]) - float(fu_o["mask_ratio"])) < 1e-6 and 0 < float(fu["mask_ratio"]) <= 1
         assert rel_err(fu["unsuper_loss"], fu_o["unsuper_loss"]) < 2e-3

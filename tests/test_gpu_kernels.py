@@ -75,6 +75,47 @@ def test_conv_fwd_dgrad_wgrad(K, cfg):
     assert rel(dw2, 2 * wd.grad) < 2e-5
 
 
+STAT_CONVS = [c for c in CONVS if not (c[6] > 1 and c[6] == c[1] == c[2])] + [
+    (1, 24, 24, 3, 1, 1, 1, 5, 5),         # a single ragged row tile
+    (160, 24, 24, 3, 1, 1, 1, 28, 28),     # many row tiles, narrow output (256x32 / 128x32 tiles)
+    (37, 256, 64, 1, 1, 0, 1, 13, 13),     # M not a multiple of any tile height
+    (16, 64, 128, 3, 2, 1, 2, 28, 28),     # grouped + strided
+]
+
+
+@pytest.mark.parametrize("cfg", STAT_CONVS, ids=[str(c) for c in STAT_CONVS])
+def test_conv_fwd_fused_bn_statistics(K, cfg):
+    """conv2d_fwd_stats == conv2d_fwd bit for bit, and its epilogue partials finish to the same batch statistics /
+    running-stat update as the stand-alone bn_stats pass (and as a float64 reference)."""
+    n, cin, cout, k, stride, pad, groups, h, w = cfg
+    g = torch.Generator().manual_seed(hash(cfg) % 1000 + 1)
+    x = torch.randn(n, cin, h, w, generator=g) + 0.3
+    wt = torch.randn(cout, cin // groups, k, k, generator=g) / (k * (cin // groups) ** 0.5)
+    wg, xg = K.to_filter_layout(wt.cuda()), nhwc(x)
+    y0 = K.conv2d_fwd(xg, wg, None, stride, pad, groups)
+    y1, part, tiles = K.conv2d_fwd_stats(xg, wg, stride, pad, groups)
+    assert torch.equal(y0, y1)
+    assert part.numel() == cout * tiles * 4
+    eps, mom = 1e-3, 0.1
+    rows = y0.numel() // cout
+
+    def fresh():
+        return (torch.full((cout,), 0.25, device="cuda"), torch.full((cout,), 1.5, device="cuda"),
+                torch.zeros((), dtype=torch.int64, device="cuda"))
+    rm0, rv0, nb0 = fresh()
+    rm1, rv1, nb1 = fresh()
+    m0, r0 = K.bn_stats(y0, cout, eps, mom, rm0, rv0, nb0)
+    m1, r1 = K.bn_stats_from_partials(part, tiles, rows, cout, eps, mom, rm1, rv1, nb1)
+    yd = y0.double().cpu().reshape(rows, cout)
+    mean = yd.mean(0)
+    var = yd.var(0, unbiased=False)
+    assert rel(m1, mean) < 2e-5 and rel(r1, (var + eps).rsqrt()) < 2e-5
+    assert rel(m1, m0.cpu()) < 2e-6 and rel(r1, r0.cpu()) < 2e-5
+    assert rel(rm1, rm0.cpu()) < 2e-6 and rel(rv1, rv0.cpu()) < 2e-5
+    assert rel(rv1, 0.9 * 1.5 + 0.1 * yd.var(0, unbiased=rows > 1)) < 2e-5
+    assert int(nb1) == int(nb0) == 1
+
+
 @pytest.mark.parametrize("n,cin,cout", [(160, 1280, 512), (32, 512, 128), (160, 128, 9), (7, 576, 128), (160, 40, 960)])
 def test_linear(K, n, cin, cout):
     g = torch.Generator().manual_seed(n + cin)
