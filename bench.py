@@ -91,7 +91,7 @@ def gpu_leg(args, rank, world, device):
         torch.cuda.synchronize()
         recs, K.PROFILE = K.PROFILE, None
         agg = {}
-        for name, flops, nbytes, e0, e1 in recs:
+        for name, flops, nbytes, e0, e1, _shape in recs:
             a = agg.setdefault(name, [0.0, 0.0, 0.0, 0])
             a[0] += e0.elapsed_time(e1) * 1e-3
             a[1] += flops

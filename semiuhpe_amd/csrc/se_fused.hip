@@ -12,26 +12,40 @@ constexpr int kMaxSq = 64;
 __device__ __forceinline__ float silu_f(float u) { return u / (1.f + expf(-u)); }
 __device__ __forceinline__ float silu_g(float u) { const float s = 1.f / (1.f + expf(-u)); return s * (1.f + u * (1.f - s)); }
 
+constexpr int kSeThreads = 1024;     // 16 wavefronts: the kernels are chains of dependent L2-latency rounds, so a sample's work is spread wide
+constexpr int kSeWaves = kSeThreads / 64;
+
 // grid = n samples.  Writes a1 (n,csq) and s (n,c).  Latency-bound: every loop keeps several independent loads in flight.
-__global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* __restrict__ p, const float* __restrict__ w1, const float* __restrict__ b1,
-                                                         const float* __restrict__ w2, const float* __restrict__ b2, int c, int csq,
-                                                         float* __restrict__ a1, float* __restrict__ s) {
+__global__ __launch_bounds__(kSeThreads) void se_mlp_fwd_kernel(const float* __restrict__ p, const float* __restrict__ w1,
+                                                                const float* __restrict__ b1, const float* __restrict__ w2,
+                                                                const float* __restrict__ b2, int c, int csq, float* __restrict__ a1,
+                                                                float* __restrict__ s) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* pl = sm;            // [c]
     float* hl = sm + c;        // [csq]
     const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    for (int i = t * 4; i < c; i += 1024) *reinterpret_cast<float4*>(pl + i) = *reinterpret_cast<const float4*>(p + (int64_t)n * c + i);
+    for (int i = t * 4; i < c; i += kSeThreads * 4) *reinterpret_cast<float4*>(pl + i) = *reinterpret_cast<const float4*>(p + (int64_t)n * c + i);
     __syncthreads();
-    // fc1: a wavefront takes 4 squeeze outputs at a time (4 independent row streams)
-    for (int j0 = wave * 4; j0 < csq; j0 += 16) {
+    // fc1: a wavefront takes 4 squeeze outputs at a time (4 independent row streams); 16 waves cover 64 outputs in one round
+    for (int j0 = wave * 4; j0 < csq; j0 += kSeWaves * 4) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-        for (int i = lane * 4; i < c; i += 256) {
-            const float4 pv = *reinterpret_cast<const float4*>(pl + i);
+        for (int i0 = lane * 4; i0 < c; i0 += 1024) {       // 16 independent 16-byte loads in flight (clamped, not branched)
+            float4 wv[4][4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 w = *reinterpret_cast<const float4*>(w1 + (int64_t)(j0 + q) * c + i);
-                acc[q] += w.x * pv.x + w.y * pv.y + w.z * pv.z + w.w * pv.w;
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256 < c ? i0 + u * 256 : c - 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) wv[u][q] = *reinterpret_cast<const float4*>(w1 + (int64_t)(j0 + q) * c + i);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = i0 + u * 256 < c;
+                const float4 pv = *reinterpret_cast<const float4*>(pl + (ok ? i0 + u * 256 : 0));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float d = wv[u][q].x * pv.x + wv[u][q].y * pv.y + wv[u][q].z * pv.z + wv[u][q].w * pv.w;
+                    acc[q] += ok ? d : 0.f;
+                }
             }
         }
 #pragma unroll
@@ -43,77 +57,108 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* __restrict
         }
     }
     __syncthreads();
-    // fc2: a thread owns up to 8 output channels (t, t+256, ...), all rows streamed together
-    float acc[8];
+    // fc2: 16 lanes share one output channel: together they read its whole w2 row (<= 64 floats) as one coalesced 256-byte
+    // request and reduce with four xor-shuffles (a lane-per-row layout fetches a full cache line per 16 useful bytes).
+    // Out-of-range rows / columns read a clamped address and are dropped afterwards: no branch around the loads.
+    {
+        const int sub = t & 15, grp = t >> 4;               // 64 row slots per pass
+        const bool okj = sub * 4 < csq;
+        const int jq = okj ? sub * 4 : csq - 4;
+        float4 hv = *reinterpret_cast<const float4*>(hl + jq);
+        if (!okj) hv = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r0 = grp; r0 < c; r0 += 64 * 8) {
+            float4 wv[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const int cc = t + 256 * k; acc[k] = cc < c ? b2[cc] : 0.f; }
-#pragma unroll 4
-    for (int j = 0; j < csq; j += 4) {              // unrolled: 32 independent 16-byte loads in flight per thread
-        const float4 hv = *reinterpret_cast<const float4*>(hl + j);
+            for (int u = 0; u < 8; ++u) {
+                const int row = r0 + u * 64 < c ? r0 + u * 64 : c - 1;
+                wv[u] = *reinterpret_cast<const float4*>(w2 + (int64_t)row * csq + jq);
+            }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int cc = t + 256 * k;
-            if (cc < c) {
-                const float4 w = *reinterpret_cast<const float4*>(w2 + (int64_t)cc * csq + j);
-                acc[k] += w.x * hv.x + w.y * hv.y + w.z * hv.z + w.w * hv.w;
+            for (int u = 0; u < 8; ++u) {
+                float d = wv[u].x * hv.x + wv[u].y * hv.y + wv[u].z * hv.z + wv[u].w * hv.w;
+                d += __shfl_xor(d, 8, 64);
+                d += __shfl_xor(d, 4, 64);
+                d += __shfl_xor(d, 2, 64);
+                d += __shfl_xor(d, 1, 64);
+                const int row = r0 + u * 64;
+                if (sub == 0 && row < c) s[(int64_t)n * c + row] = 1.f / (1.f + expf(-(d + b2[row])));
             }
         }
     }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { const int cc = t + 256 * k; if (cc < c) s[(int64_t)n * c + cc] = 1.f / (1.f + expf(-acc[k])); }
 }
 
 // grid = n samples.  ds (n,c) -> da2 (n,c), da1 (n,csq), h (n,csq), dp (n,c)
-__global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ s, const float* __restrict__ a1,
-                                                         const float* __restrict__ w1, const float* __restrict__ w2, int c, int csq,
-                                                         float* __restrict__ da2, float* __restrict__ da1, float* __restrict__ hbuf,
-                                                         float* __restrict__ dp) {
+__global__ __launch_bounds__(kSeThreads) void se_mlp_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ s,
+                                                                const float* __restrict__ a1, const float* __restrict__ w1,
+                                                                const float* __restrict__ w2, int c, int csq, float* __restrict__ da2,
+                                                                float* __restrict__ da1, float* __restrict__ hbuf, float* __restrict__ dp) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* gl = sm;                     // da2 [c]
-    float* red = sm + c;                // [4][kMaxSq] partial dh
-    float* dl = red + 4 * kMaxSq;       // da1 [kMaxSq]
+    float* gl = sm;                          // da2 [c]
+    float* red = sm + c;                     // [kSeWaves][kMaxSq] partial dh
+    float* dl = red + kSeWaves * kMaxSq;     // da1 [kMaxSq]
     const int n = blockIdx.x, t = threadIdx.x;
-    for (int cc = t; cc < c; cc += 256) {
+    for (int cc = t; cc < c; cc += kSeThreads) {
         const float sv = s[(int64_t)n * c + cc];
         const float g = ds[(int64_t)n * c + cc] * sv * (1.f - sv);
         gl[cc] = g;
         da2[(int64_t)n * c + cc] = g;
     }
     __syncthreads();
-    // dh[j] = sum_c w2[c][j] * da2[c]: thread = (j, quarter of the channels); rows of w2 are read coalesced across j
+    // dh[j] = sum_c w2[c][j] * da2[c]: lane = j, wavefront = one sixteenth of the channels; rows of w2 are read coalesced
+    // across j.  Loads go to a register block first (32 in flight), clamped instead of branched.
     {
         const int j = t & 63, q = t >> 6;
-        const int cq = (c + 3) / 4, c0 = q * cq, c1 = (c0 + cq < c) ? c0 + cq : c;
-        float acc = 0.f;
-        if (j < csq) {
-#pragma unroll 16
-            for (int cc = c0; cc < c1; ++cc) acc += w2[(int64_t)cc * csq + j] * gl[cc];
+        const int jj = j < csq ? j : csq - 1;
+        const int cq = (c + kSeWaves - 1) / kSeWaves, c0 = q * cq, c1 = (c0 + cq < c) ? c0 + cq : c;
+        float acc0 = 0.f, acc1 = 0.f;
+        for (int base = c0; base < c1; base += 32) {
+            float wv[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const int cc = base + u < c1 ? base + u : c1 - 1;
+                wv[u] = w2[(int64_t)cc * csq + jj];
+            }
+#pragma unroll
+            for (int u = 0; u < 32; u += 2) {
+                acc0 += base + u < c1 ? wv[u] * gl[base + u] : 0.f;
+                acc1 += base + u + 1 < c1 ? wv[u + 1] * gl[base + u + 1] : 0.f;
+            }
         }
-        red[q * kMaxSq + j] = acc;
+        red[q * kMaxSq + j] = acc0 + acc1;
     }
     __syncthreads();
     if (t < csq) {
         const float a = a1[(int64_t)n * csq + t];
-        const float g = (red[t] + red[kMaxSq + t] + red[2 * kMaxSq + t] + red[3 * kMaxSq + t]) * silu_g(a);
+        float r = 0.f;
+#pragma unroll
+        for (int q = 0; q < kSeWaves; ++q) r += red[q * kMaxSq + t];
+        const float g = r * silu_g(a);
         dl[t] = g;
         da1[(int64_t)n * csq + t] = g;
         hbuf[(int64_t)n * csq + t] = silu_f(a);
     }
     __syncthreads();
-    float acc[8];
+    float acc[2] = {0.f, 0.f};
+    int ccl[2];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-#pragma unroll 8
-    for (int j = 0; j < csq; ++j) {                 // unrolled: up to 64 independent loads in flight per thread
-        const float g = dl[j];
+    for (int k = 0; k < 2; ++k) { const int cc = t + kSeThreads * k; ccl[k] = cc < c ? cc : c - 1; }
+    for (int j0 = 0; j0 < csq; j0 += 16) {          // 32 independent loads in flight per thread
+        float wv[2][16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int cc = t + 256 * k;
-            if (cc < c) acc[k] += w1[(int64_t)j * c + cc] * g;
+        for (int u = 0; u < 16; ++u) {
+            const int j = j0 + u < csq ? j0 + u : csq - 1;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) wv[k][u] = w1[(int64_t)j * c + ccl[k]];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const float g = j0 + u < csq ? dl[j0 + u] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) acc[k] += wv[k][u] * g;
         }
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const int cc = t + 256 * k; if (cc < c) dp[(int64_t)n * c + cc] = acc[k]; }
+    for (int k = 0; k < 2; ++k) { const int cc = t + kSeThreads * k; if (cc < c) dp[(int64_t)n * c + cc] = acc[k]; }
 }
 
 // Weight gradients, one thread per (channel, squeeze output):
@@ -152,7 +197,7 @@ int suhpe_se_mlp_fwd(const float* p, const float* w1, const float* b1, const flo
     SUHPE_REQUIRE(p && w1 && b1 && w2 && b2 && a1 && s && n > 0, "suhpe_se_mlp_fwd: null pointer or empty batch");
     SUHPE_REQUIRE(c % 4 == 0 && csq % 4 == 0 && csq <= kMaxSq && c <= 8192, "suhpe_se_mlp_fwd: needs c %% 4 == 0, squeeze %% 4 == 0, squeeze <= %d", kMaxSq);
     SUHPE_REQUIRE(c <= 2048, "suhpe_se_mlp_fwd: c <= 2048");
-    hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(n), dim3(256), (size_t)(c + csq) * sizeof(float), as_stream(stream), p, w1, b1, w2, b2, c, csq, a1, s);
+    hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(n), dim3(kSeThreads), (size_t)(c + csq) * sizeof(float), as_stream(stream), p, w1, b1, w2, b2, c, csq, a1, s);
     return check_launch("suhpe_se_mlp_fwd");
 }
 
@@ -163,7 +208,7 @@ int suhpe_se_mlp_bwd(const float* ds, const float* s, const float* a1, const flo
     float* da2 = static_cast<float*>(workspace);            // (n,c)
     float* da1 = da2 + (int64_t)n * c;                      // (n,csq)
     float* hb = da1 + (int64_t)n * csq;                     // (n,csq)
-    hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(n), dim3(256), (size_t)(c + 5 * kMaxSq) * sizeof(float), as_stream(stream), ds, s, a1, w1, w2, c, csq,
+    hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(n), dim3(kSeThreads), (size_t)(c + (kSeWaves + 1) * kMaxSq) * sizeof(float), as_stream(stream), ds, s, a1, w1, w2, c, csq,
                        da2, da1, hb, dp);
     hipLaunchKernelGGL(se_wgrad_kernel, dim3((c + 63) / 64, (csq + 3) / 4), dim3(256), 0, as_stream(stream), p, hb, da1, da2, n, c, csq, dw1, db1, dw2,
                        db2);

@@ -80,7 +80,8 @@ class _Prof:
         self.on = PROFILE is not None
         if self.on:
             self.name = _lib.load().suhpe_conv2d_kernel_name(ctypes.byref(d), pass_id).decode()
-            self.rec = (self.name, conv_flops(d), conv_bytes(d), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.rec = (self.name, conv_flops(d), conv_bytes(d), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
+                        (pass_id, d.n, d.h, d.w, d.cin, d.cout, d.r, d.stride, d.groups))
 
     def __enter__(self):
         if self.on:
@@ -92,6 +93,34 @@ class _Prof:
             PROFILE.append(self.rec)
 
 
+# Optional live profile of the HBM-bound wrappers (tools/mem_profile.py): when MEM_PROFILE is a list every decorated call is
+# bracketed by events and recorded as (wrapper name, bytes of its tensor arguments + results, shape of the first tensor, e0, e1).
+MEM_PROFILE = None
+
+
+def _memop(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kw):
+        if MEM_PROFILE is None:
+            return fn(*args, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn(*args, **kw)
+        e1.record()
+        tens = [a for a in list(args) + list(kw.values()) if torch.is_tensor(a)]
+        outs = [o for o in (out if isinstance(out, (tuple, list)) else (out,)) if torch.is_tensor(o)]
+        seen, nbytes = set(), 0
+        for t in tens + outs:
+            if t.data_ptr() not in seen:
+                seen.add(t.data_ptr())
+                nbytes += t.numel() * t.element_size()
+        MEM_PROFILE.append((fn.__name__, nbytes, tuple(tens[0].shape) if tens else (), e0, e1))
+        return out
+    return wrapped
+
+
 def conv2d_fwd(x, w, bias=None, stride=1, pad=0, groups=1):
     _chk(x, "x"); _chk(bias, "bias")
     assert filter_is_physical(w), "filter must be stored [Cout][R][S][Cin/g]"
@@ -99,11 +128,26 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, groups=1):
     y = torch.empty((d.n, d.ho, d.wo, d.cout), dtype=torch.float32, device=x.device)
     if _is_depthwise(d) and d.cin % 4 == 0:
         assert bias is None
-        call("suhpe_dwconv_fwd", ctypes.byref(d), ptr(x), ptr(w), ptr(y))
+        _dw_fwd(d, x, w, y)
     else:
         with _Prof(d, 0):
             call("suhpe_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(y))
     return y
+
+
+@_memop
+def _dw_fwd(d, x, w, y):
+    call("suhpe_dwconv_fwd", ctypes.byref(d), ptr(x), ptr(w), ptr(y))
+
+
+@_memop
+def _dw_dgrad(d, dy, w, dx):
+    call("suhpe_dwconv_dgrad", ctypes.byref(d), ptr(dy), ptr(w), ptr(dx))
+
+
+@_memop
+def _dw_wgrad(d, x, dy, out, accumulate, ws, nbytes):
+    call("suhpe_dwconv_wgrad", ctypes.byref(d), ptr(x), ptr(dy), ptr(out), int(accumulate), ptr(ws), nbytes)
 
 
 def conv2d_fwd_stats(x, w, stride=1, pad=0, groups=1):
@@ -119,6 +163,7 @@ def conv2d_fwd_stats(x, w, stride=1, pad=0, groups=1):
     return y, part, tiles
 
 
+@_memop
 def bn_stats_from_partials(part, tiles, rows, c, eps, momentum, running_mean=None, running_var=None, nbt=None):
     mean = torch.empty(c, dtype=torch.float32, device=part.device)
     rstd = torch.empty(c, dtype=torch.float32, device=part.device)
@@ -132,7 +177,7 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, groups=1):
     d = conv_desc(x_shape, w.shape, stride, pad, groups)
     dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
     if _is_depthwise(d) and d.cin % 4 == 0:
-        call("suhpe_dwconv_dgrad", ctypes.byref(d), ptr(dy), ptr(w), ptr(dx))
+        _dw_dgrad(d, dy, w, dx)
     else:
         wt = workspace("wt", w.numel() * 4, dy.device)
         call("suhpe_conv2d_transpose_filter", ctypes.byref(d), ptr(w), ptr(wt))
@@ -154,7 +199,7 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, groups=1, out=None, accumulate
     if _is_depthwise(d) and d.cin % 4 == 0:
         nbytes = lib.suhpe_dwconv_wgrad_workspace_bytes(ctypes.byref(d))
         ws = workspace("wgrad", nbytes, x.device)
-        call("suhpe_dwconv_wgrad", ctypes.byref(d), ptr(x), ptr(dy), ptr(out), int(accumulate), ptr(ws), nbytes)
+        _dw_wgrad(d, x, dy, out, accumulate, ws, nbytes)
     else:
         nbytes = lib.suhpe_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
         ws = workspace("wgrad", nbytes, x.device)
@@ -164,6 +209,7 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, groups=1, out=None, accumulate
     return out
 
 
+@_memop
 def bias_grad(dy, c, out=None, accumulate=False):
     _chk(dy, "dy")
     rows = dy.numel() // c
@@ -177,6 +223,7 @@ def bias_grad(dy, c, out=None, accumulate=False):
 
 
 # ---------------------------------------------------------------------------------------------- normalisation
+@_memop
 def bn_stats(x, c, eps, momentum, running_mean=None, running_var=None, nbt=None):
     _chk(x, "x")
     rows = x.numel() // c
@@ -196,6 +243,7 @@ def bn_eval_stats(running_mean, running_var, eps):
     return mean, rstd
 
 
+@_memop
 def bn_act_fwd(x, c, mean, rstd, gamma, beta, act, residual=None):
     _chk(x, "x"); _chk(residual, "residual")
     y = torch.empty_like(x)
@@ -204,6 +252,7 @@ def bn_act_fwd(x, c, mean, rstd, gamma, beta, act, residual=None):
     return y
 
 
+@_memop
 def bn_act_bwd(x, dy, c, mean, rstd, gamma, beta, act, train_stats, dgamma=None, dbeta=None, accumulate=False, y_out=None):
     _chk(x, "x"); _chk(dy, "dy")
     dx = torch.empty_like(x)
@@ -213,6 +262,7 @@ def bn_act_bwd(x, dy, c, mean, rstd, gamma, beta, act, train_stats, dgamma=None,
     return dx
 
 
+@_memop
 def layernorm_fwd(x, c, eps, gamma, beta):
     _chk(x, "x")
     rows = x.numel() // c
@@ -223,6 +273,7 @@ def layernorm_fwd(x, c, eps, gamma, beta):
     return y, mean, rstd
 
 
+@_memop
 def layernorm_bwd(x, dy, c, mean, rstd, gamma, dgamma=None, dbeta=None, accumulate=False):
     _chk(x, "x"); _chk(dy, "dy")
     dx = torch.empty_like(x)
@@ -232,6 +283,7 @@ def layernorm_bwd(x, dy, c, mean, rstd, gamma, dgamma=None, dbeta=None, accumula
     return dx
 
 
+@_memop
 def act_fwd(x, c, act, bias=None):
     _chk(x, "x")
     y = torch.empty_like(x)
@@ -239,6 +291,7 @@ def act_fwd(x, c, act, bias=None):
     return y
 
 
+@_memop
 def act_bwd(x, dy, c, act, bias=None):
     _chk(x, "x"); _chk(dy, "dy")
     dx = torch.empty_like(x)
@@ -247,6 +300,7 @@ def act_bwd(x, dy, c, act, bias=None):
 
 
 # ---------------------------------------------------------------------------------------------- pooling / SE / misc
+@_memop
 def avgpool_fwd(x):
     """(N,H,W,C) or (N,L,C) -> (N,C)"""
     _chk(x, "x")
@@ -257,6 +311,7 @@ def avgpool_fwd(x):
     return y
 
 
+@_memop
 def avgpool_bwd(dy, x_shape):
     _chk(dy, "dy")
     n, c = x_shape[0], x_shape[-1]
@@ -265,6 +320,7 @@ def avgpool_bwd(dy, x_shape):
     return dx
 
 
+@_memop
 def se_scale_fwd(x, s):
     _chk(x, "x"); _chk(s, "s")
     n, c = x.shape[0], x.shape[-1]
@@ -273,6 +329,7 @@ def se_scale_fwd(x, s):
     return y
 
 
+@_memop
 def se_scale_bwd_s(dy, x):
     n, c = x.shape[0], x.shape[-1]
     ds = torch.empty((n, c), dtype=torch.float32, device=x.device)
@@ -280,6 +337,7 @@ def se_scale_bwd_s(dy, x):
     return ds
 
 
+@_memop
 def se_scale_bwd_x(dy, s, dpool):
     n, c = dy.shape[0], dy.shape[-1]
     dx = torch.empty_like(dy)
@@ -287,6 +345,7 @@ def se_scale_bwd_x(dy, s, dpool):
     return dx
 
 
+@_memop
 def se_mlp_fwd(p, w1, b1, w2, b2):
     """p (n,c) -> a1 (n,csq), s (n,c)"""
     n, c = p.shape
@@ -297,6 +356,7 @@ def se_mlp_fwd(p, w1, b1, w2, b2):
     return a1, s
 
 
+@_memop
 def se_mlp_bwd(ds, s, a1, p, w1, w2, dw1, db1, dw2, db2):
     n, c = p.shape
     csq = w1.shape[0]
@@ -307,6 +367,7 @@ def se_mlp_bwd(ds, s, a1, p, w1, w2, dw1, db1, dw2, db2):
     return dp
 
 
+@_memop
 def add_rowscale(a, b, rowscale):
     """a + b * rowscale[n]  (a or rowscale may be None)"""
     _chk(b, "b"); _chk(a, "a")
@@ -316,6 +377,7 @@ def add_rowscale(a, b, rowscale):
     return y
 
 
+@_memop
 def add(a, b):
     _chk(a, "a"); _chk(b, "b")
     y = torch.empty_like(a)
@@ -323,6 +385,7 @@ def add(a, b):
     return y
 
 
+@_memop
 def mul(a, b):
     _chk(a, "a"); _chk(b, "b")
     y = torch.empty_like(a)
@@ -345,6 +408,7 @@ def rng_counter(device, seed=None):
     return _counters[key]
 
 
+@_memop
 def dropout_mask(shape, keep, device):
     m = torch.empty(shape, dtype=torch.float32, device=device)
     ctr = rng_counter(device)
@@ -499,6 +563,7 @@ def entropy_mask(H, thres):
 
 
 # ---------------------------------------------------------------------------------------------- attention
+@_memop
 def window_attn_fwd(qkv, bias_table, bias_idx, B, H, W, ws, heads, scale, save_probs=True):
     """qkv (B*H*W, heads*96) -> out (B*H*W, heads*32), probs (or None)"""
     _chk(qkv, "qkv"); _chk(bias_table, "bias_table")
@@ -513,6 +578,7 @@ def window_attn_fwd(qkv, bias_table, bias_idx, B, H, W, ws, heads, scale, save_p
     return out, probs
 
 
+@_memop
 def window_attn_bwd(qkv, probs, dout, bias_idx, B, H, W, ws, heads, noff, scale, dbias):
     _chk(qkv, "qkv"); _chk(dout, "dout")
     dh = qkv.shape[-1] // (3 * heads)

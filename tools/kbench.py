@@ -77,7 +77,7 @@ def main():
     print("per-image-batch totals (s): fwd %.4f dgrad %.4f wgrad %.4f ; fwd TF/s overall %.2f" % (tot[0], tot[1], tot[2], totf / tot[0] / 1e12))
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "gemm"):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("gemm", "ksweep")):
     main()
 
 
@@ -95,3 +95,18 @@ def gemm_main():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "gemm":
     gemm_main()
+
+
+def ksweep_main():
+    """time = a + b*K for fixed (M, N): separates per-tile fixed cost (prologue / epilogue) from the main-loop rate"""
+    for (m, n) in ((25088, 960), (25088, 128), (6272, 1536), (6272, 256), (1568, 256)):
+        for k in (32, 64, 128, 256, 512, 1024, 2048):
+            x = torch.randn(m, 1, 1, k, device="cuda")
+            w = torch.randn(n, k, 1, 1, device="cuda")
+            fl = 2.0 * m * k * n
+            t = timeit(lambda: K.conv2d_fwd(x, w, None, 1, 0, 1), 10)
+            print(f"M={m} N={n} K={k}: fwd {t*1e6:9.1f} us {fl/t/1e12:7.2f} TF/s", flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ksweep":
+    ksweep_main()
