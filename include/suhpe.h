@@ -91,7 +91,7 @@ typedef struct {
 int suhpe_conv2d_fwd(const suhpe_conv_t* d, const float* x, const float* w, const float* bias, float* y,
                      suhpe_stream_t stream);
 /* forward without bias that also emits BatchNorm statistics partials from its epilogue (saves the separate read
- * pass of suhpe_bn_stats): stats[(channel*tiles + tile)*4 + {0..3}] = (S, Q, k, n): sums of (y-k) and (y-k)^2 over the tile's n rows,
+ * pass of suhpe_bn_stats): stats[(tile*cout + channel)*4 + {0..3}] = (S, Q, k, n): sums of (y-k) and (y-k)^2 over the tile's n rows,
  * shifted by k (the tile's first row); tiles = suhpe_conv2d_fwd_stats_tiles(d), so stats holds cout*tiles*4 floats.  Finish with suhpe_bn_stats_from_partials. */
 int suhpe_conv2d_fwd_stats_tiles(const suhpe_conv_t* d);
 int suhpe_conv2d_fwd_stats(const suhpe_conv_t* d, const float* x, const float* w, float* y, float* stats,
@@ -128,7 +128,7 @@ int64_t suhpe_bn_workspace_bytes(int c);
 int suhpe_bn_stats(const float* x, int64_t rows, int c, float eps, float momentum, float* mean, float* rstd,
                    float* running_mean, float* running_var, int64_t* num_batches_tracked, void* workspace,
                    suhpe_stream_t stream);
-/* second half of suhpe_bn_stats for partials produced elsewhere (layout [channel][gx][4] = (S, Q, k, n) shifted records) */
+/* second half of suhpe_bn_stats for partials produced elsewhere (layout [gx][channel][4] = (S, Q, k, n) shifted records) */
 int suhpe_bn_stats_from_partials(const float* part, int gx, int64_t rows, int c, float eps, float momentum, float* mean,
                                  float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                  suhpe_stream_t stream);

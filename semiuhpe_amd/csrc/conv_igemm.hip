@@ -73,8 +73,9 @@ struct NtParams {
     int ldy;
     int col_tiles;       // ceil(Ng / BN), set by the launcher
     int ldf;             // filter row length in elements (== g.K except in MODE 3)
-    float* stats;        // optional: per-(channel, row tile) partial sum / sum of squares of the output (BatchNorm statistics
-    int stat_gx;         // fused into the epilogue); layout [channel][stat_gx][4] = (S, Q, k, n), stat_gx = ceil(M / BM)
+    float* stats;        // optional BatchNorm statistics from the epilogue: records [stat_gx][stat_cout][4] = (S, Q, k, n)
+    int stat_cout;       // channels of the whole output (record pitch)
+    int stat_gx;         // row tiles = ceil(M / BM)
 };
 
 // ---------------------------------------------------------------------------------------------- igemm_nt
@@ -327,7 +328,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_nt_kernel(co
             float a = 0.f, q = 0.f;
 #pragma unroll
             for (int w = 0; w < BM / WM; ++w) { a += red[(w * BN + idx) * 2]; q += red[(w * BN + idx) * 2 + 1]; }
-            float4* dst = reinterpret_cast<float4*>(p.stats) + ((int64_t)(grp * p.Ng + col)) * p.stat_gx + row_tile;
+            float4* dst = reinterpret_cast<float4*>(p.stats) + (int64_t)row_tile * p.stat_cout + grp * p.Ng + col;
             *dst = make_float4(a, q, kk[idx], (float)nrows);
         }
     }
@@ -631,7 +632,7 @@ int suhpe_conv2d_fwd(const suhpe_conv_t* d, const float* x, const float* w, cons
     const int cg = d->cin / d->groups;
     p.g = make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0);
     p.x = x; p.f = w; p.bias = bias; p.y = y; p.Ng = d->cout / d->groups; p.ldy = d->cout; p.ldf = p.g.K;
-    p.stats = nullptr; p.stat_gx = 0;
+    p.stats = nullptr; p.stat_gx = 0; p.stat_cout = 0;
     const bool vec4 = (cg % 4 == 0) && (d->cin % 4 == 0) && aligned16(x) && aligned16(w);
     dispatch_nt(p, d->groups, vec4, as_stream(stream));
     return check_launch("suhpe_conv2d_fwd");
@@ -652,7 +653,7 @@ int suhpe_conv2d_fwd_stats(const suhpe_conv_t* d, const float* x, const float* w
     const int cg = d->cin / d->groups;
     p.g = make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0);
     p.x = x; p.f = w; p.bias = nullptr; p.y = y; p.Ng = d->cout / d->groups; p.ldy = d->cout; p.ldf = p.g.K;
-    p.stats = stats; p.stat_gx = suhpe_conv2d_fwd_stats_tiles(d);
+    p.stats = stats; p.stat_gx = suhpe_conv2d_fwd_stats_tiles(d); p.stat_cout = d->cout;
     const bool vec4 = (cg % 4 == 0) && (d->cin % 4 == 0);
     SUHPE_REQUIRE(!vec4 || (aligned16(x) && aligned16(w)), "suhpe_conv2d_fwd_stats: x / w must be 16-byte aligned");
     dispatch_nt(p, d->groups, vec4, as_stream(stream));
@@ -680,7 +681,7 @@ int suhpe_conv2d_dgrad(const suhpe_conv_t* d, const float* dy, const float* wt, 
     if (d->stride == 1) {
         p.g = make_geom(d->n, d->ho, d->wo, d->h, d->w, d->cout, ng, d->r, d->s, d->stride, d->pad, 1);
         p.x = dy; p.f = wt; p.bias = nullptr; p.y = dx; p.Ng = cg; p.ldy = d->cin; p.ldf = p.g.K;
-        p.stats = nullptr; p.stat_gx = 0;
+        p.stats = nullptr; p.stat_gx = 0; p.stat_cout = 0;
         dispatch_nt(p, d->groups, vec4, as_stream(stream));
     } else {
         // one launch per parity class of the input pixel: only the taps r = (ph+pad) mod stride (+ k*stride) reach it,
@@ -698,7 +699,7 @@ int suhpe_conv2d_dgrad(const suhpe_conv_t* d, const float* dy, const float* wt, 
                 g.off_h = (ph + d->pad - r0) / st; g.off_w = (pw + d->pad - s0) / st;
                 p.g = g;
                 p.x = dy; p.f = wt; p.bias = nullptr; p.y = dx; p.Ng = cg; p.ldy = d->cin; p.ldf = d->r * d->s * ng;
-                p.stats = nullptr; p.stat_gx = 0;
+                p.stats = nullptr; p.stat_gx = 0; p.stat_cout = 0;
                 dispatch_nt(p, d->groups, vec4, as_stream(stream));
             }
     }

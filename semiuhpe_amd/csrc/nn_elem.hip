@@ -11,7 +11,8 @@
 
 namespace suhpe {
 
-constexpr int kMaxRowBlocks = 1024;   // partial-sum slabs per channel (workspace = kMaxRowBlocks*c*4 floats)
+constexpr int kRowBlockBudget = 2048;              // row blocks x column chunks of one reduction launch (8 blocks per CU)
+constexpr int64_t kPartFloats = 2048LL * 256 * 4;  // record workspace: gx*c <= 2048*256 records of up to 4 floats
 
 // ------------------------------------------------------------------------------------------ activations
 __device__ __forceinline__ float act_apply(float u, int act) {
@@ -50,7 +51,7 @@ __device__ __forceinline__ float act_grad(float u, int act) {
 // columns (vec-columns when VEC=4) and a contiguous slab of rows; thread t -> (col = t % cw, rsub = t / cw).
 struct ColGeom {
     int cv;        // columns in vector units
-    int cw;        // columns per block (<=256)
+    int cw;        // columns per block (<=64)
     int ny;        // column chunks
     int rp;        // rows per pass = 256 / cw
     int gx;        // row blocks
@@ -60,11 +61,11 @@ struct ColGeom {
 static ColGeom col_geom(int64_t rows, int c, int vec) {
     ColGeom g;
     g.cv = c / vec;
-    g.cw = g.cv < 256 ? g.cv : 256;
+    g.cw = g.cv < 64 ? g.cv : 64;
     g.ny = (g.cv + g.cw - 1) / g.cw;
     g.rp = 256 / g.cw;
     int64_t want = ceil_div(rows, (int64_t)g.rp * 8);          // >= 8 passes per block
-    int64_t cap = kMaxRowBlocks;
+    int64_t cap = kRowBlockBudget / g.ny > 1 ? kRowBlockBudget / g.ny : 1;
     if (want > cap) want = cap;
     if (want < 1) want = 1;
     g.gx = (int)want;
@@ -112,15 +113,40 @@ template <int VEC> __device__ __forceinline__ void vstore(float* p, const float*
 }
 
 // Block-level combine of per-thread partial sums that share a column: LDS [256][2*VEC] then the first cw
-// threads add the rp partials of their column in fixed order and write part[(ch*gridDim.x + bx)*2 + {0,1}].
-// The finalisers give one wavefront to each channel: lanes stride over the row blocks (contiguous reads),
-// fp64 wave reduction in a fixed order.
-__device__ __forceinline__ void wave_channel_sums(const float* __restrict__ part, int gx, int ch, int lane, double* s, double* q) {
+// threads add the rp partials of their column in fixed order and write one record per channel to part[bx][channel]
+// (a block's records are contiguous: coalesced writes).  The finalisers give a 1024-thread block to 8 channels:
+// thread = (channel, one of 128 row-block lanes), line-sized contiguous reads, fp64 accumulation, fixed-order reduction.
+constexpr int kFinCh = 8, kFinThreads = 1024, kFinSub = kFinThreads / kFinCh;
+// thread = (channel chl = t & 7, row-block lane sub = t >> 3): adds the 128 row-block lanes of each channel in a fixed order
+// (xor-shuffles inside the wave, then 16 wave slots through LDS).  True for the thread that ends up owning the totals.
+__device__ __forceinline__ bool fin_reduce(double* a, double* b, int ch, int c) {
+    __shared__ double red[kFinThreads / 64][kFinCh][2];
+    double x = *a, y = *b;
+#pragma unroll
+    for (int m = 8; m < 64; m <<= 1) { x += __shfl_xor(x, m, 64); y += __shfl_xor(y, m, 64); }
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (lane < kFinCh) { red[wave][lane][0] = x; red[wave][lane][1] = y; }
+    __syncthreads();
+    if (t >= kFinCh || ch >= c) return false;
+    x = red[0][t][0]; y = red[0][t][1];
+#pragma unroll
+    for (int w = 1; w < kFinThreads / 64; ++w) { x += red[w][t][0]; y += red[w][t][1]; }
+    *a = x;
+    *b = y;
+    return true;
+}
+__device__ __forceinline__ bool block_channel_sums(const float* __restrict__ part, int gx, int c, double* s, double* q) {
+    const int chl = threadIdx.x & (kFinCh - 1), sub = threadIdx.x / kFinCh;
+    const int ch = blockIdx.x * kFinCh + chl;
     double a = 0.0, b = 0.0;
-    const float2* p = reinterpret_cast<const float2*>(part) + (int64_t)ch * gx;
-    for (int i = lane; i < gx; i += 64) { const float2 v = p[i]; a += (double)v.x; b += (double)v.y; }
-    *s = wave_sum(a);
-    *q = wave_sum(b);
+    if (ch < c) {
+        const float2* p = reinterpret_cast<const float2*>(part) + ch;
+#pragma unroll 8
+        for (int i = sub; i < gx; i += kFinSub) { const float2 v = p[(int64_t)i * c]; a += (double)v.x; b += (double)v.y; }
+    }
+    *s = a;
+    *q = b;
+    return fin_reduce(s, q, ch, c);
 }
 // shift != nullptr selects the 4-float statistics record (S, Q, k, n) instead of the plain pair.
 template <int VEC>
@@ -144,10 +170,9 @@ __device__ __forceinline__ void block_combine(const float* s0, const float* s1, 
         for (int v = 0; v < VEC; ++v) {
             const int ch = (col0 + t) * VEC + v;
             if (shift) {
-                reinterpret_cast<float4*>(part)[(int64_t)ch * gridDim.x + bx] = make_float4(a0[v], a1[v], shift[v], count);
+                reinterpret_cast<float4*>(part)[(int64_t)bx * c + ch] = make_float4(a0[v], a1[v], shift[v], count);
             } else {
-                part[((int64_t)ch * gridDim.x + bx) * 2 + 0] = a0[v];      // [channel][row block][2]
-                part[((int64_t)ch * gridDim.x + bx) * 2 + 1] = a1[v];
+                reinterpret_cast<float2*>(part)[(int64_t)bx * c + ch] = make_float2(a0[v], a1[v]);      // [row block][channel]
             }
         }
     }
@@ -171,52 +196,50 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
     if (rsub < rp && col0 + col < cv && r0 < rows) {
         vload<VEC>(x + (r0 * cv + col0 + col) * VEC, k);
         int64_t r = r0 + rsub;
-        // four independent row streams per thread keep 4 x 16 B loads in flight (the pass is pure HBM latency otherwise)
-        for (; r + 3 * (int64_t)rp < r1; r += 4 * (int64_t)rp) {
-            float xa[VEC], xb[VEC], xc[VEC], xd[VEC];
-            vload<VEC>(x + (r * cv + col0 + col) * VEC, xa);
-            vload<VEC>(x + ((r + rp) * cv + col0 + col) * VEC, xb);
-            vload<VEC>(x + ((r + 2 * (int64_t)rp) * cv + col0 + col) * VEC, xc);
-            vload<VEC>(x + ((r + 3 * (int64_t)rp) * cv + col0 + col) * VEC, xd);
+        // eight independent row streams per thread (8 x 16 B in flight; the pass is pure HBM latency otherwise); rows past
+        // the slab read a clamped address and are masked, so no branch separates the loads
+        for (; r < r1; r += 8 * (int64_t)rp) {
+            float xv[8][VEC];
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                const float a = xa[v] - k[v], b = xb[v] - k[v], cc = xc[v] - k[v], d = xd[v] - k[v];
-                s0[v] += (a + b) + (cc + d);
-                s1[v] += (a * a + b * b) + (cc * cc + d * d);
+            for (int u = 0; u < 8; ++u) {
+                const int64_t rr = r + u * (int64_t)rp;
+                vload<VEC>(x + ((rr < r1 ? rr : r1 - 1) * cv + col0 + col) * VEC, xv[u]);
             }
-        }
-        for (; r < r1; r += rp) {
-            float xv[VEC];
-            vload<VEC>(x + (r * cv + col0 + col) * VEC, xv);
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) { const float a = xv[v] - k[v]; s0[v] += a; s1[v] += a * a; }
+            for (int u = 0; u < 8; ++u) {
+                const bool ok = r + u * (int64_t)rp < r1;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) { const float a = ok ? xv[u][v] - k[v] : 0.f; s0[v] += a; s1[v] += a * a; }
+            }
         }
     }
     block_combine<VEC>(s0, s1, cw, rp, col0, c, blockIdx.x, part, lds, k, r1 > r0 ? (float)(r1 - r0) : 0.f);
 }
 
-// pass 2: one wavefront per channel; running-stat update as nn.BatchNorm does
-__global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict__ part, int gx, int c, int64_t rows, float eps,
+// pass 2: 8 channels per 1024-thread block; running-stat update as nn.BatchNorm does.  Records are [row block][channel] float4.
+__global__ __launch_bounds__(kFinThreads) void bn_stats_finalize(const float* __restrict__ part, int gx, int c, int64_t rows, float eps,
                                                          float momentum, float* __restrict__ mean, float* __restrict__ rstd,
                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
                                                          int64_t* __restrict__ nbt) {
-    const int lane = threadIdx.x & 63;
-    const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ch == 0 && lane == 0 && nbt) nbt[0] += 1;
-    if (ch >= c) return;
+    const int chl = threadIdx.x & (kFinCh - 1), sub = threadIdx.x / kFinCh;
+    const int ch = blockIdx.x * kFinCh + chl;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
     // re-centre every record on zero in fp64 (exact to 1e-16) and add: sum x = S + n k, sum x^2 = Q + 2 k S + n k^2
-    double a = 0.0, b = 0.0;
-    const float4* pr = reinterpret_cast<const float4*>(part) + (int64_t)ch * gx;
-    for (int i = lane; i < gx; i += 64) {
-        const float4 v = pr[i];
-        const double S = v.x, Q = v.y, k = v.z, n = v.w;
-        a += S + n * k;
-        b += Q + 2.0 * k * S + n * k * k;
+    double a = 0.0, b = 0.0, k0 = 0.0;
+    if (ch < c) {
+        const float4* pr = reinterpret_cast<const float4*>(part) + ch;
+        k0 = (double)pr[0].z;
+#pragma unroll 8
+        for (int i = sub; i < gx; i += kFinSub) {
+            const float4 v = pr[(int64_t)i * c];
+            const double S = v.x, Q = v.y, k = v.z, n = v.w;
+            a += S + n * k;
+            b += Q + 2.0 * k * S + n * k * k;
+        }
     }
+    if (!fin_reduce(&a, &b, ch, c)) return;
+    const double s = a, q = b;
     // centre on the first record's shift before the final subtraction: var = E[(x-k0)^2] - (E[x]-k0)^2
-    const double k0 = (double)pr[0].z;
-    const double s = wave_sum(a), q = wave_sum(b);
-    if (lane != 0) return;
     const double m = s / (double)rows;
     double var = (q - 2.0 * k0 * s + (double)rows * k0 * k0) / (double)rows - (m - k0) * (m - k0);
     if (var < 0.0) var = 0.0;
@@ -292,21 +315,30 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
         const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
         int64_t r1 = r0 + rows_per_block;
         if (r1 > rows) r1 = rows;
-#pragma unroll 4
-        for (int64_t r = r0 + rsub; r < r1; r += rp) {
-            float xv[VEC], dv[VEC], yv[VEC];
-            const int64_t off = (r * cv + col0 + col) * VEC;
-            vload<VEC>(x + off, xv);
-            vload<VEC>(dy + off, dv);
-            if (yout) vload<VEC>(yout + off, yv);
+        // eight rows per round: 16-24 independent 16-byte loads in flight per thread, clamped + masked instead of branched
+        for (int64_t r = r0 + rsub; r < r1; r += 8 * (int64_t)rp) {
+            float xv[8][VEC], dv[8][VEC], yv[8][VEC];
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                const float xh = (xv[v] - mu[v]) * rs[v];
-                float g;
-                if (yout) g = yv[v] > 0.f ? dv[v] : 0.f;       // ReLU applied after a pre-activation residual
-                else g = dv[v] * act_grad(xh * ga[v] + be[v], act);
-                s0[v] += g;
-                s1[v] += g * xh;
+            for (int u = 0; u < 8; ++u) {
+                const int64_t rr = r + u * (int64_t)rp;
+                const int64_t off = ((rr < r1 ? rr : r1 - 1) * cv + col0 + col) * VEC;
+                vload<VEC>(x + off, xv[u]);
+                vload<VEC>(dy + off, dv[u]);
+                if (yout) vload<VEC>(yout + off, yv[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool ok = r + u * (int64_t)rp < r1;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const float xh = (xv[u][v] - mu[v]) * rs[v];
+                    float g;
+                    if (yout) g = yv[u][v] > 0.f ? dv[u][v] : 0.f;       // ReLU applied after a pre-activation residual
+                    else g = dv[u][v] * act_grad(xh * ga[v] + be[v], act);
+                    g = ok ? g : 0.f;
+                    s0[v] += g;
+                    s1[v] += g * xh;
+                }
             }
         }
     }
@@ -314,14 +346,11 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
 }
 
 // pass 2: dbeta = sum g, dgamma = sum g*xhat (one wavefront per channel); leaves them in sums[c][2] for pass 3
-__global__ __launch_bounds__(256) void bn_bwd_finalize(const float* __restrict__ part, int gx, int c, float* __restrict__ sums,
+__global__ __launch_bounds__(kFinThreads) void bn_bwd_finalize(const float* __restrict__ part, int gx, int c, float* __restrict__ sums,
                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
-    const int lane = threadIdx.x & 63;
-    const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ch >= c) return;
     double s, q;
-    wave_channel_sums(part, gx, ch, lane, &s, &q);
-    if (lane != 0) return;
+    if (!block_channel_sums(part, gx, c, &s, &q)) return;
+    const int ch = blockIdx.x * kFinCh + (threadIdx.x & (kFinCh - 1));
     sums[2 * ch] = (float)s;
     sums[2 * ch + 1] = (float)q;
     if (dbeta) dbeta[ch] = accumulate ? dbeta[ch] + (float)s : (float)s;
@@ -664,13 +693,11 @@ __global__ __launch_bounds__(256) void colsum_partial(const float* __restrict__ 
     }
     block_combine<VEC>(s0, s1, cw, rp, col0, c, blockIdx.x, part, lds);
 }
-__global__ __launch_bounds__(256) void colsum_finalize(const float* __restrict__ part, int gx, int c, float* __restrict__ out, int accumulate) {
-    const int lane = threadIdx.x & 63;
-    const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ch >= c) return;
+__global__ __launch_bounds__(kFinThreads) void colsum_finalize(const float* __restrict__ part, int gx, int c, float* __restrict__ out, int accumulate) {
     double s, q;
-    wave_channel_sums(part, gx, ch, lane, &s, &q);
-    if (lane == 0) out[ch] = accumulate ? out[ch] + (float)s : (float)s;
+    if (!block_channel_sums(part, gx, c, &s, &q)) return;
+    const int ch = blockIdx.x * kFinCh + (threadIdx.x & (kFinCh - 1));
+    out[ch] = accumulate ? out[ch] + (float)s : (float)s;
 }
 
 // ------------------------------------------------------------------------------------------ optimiser / EMA
@@ -710,7 +737,7 @@ using namespace suhpe;
 
 extern "C" {
 
-int64_t suhpe_bn_workspace_bytes(int c) { return (int64_t)kMaxRowBlocks * c * 4 * sizeof(float) + (int64_t)c * 2 * sizeof(float); }
+int64_t suhpe_bn_workspace_bytes(int c) { return (kPartFloats + (int64_t)c * 2) * sizeof(float); }
 
 int suhpe_bn_stats(const float* x, int64_t rows, int c, float eps, float momentum, float* mean, float* rstd,
                    float* running_mean, float* running_var, int64_t* nbt, void* workspace, suhpe_stream_t stream) {
@@ -719,12 +746,12 @@ int suhpe_bn_stats(const float* x, int64_t rows, int c, float eps, float momentu
     if (vec4_ok(c, x)) {
         const ColGeom g = col_geom(rows, c, 4);
         LAUNCH(bn_stats_partial<4>, dim3(g.gx, g.ny), dim3(256), stream, x, rows, c, g.cw, g.rp, g.rows_per_block, part);
-        LAUNCH(bn_stats_finalize, dim3((c + 3) / 4), dim3(256), stream, part, g.gx, c, rows, eps, momentum, mean, rstd,
+        LAUNCH(bn_stats_finalize, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, g.gx, c, rows, eps, momentum, mean, rstd,
                running_mean, running_var, nbt);
     } else {
         const ColGeom g = col_geom(rows, c, 1);
         LAUNCH(bn_stats_partial<1>, dim3(g.gx, g.ny), dim3(256), stream, x, rows, c, g.cw, g.rp, g.rows_per_block, part);
-        LAUNCH(bn_stats_finalize, dim3((c + 3) / 4), dim3(256), stream, part, g.gx, c, rows, eps, momentum, mean, rstd,
+        LAUNCH(bn_stats_finalize, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, g.gx, c, rows, eps, momentum, mean, rstd,
                running_mean, running_var, nbt);
     }
     return check_launch("suhpe_bn_stats");
@@ -733,7 +760,7 @@ int suhpe_bn_stats(const float* x, int64_t rows, int c, float eps, float momentu
 int suhpe_bn_stats_from_partials(const float* part, int gx, int64_t rows, int c, float eps, float momentum, float* mean, float* rstd,
                                  float* running_mean, float* running_var, int64_t* nbt, suhpe_stream_t stream) {
     SUHPE_REQUIRE(part && mean && rstd && gx > 0 && rows > 0 && c > 0, "suhpe_bn_stats_from_partials: bad arguments");
-    LAUNCH(bn_stats_finalize, dim3((c + 3) / 4), dim3(256), stream, part, gx, c, rows, eps, momentum, mean, rstd, running_mean, running_var, nbt);
+    LAUNCH(bn_stats_finalize, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, gx, c, rows, eps, momentum, mean, rstd, running_mean, running_var, nbt);
     return check_launch("suhpe_bn_stats_from_partials");
 }
 
@@ -764,13 +791,13 @@ int suhpe_bn_act_bwd(const float* x, const float* dy, const float* y_out, int64_
     SUHPE_REQUIRE(x && dy && dx && mean && rstd && workspace && rows > 0 && rows < (1LL << 31) && c > 0, "suhpe_bn_act_bwd: bad arguments");
     SUHPE_REQUIRE(!y_out || act == SUHPE_ACT_RELU, "suhpe_bn_act_bwd: y_out (pre-activation residual) needs act=RELU");
     float* part = static_cast<float*>(workspace);
-    float* sums = part + (int64_t)kMaxRowBlocks * c * 2;
+    float* sums = part + kPartFloats;
     const float inv_rows = 1.0f / (float)rows;
     if (vec4_ok(c, x, dy, dx) && vec4_ok(c, y_out)) {
         const ColGeom g = col_geom(rows, c, 4);
         LAUNCH(bn_bwd_partial<4>, dim3(g.gx, g.ny), dim3(256), stream, x, dy, y_out, rows, c, g.cw, g.rp, g.rows_per_block, mean,
                rstd, gamma, beta, act, part);
-        LAUNCH(bn_bwd_finalize, dim3((c + 3) / 4), dim3(256), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
+        LAUNCH(bn_bwd_finalize, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
         const EwGeom e = ew_geom(rows, c, 4);
         LAUNCH(bn_bwd_apply<4>, dim3(e.gx, e.ny), dim3(256), stream, x, dy, y_out, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd,
                gamma, beta, act, sums, inv_rows, train_stats, dx);
@@ -778,7 +805,7 @@ int suhpe_bn_act_bwd(const float* x, const float* dy, const float* y_out, int64_
         const ColGeom g = col_geom(rows, c, 1);
         LAUNCH(bn_bwd_partial<1>, dim3(g.gx, g.ny), dim3(256), stream, x, dy, y_out, rows, c, g.cw, g.rp, g.rows_per_block, mean,
                rstd, gamma, beta, act, part);
-        LAUNCH(bn_bwd_finalize, dim3((c + 3) / 4), dim3(256), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
+        LAUNCH(bn_bwd_finalize, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
         const EwGeom e = ew_geom(rows, c, 1);
         LAUNCH(bn_bwd_apply<1>, dim3(e.gx, e.ny), dim3(256), stream, x, dy, y_out, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd,
                gamma, beta, act, sums, inv_rows, train_stats, dx);
@@ -800,15 +827,15 @@ int suhpe_layernorm_bwd(const float* x, const float* dy, int64_t rows, int c, co
     LAUNCH(layernorm_bwd_dx_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), stream, x, dy, rows, c, mean, rstd, gamma, dx);
     if (dgamma || dbeta) {
         float* part = static_cast<float*>(workspace);
-        float* sums = part + (int64_t)kMaxRowBlocks * c * 2;
+        float* sums = part + kPartFloats;
         if (vec4_ok(c, x, dy)) {
             const ColGeom g = col_geom(rows, c, 4);
             LAUNCH(layernorm_bwd_partial<4>, dim3(g.gx, g.ny), dim3(256), stream, x, dy, rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, part);
-            LAUNCH(bn_bwd_finalize, dim3((c + 3) / 4), dim3(256), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
+            LAUNCH(bn_bwd_finalize, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
         } else {
             const ColGeom g = col_geom(rows, c, 1);
             LAUNCH(layernorm_bwd_partial<1>, dim3(g.gx, g.ny), dim3(256), stream, x, dy, rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, part);
-            LAUNCH(bn_bwd_finalize, dim3((c + 3) / 4), dim3(256), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
+            LAUNCH(bn_bwd_finalize, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
         }
     }
     return check_launch("suhpe_layernorm_bwd");
@@ -946,11 +973,11 @@ int suhpe_bias_grad(const float* dy, int64_t rows, int c, float* db, int accumul
     if (vec4_ok(c, dy)) {
         const ColGeom g = col_geom(rows, c, 4);
         LAUNCH(colsum_partial<4>, dim3(g.gx, g.ny), dim3(256), stream, dy, rows, c, g.cw, g.rp, g.rows_per_block, part);
-        LAUNCH(colsum_finalize, dim3((c + 3) / 4), dim3(256), stream, part, g.gx, c, db, accumulate);
+        LAUNCH(colsum_finalize, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, g.gx, c, db, accumulate);
     } else {
         const ColGeom g = col_geom(rows, c, 1);
         LAUNCH(colsum_partial<1>, dim3(g.gx, g.ny), dim3(256), stream, dy, rows, c, g.cw, g.rp, g.rows_per_block, part);
-        LAUNCH(colsum_finalize, dim3((c + 3) / 4), dim3(256), stream, part, g.gx, c, db, accumulate);
+        LAUNCH(colsum_finalize, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, g.gx, c, db, accumulate);
     }
     return check_launch("suhpe_bias_grad");
 }
