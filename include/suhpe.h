@@ -96,6 +96,13 @@ int suhpe_conv2d_fwd(const suhpe_conv_t* d, const float* x, const float* w, cons
 int suhpe_conv2d_fwd_stats_tiles(const suhpe_conv_t* d);
 int suhpe_conv2d_fwd_stats(const suhpe_conv_t* d, const float* x, const float* w, float* y, float* stats,
                            suhpe_stream_t stream);
+/* Tile menu of the GEMM kernels.  pass: 0 forward, 1 input gradient, 2 filter gradient.  A caller that has timed the
+ * menu on a shape pins the winner with suhpe_conv2d_set_tile (tile = -1 unpins: back to the built-in heuristic); the
+ * pin is process-wide and keyed by the whole descriptor.  Results of pass 0 / 1 do not depend on the tile; pass 2
+ * changes the split-K partition (summation order) with it. */
+int suhpe_conv2d_tile_count(int pass);
+const char* suhpe_conv2d_tile_name(int pass, int tile);
+int suhpe_conv2d_set_tile(const suhpe_conv_t* d, int pass, int tile);
 /* input gradient; wt is the transposed+flipped filter made by suhpe_conv2d_transpose_filter */
 int suhpe_conv2d_dgrad(const suhpe_conv_t* d, const float* dy, const float* wt, float* dx, suhpe_stream_t stream);
 int suhpe_conv2d_transpose_filter(const suhpe_conv_t* d, const float* w, float* wt, suhpe_stream_t stream);

@@ -14,6 +14,10 @@
 // Replaces the cuDNN / cuBLAS calls behind nn.Conv2d / nn.Linear in src/networks.py:229-332,407-441,
 // src/repvgg.py:28-32,67-76 and src/tiny_vit.py:28-50,84-151 (forward, input gradient, filter gradient).
 #include "common.h"
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <unordered_map>
 
 namespace suhpe {
 
@@ -85,11 +89,16 @@ struct NtParams {
 // In every mode the tap of a thread's k advances incrementally (no division in the k loop), addresses are 32-bit
 // element offsets from a uniform base, and out-of-range taps are predicated (offset 0, value zeroed): no branches.
 template <int BM, int BN, int WM, int WN, int VEC, int MODE>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_nt_kernel(const NtParams p) {
+// The second launch bound (minimum waves per SIMD) caps the register budget: left alone the compiler spends 88-148 VGPRs on
+// prefetch depth, which leaves 2 workgroups (or 1, for the wgrad kernel) per CU; at <= 80 VGPRs three 8-wave workgroups are
+// resident and the MFMA pipe sees 6 waves per SIMD.
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64,
+                             (VEC == 1 || BM == 256) ? 1 : (((BM / WM) * (BN / WN) > 8 || BN == 32 || MODE == 0) ? 5 : 6))
+void igemm_nt_kernel(const NtParams p) {
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int NT = (BM / WM) * (BN / WN) * 64;          // threads: 4 or 8 wavefronts
-    static_assert(NT == 256 || NT == 512, "4 or 8 waves per workgroup");
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;          // threads: 4 to 10 wavefronts (tile widths are multiples of 32)
+    static_assert(NT >= 256 && NT <= 1024 && NT % 32 == 0, "4 to 16 waves per workgroup");
     __shared__ __attribute__((aligned(16))) float As[BM * LDK];
     __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
 
@@ -112,9 +121,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_nt_kernel(co
 
     // ---- loader geometry.  VEC=4: thread -> (vector column j = t&7, rows (t>>3)+32i).  VEC=1: (k = t&31, rows (t>>5)+8i)
     constexpr int ROW_STEP = VEC == 4 ? NT / 8 : NT / 32;
-    constexpr int A_ROWS = BM / ROW_STEP;
+    constexpr int A_ROWS = (BM + ROW_STEP - 1) / ROW_STEP;     // the last pass may run past the tile: those rows are predicated
     constexpr int B_ROWS = (BN + ROW_STEP - 1) / ROW_STEP;
-    static_assert(BM % ROW_STEP == 0, "tile rows must be a multiple of the loader pass");
     const int lcol = VEC == 4 ? (t & 7) * 4 : (t & 31);
     const int lrow = VEC == 4 ? (t >> 3) : (t >> 5);
 
@@ -125,7 +133,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_nt_kernel(co
     for (int i = 0; i < A_ROWS; ++i) {
         const int64_t m = m0 + lrow + i * ROW_STEP;
         a_h[i] = 0; a_w[i] = 0;
-        if (m < g.M) {
+        if (m < g.M && lrow + i * ROW_STEP < BM) {
             if (MODE == 1) {
                 a_pix[i] = (int)m;
             } else {
@@ -210,6 +218,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_nt_kernel(co
     auto store_tiles = [&]() {
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
+            if (BM % ROW_STEP != 0 && lrow + i * ROW_STEP >= BM) continue;
             float* dst = &As[(lrow + i * ROW_STEP) * LDK + lcol];
             if (VEC == 4) *reinterpret_cast<float4*>(dst) = make_float4(a_reg[i][0], a_reg[i][1], a_reg[i][2], a_reg[i][3]);
             else dst[0] = a_reg[i][0];
@@ -347,11 +356,12 @@ struct TnParams {
 };
 
 template <int BM, int BN, int WM, int WN, int VECA, int VECB>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_tn_kernel(const TnParams p) {
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (VECA == 1 || VECB == 1) ? 1 : ((BM == 128 && BN == 128) ? 6 : 5))
+void igemm_tn_kernel(const TnParams p) {
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
-    static_assert(NT == 256 || NT == 512, "4 or 8 waves per workgroup");
+    static_assert(NT >= 256 && NT <= 1024, "4 to 16 waves per workgroup");
     __shared__ __attribute__((aligned(16))) float As[BK * BM];   // [m][cout]
     __shared__ __attribute__((aligned(16))) float Bs[BK * BN];   // [m][k']
 
@@ -376,13 +386,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_tn_kernel(co
     // A loader: dy rows.  VECA=4: col group = t % (BM/4), row = t / (BM/4) + RA*i ; VECA=1: col = t % BM
     constexpr int A_CG = BM / VECA;                 // column groups per row
     constexpr int RA = NT / A_CG;                   // rows covered per pass
-    constexpr int A_IT = BK / RA;
-    static_assert(A_IT >= 1, "tile too wide for the A loader");
+    constexpr int A_IT = (BK + RA - 1) / RA;        // the last pass may run past BK rows: predicated
+    static_assert(NT % A_CG == 0 && RA >= 1, "thread count must be a multiple of the A tile's column groups");
     const int a_col = (t % A_CG) * VECA, a_row = t / A_CG;
     constexpr int B_CG = BN / VECB;
     constexpr int RB = NT / B_CG;
-    constexpr int B_IT = BK / RB;
-    static_assert(B_IT >= 1, "tile too wide for the B loader");
+    constexpr int B_IT = (BK + RB - 1) / RB;
+    static_assert(NT % B_CG == 0 && RB >= 1, "thread count must be a multiple of the B tile's column groups");
     const int b_col = (t % B_CG) * VECB, b_row = t / B_CG;
 
     // this thread's k' is fixed for the whole reduction: decode its filter tap once
@@ -398,7 +408,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_tn_kernel(co
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int64_t m = mb + a_row + i * RA;
-            const bool ok = a_valid_col && m < mend;
+            const bool ok = a_valid_col && m < mend && (BK % RA == 0 || a_row + i * RA < BK);
             const float* src = dy + (ok ? m * p.lddy + i0 + a_col : 0);
             if (VECA == 4) {
                 float4 v = *reinterpret_cast<const float4*>(src);
@@ -412,7 +422,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_tn_kernel(co
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             const int64_t m = mb + b_row + i * RB;
-            bool ok = kq_valid && m < mend;
+            bool ok = kq_valid && m < mend && (BK % RB == 0 || b_row + i * RB < BK);
             const unsigned mu = ok ? (unsigned)m : 0u;
             const unsigned n = fast_div(mu, g.div_hw_mul, g.div_hw_shr);
             const unsigned rem = mu - n * (unsigned)(g.OH * g.OW);
@@ -434,12 +444,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_tn_kernel(co
     auto store_tiles = [&]() {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
+            if (BK % RA != 0 && a_row + i * RA >= BK) continue;
             float* dst = &As[(a_row + i * RA) * BM + a_col];
             if (VECA == 4) *reinterpret_cast<float4*>(dst) = make_float4(a_reg[i][0], a_reg[i][1], a_reg[i][2], a_reg[i][3]);
             else dst[0] = a_reg[i][0];
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
+            if (BK % RB != 0 && b_row + i * RB >= BK) continue;
             float* dst = &Bs[(b_row + i * RB) * BN + b_col];
             if (VECB == 4) *reinterpret_cast<float4*>(dst) = make_float4(b_reg[i][0], b_reg[i][1], b_reg[i][2], b_reg[i][3]);
             else dst[0] = b_reg[i][0];
@@ -586,36 +598,80 @@ static void launch_nt(const NtParams& p_in, int groups, hipStream_t st) {
     }
 }
 
-// tile selection for igemm_nt; returns the kernel's name (as rocprofv3 prints the template arguments)
-enum NtTile { NT_64x64_S = 0, NT_64x64, NT_128x32, NT_128x128, NT_128x64, NT_256x32 };
+// ---- tile menus.  Which tile is fastest depends on the shape in ways a padding/efficiency model does not capture
+// (tools/tune_tiles.py: the small tiles win most 1x1 layers, 128x64 the large-K 3x3 ones), so the caller may pin the tile
+// of a (descriptor, pass) after measuring the menu (suhpe_conv2d_set_tile; semiuhpe_amd.kernels.AUTOTUNE does that the
+// first time a shape is seen).  Unpinned shapes use the heuristics below.
+enum NtTile { NT_64x64_S = 0, NT_64x64, NT_128x32, NT_128x128, NT_128x64, NT_256x32, NT_TILES };
 static const char* kNtNames[] = {"igemm_nt_kernel<64,64,32,32,1>", "igemm_nt_kernel<64,64,32,32,4>", "igemm_nt_kernel<128,32,32,32,4>",
                                  "igemm_nt_kernel<128,128,64,32,4>", "igemm_nt_kernel<128,64,32,32,4>", "igemm_nt_kernel<256,32,64,32,4>"};
 
-static NtTile choose_nt(int64_t M, int ng, bool vec4) {
+struct TnTile { int bm, bn; const char* name; };
+static const TnTile kTnTiles[] = {
+    {128, 128, "igemm_tn_kernel<128,128,64,32,4,4>"}, {128, 64, "igemm_tn_kernel<128,64,64,32,4,4>"},
+    {64, 128, "igemm_tn_kernel<64,128,32,64,4,4>"},   {64, 64, "igemm_tn_kernel<64,64,32,32,4,4>"},
+    {32, 128, "igemm_tn_kernel<32,128,32,32,4,4>"},
+};
+constexpr int TN_TILES = (int)(sizeof(kTnTiles) / sizeof(kTnTiles[0]));
+
+struct TileKey {
+    int v[11];
+    bool operator==(const TileKey& o) const { return memcmp(v, o.v, sizeof(v)) == 0; }
+};
+struct TileKeyHash {
+    size_t operator()(const TileKey& k) const {
+        uint64_t h = 1469598103934665603ull;
+        for (int x : k.v) { h ^= (uint64_t)(uint32_t)x; h *= 1099511628211ull; }
+        return (size_t)h;
+    }
+};
+static std::unordered_map<TileKey, int, TileKeyHash>& tile_table() { static std::unordered_map<TileKey, int, TileKeyHash> t; return t; }
+static std::mutex& tile_mutex() { static std::mutex m; return m; }
+static TileKey tile_key(const suhpe_conv_t* d, int pass) {
+    return TileKey{{pass, d->n, d->h, d->w, d->cin, d->cout, d->r, d->s, d->stride, d->pad, d->groups}};
+}
+static int pinned_tile(const suhpe_conv_t* d, int pass) {
+    std::lock_guard<std::mutex> lock(tile_mutex());
+    auto it = tile_table().find(tile_key(d, pass));
+    return it == tile_table().end() ? -1 : it->second;
+}
+
+static NtTile choose_nt(int64_t M, int ng, bool vec4, int pinned) {
     if (!vec4) return NT_64x64_S;
+    if (pinned >= 1 && pinned < (int)NT_TILES) return (NtTile)pinned;
     if (M < 2048) return ng > 32 ? NT_64x64 : NT_128x32;     // small row counts (Linear, SE): more, smaller tiles
     if (ng <= 32) return NT_256x32;                           // narrow outputs are operand-bandwidth bound anyway
-    // padded columns / relative efficiency of the tile (measured: 128-wide ~1.0, 64-wide ~0.85)
-    const double c128 = (double)(ceil_div(ng, 128) * 128), c64 = (double)(ceil_div(ng, 64) * 64) / 0.85;
-    NtTile tile = c128 <= c64 ? NT_128x128 : NT_128x64;
-    // keep >= ~1.5 workgroups per CU: shrink the tile when the grid would under-fill the 256 CUs
-    auto blocks = [&](int bm, int bn) { return ceil_div(M, bm) * ceil_div(ng, bn); };
-    if (tile == NT_128x128 && blocks(128, 128) < 384) tile = NT_128x64;
-    if (tile == NT_128x64 && blocks(128, 64) < 384) tile = NT_64x64;
-    return tile;
+    // measured on the EfficientNetV2-S / RepVGG layer shapes: 128x64 (8 waves of 32x32) wins or ties nearly everywhere
+    // once the grid fills the chip; below ~2 workgroups per CU the 64x64 tile does
+    return ceil_div(M, 128) * ceil_div(ng, 64) >= 512 ? NT_128x64 : NT_64x64;
 }
 
 static int nt_tile_bm(NtTile t) { return (t == NT_64x64_S || t == NT_64x64) ? 64 : (t == NT_256x32 ? 256 : 128); }
 
-static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st) {
-    switch (choose_nt(p.g.M, p.Ng, vec4)) {
+static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st, int pinned) {
+    switch (choose_nt(p.g.M, p.Ng, vec4, pinned)) {
         case NT_64x64_S: launch_nt<64, 64, 32, 32, 1>(p, groups, st); break;
         case NT_64x64: launch_nt<64, 64, 32, 32, 4>(p, groups, st); break;
         case NT_128x32: launch_nt<128, 32, 32, 32, 4>(p, groups, st); break;
         case NT_128x128: launch_nt<128, 128, 64, 32, 4>(p, groups, st); break;      // 8 wavefronts of 64x32
         case NT_128x64: launch_nt<128, 64, 32, 32, 4>(p, groups, st); break;        // 8 wavefronts of 32x32
         case NT_256x32: launch_nt<256, 32, 64, 32, 4>(p, groups, st); break;
+        default: break;
     }
+}
+
+// wgrad (rows = cout, columns = k'): both extents pad; cost = padded area / measured relative efficiency
+static int choose_tn(int ng, int K, int pinned) {
+    if (pinned >= 0 && pinned < TN_TILES) return pinned;
+    static const double eff[TN_TILES] = {0.85, 0.95, 0.95, 1.0, 0.9};
+    int best = 3;
+    double best_cost = 1e30;
+    for (int i = 0; i < TN_TILES; ++i) {
+        const TnTile& c = kTnTiles[i];
+        const double cost = (double)(ceil_div(ng, c.bm) * c.bm) * (double)(ceil_div(K, c.bn) * c.bn) / eff[i];
+        if (cost < best_cost) { best_cost = cost; best = i; }
+    }
+    return best;
 }
 
 }  // namespace suhpe
@@ -634,7 +690,7 @@ int suhpe_conv2d_fwd(const suhpe_conv_t* d, const float* x, const float* w, cons
     p.x = x; p.f = w; p.bias = bias; p.y = y; p.Ng = d->cout / d->groups; p.ldy = d->cout; p.ldf = p.g.K;
     p.stats = nullptr; p.stat_gx = 0; p.stat_cout = 0;
     const bool vec4 = (cg % 4 == 0) && (d->cin % 4 == 0) && aligned16(x) && aligned16(w);
-    dispatch_nt(p, d->groups, vec4, as_stream(stream));
+    dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 0));
     return check_launch("suhpe_conv2d_fwd");
 }
 
@@ -642,7 +698,7 @@ int suhpe_conv2d_fwd_stats_tiles(const suhpe_conv_t* d) {
     if (!d || d->groups <= 0) return 0;
     const int cg = d->cin / d->groups, ng = d->cout / d->groups;
     const int64_t M = (int64_t)d->n * d->ho * d->wo;
-    return (int)ceil_div(M, nt_tile_bm(choose_nt(M, ng, cg % 4 == 0 && d->cin % 4 == 0)));
+    return (int)ceil_div(M, nt_tile_bm(choose_nt(M, ng, cg % 4 == 0 && d->cin % 4 == 0, pinned_tile(d, 0))));
 }
 
 int suhpe_conv2d_fwd_stats(const suhpe_conv_t* d, const float* x, const float* w, float* y, float* stats, suhpe_stream_t stream) {
@@ -656,7 +712,7 @@ int suhpe_conv2d_fwd_stats(const suhpe_conv_t* d, const float* x, const float* w
     p.stats = stats; p.stat_gx = suhpe_conv2d_fwd_stats_tiles(d); p.stat_cout = d->cout;
     const bool vec4 = (cg % 4 == 0) && (d->cin % 4 == 0);
     SUHPE_REQUIRE(!vec4 || (aligned16(x) && aligned16(w)), "suhpe_conv2d_fwd_stats: x / w must be 16-byte aligned");
-    dispatch_nt(p, d->groups, vec4, as_stream(stream));
+    dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 0));
     return check_launch("suhpe_conv2d_fwd_stats");
 }
 
@@ -682,7 +738,7 @@ int suhpe_conv2d_dgrad(const suhpe_conv_t* d, const float* dy, const float* wt, 
         p.g = make_geom(d->n, d->ho, d->wo, d->h, d->w, d->cout, ng, d->r, d->s, d->stride, d->pad, 1);
         p.x = dy; p.f = wt; p.bias = nullptr; p.y = dx; p.Ng = cg; p.ldy = d->cin; p.ldf = p.g.K;
         p.stats = nullptr; p.stat_gx = 0; p.stat_cout = 0;
-        dispatch_nt(p, d->groups, vec4, as_stream(stream));
+        dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 1));
     } else {
         // one launch per parity class of the input pixel: only the taps r = (ph+pad) mod stride (+ k*stride) reach it,
         // so no MFMA work is spent on taps that are structurally zero (a masked gather would waste 1 - 1/stride^2).
@@ -700,7 +756,7 @@ int suhpe_conv2d_dgrad(const suhpe_conv_t* d, const float* dy, const float* wt, 
                 p.g = g;
                 p.x = dy; p.f = wt; p.bias = nullptr; p.y = dx; p.Ng = cg; p.ldy = d->cin; p.ldf = d->r * d->s * ng;
                 p.stats = nullptr; p.stat_gx = 0; p.stat_cout = 0;
-                dispatch_nt(p, d->groups, vec4, as_stream(stream));
+                dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 1));
             }
     }
     return check_launch("suhpe_conv2d_dgrad");
@@ -721,26 +777,46 @@ static int wgrad_splits(const suhpe_conv_t* d, int bm, int bn) {
 }
 
 static void wgrad_tile(const suhpe_conv_t* d, int* bm, int* bn) {
-    const int ng = d->cout / d->groups, K = d->r * d->s * (d->cin / d->groups);
-    *bm = ng > 64 ? 128 : 64;
-    *bn = (K > 64) ? 128 : 64;
-    if (*bm == 64 && *bn == 128) { *bm = 64; *bn = 128; }
+    const int ng = d->cout / d->groups, cg = d->cin / d->groups, K = d->r * d->s * cg;
+    const bool va = ng % 4 == 0 && d->cout % 4 == 0, vb = cg % 4 == 0 && d->cin % 4 == 0;
+    if (!(va && vb)) { *bm = 64; *bn = 64; return; }       // scalar loaders: generic 64x64 tile
+    const TnTile& t = kTnTiles[choose_tn(ng, K, pinned_tile(d, 2))];
+    *bm = t.bm;
+    *bn = t.bn;
+}
+
+int suhpe_conv2d_tile_count(int pass) { return pass == 2 ? TN_TILES : (int)NT_TILES; }
+
+const char* suhpe_conv2d_tile_name(int pass, int tile) {
+    if (tile < 0 || tile >= suhpe_conv2d_tile_count(pass)) return "";
+    return pass == 2 ? kTnTiles[tile].name : kNtNames[tile];
+}
+
+int suhpe_conv2d_set_tile(const suhpe_conv_t* d, int pass, int tile) {
+    int rc = check_desc(d, "suhpe_conv2d_set_tile");
+    if (rc) return rc;
+    SUHPE_REQUIRE(pass >= 0 && pass <= 2, "suhpe_conv2d_set_tile: pass must be 0 (fwd), 1 (dgrad) or 2 (wgrad)");
+    SUHPE_REQUIRE(tile >= -1 && tile < suhpe_conv2d_tile_count(pass), "suhpe_conv2d_set_tile: tile %d outside the menu", tile);
+    const int ng = d->cout / d->groups, cg = d->cin / d->groups;
+    const bool v4 = ng % 4 == 0 && d->cout % 4 == 0 && cg % 4 == 0 && d->cin % 4 == 0;
+    SUHPE_REQUIRE(tile < 0 || (v4 && !(pass != 2 && tile == (int)NT_64x64_S)), "suhpe_conv2d_set_tile: the vector tiles need channel counts that are multiples of 4");
+    std::lock_guard<std::mutex> lock(tile_mutex());
+    if (tile < 0) tile_table().erase(tile_key(d, pass));
+    else tile_table()[tile_key(d, pass)] = tile;
+    return SUHPE_OK;
 }
 
 const char* suhpe_conv2d_kernel_name(const suhpe_conv_t* d, int pass) {
     if (!d || d->groups <= 0) return "";
     const int ng = d->cout / d->groups, cg = d->cin / d->groups;
-    if (pass == 0) return kNtNames[choose_nt((int64_t)d->n * d->ho * d->wo, ng, cg % 4 == 0 && d->cin % 4 == 0)];
+    if (pass == 0) return kNtNames[choose_nt((int64_t)d->n * d->ho * d->wo, ng, cg % 4 == 0 && d->cin % 4 == 0, pinned_tile(d, 0))];
     if (pass == 1) {
         const int st = d->stride;
-        return kNtNames[choose_nt((int64_t)d->n * ((d->h + st - 1) / st) * ((d->w + st - 1) / st), cg, ng % 4 == 0 && d->cout % 4 == 0)];
+        return kNtNames[choose_nt((int64_t)d->n * ((d->h + st - 1) / st) * ((d->w + st - 1) / st), cg, ng % 4 == 0 && d->cout % 4 == 0, pinned_tile(d, 1))];
     }
     const bool va = ng % 4 == 0 && d->cout % 4 == 0, vb = cg % 4 == 0 && d->cin % 4 == 0;
     if (!(va && vb)) return va ? "igemm_tn_kernel<64,64,32,32,4,1>" : (vb ? "igemm_tn_kernel<64,64,32,32,1,4>" : "igemm_tn_kernel<64,64,32,32,1,1>");
-    int bm, bn;
-    wgrad_tile(d, &bm, &bn);
-    if (bm == 128) return bn == 128 ? "igemm_tn_kernel<128,128,64,32,4,4>" : "igemm_tn_kernel<128,64,64,32,4,4>";
-    return bn == 128 ? "igemm_tn_kernel<64,128,32,64,4,4>" : "igemm_tn_kernel<64,64,32,32,4,4>";
+    return kTnTiles[choose_tn(ng, d->r * d->s * cg, pinned_tile(d, 2))].name;
 }
 
 int64_t suhpe_conv2d_wgrad_workspace_bytes(const suhpe_conv_t* d) {
@@ -780,12 +856,10 @@ int suhpe_conv2d_wgrad_partial(const suhpe_conv_t* d, const float* x, const floa
         if (bm == 128 && bn == 128) TN_LAUNCH(128, 128, 64, 32, 4, 4);       // 8 wavefronts of 64x32
         else if (bm == 128 && bn == 64) TN_LAUNCH(128, 64, 64, 32, 4, 4);
         else if (bm == 64 && bn == 128) TN_LAUNCH(64, 128, 32, 64, 4, 4);
+        else if (bm == 32 && bn == 128) TN_LAUNCH(32, 128, 32, 32, 4, 4);
         else TN_LAUNCH(64, 64, 32, 32, 4, 4);
     } else {
-        // odd channel counts (RGB stem, 9-D head): scalar loaders, generic 64x64 tile
-        p.tiles_n = (int)ceil_div(p.g.K, 64);
-        p.tiles_m = (int)ceil_div(ng, 64);
-        grid = dim3((unsigned)(p.tiles_m * p.tiles_n * splits), 1, d->groups);
+        // odd channel counts (RGB stem, 9-D head): scalar loaders, generic 64x64 tile (wgrad_tile returned 64x64)
         if (va) TN_LAUNCH(64, 64, 32, 32, 4, 1);
         else if (vb) TN_LAUNCH(64, 64, 32, 32, 1, 4);
         else TN_LAUNCH(64, 64, 32, 32, 1, 1);

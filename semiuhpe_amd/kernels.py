@@ -121,6 +121,45 @@ def _memop(fn):
     return wrapped
 
 
+# Tile autotuning: the first time a dense conv shape is seen in a pass, every tile of the kernel menu is timed on the real
+# operands (cold: a 256 MiB memset between runs evicts L2 / MALL like the rest of a training step does) and the winner is
+# pinned in the library (suhpe_conv2d_set_tile).  Off by default; bench.py, train.py and the agent switch it on.
+AUTOTUNE = False
+_tuned = set()
+_flush = {}
+
+
+def _autotune(d, pass_id, run):
+    key = (pass_id, d.n, d.h, d.w, d.cin, d.cout, d.r, d.s, d.stride, d.pad, d.groups)
+    if key in _tuned:
+        return
+    _tuned.add(key)
+    cg, ng = d.cin // d.groups, d.cout // d.groups
+    if cg % 4 or ng % 4 or d.cin % 4 or d.cout % 4:
+        return                                          # scalar-loader shapes have a single tile
+    lib = _lib.load()
+    dev = torch.cuda.current_device()
+    if dev not in _flush:
+        _flush[dev] = torch.empty(1 << 26, dtype=torch.float32, device="cuda")
+    best = (float("inf"), -1)
+    for tile in range(lib.suhpe_conv2d_tile_count(pass_id)):
+        if lib.suhpe_conv2d_set_tile(ctypes.byref(d), pass_id, tile) != 0:
+            continue
+        run()
+        ms = 0.0
+        for _ in range(3):
+            _flush[dev].zero_()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            run()
+            e1.record()
+            e1.synchronize()
+            ms += e0.elapsed_time(e1)
+        if ms < best[0]:
+            best = (ms, tile)
+    lib.suhpe_conv2d_set_tile(ctypes.byref(d), pass_id, best[1])
+
+
 def conv2d_fwd(x, w, bias=None, stride=1, pad=0, groups=1):
     _chk(x, "x"); _chk(bias, "bias")
     assert filter_is_physical(w), "filter must be stored [Cout][R][S][Cin/g]"
@@ -130,6 +169,8 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, groups=1):
         assert bias is None
         _dw_fwd(d, x, w, y)
     else:
+        if AUTOTUNE:
+            _autotune(d, 0, lambda: call("suhpe_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(y)))
         with _Prof(d, 0):
             call("suhpe_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(y))
     return y
@@ -155,8 +196,10 @@ def conv2d_fwd_stats(x, w, stride=1, pad=0, groups=1):
     _chk(x, "x")
     assert filter_is_physical(w)
     d = conv_desc(x.shape, w.shape, stride, pad, groups)
-    tiles = _lib.load().suhpe_conv2d_fwd_stats_tiles(ctypes.byref(d))
     y = torch.empty((d.n, d.ho, d.wo, d.cout), dtype=torch.float32, device=x.device)
+    if AUTOTUNE:
+        _autotune(d, 0, lambda: call("suhpe_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(w), None, ptr(y)))
+    tiles = _lib.load().suhpe_conv2d_fwd_stats_tiles(ctypes.byref(d))
     part = torch.empty(d.cout * tiles * 4, dtype=torch.float32, device=x.device)
     with _Prof(d, 0):
         call("suhpe_conv2d_fwd_stats", ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(part))
@@ -181,6 +224,8 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, groups=1):
     else:
         wt = workspace("wt", w.numel() * 4, dy.device)
         call("suhpe_conv2d_transpose_filter", ctypes.byref(d), ptr(w), ptr(wt))
+        if AUTOTUNE:
+            _autotune(d, 1, lambda: call("suhpe_conv2d_dgrad", ctypes.byref(d), ptr(dy), ptr(wt), ptr(dx)))
         with _Prof(d, 1):
             call("suhpe_conv2d_dgrad", ctypes.byref(d), ptr(dy), ptr(wt), ptr(dx))
     return dx
@@ -201,6 +246,12 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, groups=1, out=None, accumulate
         ws = workspace("wgrad", nbytes, x.device)
         _dw_wgrad(d, x, dy, out, accumulate, ws, nbytes)
     else:
+        if AUTOTUNE:
+            def trial():                                # whole wgrad (split-K GEMM + slab reduction) into a scratch filter
+                nb = lib.suhpe_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
+                call("suhpe_conv2d_wgrad", ctypes.byref(d), ptr(x), ptr(dy), ptr(workspace("wgrad_tune", out.numel() * 4, x.device)), 0,
+                     ptr(workspace("wgrad", nb, x.device)), nb)
+            _autotune(d, 2, trial)
         nbytes = lib.suhpe_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
         ws = workspace("wgrad", nbytes, x.device)
         with _Prof(d, 2):           # the profile brackets the split-K GEMM launch alone

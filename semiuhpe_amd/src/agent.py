@@ -67,6 +67,8 @@ class SSLAgent:
     def __init__(self, config):
         self.config = config
         self.clock = utils.TrainClock()
+        # time the GEMM tile menu on each new conv shape during the first steps and pin the winners (kernels._autotune)
+        K.AUTOTUNE = bool(getattr(config, "autotune", True))
         self.net = get_network(config)
         self.ema_net = get_network(config)
         for param in self.ema_net.parameters():      # reference :34-35: the teacher is never trained by gradients

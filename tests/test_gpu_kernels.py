@@ -49,6 +49,9 @@ CONVS = [
     (3, 1536, 1536, 3, 1, 1, 1536, 7, 7),  # > 256 channel vectors: two column chunks
     (40, 160, 960, 1, 1, 0, 1, 14, 14),    # larger M: wide tiles
     (33, 48, 192, 3, 1, 1, 1, 28, 28),
+    (40, 960, 160, 1, 1, 0, 1, 14, 14),    # 160-wide tiles (fwd columns, wgrad rows)
+    (20, 24, 96, 3, 2, 1, 1, 56, 56),      # 96-wide tile
+    (20, 96, 48, 1, 1, 0, 1, 28, 28),
 ]
 
 
