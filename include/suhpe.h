@@ -90,6 +90,12 @@ typedef struct {
  * src/tiny_vit.py:28-50).  w: [cout][r][s][cin/groups]; bias NULL or [cout]. */
 int suhpe_conv2d_fwd(const suhpe_conv_t* d, const float* x, const float* w, const float* bias, float* y,
                      suhpe_stream_t stream);
+/* forward with a folded per-channel affine map + activation (+ residual) in the epilogue: eval-mode conv -> BatchNorm ->
+ * act [-> + skip] in one pass over the output (torchvision Conv2dNormActivation / MBConv / RepVGG blocks in eval()).
+ * y = act(conv(x,w)*scale[c] + shift[c] (+ residual)) (+ residual); residual (same shape as y) may be NULL;
+ * residual_after_act selects which.  scale / shift come from suhpe_bn_eval_affine. */
+int suhpe_conv2d_fwd_affine(const suhpe_conv_t* d, const float* x, const float* w, const float* scale, const float* shift,
+                            int act, const float* residual, int residual_after_act, float* y, suhpe_stream_t stream);
 /* forward without bias that also emits BatchNorm statistics partials from its epilogue (saves the separate read
  * pass of suhpe_bn_stats): stats[(tile*cout + channel)*4 + {0..3}] = (S, Q, k, n): sums of (y-k) and (y-k)^2 over the tile's n rows,
  * shifted by k (the tile's first row); tiles = suhpe_conv2d_fwd_stats_tiles(d), so stats holds cout*tiles*4 floats.  Finish with suhpe_bn_stats_from_partials. */
@@ -139,6 +145,9 @@ int suhpe_bn_stats(const float* x, int64_t rows, int c, float eps, float momentu
 int suhpe_bn_stats_from_partials(const float* part, int gx, int64_t rows, int c, float eps, float momentum, float* mean,
                                  float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                  suhpe_stream_t stream);
+/* eval: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale (gamma / beta may be NULL) */
+int suhpe_bn_eval_affine(const float* running_mean, const float* running_var, const float* gamma, const float* beta, int c,
+                         float eps, float* scale, float* shift, suhpe_stream_t stream);
 /* eval: mean/rstd from running stats */
 int suhpe_bn_eval_stats(const float* running_mean, const float* running_var, int c, float eps, float* mean,
                         float* rstd, suhpe_stream_t stream);

@@ -57,4 +57,36 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ------------------------------------------------------------------------------------------ activations
+__device__ __forceinline__ float act_apply(float u, int act) {
+    switch (act) {
+        case SUHPE_ACT_RELU: return u > 0.f ? u : 0.f;
+        case SUHPE_ACT_RELU6: return fminf(fmaxf(u, 0.f), 6.f);
+        case SUHPE_ACT_SILU: return u / (1.f + expf(-u));
+        case SUHPE_ACT_GELU: return 0.5f * u * (1.f + erff(u * 0.70710678118654752f));
+        case SUHPE_ACT_SIGMOID: return 1.f / (1.f + expf(-u));
+        default: return u;
+    }
+}
+// d act(u) / du
+__device__ __forceinline__ float act_grad(float u, int act) {
+    switch (act) {
+        case SUHPE_ACT_RELU: return u > 0.f ? 1.f : 0.f;
+        case SUHPE_ACT_RELU6: return (u > 0.f && u < 6.f) ? 1.f : 0.f;
+        case SUHPE_ACT_SILU: {
+            const float s = 1.f / (1.f + expf(-u));
+            return s * (1.f + u * (1.f - s));
+        }
+        case SUHPE_ACT_GELU: {
+            const float cdf = 0.5f * (1.f + erff(u * 0.70710678118654752f));
+            return cdf + u * 0.3989422804014327f * expf(-0.5f * u * u);
+        }
+        case SUHPE_ACT_SIGMOID: {
+            const float s = 1.f / (1.f + expf(-u));
+            return s * (1.f - s);
+        }
+        default: return 1.f;
+    }
+}
+
 }  // namespace suhpe

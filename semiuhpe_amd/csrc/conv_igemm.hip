@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 #include <unordered_map>
 
 namespace suhpe {
@@ -77,6 +78,10 @@ struct NtParams {
     int ldy;
     int col_tiles;       // ceil(Ng / BN), set by the launcher
     int ldf;             // filter row length in elements (== g.K except in MODE 3)
+    const float* scale;  // optional per-channel affine + activation + residual in the epilogue (eval-mode BatchNorm folded into
+    const float* shift;  // the conv): y = act(acc*scale + shift [+ res]) [+ res], res_mode 1 = before / 2 = after the activation
+    const float* residual;
+    int act, res_mode;
     float* stats;        // optional BatchNorm statistics from the epilogue: records [stat_gx][stat_cout][4] = (S, Q, k, n)
     int stat_cout;       // channels of the whole output (record pitch)
     int stat_gx;         // row tiles = ceil(M / BM)
@@ -93,7 +98,7 @@ template <int BM, int BN, int WM, int WN, int VEC, int MODE>
 // prefetch depth, which leaves 2 workgroups (or 1, for the wgrad kernel) per CU; at <= 80 VGPRs three 8-wave workgroups are
 // resident and the MFMA pipe sees 6 waves per SIMD.
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64,
-                             (VEC == 1 || BM == 256) ? 1 : (((BM / WM) * (BN / WN) > 8 || BN == 32 || MODE == 0) ? 5 : 6))
+                             (VEC == 1 || BM == 256) ? 1 : (((BM / WM) * (BN / WN) > 8 || BN == 32 || BN == 128 || MODE == 0) ? 5 : 6))
 void igemm_nt_kernel(const NtParams p) {
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -163,9 +168,13 @@ void igemm_nt_kernel(const NtParams p) {
         b_off[i] = (col < p.Ng && lrow + i * ROW_STEP < BN) ? col * p.ldf : -1;
     }
 
-    float a_reg[A_ROWS][VEC], b_reg[B_ROWS][VEC];
+    // two register stages: the loads of tile kt+2 are issued while tile kt is multiplied, so a workgroup covers the global
+    // latency with two MFMA phases of its own instead of relying on co-resident workgroups
+    float a_stage[2][A_ROWS][VEC], b_stage[2][B_ROWS][VEC];
 
-    auto load_tiles = [&]() {
+    auto load_tiles = [&](auto stage) {
+        auto& a_reg = a_stage[decltype(stage)::value];
+        auto& b_reg = b_stage[decltype(stage)::value];
         const bool kvalid = kk < g.K;
         int dh = 0, dw = 0, dpix = 0;
         if (MODE == 2) { dh = g.sgn * tr + g.off; dw = g.sgn * ts + g.off; dpix = dh * g.GW + dw; }
@@ -186,7 +195,7 @@ void igemm_nt_kernel(const NtParams p) {
                 pix += gh * g.GW + gw;
             }
             const unsigned off = ok ? (unsigned)pix * (unsigned)g.ldg + (unsigned)ci : 0u;
-            if (VEC == 4) {
+            if constexpr (VEC == 4) {
                 float4 v = *reinterpret_cast<const float4*>(x + off);
                 if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 a_reg[i][0] = v.x; a_reg[i][1] = v.y; a_reg[i][2] = v.z; a_reg[i][3] = v.w;
@@ -199,7 +208,7 @@ void igemm_nt_kernel(const NtParams p) {
         for (int i = 0; i < B_ROWS; ++i) {
             const bool ok = kvalid && b_off[i] >= 0;
             const unsigned off = ok ? (unsigned)b_off[i] + (unsigned)fk : 0u;
-            if (VEC == 4) {
+            if constexpr (VEC == 4) {
                 float4 v = *reinterpret_cast<const float4*>(f + off);
                 if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 b_reg[i][0] = v.x; b_reg[i][1] = v.y; b_reg[i][2] = v.z; b_reg[i][3] = v.w;
@@ -215,19 +224,21 @@ void igemm_nt_kernel(const NtParams p) {
             while (ci >= g.Cg && g.R * g.S > 1) { ci -= g.Cg; if (++ts == g.S) { ts = 0; ++tr; } }
         }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](auto stage) {
+        auto& a_reg = a_stage[decltype(stage)::value];
+        auto& b_reg = b_stage[decltype(stage)::value];
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
             if (BM % ROW_STEP != 0 && lrow + i * ROW_STEP >= BM) continue;
             float* dst = &As[(lrow + i * ROW_STEP) * LDK + lcol];
-            if (VEC == 4) *reinterpret_cast<float4*>(dst) = make_float4(a_reg[i][0], a_reg[i][1], a_reg[i][2], a_reg[i][3]);
+            if constexpr (VEC == 4) *reinterpret_cast<float4*>(dst) = make_float4(a_reg[i][0], a_reg[i][1], a_reg[i][2], a_reg[i][3]);
             else dst[0] = a_reg[i][0];
         }
 #pragma unroll
         for (int i = 0; i < B_ROWS; ++i) {
             if (lrow + i * ROW_STEP >= BN) continue;
             float* dst = &Bs[(lrow + i * ROW_STEP) * LDK + lcol];
-            if (VEC == 4) *reinterpret_cast<float4*>(dst) = make_float4(b_reg[i][0], b_reg[i][1], b_reg[i][2], b_reg[i][3]);
+            if constexpr (VEC == 4) *reinterpret_cast<float4*>(dst) = make_float4(b_reg[i][0], b_reg[i][1], b_reg[i][2], b_reg[i][3]);
             else dst[0] = b_reg[i][0];
         }
     };
@@ -242,11 +253,9 @@ void igemm_nt_kernel(const NtParams p) {
 
     const int r32 = lane & 31, h = lane >> 5;
     const int nk = (g.K + BK - 1) / BK;
-    load_tiles();
-    store_tiles();
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_tiles();                // global loads in flight under the MFMAs below
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    auto mma_tile = [&]() {
 #pragma unroll
         for (int kg = 0; kg < BK / 8; ++kg) {
             float4 af[TM], bf[TN];
@@ -264,11 +273,24 @@ void igemm_nt_kernel(const NtParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
                 }
         }
+    };
+    // tile j lives in register stage j & 1
+    auto step = [&](int kt, auto cur, auto nxt) {
+        if (kt + 2 < nk) load_tiles(cur);             // stage `cur` held tile kt, already in LDS: refill it with tile kt+2
+        mma_tile();
         __syncthreads();
         if (kt + 1 < nk) {
-            store_tiles();
+            store_tiles(nxt);                         // tile kt+1, loaded one iteration ago
             __syncthreads();
         }
+    };
+    load_tiles(S0{});
+    store_tiles(S0{});
+    __syncthreads();
+    if (nk > 1) load_tiles(S1{});
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(kt, S0{}, S1{});
+        if (kt + 1 < nk) step(kt + 1, S1{}, S0{});
     }
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -278,6 +300,8 @@ void igemm_nt_kernel(const NtParams p) {
         const int col = n0 + wn * WN + j * 32 + r32;
         if (col >= p.Ng) continue;
         const float bv = p.bias ? p.bias[grp * p.Ng + col] : 0.f;
+        const float sc = p.scale ? p.scale[grp * p.Ng + col] : 1.f;
+        const float sh = p.scale ? p.shift[grp * p.Ng + col] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -292,7 +316,15 @@ void igemm_nt_kernel(const NtParams p) {
                     const unsigned bb = rem - a * (unsigned)g.OW;
                     orow = ((int64_t)n * g.YH + a * g.om + g.ph) * g.YW + bb * g.om + g.pw;
                 }
-                y[orow * p.ldy + col] = acc[i][j][e] + bv;
+                float v = acc[i][j][e] + bv;
+                if (p.scale) {
+                    v = v * sc + sh;
+                    const float rv = p.res_mode ? p.residual[orow * p.ldy + grp * p.Ng + col] : 0.f;
+                    if (p.res_mode == 1) v += rv;
+                    v = act_apply(v, p.act);
+                    if (p.res_mode == 2) v += rv;
+                }
+                y[orow * p.ldy + col] = v;
             }
     }
 
@@ -688,10 +720,27 @@ int suhpe_conv2d_fwd(const suhpe_conv_t* d, const float* x, const float* w, cons
     const int cg = d->cin / d->groups;
     p.g = make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0);
     p.x = x; p.f = w; p.bias = bias; p.y = y; p.Ng = d->cout / d->groups; p.ldy = d->cout; p.ldf = p.g.K;
-    p.stats = nullptr; p.stat_gx = 0; p.stat_cout = 0;
+    p.stats = nullptr; p.stat_gx = 0; p.stat_cout = 0; p.scale = p.shift = p.residual = nullptr; p.act = 0; p.res_mode = 0;
     const bool vec4 = (cg % 4 == 0) && (d->cin % 4 == 0) && aligned16(x) && aligned16(w);
     dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 0));
     return check_launch("suhpe_conv2d_fwd");
+}
+
+int suhpe_conv2d_fwd_affine(const suhpe_conv_t* d, const float* x, const float* w, const float* scale, const float* shift, int act,
+                            const float* residual, int residual_after_act, float* y, suhpe_stream_t stream) {
+    int rc = check_desc(d, "suhpe_conv2d_fwd_affine");
+    if (rc) return rc;
+    SUHPE_REQUIRE(x && w && y && scale && shift, "suhpe_conv2d_fwd_affine: null pointer");
+    SUHPE_REQUIRE(act >= SUHPE_ACT_NONE && act <= SUHPE_ACT_SIGMOID, "suhpe_conv2d_fwd_affine: unknown activation %d", act);
+    NtParams p;
+    const int cg = d->cin / d->groups;
+    p.g = make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0);
+    p.x = x; p.f = w; p.bias = nullptr; p.y = y; p.Ng = d->cout / d->groups; p.ldy = d->cout; p.ldf = p.g.K;
+    p.stats = nullptr; p.stat_gx = 0; p.stat_cout = 0;
+    p.scale = scale; p.shift = shift; p.residual = residual; p.act = act; p.res_mode = residual ? (residual_after_act ? 2 : 1) : 0;
+    const bool vec4 = (cg % 4 == 0) && (d->cin % 4 == 0) && aligned16(x) && aligned16(w);
+    dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 0));
+    return check_launch("suhpe_conv2d_fwd_affine");
 }
 
 int suhpe_conv2d_fwd_stats_tiles(const suhpe_conv_t* d) {
@@ -709,7 +758,7 @@ int suhpe_conv2d_fwd_stats(const suhpe_conv_t* d, const float* x, const float* w
     const int cg = d->cin / d->groups;
     p.g = make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0);
     p.x = x; p.f = w; p.bias = nullptr; p.y = y; p.Ng = d->cout / d->groups; p.ldy = d->cout; p.ldf = p.g.K;
-    p.stats = stats; p.stat_gx = suhpe_conv2d_fwd_stats_tiles(d); p.stat_cout = d->cout;
+    p.stats = stats; p.stat_gx = suhpe_conv2d_fwd_stats_tiles(d); p.stat_cout = d->cout; p.scale = p.shift = p.residual = nullptr; p.act = 0; p.res_mode = 0;
     const bool vec4 = (cg % 4 == 0) && (d->cin % 4 == 0);
     SUHPE_REQUIRE(!vec4 || (aligned16(x) && aligned16(w)), "suhpe_conv2d_fwd_stats: x / w must be 16-byte aligned");
     dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 0));
@@ -737,7 +786,7 @@ int suhpe_conv2d_dgrad(const suhpe_conv_t* d, const float* dy, const float* wt, 
     if (d->stride == 1) {
         p.g = make_geom(d->n, d->ho, d->wo, d->h, d->w, d->cout, ng, d->r, d->s, d->stride, d->pad, 1);
         p.x = dy; p.f = wt; p.bias = nullptr; p.y = dx; p.Ng = cg; p.ldy = d->cin; p.ldf = p.g.K;
-        p.stats = nullptr; p.stat_gx = 0; p.stat_cout = 0;
+        p.stats = nullptr; p.stat_gx = 0; p.stat_cout = 0; p.scale = p.shift = p.residual = nullptr; p.act = 0; p.res_mode = 0;
         dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 1));
     } else {
         // one launch per parity class of the input pixel: only the taps r = (ph+pad) mod stride (+ k*stride) reach it,
@@ -755,7 +804,7 @@ int suhpe_conv2d_dgrad(const suhpe_conv_t* d, const float* dy, const float* wt, 
                 g.off_h = (ph + d->pad - r0) / st; g.off_w = (pw + d->pad - s0) / st;
                 p.g = g;
                 p.x = dy; p.f = wt; p.bias = nullptr; p.y = dx; p.Ng = cg; p.ldy = d->cin; p.ldf = d->r * d->s * ng;
-                p.stats = nullptr; p.stat_gx = 0; p.stat_cout = 0;
+                p.stats = nullptr; p.stat_gx = 0; p.stat_cout = 0; p.scale = p.shift = p.residual = nullptr; p.act = 0; p.res_mode = 0;
                 dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 1));
             }
     }

@@ -14,38 +14,6 @@ namespace suhpe {
 constexpr int kRowBlockBudget = 2048;              // row blocks x column chunks of one reduction launch (8 blocks per CU)
 constexpr int64_t kPartFloats = 2048LL * 256 * 4;  // record workspace: gx*c <= 2048*256 records of up to 4 floats
 
-// ------------------------------------------------------------------------------------------ activations
-__device__ __forceinline__ float act_apply(float u, int act) {
-    switch (act) {
-        case SUHPE_ACT_RELU: return u > 0.f ? u : 0.f;
-        case SUHPE_ACT_RELU6: return fminf(fmaxf(u, 0.f), 6.f);
-        case SUHPE_ACT_SILU: return u / (1.f + expf(-u));
-        case SUHPE_ACT_GELU: return 0.5f * u * (1.f + erff(u * 0.70710678118654752f));
-        case SUHPE_ACT_SIGMOID: return 1.f / (1.f + expf(-u));
-        default: return u;
-    }
-}
-// d act(u) / du
-__device__ __forceinline__ float act_grad(float u, int act) {
-    switch (act) {
-        case SUHPE_ACT_RELU: return u > 0.f ? 1.f : 0.f;
-        case SUHPE_ACT_RELU6: return (u > 0.f && u < 6.f) ? 1.f : 0.f;
-        case SUHPE_ACT_SILU: {
-            const float s = 1.f / (1.f + expf(-u));
-            return s * (1.f + u * (1.f - s));
-        }
-        case SUHPE_ACT_GELU: {
-            const float cdf = 0.5f * (1.f + erff(u * 0.70710678118654752f));
-            return cdf + u * 0.3989422804014327f * expf(-0.5f * u * u);
-        }
-        case SUHPE_ACT_SIGMOID: {
-            const float s = 1.f / (1.f + expf(-u));
-            return s * (1.f - s);
-        }
-        default: return 1.f;
-    }
-}
-
 // ------------------------------------------------------------------------------------------ column reductions
 // Geometry shared by every per-channel reduction over a (rows, c) matrix.  A block owns `cw` consecutive
 // columns (vec-columns when VEC=4) and a contiguous slab of rows; thread t -> (col = t % cw, rsub = t / cw).
@@ -258,6 +226,17 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ rm, const float* 
     if (ch >= c) return;
     mean[ch] = rm[ch];
     rstd[ch] = 1.f / sqrtf(rv[ch] + eps);
+}
+
+// eval-mode BatchNorm as a per-channel affine map: scale = gamma*rstd, shift = beta - mean*scale
+__global__ void bn_eval_affine_kernel(const float* __restrict__ rm, const float* __restrict__ rv, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta, int c, float eps, float* __restrict__ scale,
+                                      float* __restrict__ shift) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    const float sc = (gamma ? gamma[ch] : 1.f) / sqrtf(rv[ch] + eps);
+    scale[ch] = sc;
+    shift[ch] = (beta ? beta[ch] : 0.f) - rm[ch] * sc;
 }
 
 // y = act(gamma*(x-mean)*rstd + beta + residual)
@@ -768,6 +747,13 @@ int suhpe_bn_eval_stats(const float* rm, const float* rv, int c, float eps, floa
     SUHPE_REQUIRE(rm && rv && mean && rstd && c > 0, "suhpe_bn_eval_stats: bad arguments");
     LAUNCH(bn_eval_stats_kernel, dim3((c + 255) / 256), dim3(256), stream, rm, rv, c, eps, mean, rstd);
     return check_launch("suhpe_bn_eval_stats");
+}
+
+int suhpe_bn_eval_affine(const float* rm, const float* rv, const float* gamma, const float* beta, int c, float eps, float* scale,
+                         float* shift, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(rm && rv && scale && shift && c > 0, "suhpe_bn_eval_affine: bad arguments");
+    LAUNCH(bn_eval_affine_kernel, dim3((c + 255) / 256), dim3(256), stream, rm, rv, gamma, beta, c, eps, scale, shift);
+    return check_launch("suhpe_bn_eval_affine");
 }
 
 int suhpe_bn_act_fwd(const float* x, int64_t rows, int c, const float* mean, const float* rstd, const float* gamma,

@@ -191,6 +191,28 @@ def _dw_wgrad(d, x, dy, out, accumulate, ws, nbytes):
     call("suhpe_dwconv_wgrad", ctypes.byref(d), ptr(x), ptr(dy), ptr(out), int(accumulate), ptr(ws), nbytes)
 
 
+def conv2d_fwd_affine(x, w, scale, shift, act, residual=None, residual_after_act=False, stride=1, pad=0, groups=1):
+    """eval-mode conv -> BatchNorm -> act (-> + skip) in the GEMM epilogue; scale / shift from bn_eval_affine"""
+    _chk(x, "x"); _chk(residual, "residual")
+    assert filter_is_physical(w)
+    d = conv_desc(x.shape, w.shape, stride, pad, groups)
+    y = torch.empty((d.n, d.ho, d.wo, d.cout), dtype=torch.float32, device=x.device)
+    assert residual is None or residual.shape == y.shape
+    if AUTOTUNE:
+        _autotune(d, 0, lambda: call("suhpe_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(w), None, ptr(y)))
+    with _Prof(d, 0):
+        call("suhpe_conv2d_fwd_affine", ctypes.byref(d), ptr(x), ptr(w), ptr(scale), ptr(shift), ACT[act], ptr(residual),
+             int(residual_after_act), ptr(y))
+    return y
+
+
+def bn_eval_affine(running_mean, running_var, gamma, beta, eps):
+    c = running_mean.numel()
+    out = torch.empty(2, c, dtype=torch.float32, device=running_mean.device)
+    call("suhpe_bn_eval_affine", ptr(running_mean), ptr(running_var), ptr(gamma), ptr(beta), c, float(eps), ptr(out[0]), ptr(out[1]))
+    return out[0], out[1]
+
+
 def conv2d_fwd_stats(x, w, stride=1, pad=0, groups=1):
     """Dense conv forward that also returns BatchNorm partial sums from its epilogue: (y, partials, tiles)."""
     _chk(x, "x")

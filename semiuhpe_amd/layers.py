@@ -365,8 +365,15 @@ class Sequential(Layer):
         return dy
 
 
-def conv_bn_fwd(conv, bn, x, tape, residual=None):
-    """conv -> BatchNorm(+act): in training the statistics come out of the conv's epilogue when the conv is dense"""
+def conv_bn_fwd(conv, bn, x, tape, residual=None, residual_after_act=False):
+    """conv -> BatchNorm(+act): in training the statistics come out of the conv's epilogue when the conv is dense; in
+    eval() without a tape (teacher pass, eval.py) BatchNorm, activation and the skip add are folded into that epilogue."""
+    if not bn.training and tape is None and conv.fuses_stats():
+        if not K.filter_is_physical(conv.weight):
+            conv.weight.data = K.to_filter_layout(conv.weight.data)
+        scale, shift = K.bn_eval_affine(bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps)
+        return K.conv2d_fwd_affine(x, conv.weight, scale, shift, bn.act, residual, residual_after_act, conv.stride, conv.padding, conv.groups)
+    assert not residual_after_act
     if bn.training and conv.fuses_stats():
         y, partials = conv.fwd_stats(x, tape)
         return bn.fwd(y, tape, residual=residual, partials=partials)

@@ -68,7 +68,7 @@ class SSLAgent:
         self.config = config
         self.clock = utils.TrainClock()
         # time the GEMM tile menu on each new conv shape during the first steps and pin the winners (kernels._autotune)
-        K.AUTOTUNE = bool(getattr(config, "autotune", True))
+        K.AUTOTUNE = bool(getattr(config, "autotune", True)) and os.environ.get("SUHPE_AUTOTUNE", "1") != "0"
         self.net = get_network(config)
         self.ema_net = get_network(config)
         for param in self.ema_net.parameters():      # reference :34-35: the teacher is never trained by gradients

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from .. import kernels as K
-from ..layers import (BatchNorm1d, Conv2d, ConvNormActivation, Dropout, GlobalAvgPool, Identity, Layer, Linear, Network,
+from ..layers import (conv_bn_fwd, BatchNorm1d, Conv2d, ConvNormActivation, Dropout, GlobalAvgPool, Identity, Layer, Linear, Network,
                       Sequential, SqueezeExcitation, StochasticDepth)
 
 # (block, expand_ratio, kernel, stride, in, out, layers) — torchvision `_efficientnet_conf("efficientnet_v2_s")`
@@ -41,6 +41,13 @@ class _ResidualBlock(Layer):
         return self.stochastic_depth.fwd2(y, x, tape) if self.use_res_connect else y
 
     def fwd(self, x, tape):
+        last = self.block[-1]
+        if tape is None and not self.training and self.use_res_connect and last[0].fuses_stats():
+            # eval without a tape: StochasticDepth is the identity and the skip add rides in the last conv's epilogue
+            y = x
+            for layer in list(self.block)[:-1]:
+                y = layer.fwd(y, None)
+            return conv_bn_fwd(last[0], last[1], y, None, residual=x, residual_after_act=True)
         return self._fwd_res(x, self.block.fwd(x, tape), tape)
 
     def bwd(self, dy, tape):

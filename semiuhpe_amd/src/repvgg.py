@@ -8,7 +8,7 @@ with per-branch batch statistics.  Blocks are Layers with explicit forward/backw
 import torch.nn as nn
 
 from .. import kernels as K
-from ..layers import BatchNorm2d, Conv2d, GlobalAvgPool, Layer, Network, Sequential
+from ..layers import BatchNorm2d, Conv2d, GlobalAvgPool, Layer, Network, Sequential, conv_bn_fwd
 from .efficientnet_v2 import init_regression_head_, regression_head
 
 
@@ -32,6 +32,11 @@ class RepVGGBlock(Layer):
 
     def fwd(self, x, tape):
         train = self.rbr_dense.bn.training
+        if not train and tape is None and self.rbr_dense.conv.fuses_stats():
+            # eval without a tape: each branch's BatchNorm rides in its conv's epilogue, the branch sum and the ReLU in the last one
+            u = self.rbr_identity.fwd(x, None) if self.rbr_identity is not None else None
+            u = conv_bn_fwd(self.rbr_1x1.conv, self.rbr_1x1.bn, x, None, residual=u)
+            return conv_bn_fwd(self.rbr_dense.conv, self.rbr_dense.bn, x, None, residual=u)          # relu(bn(t3) + u)
         t3, p3 = self.rbr_dense.conv.fwd_stats(x, tape) if train else (self.rbr_dense.conv.fwd(x, tape), None)
         t1, p1 = self.rbr_1x1.conv.fwd_stats(x, tape) if train else (self.rbr_1x1.conv.fwd(x, tape), None)
         u = self.rbr_1x1.bn.fwd(t1, tape, partials=p1)

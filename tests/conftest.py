@@ -9,6 +9,11 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# Parity tests run with the built-in tile heuristics: the first-use autotuner may pin a different wgrad tile from run to
+# run (a different split-K summation order), which the gradient yardsticks of the deep-network tests would see as noise.
+# tests/test_gpu_kernels.py::test_tile_menu_* covers the pinned tiles explicitly.
+os.environ.setdefault("SUHPE_AUTOTUNE", "0")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")

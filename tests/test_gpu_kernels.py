@@ -78,6 +78,52 @@ def test_conv_fwd_dgrad_wgrad(K, cfg):
     assert rel(dw2, 2 * wd.grad) < 2e-5
 
 
+@pytest.mark.parametrize("cfg", [(6, 48, 192, 3, 1, 1, 1, 28, 28), (40, 160, 960, 1, 1, 0, 1, 14, 14), (4, 64, 128, 3, 2, 1, 1, 30, 30),
+                                 (2, 128, 128, 3, 1, 1, 2, 14, 14)], ids=str)
+def test_tile_menu_every_pinned_tile_matches(K, cfg):
+    """suhpe_conv2d_set_tile: every tile of the menu gives the same forward / input gradient bit for bit (the k order of an
+    output element does not depend on the tile) and the same filter gradient within fp32 summation-order noise; the
+    autotuner (kernels._autotune) then pins one of them."""
+    import ctypes
+    from semiuhpe_amd import _lib
+    lib = _lib.load()
+    n, cin, cout, k, stride, pad, groups, h, w = cfg
+    g = torch.Generator().manual_seed(11)
+    x = nhwc(torch.randn(n, cin, h, w, generator=g))
+    wg = K.to_filter_layout((torch.randn(cout, cin // groups, k, k, generator=g) / (k * (cin // groups) ** 0.5)).cuda())
+    d = K.conv_desc(x.shape, wg.shape, stride, pad, groups)
+    y0 = K.conv2d_fwd(x, wg, None, stride, pad, groups)
+    dy = torch.randn_like(y0)
+    dx0 = K.conv2d_dgrad(dy, wg, x.shape, stride, pad, groups)
+    dw0 = K.conv2d_wgrad(x, dy, wg.shape, stride, pad, groups)
+    try:
+        for pid in (0, 1, 2):
+            for tile in range(lib.suhpe_conv2d_tile_count(pid)):
+                if lib.suhpe_conv2d_set_tile(ctypes.byref(d), pid, tile) != 0:
+                    assert pid < 2 and tile == 0            # the scalar-loader tile is refused for vector shapes
+                    continue
+                if pid == 0:
+                    assert torch.equal(K.conv2d_fwd(x, wg, None, stride, pad, groups), y0), tile
+                elif pid == 1:
+                    assert torch.equal(K.conv2d_dgrad(dy, wg, x.shape, stride, pad, groups), dx0), tile
+                else:
+                    assert rel(K.conv2d_wgrad(x, dy, wg.shape, stride, pad, groups), dw0.cpu()) < 2e-5, tile
+        assert lib.suhpe_conv2d_set_tile(ctypes.byref(d), 0, 99) != 0
+        # autotuner: pins something valid and leaves results unchanged
+        for pid in (0, 1, 2):
+            lib.suhpe_conv2d_set_tile(ctypes.byref(d), pid, -1)
+        K._tuned.clear()
+        K.AUTOTUNE = True
+        assert torch.equal(K.conv2d_fwd(x, wg, None, stride, pad, groups), y0)
+        assert torch.equal(K.conv2d_dgrad(dy, wg, x.shape, stride, pad, groups), dx0)
+        assert rel(K.conv2d_wgrad(x, dy, wg.shape, stride, pad, groups), dw0.cpu()) < 2e-5
+        assert len(K._tuned) == 3
+    finally:
+        K.AUTOTUNE = False
+        for pid in (0, 1, 2):
+            lib.suhpe_conv2d_set_tile(ctypes.byref(d), pid, -1)
+
+
 STAT_CONVS = [c for c in CONVS if not (c[6] > 1 and c[6] == c[1] == c[2])] + [
     (1, 24, 24, 3, 1, 1, 1, 5, 5),         # a single ragged row tile
     (160, 24, 24, 3, 1, 1, 1, 28, 28),     # many row tiles, narrow output (256x32 / 128x32 tiles)
@@ -117,6 +163,29 @@ def test_conv_fwd_fused_bn_statistics(K, cfg):
     assert rel(rm1, rm0.cpu()) < 2e-6 and rel(rv1, rv0.cpu()) < 2e-5
     assert rel(rv1, 0.9 * 1.5 + 0.1 * yd.var(0, unbiased=rows > 1)) < 2e-5
     assert int(nb1) == int(nb0) == 1
+
+
+@pytest.mark.parametrize("cfg", [(4, 24, 24, 3, 1, 1, 1, 28, 28), (3, 96, 48, 1, 1, 0, 1, 14, 14), (2, 128, 128, 3, 1, 1, 2, 14, 14),
+                                 (2, 64, 128, 3, 2, 1, 1, 15, 15), (40, 160, 960, 1, 1, 0, 1, 14, 14)], ids=str)
+@pytest.mark.parametrize("act,res", [("silu", 0), ("none", 2), ("relu", 1), ("silu", 2)])
+def test_conv_fwd_folded_eval_batchnorm(K, cfg, act, res):
+    """conv -> eval BatchNorm -> activation (-> skip add before / after the activation) folded into the GEMM epilogue"""
+    n, cin, cout, k, stride, pad, groups, h, w = cfg
+    g = torch.Generator().manual_seed(hash(cfg) % 1000 + 7)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin // groups, k, k, generator=g) / (k * (cin // groups) ** 0.5)
+    rm, rv = torch.randn(cout, generator=g) * 0.3, torch.rand(cout, generator=g) + 0.4
+    gamma, beta = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
+    eps = 1e-3
+    t = F.conv2d(x.double(), wt.double(), None, stride, pad, 1, groups)
+    r = torch.randn(t.shape, generator=g)
+    u = F.batch_norm(t, rm.double(), rv.double(), gamma.double(), beta.double(), False, 0.0, eps)
+    fn = {"silu": F.silu, "relu": F.relu, "none": lambda z: z}[act]
+    ref = fn(u + r.double()) if res == 1 else (fn(u) + r.double() if res == 2 else fn(u))
+    scale, shift = K.bn_eval_affine(rm.cuda(), rv.cuda(), gamma.cuda(), beta.cuda(), eps)
+    assert rel(scale, gamma.double() / (rv.double() + eps).sqrt()) < 1e-6
+    y = K.conv2d_fwd_affine(nhwc(x), K.to_filter_layout(wt.cuda()), scale, shift, act, nhwc(r) if res else None, res == 2, stride, pad, groups)
+    assert rel(from_nhwc(y), ref) < 2e-5
 
 
 @pytest.mark.parametrize("n,cin,cout", [(160, 1280, 512), (32, 512, 128), (160, 128, 9), (7, 576, 128), (160, 40, 960)])
