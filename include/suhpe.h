@@ -161,6 +161,15 @@ int suhpe_bn_act_fwd(const float* x, int64_t rows, int c, const float* mean, con
 int suhpe_bn_act_bwd(const float* x, const float* dy, const float* y_out, int64_t rows, int c, const float* mean,
                      const float* rstd, const float* gamma, const float* beta, int act, int train_stats, float* dx,
                      float* dgamma, float* dbeta, int accumulate, void* workspace, suhpe_stream_t stream);
+/* The residual block's tail in one pass: y = skip + rowscale[row / hw] * act(BN(x)) (torchvision MBConv / FusedMBConv:
+ * x + StochasticDepth('row')(block(x)); rowscale (rows/hw floats: keep mask / keep probability) may be NULL = 1), and
+ * its backward: the gradient entering the BatchNorm is dy * rowscale; d(skip) = dy is the caller's. */
+int suhpe_bn_act_skip_fwd(const float* x, int64_t rows, int c, const float* mean, const float* rstd, const float* gamma,
+                          const float* beta, int act, const float* skip, const float* rowscale, int hw, float* y,
+                          suhpe_stream_t stream);
+int suhpe_bn_act_skip_bwd(const float* x, const float* dy, int64_t rows, int c, const float* mean, const float* rstd,
+                          const float* gamma, const float* beta, int act, int train_stats, const float* rowscale, int hw,
+                          float* dx, float* dgamma, float* dbeta, int accumulate, void* workspace, suhpe_stream_t stream);
 /* LayerNorm over the last dim (rows, c) (src/tiny_vit.py nn.LayerNorm) */
 int suhpe_layernorm_fwd(const float* x, int64_t rows, int c, float eps, const float* gamma, const float* beta,
                         float* y, float* mean, float* rstd, suhpe_stream_t stream);

@@ -98,7 +98,7 @@ template <int BM, int BN, int WM, int WN, int VEC, int MODE>
 // prefetch depth, which leaves 2 workgroups (or 1, for the wgrad kernel) per CU; at <= 80 VGPRs three 8-wave workgroups are
 // resident and the MFMA pipe sees 6 waves per SIMD.
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64,
-                             (VEC == 1 || BM == 256) ? 1 : (((BM / WM) * (BN / WN) > 8 || BN == 32 || BN == 128 || MODE == 0) ? 5 : 6))
+                             (VEC == 1 || BM == 256) ? 1 : ((WM == 64 && WN == 64) ? 3 : (((BM / WM) * (BN / WN) > 8 || BN == 32 || BN == 128 || MODE == 0) ? 5 : 6)))
 void igemm_nt_kernel(const NtParams p) {
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -295,38 +295,46 @@ void igemm_nt_kernel(const NtParams p) {
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     float* __restrict__ y = p.y + (int64_t)grp * p.Ng;
+    // two compile-time copies of the store loop (plain / folded affine+activation+skip) behind one uniform branch, so the
+    // plain path carries no per-element tests
+    auto store_out = [&](auto aff) __attribute__((always_inline)) {
+        constexpr bool AFF = decltype(aff)::value;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * WN + j * 32 + r32;
-        if (col >= p.Ng) continue;
-        const float bv = p.bias ? p.bias[grp * p.Ng + col] : 0.f;
-        const float sc = p.scale ? p.scale[grp * p.Ng + col] : 1.f;
-        const float sh = p.scale ? p.shift[grp * p.Ng + col] : 0.f;
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * WN + j * 32 + r32;
+            if (col >= p.Ng) continue;
+            const float bv = (!AFF && p.bias) ? p.bias[grp * p.Ng + col] : 0.f;
+            const float sc = AFF ? p.scale[grp * p.Ng + col] : 1.f;
+            const float sh = AFF ? p.shift[grp * p.Ng + col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int64_t row = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row >= g.M) continue;
-                int64_t orow = row;
-                if (MODE == 3) {        // sub-grid row (n,a,b) -> pixel (n, a*om+ph, b*om+pw) of the full output
-                    const unsigned n = fast_div((unsigned)row, g.div_hw_mul, g.div_hw_shr);
-                    const unsigned rem = (unsigned)row - n * (unsigned)(g.OH * g.OW);
-                    const unsigned a = fast_div(rem, g.div_w_mul, g.div_w_shr);
-                    const unsigned bb = rem - a * (unsigned)g.OW;
-                    orow = ((int64_t)n * g.YH + a * g.om + g.ph) * g.YW + bb * g.om + g.pw;
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t row = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (row >= g.M) continue;
+                    int64_t orow = row;
+                    if (MODE == 3) {        // sub-grid row (n,a,b) -> pixel (n, a*om+ph, b*om+pw) of the full output
+                        const unsigned n = fast_div((unsigned)row, g.div_hw_mul, g.div_hw_shr);
+                        const unsigned rem = (unsigned)row - n * (unsigned)(g.OH * g.OW);
+                        const unsigned a = fast_div(rem, g.div_w_mul, g.div_w_shr);
+                        const unsigned bb = rem - a * (unsigned)g.OW;
+                        orow = ((int64_t)n * g.YH + a * g.om + g.ph) * g.YW + bb * g.om + g.pw;
+                    }
+                    if constexpr (!AFF) {
+                        y[orow * p.ldy + col] = acc[i][j][e] + bv;
+                    } else {
+                        float v = acc[i][j][e] * sc + sh;
+                        const float rv = p.res_mode ? p.residual[orow * p.ldy + grp * p.Ng + col] : 0.f;
+                        if (p.res_mode == 1) v += rv;
+                        v = act_apply(v, p.act);
+                        if (p.res_mode == 2) v += rv;
+                        y[orow * p.ldy + col] = v;
+                    }
                 }
-                float v = acc[i][j][e] + bv;
-                if (p.scale) {
-                    v = v * sc + sh;
-                    const float rv = p.res_mode ? p.residual[orow * p.ldy + grp * p.Ng + col] : 0.f;
-                    if (p.res_mode == 1) v += rv;
-                    v = act_apply(v, p.act);
-                    if (p.res_mode == 2) v += rv;
-                }
-                y[orow * p.ldy + col] = v;
-            }
-    }
+        }
+    };
+    if (p.scale == nullptr) store_out(std::false_type{});
+    else store_out(std::true_type{});
 
     // ---- fused BatchNorm statistics.  Each tile emits (S, Q, k, n) per column: sums of (y-k) and (y-k)^2 over its n valid
     // rows, shifted by k = the tile's first-row value so the variance never forms from two large cancelling sums.
@@ -373,6 +381,235 @@ void igemm_nt_kernel(const NtParams p) {
             *dst = make_float4(a, q, kk[idx], (float)nrows);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------- gemm_nt_persistent
+// Pointwise (1x1, stride 1) convolutions are plain GEMMs with a short reduction (K = 24..1536, often 5-8 slabs of 32):
+// with one tile per workgroup most of a workgroup's life is its prologue (first loads) and epilogue (stores), and since
+// all resident workgroups start together their MFMA phases coincide too: the matrix pipe measured 50 % busy.  Here a
+// workgroup is persistent: it walks tiles vb = blockIdx.x, +gridDim.x, ... and streams k-slabs through the two register
+// stages ACROSS tile boundaries, so the loads of the next tile's first slabs are in flight during the current tile's
+// last MFMAs and its stores, and the pipe only idles for the stores themselves.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (WM == 64 && WN == 64) ? 3 : ((BM * BN >= 128 * 128) ? 4 : 5)) void gemm_nt_persistent(const NtParams p, int total_vb) {
+    constexpr int WAVES_N = BN / WN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;
+    __shared__ __attribute__((aligned(16))) float As[BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
+
+    const GatherGeom& g = p.g;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int grp = blockIdx.z;
+    const float* __restrict__ x = p.x + (int64_t)grp * g.Cg;
+    const float* __restrict__ f = p.f + (int64_t)grp * p.Ng * p.ldf;
+    constexpr int ROW_STEP = NT / 8;
+    constexpr int A_ROWS = (BM + ROW_STEP - 1) / ROW_STEP;
+    constexpr int B_ROWS = (BN + ROW_STEP - 1) / ROW_STEP;
+    const int lcol = (t & 7) * 4, lrow = t >> 3;
+    const int nk = (g.K + BK - 1) / BK;
+    const int M = (int)g.M;
+
+    // tile cursors (same XCD-aware order as igemm_nt_kernel; gridDim.x is a multiple of 8, so a workgroup stays on its XCD's
+    // tile sequence).  Padding tiles (row tile beyond M) load nothing and store nothing.  Plain scalars, no aggregate: the
+    // cursors must live in registers.
+    const int gstride = gridDim.x;
+    int l_vb = blockIdx.x, l_kt = 0, l_m0, l_n0;              // loader: runs two slabs ahead of the MFMAs
+    int c_vb = blockIdx.x, c_kt = 0, c_m0, c_n0, c_rt;        // compute
+    {
+        const int jx = l_vb >> 3;
+        const int ct = jx % p.col_tiles, rt = (jx / p.col_tiles) * 8 + (l_vb & 7);
+        l_m0 = c_m0 = rt * BM; l_n0 = c_n0 = ct * BN; c_rt = rt;
+    }
+    if (c_vb >= total_vb) return;
+
+    float a_stage[2][A_ROWS][4], b_stage[2][B_ROWS][4];
+    auto load_slab = [&](auto stage) __attribute__((always_inline)) {
+        if (l_vb >= total_vb) return;
+        auto& a_reg = a_stage[decltype(stage)::value];
+        auto& b_reg = b_stage[decltype(stage)::value];
+        const int kk = l_kt * BK + lcol;
+        const bool kvalid = kk < g.K;
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+            const int row = lrow + i * ROW_STEP, m = l_m0 + row;
+            const bool ok = kvalid && (BM % ROW_STEP == 0 || row < BM) && m < M;
+            const unsigned off = ok ? (unsigned)m * (unsigned)g.ldg + (unsigned)kk : 0u;
+            float4 v = *reinterpret_cast<const float4*>(x + off);
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            a_reg[i][0] = v.x; a_reg[i][1] = v.y; a_reg[i][2] = v.z; a_reg[i][3] = v.w;
+        }
+#pragma unroll
+        for (int i = 0; i < B_ROWS; ++i) {
+            const int row = lrow + i * ROW_STEP, col = l_n0 + row;
+            const bool ok = kvalid && (BN % ROW_STEP == 0 || row < BN) && col < p.Ng;
+            const unsigned off = ok ? (unsigned)col * (unsigned)p.ldf + (unsigned)kk : 0u;
+            float4 v = *reinterpret_cast<const float4*>(f + off);
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            b_reg[i][0] = v.x; b_reg[i][1] = v.y; b_reg[i][2] = v.z; b_reg[i][3] = v.w;
+        }
+        if (++l_kt == nk) {
+            l_kt = 0;
+            l_vb += gstride;
+            const int jx = l_vb >> 3;
+            const int ct = jx % p.col_tiles;
+            l_m0 = ((jx / p.col_tiles) * 8 + (l_vb & 7)) * BM;
+            l_n0 = ct * BN;
+        }
+    };
+    auto store_slab = [&](auto stage) __attribute__((always_inline)) {
+        auto& a_reg = a_stage[decltype(stage)::value];
+        auto& b_reg = b_stage[decltype(stage)::value];
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+            if (BM % ROW_STEP != 0 && lrow + i * ROW_STEP >= BM) continue;
+            *reinterpret_cast<float4*>(&As[(lrow + i * ROW_STEP) * LDK + lcol]) = make_float4(a_reg[i][0], a_reg[i][1], a_reg[i][2], a_reg[i][3]);
+        }
+#pragma unroll
+        for (int i = 0; i < B_ROWS; ++i) {
+            if (BN % ROW_STEP != 0 && lrow + i * ROW_STEP >= BN) continue;
+            *reinterpret_cast<float4*>(&Bs[(lrow + i * ROW_STEP) * LDK + lcol]) = make_float4(b_reg[i][0], b_reg[i][1], b_reg[i][2], b_reg[i][3]);
+        }
+    };
+
+    floatx16 acc[TM][TN];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    };
+    zero_acc();
+    const int r32 = lane & 31, h = lane >> 5;
+    auto mma_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int kg = 0; kg < BK / 8; ++kg) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(&As[(wm * WM + i * 32 + r32) * LDK + kg * 8 + h * 4]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(&Bs[(wn * WN + j * 32 + r32) * LDK + kg * 8 + h * 4]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+    // epilogue of the tile under the compute cursor (same arithmetic as igemm_nt_kernel's)
+    auto epilogue = [&]() __attribute__((always_inline)) {
+        const int m0 = c_m0, n0 = c_n0;
+        float* __restrict__ y = p.y + (int64_t)grp * p.Ng;
+        auto store_out = [&](auto aff) __attribute__((always_inline)) {
+            constexpr bool AFF = decltype(aff)::value;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * WN + j * 32 + r32;
+                if (col >= p.Ng) continue;
+                const float bv = (!AFF && p.bias) ? p.bias[grp * p.Ng + col] : 0.f;
+                const float sc = AFF ? p.scale[grp * p.Ng + col] : 1.f;
+                const float sh = AFF ? p.shift[grp * p.Ng + col] : 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        if (row >= M) continue;
+                        if constexpr (!AFF) {
+                            y[(int64_t)row * p.ldy + col] = acc[i][j][e] + bv;
+                        } else {
+                            float v = acc[i][j][e] * sc + sh;
+                            const float rv = p.res_mode ? p.residual[(int64_t)row * p.ldy + grp * p.Ng + col] : 0.f;
+                            if (p.res_mode == 1) v += rv;
+                            v = act_apply(v, p.act);
+                            if (p.res_mode == 2) v += rv;
+                            y[(int64_t)row * p.ldy + col] = v;
+                        }
+                    }
+            }
+        };
+        if (p.scale == nullptr) store_out(std::false_type{});
+        else store_out(std::true_type{});
+        if (p.stats) {                                          // BatchNorm statistics records, as in igemm_nt_kernel
+            float* red = As;                                    // [BM/WM][BN][2]   (every wave is past its last LDS read: barrier above)
+            float* kk = As + (BM / WM) * BN * 2;                // [BN]
+            if (wm == 0 && h == 0) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) kk[wn * WN + j * 32 + r32] = acc[0][j][0];
+            }
+            __syncthreads();
+            const int rows_left = M - (m0 + wm * WM);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float k = kk[wn * WN + j * 32 + r32];
+                float a = 0.f, q = 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int lr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        const float v = lr < rows_left ? acc[i][j][e] - k : 0.f;
+                        a += v;
+                        q += v * v;
+                    }
+                a += __shfl_xor(a, 32, 64);
+                q += __shfl_xor(q, 32, 64);
+                if (h == 0) {
+                    const int idx = wm * BN + wn * WN + j * 32 + r32;
+                    red[idx * 2] = a;
+                    red[idx * 2 + 1] = q;
+                }
+            }
+            __syncthreads();
+            const int nrows = M - m0 < BM ? M - m0 : BM;
+            for (int idx = t; idx < BN; idx += NT) {
+                const int col = n0 + idx;
+                if (col >= p.Ng) continue;
+                float a = 0.f, q = 0.f;
+#pragma unroll
+                for (int w = 0; w < BM / WM; ++w) { a += red[(w * BN + idx) * 2]; q += red[(w * BN + idx) * 2 + 1]; }
+                float4* dst = reinterpret_cast<float4*>(p.stats) + (int64_t)c_rt * p.stat_cout + grp * p.Ng + col;
+                if (nrows > 0) *dst = make_float4(a, q, kk[idx], (float)nrows);
+            }
+            __syncthreads();                                    // the scratch is tile storage again from here on
+        }
+    };
+
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    // slab s lives in register stage s & 1; returns false after the workgroup's last slab
+    auto step = [&](auto cur, auto nxt) __attribute__((always_inline)) -> bool {
+        load_slab(cur);                               // slab s+2 (possibly the next tile's) refills the stage slab s came from
+        mma_tile();
+        __syncthreads();
+        if (++c_kt == nk) {
+            epilogue();
+            zero_acc();
+            c_kt = 0;
+            c_vb += gstride;
+            const int jx = c_vb >> 3;
+            const int ct = jx % p.col_tiles;
+            c_rt = (jx / p.col_tiles) * 8 + (c_vb & 7);
+            c_m0 = c_rt * BM;
+            c_n0 = ct * BN;
+        }
+        if (c_vb >= total_vb) return false;
+        store_slab(nxt);                              // slab s+1, loaded one step ago
+        __syncthreads();
+        return true;
+    };
+    load_slab(S0{});
+    store_slab(S0{});
+    __syncthreads();
+    load_slab(S1{});
+    while (step(S0{}, S1{}) && step(S1{}, S0{})) {}
 }
 
 // ---------------------------------------------------------------------------------------------- igemm_tn (wgrad)
@@ -442,7 +679,7 @@ void igemm_tn_kernel(const TnParams p) {
             const int64_t m = mb + a_row + i * RA;
             const bool ok = a_valid_col && m < mend && (BK % RA == 0 || a_row + i * RA < BK);
             const float* src = dy + (ok ? m * p.lddy + i0 + a_col : 0);
-            if (VECA == 4) {
+            if constexpr (VECA == 4) {
                 float4 v = *reinterpret_cast<const float4*>(src);
                 if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 a_reg[i][0] = v.x; a_reg[i][1] = v.y; a_reg[i][2] = v.z; a_reg[i][3] = v.w;
@@ -463,7 +700,7 @@ void igemm_tn_kernel(const TnParams p) {
             const int gh = (int)oh * g.stride + dr, gw = (int)ow * g.stride + ds;
             ok = ok && (unsigned)gh < (unsigned)g.GH && (unsigned)gw < (unsigned)g.GW;
             const unsigned off = ok ? ((unsigned)n * (unsigned)(g.GH * g.GW) + (unsigned)(gh * g.GW + gw)) * (unsigned)g.ldg + (unsigned)ci : 0u;
-            if (VECB == 4) {
+            if constexpr (VECB == 4) {
                 float4 v = *reinterpret_cast<const float4*>(x + off);
                 if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 b_reg[i][0] = v.x; b_reg[i][1] = v.y; b_reg[i][2] = v.z; b_reg[i][3] = v.w;
@@ -478,14 +715,14 @@ void igemm_tn_kernel(const TnParams p) {
         for (int i = 0; i < A_IT; ++i) {
             if (BK % RA != 0 && a_row + i * RA >= BK) continue;
             float* dst = &As[(a_row + i * RA) * BM + a_col];
-            if (VECA == 4) *reinterpret_cast<float4*>(dst) = make_float4(a_reg[i][0], a_reg[i][1], a_reg[i][2], a_reg[i][3]);
+            if constexpr (VECA == 4) *reinterpret_cast<float4*>(dst) = make_float4(a_reg[i][0], a_reg[i][1], a_reg[i][2], a_reg[i][3]);
             else dst[0] = a_reg[i][0];
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             if (BK % RB != 0 && b_row + i * RB >= BK) continue;
             float* dst = &Bs[(b_row + i * RB) * BN + b_col];
-            if (VECB == 4) *reinterpret_cast<float4*>(dst) = make_float4(b_reg[i][0], b_reg[i][1], b_reg[i][2], b_reg[i][3]);
+            if constexpr (VECB == 4) *reinterpret_cast<float4*>(dst) = make_float4(b_reg[i][0], b_reg[i][1], b_reg[i][2], b_reg[i][3]);
             else dst[0] = b_reg[i][0];
         }
     };
@@ -634,9 +871,13 @@ static void launch_nt(const NtParams& p_in, int groups, hipStream_t st) {
 // (tools/tune_tiles.py: the small tiles win most 1x1 layers, 128x64 the large-K 3x3 ones), so the caller may pin the tile
 // of a (descriptor, pass) after measuring the menu (suhpe_conv2d_set_tile; semiuhpe_amd.kernels.AUTOTUNE does that the
 // first time a shape is seen).  Unpinned shapes use the heuristics below.
-enum NtTile { NT_64x64_S = 0, NT_64x64, NT_128x32, NT_128x128, NT_128x64, NT_256x32, NT_TILES };
+// NT_P*: the persistent pointwise kernel (gemm_nt_persistent); on a shape that is not a plain GEMM (3x3, strided) a pinned
+// NT_P* tile falls back to the igemm tile of the same size
+enum NtTile { NT_64x64_S = 0, NT_64x64, NT_128x32, NT_128x128, NT_128x64, NT_256x32, NT_P64x64, NT_P128x32, NT_P128x64, NT_P128x128, NT_TILES };
 static const char* kNtNames[] = {"igemm_nt_kernel<64,64,32,32,1>", "igemm_nt_kernel<64,64,32,32,4>", "igemm_nt_kernel<128,32,32,32,4>",
-                                 "igemm_nt_kernel<128,128,64,32,4>", "igemm_nt_kernel<128,64,32,32,4>", "igemm_nt_kernel<256,32,64,32,4>"};
+                                 "igemm_nt_kernel<128,128,64,32,4>", "igemm_nt_kernel<128,64,32,32,4>", "igemm_nt_kernel<256,32,64,32,4>",
+                                 "gemm_nt_persistent<64,64,32,32>", "gemm_nt_persistent<128,32,32,32>", "gemm_nt_persistent<128,64,32,32>",
+                                 "gemm_nt_persistent<128,128,64,32>"};
 
 struct TnTile { int bm, bn; const char* name; };
 static const TnTile kTnTiles[] = {
@@ -678,10 +919,50 @@ static NtTile choose_nt(int64_t M, int ng, bool vec4, int pinned) {
     return ceil_div(M, 128) * ceil_div(ng, 64) >= 512 ? NT_128x64 : NT_64x64;
 }
 
-static int nt_tile_bm(NtTile t) { return (t == NT_64x64_S || t == NT_64x64) ? 64 : (t == NT_256x32 ? 256 : 128); }
+static int nt_tile_bm(NtTile t) { return (t == NT_64x64_S || t == NT_64x64 || t == NT_P64x64) ? 64 : (t == NT_256x32 ? 256 : 128); }
+
+template <int BM, int BN, int WM, int WN>
+static void launch_persistent(const NtParams& p_in, int groups, hipStream_t st) {
+    static int slots = 0;                                      // resident workgroups of this instantiation on the whole device
+    if (slots == 0) {
+        int occ = 0, dev = 0, cus = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gemm_nt_persistent<BM, BN, WM, WN>, (BM / WM) * (BN / WN) * 64, 0);
+        slots = (occ > 0 ? occ : 1) * (cus > 0 ? cus : 256);
+    }
+    NtParams p = p_in;
+    p.col_tiles = (int)ceil_div(p.Ng, BN);
+    const int64_t row_tiles8 = ceil_div(ceil_div(p.g.M, BM), 8) * 8;
+    const int total_vb = (int)(row_tiles8 * p.col_tiles);
+    int per_group = slots / groups;
+    per_group = per_group / 8 * 8;
+    if (per_group < 8) per_group = 8;
+    const int gx = total_vb < per_group ? total_vb : per_group;     // total_vb is a multiple of 8 too
+    hipLaunchKernelGGL((gemm_nt_persistent<BM, BN, WM, WN>), dim3(gx, 1, groups), dim3((BM / WM) * (BN / WN) * 64), 0, st, p, total_vb);
+}
+
+// a pinned persistent tile on a shape that is not a plain GEMM runs the igemm tile of the same size
+static NtTile effective_nt(NtTile tile, bool plain) {
+    if (tile < NT_P64x64 || plain) return tile;
+    return tile == NT_P64x64 ? NT_64x64 : (tile == NT_P128x32 ? NT_128x32 : (tile == NT_P128x64 ? NT_128x64 : NT_128x128));
+}
 
 static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st, int pinned) {
-    switch (choose_nt(p.g.M, p.Ng, vec4, pinned)) {
+    NtTile tile = choose_nt(p.g.M, p.Ng, vec4, pinned);
+    if (tile >= NT_P64x64) {
+        const bool plain = nt_mode(p.g) == 1 && p.g.M < (1LL << 31);
+        if (plain) {
+            switch (tile) {
+                case NT_P64x64: launch_persistent<64, 64, 32, 32>(p, groups, st); return;
+                case NT_P128x32: launch_persistent<128, 32, 32, 32>(p, groups, st); return;
+                case NT_P128x64: launch_persistent<128, 64, 32, 32>(p, groups, st); return;
+                default: launch_persistent<128, 128, 64, 32>(p, groups, st); return;
+            }
+        }
+        tile = effective_nt(tile, false);
+    }
+    switch (tile) {
         case NT_64x64_S: launch_nt<64, 64, 32, 32, 1>(p, groups, st); break;
         case NT_64x64: launch_nt<64, 64, 32, 32, 4>(p, groups, st); break;
         case NT_128x32: launch_nt<128, 32, 32, 32, 4>(p, groups, st); break;
@@ -858,10 +1139,11 @@ int suhpe_conv2d_set_tile(const suhpe_conv_t* d, int pass, int tile) {
 const char* suhpe_conv2d_kernel_name(const suhpe_conv_t* d, int pass) {
     if (!d || d->groups <= 0) return "";
     const int ng = d->cout / d->groups, cg = d->cin / d->groups;
-    if (pass == 0) return kNtNames[choose_nt((int64_t)d->n * d->ho * d->wo, ng, cg % 4 == 0 && d->cin % 4 == 0, pinned_tile(d, 0))];
+    const bool plain = d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0;
+    if (pass == 0) return kNtNames[effective_nt(choose_nt((int64_t)d->n * d->ho * d->wo, ng, cg % 4 == 0 && d->cin % 4 == 0, pinned_tile(d, 0)), plain)];
     if (pass == 1) {
         const int st = d->stride;
-        return kNtNames[choose_nt((int64_t)d->n * ((d->h + st - 1) / st) * ((d->w + st - 1) / st), cg, ng % 4 == 0 && d->cout % 4 == 0, pinned_tile(d, 1))];
+        return kNtNames[effective_nt(choose_nt((int64_t)d->n * ((d->h + st - 1) / st) * ((d->w + st - 1) / st), cg, ng % 4 == 0 && d->cout % 4 == 0, pinned_tile(d, 1)), plain)];
     }
     const bool va = ng % 4 == 0 && d->cout % 4 == 0, vb = cg % 4 == 0 && d->cin % 4 == 0;
     if (!(va && vb)) return va ? "igemm_tn_kernel<64,64,32,32,4,1>" : (vb ? "igemm_tn_kernel<64,64,32,32,1,4>" : "igemm_tn_kernel<64,64,32,32,1,1>");

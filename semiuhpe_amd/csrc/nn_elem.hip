@@ -239,12 +239,15 @@ __global__ void bn_eval_affine_kernel(const float* __restrict__ rm, const float*
     shift[ch] = (beta ? beta[ch] : 0.f) - rm[ch] * sc;
 }
 
-// y = act(gamma*(x-mean)*rstd + beta + residual)
+// y = act(gamma*(x-mean)*rstd + beta + residual)                       (post == 0: pre-activation residual)
+// y = residual + rowscale[row / hw] * act(gamma*(x-mean)*rstd + beta)   (post == 1: the block's skip connection with
+//                                                                        StochasticDepth('row') folded in; rowscale may be NULL)
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, int rows, int c, int cw, int rp, int rows_per_block,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         int act, const float* __restrict__ residual,
+                                                         int act, const float* __restrict__ residual, int post,
+                                                         const float* __restrict__ rowscale, int hw,
                                                          float* __restrict__ y) {
     EW_THREAD_SETUP(VEC)
     float sc[VEC], sh[VEC];
@@ -259,11 +262,13 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
         float xv[VEC], rv[VEC], o[VEC];
         vload<VEC>(x + off, xv);
         if (residual) vload<VEC>(residual + off, rv);
+        const float rsc = (post && rowscale) ? rowscale[r / hw] : 1.f;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             float u = xv[v] * sc[v] + sh[v];
-            if (residual) u += rv[v];
+            if (residual && !post) u += rv[v];
             o[v] = act_apply(u, act);
+            if (post) o[v] = rv[v] + rsc * o[v];
         }
         vstore<VEC>(y + off, o);
     }
@@ -275,7 +280,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
                                                       const float* __restrict__ yout, int64_t rows, int c, int cw, int rp,
                                                       int64_t rows_per_block, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, int act, float* __restrict__ part) {
+                                                      const float* __restrict__ beta, int act, const float* __restrict__ rowscale,
+                                                      int hw, float* __restrict__ part) {
     __shared__ float lds[256 * 2 * VEC];
     const int t = threadIdx.x, col = t % cw, rsub = t / cw;
     const int col0 = blockIdx.y * cw;
@@ -307,13 +313,15 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const bool ok = r + u * (int64_t)rp < r1;
+                const int64_t rr = r + u * (int64_t)rp;
+                const bool ok = rr < r1;
+                const float rsc = (rowscale && ok) ? rowscale[rr / hw] : 1.f;     // StochasticDepth scale of the sample
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
                     const float xh = (xv[u][v] - mu[v]) * rs[v];
                     float g;
                     if (yout) g = yv[u][v] > 0.f ? dv[u][v] : 0.f;       // ReLU applied after a pre-activation residual
-                    else g = dv[u][v] * act_grad(xh * ga[v] + be[v], act);
+                    else g = dv[u][v] * rsc * act_grad(xh * ga[v] + be[v], act);
                     g = ok ? g : 0.f;
                     s0[v] += g;
                     s1[v] += g * xh;
@@ -343,7 +351,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ x,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta, int act,
                                                     const float* __restrict__ sums, float inv_rows, int train_stats,
-                                                    float* __restrict__ dx) {
+                                                    const float* __restrict__ rowscale, int hw, float* __restrict__ dx) {
     EW_THREAD_SETUP(VEC)
     float mu[VEC], rs[VEC], ga[VEC], be[VEC], m0[VEC], m1[VEC];
 #pragma unroll
@@ -359,12 +367,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ x,
         vload<VEC>(x + off, xv);
         vload<VEC>(dy + off, dv);
         if (yout) vload<VEC>(yout + off, yv);
+        const float rsc = rowscale ? rowscale[r / hw] : 1.f;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             const float xh = (xv[v] - mu[v]) * rs[v];
             float g;
             if (yout) g = yv[v] > 0.f ? dv[v] : 0.f;
-            else g = dv[v] * act_grad(xh * ga[v] + be[v], act);
+            else g = dv[v] * rsc * act_grad(xh * ga[v] + be[v], act);
             g = g - m0[v] - xh * m1[v];
             o[v] = ga[v] * rs[v] * g;
         }
@@ -756,47 +765,76 @@ int suhpe_bn_eval_affine(const float* rm, const float* rv, const float* gamma, c
     return check_launch("suhpe_bn_eval_affine");
 }
 
-int suhpe_bn_act_fwd(const float* x, int64_t rows, int c, const float* mean, const float* rstd, const float* gamma,
-                     const float* beta, int act, const float* residual, float* y, suhpe_stream_t stream) {
-    SUHPE_REQUIRE(x && y && mean && rstd && rows > 0 && rows < (1LL << 31) && c > 0, "suhpe_bn_act_fwd: bad arguments");
+static int bn_act_fwd_impl(const float* x, int64_t rows, int c, const float* mean, const float* rstd, const float* gamma,
+                           const float* beta, int act, const float* residual, int post, const float* rowscale, int hw, float* y,
+                           suhpe_stream_t stream, const char* who) {
+    if (!(x && y && mean && rstd && rows > 0 && rows < (1LL << 31) && c > 0)) { set_error("%s: bad arguments", who); return SUHPE_EINVAL; }
+    if (post && !(residual && hw > 0 && rows % hw == 0)) { set_error("%s: the skip form needs a skip tensor and rows %% hw == 0", who); return SUHPE_EINVAL; }
     if (vec4_ok(c, x, y, residual)) {
         const EwGeom g = ew_geom(rows, c, 4);
         LAUNCH(bn_act_fwd_kernel<4>, dim3(g.gx, g.ny), dim3(256), stream, x, (int)rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta,
-               act, residual, y);
+               act, residual, post, rowscale, hw, y);
     } else {
         const EwGeom g = ew_geom(rows, c, 1);
         LAUNCH(bn_act_fwd_kernel<1>, dim3(g.gx, g.ny), dim3(256), stream, x, (int)rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta,
-               act, residual, y);
+               act, residual, post, rowscale, hw, y);
     }
-    return check_launch("suhpe_bn_act_fwd");
+    return check_launch(who);
 }
 
-int suhpe_bn_act_bwd(const float* x, const float* dy, const float* y_out, int64_t rows, int c, const float* mean,
-                     const float* rstd, const float* gamma, const float* beta, int act, int train_stats, float* dx,
-                     float* dgamma, float* dbeta, int accumulate, void* workspace, suhpe_stream_t stream) {
-    SUHPE_REQUIRE(x && dy && dx && mean && rstd && workspace && rows > 0 && rows < (1LL << 31) && c > 0, "suhpe_bn_act_bwd: bad arguments");
-    SUHPE_REQUIRE(!y_out || act == SUHPE_ACT_RELU, "suhpe_bn_act_bwd: y_out (pre-activation residual) needs act=RELU");
+int suhpe_bn_act_fwd(const float* x, int64_t rows, int c, const float* mean, const float* rstd, const float* gamma,
+                     const float* beta, int act, const float* residual, float* y, suhpe_stream_t stream) {
+    return bn_act_fwd_impl(x, rows, c, mean, rstd, gamma, beta, act, residual, 0, nullptr, 1, y, stream, "suhpe_bn_act_fwd");
+}
+
+int suhpe_bn_act_skip_fwd(const float* x, int64_t rows, int c, const float* mean, const float* rstd, const float* gamma,
+                          const float* beta, int act, const float* skip, const float* rowscale, int hw, float* y,
+                          suhpe_stream_t stream) {
+    return bn_act_fwd_impl(x, rows, c, mean, rstd, gamma, beta, act, skip, 1, rowscale, hw, y, stream, "suhpe_bn_act_skip_fwd");
+}
+
+static int bn_act_bwd_impl(const float* x, const float* dy, const float* y_out, int64_t rows, int c, const float* mean,
+                           const float* rstd, const float* gamma, const float* beta, int act, int train_stats, const float* rowscale,
+                           int hw, float* dx, float* dgamma, float* dbeta, int accumulate, void* workspace, suhpe_stream_t stream,
+                           const char* who) {
+    if (!(x && dy && dx && mean && rstd && workspace && rows > 0 && rows < (1LL << 31) && c > 0)) { set_error("%s: bad arguments", who); return SUHPE_EINVAL; }
+    if (y_out && act != SUHPE_ACT_RELU) { set_error("%s: y_out (pre-activation residual) needs act=RELU", who); return SUHPE_EINVAL; }
+    if (rowscale && !(hw > 0 && rows % hw == 0 && !y_out)) { set_error("%s: rowscale needs rows %% hw == 0 and no y_out", who); return SUHPE_EINVAL; }
     float* part = static_cast<float*>(workspace);
     float* sums = part + kPartFloats;
     const float inv_rows = 1.0f / (float)rows;
     if (vec4_ok(c, x, dy, dx) && vec4_ok(c, y_out)) {
         const ColGeom g = col_geom(rows, c, 4);
         LAUNCH(bn_bwd_partial<4>, dim3(g.gx, g.ny), dim3(256), stream, x, dy, y_out, rows, c, g.cw, g.rp, g.rows_per_block, mean,
-               rstd, gamma, beta, act, part);
+               rstd, gamma, beta, act, rowscale, hw, part);
         LAUNCH(bn_bwd_finalize, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
         const EwGeom e = ew_geom(rows, c, 4);
         LAUNCH(bn_bwd_apply<4>, dim3(e.gx, e.ny), dim3(256), stream, x, dy, y_out, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd,
-               gamma, beta, act, sums, inv_rows, train_stats, dx);
+               gamma, beta, act, sums, inv_rows, train_stats, rowscale, hw, dx);
     } else {
         const ColGeom g = col_geom(rows, c, 1);
         LAUNCH(bn_bwd_partial<1>, dim3(g.gx, g.ny), dim3(256), stream, x, dy, y_out, rows, c, g.cw, g.rp, g.rows_per_block, mean,
-               rstd, gamma, beta, act, part);
+               rstd, gamma, beta, act, rowscale, hw, part);
         LAUNCH(bn_bwd_finalize, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
         const EwGeom e = ew_geom(rows, c, 1);
         LAUNCH(bn_bwd_apply<1>, dim3(e.gx, e.ny), dim3(256), stream, x, dy, y_out, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd,
-               gamma, beta, act, sums, inv_rows, train_stats, dx);
+               gamma, beta, act, sums, inv_rows, train_stats, rowscale, hw, dx);
     }
-    return check_launch("suhpe_bn_act_bwd");
+    return check_launch(who);
+}
+
+int suhpe_bn_act_bwd(const float* x, const float* dy, const float* y_out, int64_t rows, int c, const float* mean,
+                     const float* rstd, const float* gamma, const float* beta, int act, int train_stats, float* dx,
+                     float* dgamma, float* dbeta, int accumulate, void* workspace, suhpe_stream_t stream) {
+    return bn_act_bwd_impl(x, dy, y_out, rows, c, mean, rstd, gamma, beta, act, train_stats, nullptr, 1, dx, dgamma, dbeta, accumulate,
+                           workspace, stream, "suhpe_bn_act_bwd");
+}
+
+int suhpe_bn_act_skip_bwd(const float* x, const float* dy, int64_t rows, int c, const float* mean, const float* rstd,
+                          const float* gamma, const float* beta, int act, int train_stats, const float* rowscale, int hw,
+                          float* dx, float* dgamma, float* dbeta, int accumulate, void* workspace, suhpe_stream_t stream) {
+    return bn_act_bwd_impl(x, dy, nullptr, rows, c, mean, rstd, gamma, beta, act, train_stats, rowscale, hw, dx, dgamma, dbeta, accumulate,
+                           workspace, stream, "suhpe_bn_act_skip_bwd");
 }
 
 int suhpe_layernorm_fwd(const float* x, int64_t rows, int c, float eps, const float* gamma, const float* beta, float* y,

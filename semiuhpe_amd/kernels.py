@@ -317,19 +317,29 @@ def bn_eval_stats(running_mean, running_var, eps):
 
 
 @_memop
-def bn_act_fwd(x, c, mean, rstd, gamma, beta, act, residual=None):
-    _chk(x, "x"); _chk(residual, "residual")
+def bn_act_fwd(x, c, mean, rstd, gamma, beta, act, residual=None, post=False, rowscale=None, hw=1):
+    """post=False: act(BN(x) + residual).  post=True: residual + rowscale[sample] * act(BN(x)) (skip + StochasticDepth)."""
+    _chk(x, "x"); _chk(residual, "residual"); _chk(rowscale, "rowscale")
     y = torch.empty_like(x)
+    if post:
+        call("suhpe_bn_act_skip_fwd", ptr(x), x.numel() // c, c, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ACT[act],
+             ptr(residual), ptr(rowscale), int(hw), ptr(y))
+        return y
     call("suhpe_bn_act_fwd", ptr(x), x.numel() // c, c, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ACT[act],
          ptr(residual), ptr(y))
     return y
 
 
 @_memop
-def bn_act_bwd(x, dy, c, mean, rstd, gamma, beta, act, train_stats, dgamma=None, dbeta=None, accumulate=False, y_out=None):
+def bn_act_bwd(x, dy, c, mean, rstd, gamma, beta, act, train_stats, dgamma=None, dbeta=None, accumulate=False, y_out=None,
+               rowscale=None, hw=1):
     _chk(x, "x"); _chk(dy, "dy")
     dx = torch.empty_like(x)
     ws = workspace("bn", _lib.load().suhpe_bn_workspace_bytes(c), x.device)
+    if rowscale is not None:
+        call("suhpe_bn_act_skip_bwd", ptr(x), ptr(dy), x.numel() // c, c, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ACT[act],
+             int(train_stats), ptr(rowscale), int(hw), ptr(dx), ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws))
+        return dx
     call("suhpe_bn_act_bwd", ptr(x), ptr(dy), ptr(y_out), x.numel() // c, c, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
          ACT[act], int(train_stats), ptr(dx), ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws))
     return dx

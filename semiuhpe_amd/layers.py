@@ -156,7 +156,9 @@ class _BatchNorm(Layer):
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
-    def fwd(self, x, tape, residual=None, partials=None):
+    def fwd(self, x, tape, residual=None, partials=None, post=False, rowscale=None):
+        """residual, post=False: act(BN(x) + residual).  post=True: residual + rowscale[n] * act(BN(x)), the skip
+        connection of a residual block with StochasticDepth('row') folded in (rowscale None = 1)."""
         c = self.num_features
         if self.training and partials is not None:          # statistics already accumulated by the producing conv's epilogue
             mean, rstd = K.bn_stats_from_partials(partials[0], partials[1], x.numel() // c, c, self.eps, self.momentum,
@@ -165,15 +167,17 @@ class _BatchNorm(Layer):
             mean, rstd = K.bn_stats(x, c, self.eps, self.momentum, self.running_mean, self.running_var, self.num_batches_tracked)
         else:
             mean, rstd = K.bn_eval_stats(self.running_mean, self.running_var, self.eps)
-        y = K.bn_act_fwd(x, c, mean, rstd, self.weight, self.bias, self.act, residual)
+        hw = x.numel() // (c * x.shape[0])
+        y = K.bn_act_fwd(x, c, mean, rstd, self.weight, self.bias, self.act, residual, post, rowscale, hw)
         if tape is not None:
-            tape.append((x, mean, rstd, self.training, y if residual is not None and self.act == "relu" else None))
+            keep_y = y if (residual is not None and not post and self.act == "relu") else None
+            tape.append((x, mean, rstd, self.training, keep_y, rowscale if post else None, hw))
         return y
 
     def bwd(self, dy, tape):
-        x, mean, rstd, train_stats, y_out = tape.pop()
+        x, mean, rstd, train_stats, y_out, rowscale, hw = tape.pop()
         return K.bn_act_bwd(x, dy, self.num_features, mean, rstd, self.weight, self.bias, self.act, train_stats,
-                            grad_of(self.weight), grad_of(self.bias), True, y_out)
+                            grad_of(self.weight), grad_of(self.bias), True, y_out, rowscale, hw)
 
     def extra_repr(self):
         return f"{self.num_features}, eps={self.eps}, momentum={self.momentum}, act={self.act}"
@@ -365,19 +369,18 @@ class Sequential(Layer):
         return dy
 
 
-def conv_bn_fwd(conv, bn, x, tape, residual=None, residual_after_act=False):
+def conv_bn_fwd(conv, bn, x, tape, residual=None, residual_after_act=False, rowscale=None):
     """conv -> BatchNorm(+act): in training the statistics come out of the conv's epilogue when the conv is dense; in
     eval() without a tape (teacher pass, eval.py) BatchNorm, activation and the skip add are folded into that epilogue."""
-    if not bn.training and tape is None and conv.fuses_stats():
+    if not bn.training and tape is None and conv.fuses_stats() and rowscale is None:
         if not K.filter_is_physical(conv.weight):
             conv.weight.data = K.to_filter_layout(conv.weight.data)
         scale, shift = K.bn_eval_affine(bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps)
         return K.conv2d_fwd_affine(x, conv.weight, scale, shift, bn.act, residual, residual_after_act, conv.stride, conv.padding, conv.groups)
-    assert not residual_after_act
     if bn.training and conv.fuses_stats():
         y, partials = conv.fwd_stats(x, tape)
-        return bn.fwd(y, tape, residual=residual, partials=partials)
-    return bn.fwd(conv.fwd(x, tape), tape, residual=residual)
+        return bn.fwd(y, tape, residual=residual, partials=partials, post=residual_after_act, rowscale=rowscale)
+    return bn.fwd(conv.fwd(x, tape), tape, residual=residual, post=residual_after_act, rowscale=rowscale)
 
 
 class ConvNormActivation(Sequential):

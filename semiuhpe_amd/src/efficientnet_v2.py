@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from .. import kernels as K
-from ..layers import (conv_bn_fwd, BatchNorm1d, Conv2d, ConvNormActivation, Dropout, GlobalAvgPool, Identity, Layer, Linear, Network,
+from ..layers import (conv_bn_fwd, draw_mask, BatchNorm1d, Conv2d, ConvNormActivation, Dropout, GlobalAvgPool, Identity, Layer, Linear, Network,
                       Sequential, SqueezeExcitation, StochasticDepth)
 
 # (block, expand_ratio, kernel, stride, in, out, layers) — torchvision `_efficientnet_conf("efficientnet_v2_s")`
@@ -35,26 +35,26 @@ def _make_divisible(v, divisor=8):
 
 
 class _ResidualBlock(Layer):
-    """Shared tail: optional skip connection through StochasticDepth('row')."""
-
-    def _fwd_res(self, x, y, tape):
-        return self.stochastic_depth.fwd2(y, x, tape) if self.use_res_connect else y
+    """Shared tail: x + StochasticDepth('row')(block(x)).  The add and the per-sample keep scale run inside the last
+    BatchNorm's apply kernel (and its backward), so the skip costs no pass of its own."""
 
     def fwd(self, x, tape):
+        if not self.use_res_connect:
+            return self.block.fwd(x, tape)
+        y = x
+        for layer in list(self.block)[:-1]:
+            y = layer.fwd(y, tape)
         last = self.block[-1]
-        if tape is None and not self.training and self.use_res_connect and last[0].fuses_stats():
-            # eval without a tape: StochasticDepth is the identity and the skip add rides in the last conv's epilogue
-            y = x
-            for layer in list(self.block)[:-1]:
-                y = layer.fwd(y, None)
-            return conv_bn_fwd(last[0], last[1], y, None, residual=x, residual_after_act=True)
-        return self._fwd_res(x, self.block.fwd(x, tape), tape)
+        sd = self.stochastic_depth
+        rowscale = None
+        if sd.training and sd.p > 0.0:
+            rowscale = draw_mask("stochastic_depth", (x.shape[0],), 1.0 - sd.p, x.device)
+        return conv_bn_fwd(last[0], last[1], y, tape, residual=x, residual_after_act=True, rowscale=rowscale)
 
     def bwd(self, dy, tape):
         if not self.use_res_connect:
             return self.block.bwd(dy, tape)
-        d_branch, d_skip = self.stochastic_depth.bwd2(dy, tape)
-        return K.add(self.block.bwd(d_branch, tape), d_skip)
+        return K.add(self.block.bwd(dy, tape), dy)           # the last BatchNorm's backward applies the keep scale
 
 
 class FusedMBConv(_ResidualBlock):

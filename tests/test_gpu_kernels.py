@@ -251,6 +251,39 @@ def test_batchnorm_act_train(K, shape, act):
     assert rel(dx2.reshape(-1, c), xe.grad) < 5e-5
 
 
+@pytest.mark.parametrize("shape,act,masked", [((6, 7, 7, 256), "none", True), ((5, 14, 14, 24), "silu", True), ((4, 3, 3, 10), "silu", False)])
+def test_bn_skip_stochastic_depth(K, shape, act, masked):
+    """y = skip + rowscale[n] * act(BN_train(x)) and its backward (the residual block tail in one pass)"""
+    g = torch.Generator().manual_seed(5)
+    n, c = shape[0], shape[-1]
+    x = (torch.randn(shape, generator=g) * 1.5 + 0.3).double().requires_grad_(True)
+    skip = torch.randn(shape, generator=g).double()
+    gamma = (torch.rand(c, generator=g) + 0.5).double().requires_grad_(True)
+    beta = torch.randn(c, generator=g).double().requires_grad_(True)
+    rs = ((torch.rand(n, generator=g) > 0.3).double() / 0.7) if masked else None
+    eps = 1e-3
+    xn = x.permute(0, 3, 1, 2)
+    u = F.batch_norm(xn, None, None, gamma, beta, True, 0.1, eps)
+    u = F.silu(u) if act == "silu" else u
+    if rs is not None:
+        u = u * rs.view(n, 1, 1, 1)
+    y_ref = skip.permute(0, 3, 1, 2) + u
+    dy = torch.randn(shape, generator=g)
+    y_ref.backward(dy.permute(0, 3, 1, 2).double())
+    xg = x.detach().float().cuda()
+    mean, rstd = K.bn_stats(xg, c, eps, 0.1)
+    rsg = rs.float().cuda() if rs is not None else None
+    hw = shape[1] * shape[2]
+    y = K.bn_act_fwd(xg, c, mean, rstd, gamma.detach().float().cuda(), beta.detach().float().cuda(), act, skip.float().cuda(), True, rsg, hw)
+    assert rel(from_nhwc(y), y_ref) < 2e-5
+    dg, db = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
+    if rsg is None:
+        rsg = torch.ones(n, device="cuda")
+    dx = K.bn_act_bwd(xg, dy.cuda(), c, mean, rstd, gamma.detach().float().cuda(), beta.detach().float().cuda(), act, True, dg, db, False,
+                      None, rsg, hw)
+    assert rel(dx, x.grad) < 5e-5 and rel(dg, gamma.grad) < 2e-5 and rel(db, beta.grad) < 2e-5
+
+
 def test_bn_residual_relu(K):
     g = torch.Generator().manual_seed(4)
     shape, c = (4, 6, 6, 32), 32

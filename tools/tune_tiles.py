@@ -13,7 +13,7 @@ lib.suhpe_conv2d_tile_name.restype = ctypes.c_char_p
 
 
 def menu(pass_id):
-    return {i: lib.suhpe_conv2d_tile_name(pass_id, i).decode().split("<")[1].rsplit(",", 3 if pass_id < 2 else 4)[0].replace(",", "x")
+    return {i: ("P" if "persistent" in lib.suhpe_conv2d_tile_name(pass_id, i).decode() else "") + "x".join(lib.suhpe_conv2d_tile_name(pass_id, i).decode().split("<")[1].split(",")[:2])
             for i in range(lib.suhpe_conv2d_tile_count(pass_id))}
 flush = torch.empty(1 << 26, dtype=torch.float32, device="cuda")
 
