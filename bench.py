@@ -101,7 +101,8 @@ def gpu_leg(args, rank, world, device):
         name, (secs, flops, nbytes, launches) = max(agg.items(), key=lambda kv: kv[1][0])
         tf = flops / secs / 1e12
         roof = {"bound": "mfma", "kernel": name, "achieved": round(tf, 2), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tf / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+                "frac": round(tf / PEAK_MFMA_F32_TFLOPS, 4), "traffic": pmc_traffic(name),
+                "algorithmic_bytes_per_launch": round(nbytes / launches),
                 "launches_per_step": launches // nprof, "avg_launch_us": round(secs / launches * 1e6, 2),
                 "avg_launch_gflop": round(flops / launches / 1e9, 3),
                 "kernel_share_of_step": round(secs / nprof / (dt / args.steps), 3),
@@ -110,6 +111,17 @@ def gpu_leg(args, rank, world, device):
                 "gemm_ms_per_step": round(total_gemm_s / nprof * 1e3, 2)}
     agent.logs_writer.close()
     return dt, info, roof
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see
+    tools/pmc_traffic.py and profiles/README.md); None when that kernel was not in the profiled run."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        rec = json.load(fh).get("kernels", {}).get(kernel)
+    return rec["hbm_bytes_per_launch"] if rec else None
 
 
 def cpu_leg():

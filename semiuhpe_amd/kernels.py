@@ -7,6 +7,8 @@ Conv filters keep torch's logical shape (Cout, Cin/g, R, S) in channels_last mem
 [Cout][R][S][Cin/g].
 """
 import ctypes
+import os
+import json
 
 import torch
 
@@ -123,10 +125,42 @@ def _memop(fn):
 
 # Tile autotuning: the first time a dense conv shape is seen in a pass, every tile of the kernel menu is timed on the real
 # operands (cold: a 256 MiB memset between runs evicts L2 / MALL like the rest of a training step does) and the winner is
-# pinned in the library (suhpe_conv2d_set_tile).  Off by default; bench.py, train.py and the agent switch it on.
+# pinned in the library (suhpe_conv2d_set_tile).  Winners are remembered by tile name in a small JSON database
+# (semiuhpe_amd/tiles_mi355x.json ships the shapes of the BASELINE configs; SUHPE_TILE_DB_SAVE=<path> writes the merged
+# database at exit), so known shapes are pinned without measuring and runs are reproducible.
+# Off by default; bench.py, train.py and the agent switch it on (SUHPE_AUTOTUNE=0 keeps the built-in heuristics).
 AUTOTUNE = False
 _tuned = set()
 _flush = {}
+_TILE_DB = None
+_TILE_DB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tiles_mi355x.json")
+
+
+def _tile_db():
+    global _TILE_DB
+    if _TILE_DB is None:
+        _TILE_DB = {}
+        path = os.environ.get("SUHPE_TILE_DB", _TILE_DB_PATH)
+        if os.path.exists(path):
+            with open(path) as fh:
+                _TILE_DB = dict(json.load(fh).get("tiles", {}))
+        save = os.environ.get("SUHPE_TILE_DB_SAVE")
+        if save:
+            import atexit
+            atexit.register(save_tile_db, save)
+    return _TILE_DB
+
+
+def save_tile_db(path):
+    os.makedirs(os.path.dirname(os.path.abspath(path)) or ".", exist_ok=True)
+    with open(path, "w") as fh:
+        json.dump({"device": "MI355X (gfx950)", "key": "pass,n,h,w,cin,cout,r,s,stride,pad,groups",
+                   "tiles": dict(sorted(_tile_db().items()))}, fh, indent=0)
+
+
+def _tile_names(lib, pass_id):
+    lib.suhpe_conv2d_tile_name.restype = ctypes.c_char_p
+    return [lib.suhpe_conv2d_tile_name(pass_id, i).decode() for i in range(lib.suhpe_conv2d_tile_count(pass_id))]
 
 
 def _autotune(d, pass_id, run):
@@ -138,26 +172,32 @@ def _autotune(d, pass_id, run):
     if cg % 4 or ng % 4 or d.cin % 4 or d.cout % 4:
         return                                          # scalar-loader shapes have a single tile
     lib = _lib.load()
+    names = _tile_names(lib, pass_id)
+    skey = ",".join(str(v) for v in key)
+    known = _tile_db().get(skey)
+    if known in names and lib.suhpe_conv2d_set_tile(ctypes.byref(d), pass_id, names.index(known)) == 0:
+        return
     dev = torch.cuda.current_device()
     if dev not in _flush:
         _flush[dev] = torch.empty(1 << 26, dtype=torch.float32, device="cuda")
     best = (float("inf"), -1)
-    for tile in range(lib.suhpe_conv2d_tile_count(pass_id)):
+    for tile in range(len(names)):
         if lib.suhpe_conv2d_set_tile(ctypes.byref(d), pass_id, tile) != 0:
             continue
         run()
-        ms = 0.0
-        for _ in range(3):
+        ms = float("inf")
+        for _ in range(4):                              # the minimum of a few cold runs is the stable statistic
             _flush[dev].zero_()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             run()
             e1.record()
             e1.synchronize()
-            ms += e0.elapsed_time(e1)
+            ms = min(ms, e0.elapsed_time(e1))
         if ms < best[0]:
             best = (ms, tile)
     lib.suhpe_conv2d_set_tile(ctypes.byref(d), pass_id, best[1])
+    _tile_db()[skey] = names[best[1]]
 
 
 def conv2d_fwd(x, w, bias=None, stride=1, pad=0, groups=1):

@@ -1,0 +1,48 @@
+"""HBM traffic per launch of every kernel from two rocprofv3 --pmc passes over the same command (FETCH_SIZE and WRITE_SIZE
+cannot share a pass on gfx950: TCC has 4 slots, FETCH_SIZE takes 3 and WRITE_SIZE 2):
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out/f -- python3 bench.py ...
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d out/w -- python3 bench.py ...
+    python tools/pmc_traffic.py out/f out/w profiles/r01_pmc_traffic.json
+
+Units and corrections (MI355X_MICROARCH.md "HBM", re-checked here with tools/bnbench.py and tools/micro/store_patterns on
+known byte counts): both counters are KiB; FETCH_SIZE reports exactly half the bytes of 16-byte-per-lane streaming loads
+on gfx950 (every load in these kernels is one), so it is doubled; WRITE_SIZE is exact for the 16-byte stores and for the
+dword-per-lane stores of the GEMM epilogue.
+"""
+import csv, glob, json, re, sys
+
+
+def normalize(name):
+    """rocprofv3 kernel name -> the name bench.py / suhpe_conv2d_kernel_name uses"""
+    name = re.sub(r"\(.*$", "", name.replace("void ", "").replace("suhpe::", "")).replace(" ", "")
+    m = re.match(r"(igemm_nt_kernel<\d+,\d+,\d+,\d+,\d+),\d+>", name)     # drop the MODE argument
+    return m.group(1) + ">" if m else name
+
+
+def collect(d, counter):
+    agg = {}
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            a = agg.setdefault(normalize(r["Kernel_Name"]), [0.0, 0])
+            a[0] += float(r["Counter_Value"]) * 1024.0
+            a[1] += 1
+    return agg
+
+
+if __name__ == "__main__":
+    fdir, wdir, out = sys.argv[1:4]
+    fetch, write = collect(fdir, "FETCH_SIZE"), collect(wdir, "WRITE_SIZE")
+    res = {}
+    for k in sorted(set(fetch) | set(write)):
+        fb, fn = fetch.get(k, [0.0, 0])
+        wb, wn = write.get(k, [0.0, 0])
+        res[k] = {"launches": max(fn, wn), "fetch_bytes_per_launch": round(2.0 * fb / max(fn, 1)), "write_bytes_per_launch": round(wb / max(wn, 1))}
+        res[k]["hbm_bytes_per_launch"] = res[k]["fetch_bytes_per_launch"] + res[k]["write_bytes_per_launch"]
+    json.dump({"note": "FETCH_SIZE x2 (gfx950 16-B/lane loads) + WRITE_SIZE, KiB -> bytes, averaged per launch over the profiled run",
+               "kernels": res}, open(out, "w"), indent=1)
+    top = sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]
+    for k, v in top:
+        print(f"{k[:60]:60s} x{v['launches']:6d} fetch {v['fetch_bytes_per_launch']/1e6:9.2f} MB write {v['write_bytes_per_launch']/1e6:9.2f} MB")
