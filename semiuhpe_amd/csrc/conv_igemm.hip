@@ -15,6 +15,12 @@
 // src/repvgg.py:28-32,67-76 and src/tiny_vit.py:28-50,84-151 (forward, input gradient, filter gradient).
 #include "common.h"
 #include <cstdlib>
+#ifndef SUHPE_STAGES
+#define SUHPE_STAGES 2     // register stages of the persistent kernel (3 = one more slab of prefetch distance; experiment)
+#endif
+#ifndef SUHPE_PROBE
+#define SUHPE_PROBE 0      // tools/micro/probe_gemm.sh builds instrumented copies (1-4) to split the persistent kernel's time
+#endif
 #include <cstring>
 #include <mutex>
 #include <type_traits>
@@ -424,9 +430,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (WM == 64 && WN == 64) 
     }
     if (c_vb >= total_vb) return;
 
-    float a_stage[2][A_ROWS][4], b_stage[2][B_ROWS][4];
+    float a_stage[SUHPE_STAGES][A_ROWS][4], b_stage[SUHPE_STAGES][B_ROWS][4];
     auto load_slab = [&](auto stage) __attribute__((always_inline)) {
         if (l_vb >= total_vb) return;
+#if SUHPE_PROBE >= 1 && SUHPE_PROBE <= 3
+        if (++l_kt == nk) { l_kt = 0; l_vb += gstride; }
+        return;
+#endif
         auto& a_reg = a_stage[decltype(stage)::value];
         auto& b_reg = b_stage[decltype(stage)::value];
         const int kk = l_kt * BK + lcol;
@@ -459,6 +469,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (WM == 64 && WN == 64) 
         }
     };
     auto store_slab = [&](auto stage) __attribute__((always_inline)) {
+#if SUHPE_PROBE >= 2 && SUHPE_PROBE <= 3
+        return;
+#endif
         auto& a_reg = a_stage[decltype(stage)::value];
         auto& b_reg = b_stage[decltype(stage)::value];
 #pragma unroll
@@ -523,6 +536,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (WM == 64 && WN == 64) 
                         const int row = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                         if (row >= M) continue;
                         if constexpr (!AFF) {
+#if SUHPE_PROBE == 4
+                            if (acc[i][j][e] == 12345.678f)
+#endif
                             y[(int64_t)row * p.ldy + col] = acc[i][j][e] + bv;
                         } else {
                             float v = acc[i][j][e] * sc + sh;
@@ -588,7 +604,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (WM == 64 && WN == 64) 
     auto step = [&](auto cur, auto nxt) __attribute__((always_inline)) -> bool {
         load_slab(cur);                               // slab s+2 (possibly the next tile's) refills the stage slab s came from
         mma_tile();
+#if SUHPE_PROBE != 3
         __syncthreads();
+#endif
         if (++c_kt == nk) {
             epilogue();
             zero_acc();
@@ -602,14 +620,22 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (WM == 64 && WN == 64) 
         }
         if (c_vb >= total_vb) return false;
         store_slab(nxt);                              // slab s+1, loaded one step ago
+#if SUHPE_PROBE != 3
         __syncthreads();
+#endif
         return true;
     };
     load_slab(S0{});
     store_slab(S0{});
     __syncthreads();
     load_slab(S1{});
+#if SUHPE_STAGES == 3
+    using S2 = std::integral_constant<int, 2>;
+    load_slab(S2{});
+    while (step(S0{}, S1{}) && step(S1{}, S2{}) && step(S2{}, S0{})) {}
+#else
     while (step(S0{}, S1{}) && step(S1{}, S0{})) {}
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------- igemm_tn (wgrad)
