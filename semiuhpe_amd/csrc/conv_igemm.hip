@@ -84,6 +84,7 @@ struct NtParams {
     int ldy;
     int col_tiles;       // ceil(Ng / BN), set by the launcher
     int ldf;             // filter row length in elements (== g.K except in MODE 3)
+    int64_t x_bytes, f_bytes;   // extents of the gathered tensor and of the filter matrix (buffer descriptors)
     const float* scale;  // optional per-channel affine + activation + residual in the epilogue (eval-mode BatchNorm folded into
     const float* shift;  // the conv): y = act(acc*scale + shift [+ res]) [+ res], res_mode 1 = before / 2 = after the activation
     const float* residual;
@@ -93,13 +94,36 @@ struct NtParams {
     int stat_gx;         // row tiles = ceil(M / BM)
 };
 
+// Predicated loads go through buffer descriptors: a lane that must read zero (padding tap, row beyond M, column beyond N)
+// gets an out-of-range offset and the hardware bounds check returns 0.  With a plain load + select the select sits right
+// behind the load, and the compiler then waits for the data there (before the MFMAs of the current slab) instead of at
+// the LDS store one or two slabs later: that wait alone cost the pointwise GEMM a third of its rate.
+using BufRsrc = __amdgpu_buffer_rsrc_t;
+constexpr unsigned kOob = 0x80000000u;          // beyond any descriptor (tensors are < 2 GiB, checked by the host)
+__device__ __forceinline__ BufRsrc make_rsrc(const float* base, int64_t bytes) {
+    // readfirstlane makes the descriptor inputs provably wave-uniform (otherwise every buffer op gets a waterfall loop)
+    const uint64_t addr = reinterpret_cast<uint64_t>(base);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)addr), hi = __builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32));
+    const int nb = __builtin_amdgcn_readfirstlane((int)(bytes > 0x7fffffff ? 0x7fffffff : bytes));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((uint64_t)hi << 32) | lo), 0, nb, 0x00020000);
+}
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int VEC> __device__ __forceinline__ void buf_load(BufRsrc r, unsigned byte_off, float* dst) {
+    if constexpr (VEC == 4) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+        dst[0] = __uint_as_float(v.x); dst[1] = __uint_as_float(v.y); dst[2] = __uint_as_float(v.z); dst[3] = __uint_as_float(v.w);
+    } else {
+        dst[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- igemm_nt
 // MODE 0: generic gather (any stride, dgrad with stride > 1: per-tap divisibility test)
 // MODE 1: pointwise (1x1, stride 1, no padding): the gathered row IS row m
 // MODE 2: affine taps, coordinate = o*gm + sgn*tap + off (forward with any stride, dgrad with stride 1)
 // In every mode the tap of a thread's k advances incrementally (no division in the k loop), addresses are 32-bit
 // element offsets from a uniform base, and out-of-range taps are predicated (offset 0, value zeroed): no branches.
-template <int BM, int BN, int WM, int WN, int VEC, int MODE>
+template <int BM, int BN, int WM, int WN, int VEC, int MODE, bool AFF = false>
 // The second launch bound (minimum waves per SIMD) caps the register budget: left alone the compiler spends 88-148 VGPRs on
 // prefetch depth, which leaves 2 workgroups (or 1, for the wgrad kernel) per CU; at <= 80 VGPRs three 8-wave workgroups are
 // resident and the MFMA pipe sees 6 waves per SIMD.
@@ -127,8 +151,8 @@ void igemm_nt_kernel(const NtParams p) {
     const int64_t m0 = (int64_t)row_tile * BM;
     if (m0 >= g.M) return;                               // padding workgroup (whole block exits before any barrier)
     const int n0 = col_tile * BN;
-    const float* __restrict__ x = p.x + (int64_t)grp * g.Cg;
-    const float* __restrict__ f = p.f + (int64_t)grp * p.Ng * p.ldf;
+    const BufRsrc xr = make_rsrc(p.x + (int64_t)grp * g.Cg, p.x_bytes - (int64_t)grp * g.Cg * 4);
+    const BufRsrc fr = make_rsrc(p.f + (int64_t)grp * p.Ng * p.ldf, p.f_bytes - (int64_t)grp * p.Ng * p.ldf * 4);
 
     // ---- loader geometry.  VEC=4: thread -> (vector column j = t&7, rows (t>>3)+32i).  VEC=1: (k = t&31, rows (t>>5)+8i)
     constexpr int ROW_STEP = VEC == 4 ? NT / 8 : NT / 32;
@@ -189,10 +213,10 @@ void igemm_nt_kernel(const NtParams p) {
         const int fk = MODE == 3 ? ((g.r0 + g.om * tr) * g.Sfull + g.s0 + g.om * ts) * g.Cg + ci : kk;
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
-            bool ok = kvalid && a_pix[i] >= 0;
+            bool ok = kvalid & (a_pix[i] >= 0);                  // bitwise: no short-circuit branches around the address math
             int pix = a_pix[i];
             if (MODE == 2 || MODE == 3) {
-                ok = ok && (unsigned)(a_h[i] + dh) < (unsigned)g.GH && (unsigned)(a_w[i] + dw) < (unsigned)g.GW;
+                ok = ok & ((unsigned)(a_h[i] + dh) < (unsigned)g.GH) & ((unsigned)(a_w[i] + dw) < (unsigned)g.GW);
                 pix += dpix;
             } else if (MODE == 0) {
                 int gh = 0, gw = 0;
@@ -200,28 +224,12 @@ void igemm_nt_kernel(const NtParams p) {
                 ok = ok && gather_coord(g, a_w[i], ts, g.GW, &gw);
                 pix += gh * g.GW + gw;
             }
-            const unsigned off = ok ? (unsigned)pix * (unsigned)g.ldg + (unsigned)ci : 0u;
-            if constexpr (VEC == 4) {
-                float4 v = *reinterpret_cast<const float4*>(x + off);
-                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                a_reg[i][0] = v.x; a_reg[i][1] = v.y; a_reg[i][2] = v.z; a_reg[i][3] = v.w;
-            } else {
-                const float v = x[off];
-                a_reg[i][0] = ok ? v : 0.f;
-            }
+            buf_load<VEC>(xr, ok ? ((unsigned)pix * (unsigned)g.ldg + (unsigned)ci) * 4u : kOob, a_reg[i]);
         }
 #pragma unroll
         for (int i = 0; i < B_ROWS; ++i) {
-            const bool ok = kvalid && b_off[i] >= 0;
-            const unsigned off = ok ? (unsigned)b_off[i] + (unsigned)fk : 0u;
-            if constexpr (VEC == 4) {
-                float4 v = *reinterpret_cast<const float4*>(f + off);
-                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                b_reg[i][0] = v.x; b_reg[i][1] = v.y; b_reg[i][2] = v.z; b_reg[i][3] = v.w;
-            } else {
-                const float v = f[off];
-                b_reg[i][0] = ok ? v : 0.f;
-            }
+            const bool ok = kvalid & (b_off[i] >= 0);
+            buf_load<VEC>(fr, ok ? ((unsigned)b_off[i] + (unsigned)fk) * 4u : kOob, b_reg[i]);
         }
         // advance to the next tile
         kk += BK;
@@ -262,21 +270,27 @@ void igemm_nt_kernel(const NtParams p) {
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     auto mma_tile = [&]() {
+        // fragments of k-group kg+1 are read from LDS before the MFMAs of kg issue (two register sets)
+        float4 af[2][TM], bf[2][TN];
+        auto read_frags = [&](int kg, int set) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[set][i] = *reinterpret_cast<const float4*>(&As[(wm * WM + i * 32 + r32) * LDK + kg * 8 + h * 4]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[set][j] = *reinterpret_cast<const float4*>(&Bs[(wn * WN + j * 32 + r32) * LDK + kg * 8 + h * 4]);
+        };
+        read_frags(0, 0);
 #pragma unroll
         for (int kg = 0; kg < BK / 8; ++kg) {
-            float4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(&As[(wm * WM + i * 32 + r32) * LDK + kg * 8 + h * 4]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(&Bs[(wn * WN + j * 32 + r32) * LDK + kg * 8 + h * 4]);
+            const int cur = kg & 1;
+            if (kg + 1 < BK / 8) read_frags(kg + 1, cur ^ 1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i].x, bf[cur][j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i].y, bf[cur][j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i].z, bf[cur][j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i].w, bf[cur][j].w, acc[i][j], 0, 0, 0);
                 }
         }
     };
@@ -304,14 +318,14 @@ void igemm_nt_kernel(const NtParams p) {
     // two compile-time copies of the store loop (plain / folded affine+activation+skip) behind one uniform branch, so the
     // plain path carries no per-element tests
     auto store_out = [&](auto aff) __attribute__((always_inline)) {
-        constexpr bool AFF = decltype(aff)::value;
+        constexpr bool AFF_ = decltype(aff)::value;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + wn * WN + j * 32 + r32;
             if (col >= p.Ng) continue;
-            const float bv = (!AFF && p.bias) ? p.bias[grp * p.Ng + col] : 0.f;
-            const float sc = AFF ? p.scale[grp * p.Ng + col] : 1.f;
-            const float sh = AFF ? p.shift[grp * p.Ng + col] : 0.f;
+            const float bv = (!AFF_ && p.bias) ? p.bias[grp * p.Ng + col] : 0.f;
+            const float sc = AFF_ ? p.scale[grp * p.Ng + col] : 1.f;
+            const float sh = AFF_ ? p.shift[grp * p.Ng + col] : 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -326,7 +340,7 @@ void igemm_nt_kernel(const NtParams p) {
                         const unsigned bb = rem - a * (unsigned)g.OW;
                         orow = ((int64_t)n * g.YH + a * g.om + g.ph) * g.YW + bb * g.om + g.pw;
                     }
-                    if constexpr (!AFF) {
+                    if constexpr (!AFF_) {
                         y[orow * p.ldy + col] = acc[i][j][e] + bv;
                     } else {
                         float v = acc[i][j][e] * sc + sh;
@@ -339,8 +353,7 @@ void igemm_nt_kernel(const NtParams p) {
                 }
         }
     };
-    if (p.scale == nullptr) store_out(std::false_type{});
-    else store_out(std::true_type{});
+    store_out(std::integral_constant<bool, AFF>{});       // AFF: a separate instantiation, so the plain kernel carries no affine code
 
     // ---- fused BatchNorm statistics.  Each tile emits (S, Q, k, n) per column: sums of (y-k) and (y-k)^2 over its n valid
     // rows, shifted by k = the tile's first-row value so the variance never forms from two large cancelling sums.
@@ -396,8 +409,8 @@ void igemm_nt_kernel(const NtParams p) {
 // workgroup is persistent: it walks tiles vb = blockIdx.x, +gridDim.x, ... and streams k-slabs through the two register
 // stages ACROSS tile boundaries, so the loads of the next tile's first slabs are in flight during the current tile's
 // last MFMAs and its stores, and the pipe only idles for the stores themselves.
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (WM == 64 && WN == 64) ? 3 : ((BM * BN >= 128 * 128) ? 4 : 5)) void gemm_nt_persistent(const NtParams p, int total_vb) {
+template <int BM, int BN, int WM, int WN, bool AFF>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM * BN >= 128 * 128) ? 4 : 5) void gemm_nt_persistent(const NtParams p, int total_vb) {
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
@@ -408,8 +421,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (WM == 64 && WN == 64) 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int grp = blockIdx.z;
-    const float* __restrict__ x = p.x + (int64_t)grp * g.Cg;
-    const float* __restrict__ f = p.f + (int64_t)grp * p.Ng * p.ldf;
+    const BufRsrc xr = make_rsrc(p.x + (int64_t)grp * g.Cg, p.x_bytes - (int64_t)grp * g.Cg * 4);
+    const BufRsrc fr = make_rsrc(p.f + (int64_t)grp * p.Ng * p.ldf, p.f_bytes - (int64_t)grp * p.Ng * p.ldf * 4);
     constexpr int ROW_STEP = NT / 8;
     constexpr int A_ROWS = (BM + ROW_STEP - 1) / ROW_STEP;
     constexpr int B_ROWS = (BN + ROW_STEP - 1) / ROW_STEP;
@@ -444,20 +457,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (WM == 64 && WN == 64) 
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
             const int row = lrow + i * ROW_STEP, m = l_m0 + row;
-            const bool ok = kvalid && (BM % ROW_STEP == 0 || row < BM) && m < M;
-            const unsigned off = ok ? (unsigned)m * (unsigned)g.ldg + (unsigned)kk : 0u;
-            float4 v = *reinterpret_cast<const float4*>(x + off);
-            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            a_reg[i][0] = v.x; a_reg[i][1] = v.y; a_reg[i][2] = v.z; a_reg[i][3] = v.w;
+            const bool ok = kvalid & (BM % ROW_STEP == 0 || row < BM) & (m < M);
+            buf_load<4>(xr, ok ? ((unsigned)m * (unsigned)g.ldg + (unsigned)kk) * 4u : kOob, a_reg[i]);
         }
 #pragma unroll
         for (int i = 0; i < B_ROWS; ++i) {
             const int row = lrow + i * ROW_STEP, col = l_n0 + row;
-            const bool ok = kvalid && (BN % ROW_STEP == 0 || row < BN) && col < p.Ng;
-            const unsigned off = ok ? (unsigned)col * (unsigned)p.ldf + (unsigned)kk : 0u;
-            float4 v = *reinterpret_cast<const float4*>(f + off);
-            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            b_reg[i][0] = v.x; b_reg[i][1] = v.y; b_reg[i][2] = v.z; b_reg[i][3] = v.w;
+            const bool ok = kvalid & (BN % ROW_STEP == 0 || row < BN) & (col < p.Ng);
+            buf_load<4>(fr, ok ? ((unsigned)col * (unsigned)p.ldf + (unsigned)kk) * 4u : kOob, b_reg[i]);
         }
         if (++l_kt == nk) {
             l_kt = 0;
@@ -498,21 +505,27 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (WM == 64 && WN == 64) 
     zero_acc();
     const int r32 = lane & 31, h = lane >> 5;
     auto mma_tile = [&]() __attribute__((always_inline)) {
+        // fragments of k-group kg+1 are read from LDS before the MFMAs of kg issue (two register sets)
+        float4 af[2][TM], bf[2][TN];
+        auto read_frags = [&](int kg, int set) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[set][i] = *reinterpret_cast<const float4*>(&As[(wm * WM + i * 32 + r32) * LDK + kg * 8 + h * 4]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[set][j] = *reinterpret_cast<const float4*>(&Bs[(wn * WN + j * 32 + r32) * LDK + kg * 8 + h * 4]);
+        };
+        read_frags(0, 0);
 #pragma unroll
         for (int kg = 0; kg < BK / 8; ++kg) {
-            float4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(&As[(wm * WM + i * 32 + r32) * LDK + kg * 8 + h * 4]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(&Bs[(wn * WN + j * 32 + r32) * LDK + kg * 8 + h * 4]);
+            const int cur = kg & 1;
+            if (kg + 1 < BK / 8) read_frags(kg + 1, cur ^ 1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i].x, bf[cur][j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i].y, bf[cur][j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i].z, bf[cur][j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i].w, bf[cur][j].w, acc[i][j], 0, 0, 0);
                 }
         }
     };
@@ -521,21 +534,21 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (WM == 64 && WN == 64) 
         const int m0 = c_m0, n0 = c_n0;
         float* __restrict__ y = p.y + (int64_t)grp * p.Ng;
         auto store_out = [&](auto aff) __attribute__((always_inline)) {
-            constexpr bool AFF = decltype(aff)::value;
+            constexpr bool AFF_ = decltype(aff)::value;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = n0 + wn * WN + j * 32 + r32;
                 if (col >= p.Ng) continue;
-                const float bv = (!AFF && p.bias) ? p.bias[grp * p.Ng + col] : 0.f;
-                const float sc = AFF ? p.scale[grp * p.Ng + col] : 1.f;
-                const float sh = AFF ? p.shift[grp * p.Ng + col] : 0.f;
+                const float bv = (!AFF_ && p.bias) ? p.bias[grp * p.Ng + col] : 0.f;
+                const float sc = AFF_ ? p.scale[grp * p.Ng + col] : 1.f;
+                const float sh = AFF_ ? p.shift[grp * p.Ng + col] : 0.f;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int row = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                         if (row >= M) continue;
-                        if constexpr (!AFF) {
+                        if constexpr (!AFF_) {
 #if SUHPE_PROBE == 4
                             if (acc[i][j][e] == 12345.678f)
 #endif
@@ -551,8 +564,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (WM == 64 && WN == 64) 
                     }
             }
         };
-        if (p.scale == nullptr) store_out(std::false_type{});
-        else store_out(std::true_type{});
+        store_out(std::integral_constant<bool, AFF>{});
         if (p.stats) {                                          // BatchNorm statistics records, as in igemm_nt_kernel
             float* red = As;                                    // [BM/WM][BN][2]   (every wave is past its last LDS read: barrier above)
             float* kk = As + (BM / WM) * BN * 2;                // [BN]
@@ -646,6 +658,7 @@ struct TnParams {
     float* slab;         // [splits][groups*Ng][K]
     int Ng;              // output channels per group (rows of dW per group)
     int lddy;
+    int64_t dy_bytes, x_bytes;  // tensor extents (buffer descriptors)
     int64_t m_per_split; // multiple of BK
     int tiles_m, tiles_n; // output tiles along cout and along k'
 };
@@ -675,8 +688,8 @@ void igemm_tn_kernel(const TnParams p) {
     const int64_t mbeg = (int64_t)split * p.m_per_split;
     int64_t mend = mbeg + p.m_per_split;
     if (mend > g.M) mend = g.M;
-    const float* __restrict__ dy = p.dy + (int64_t)grp * p.Ng;
-    const float* __restrict__ x = p.x + (int64_t)grp * g.Cg;
+    const BufRsrc dyr = make_rsrc(p.dy + (int64_t)grp * p.Ng, p.dy_bytes - (int64_t)grp * p.Ng * 4);
+    const BufRsrc xr = make_rsrc(p.x + (int64_t)grp * g.Cg, p.x_bytes - (int64_t)grp * g.Cg * 4);
 
     // A loader: dy rows.  VECA=4: col group = t % (BM/4), row = t / (BM/4) + RA*i ; VECA=1: col = t % BM
     constexpr int A_CG = BM / VECA;                 // column groups per row
@@ -703,37 +716,22 @@ void igemm_tn_kernel(const TnParams p) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int64_t m = mb + a_row + i * RA;
-            const bool ok = a_valid_col && m < mend && (BK % RA == 0 || a_row + i * RA < BK);
-            const float* src = dy + (ok ? m * p.lddy + i0 + a_col : 0);
-            if constexpr (VECA == 4) {
-                float4 v = *reinterpret_cast<const float4*>(src);
-                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                a_reg[i][0] = v.x; a_reg[i][1] = v.y; a_reg[i][2] = v.z; a_reg[i][3] = v.w;
-            } else {
-                const float v = src[0];
-                a_reg[i][0] = ok ? v : 0.f;
-            }
+            const bool ok = a_valid_col & (m < mend) & (BK % RA == 0 || a_row + i * RA < BK);
+            buf_load<VECA>(dyr, ok ? ((unsigned)m * (unsigned)p.lddy + (unsigned)(i0 + a_col)) * 4u : kOob, a_reg[i]);
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             const int64_t m = mb + b_row + i * RB;
-            bool ok = kq_valid && m < mend && (BK % RB == 0 || b_row + i * RB < BK);
+            bool ok = kq_valid & (m < mend) & (BK % RB == 0 || b_row + i * RB < BK);
             const unsigned mu = ok ? (unsigned)m : 0u;
             const unsigned n = fast_div(mu, g.div_hw_mul, g.div_hw_shr);
             const unsigned rem = mu - n * (unsigned)(g.OH * g.OW);
             const unsigned oh = fast_div(rem, g.div_w_mul, g.div_w_shr);
             const unsigned ow = rem - oh * (unsigned)g.OW;
             const int gh = (int)oh * g.stride + dr, gw = (int)ow * g.stride + ds;
-            ok = ok && (unsigned)gh < (unsigned)g.GH && (unsigned)gw < (unsigned)g.GW;
-            const unsigned off = ok ? ((unsigned)n * (unsigned)(g.GH * g.GW) + (unsigned)(gh * g.GW + gw)) * (unsigned)g.ldg + (unsigned)ci : 0u;
-            if constexpr (VECB == 4) {
-                float4 v = *reinterpret_cast<const float4*>(x + off);
-                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                b_reg[i][0] = v.x; b_reg[i][1] = v.y; b_reg[i][2] = v.z; b_reg[i][3] = v.w;
-            } else {
-                const float v = x[off];
-                b_reg[i][0] = ok ? v : 0.f;
-            }
+            ok = ok & ((unsigned)gh < (unsigned)g.GH) & ((unsigned)gw < (unsigned)g.GW);
+            buf_load<VECB>(xr, ok ? (((unsigned)n * (unsigned)(g.GH * g.GW) + (unsigned)(gh * g.GW + gw)) * (unsigned)g.ldg + (unsigned)ci) * 4u : kOob,
+                           b_reg[i]);
         }
     };
     auto store_tiles = [&]() {
@@ -840,10 +838,10 @@ static int check_desc(const suhpe_conv_t* d, const char* who) {
     }
     const int ho = (d->h + 2 * d->pad - d->r) / d->stride + 1, wo = (d->w + 2 * d->pad - d->s) / d->stride + 1;
     if (ho != d->ho || wo != d->wo) { set_error("%s: ho/wo (%d,%d) do not match the geometry (%d,%d)", who, d->ho, d->wo, ho, wo); return SUHPE_EINVAL; }
-    const int64_t lim = (int64_t)1 << 31;      // kernels address tensors with 32-bit element offsets
+    const int64_t lim = (int64_t)1 << 29;      // operands are addressed through buffer descriptors with 32-bit byte offsets: < 2 GiB each
     if ((int64_t)d->n * d->h * d->w * d->cin >= lim || (int64_t)d->n * d->ho * d->wo * d->cout >= lim ||
         (int64_t)d->cout * d->r * d->s * (d->cin / d->groups) >= lim) {
-        set_error("%s: tensor larger than 2^31 elements", who);
+        set_error("%s: tensor of 2 GiB or more (2^29 fp32 elements)", who);
         return SUHPE_EINVAL;
     }
     return SUHPE_OK;
@@ -886,8 +884,14 @@ static void launch_nt(const NtParams& p_in, int groups, hipStream_t st) {
     dim3 grid((unsigned)(row_tiles8 * p.col_tiles), 1, groups);
     const dim3 block((BM / WM) * (BN / WN) * 64);
     switch (nt_mode(p.g)) {
-        case 1: hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1>), grid, block, 0, st, p); break;
-        case 2: hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 2>), grid, block, 0, st, p); break;
+        case 1:
+            if (p.scale) hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1, true>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1>), grid, block, 0, st, p);
+            break;
+        case 2:
+            if (p.scale) hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 2, true>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 2>), grid, block, 0, st, p);
+            break;
         case 3: hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 3>), grid, block, 0, st, p); break;
         default: hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 0>), grid, block, 0, st, p); break;
     }
@@ -954,7 +958,7 @@ static void launch_persistent(const NtParams& p_in, int groups, hipStream_t st) 
         int occ = 0, dev = 0, cus = 0;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gemm_nt_persistent<BM, BN, WM, WN>, (BM / WM) * (BN / WN) * 64, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gemm_nt_persistent<BM, BN, WM, WN, false>, (BM / WM) * (BN / WN) * 64, 0);
         slots = (occ > 0 ? occ : 1) * (cus > 0 ? cus : 256);
     }
     NtParams p = p_in;
@@ -965,7 +969,9 @@ static void launch_persistent(const NtParams& p_in, int groups, hipStream_t st) 
     per_group = per_group / 8 * 8;
     if (per_group < 8) per_group = 8;
     const int gx = total_vb < per_group ? total_vb : per_group;     // total_vb is a multiple of 8 too
-    hipLaunchKernelGGL((gemm_nt_persistent<BM, BN, WM, WN>), dim3(gx, 1, groups), dim3((BM / WM) * (BN / WN) * 64), 0, st, p, total_vb);
+    const dim3 grid(gx, 1, groups), block((BM / WM) * (BN / WN) * 64);
+    if (p.scale) hipLaunchKernelGGL((gemm_nt_persistent<BM, BN, WM, WN, true>), grid, block, 0, st, p, total_vb);
+    else hipLaunchKernelGGL((gemm_nt_persistent<BM, BN, WM, WN, false>), grid, block, 0, st, p, total_vb);
 }
 
 // a pinned persistent tile on a shape that is not a plain GEMM runs the igemm tile of the same size
@@ -1027,6 +1033,7 @@ int suhpe_conv2d_fwd(const suhpe_conv_t* d, const float* x, const float* w, cons
     const int cg = d->cin / d->groups;
     p.g = make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0);
     p.x = x; p.f = w; p.bias = bias; p.y = y; p.Ng = d->cout / d->groups; p.ldy = d->cout; p.ldf = p.g.K;
+    p.x_bytes = (int64_t)d->n * d->h * d->w * d->cin * 4; p.f_bytes = (int64_t)d->cout * p.g.K * 4;
     p.stats = nullptr; p.stat_gx = 0; p.stat_cout = 0; p.scale = p.shift = p.residual = nullptr; p.act = 0; p.res_mode = 0;
     const bool vec4 = (cg % 4 == 0) && (d->cin % 4 == 0) && aligned16(x) && aligned16(w);
     dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 0));
@@ -1043,6 +1050,7 @@ int suhpe_conv2d_fwd_affine(const suhpe_conv_t* d, const float* x, const float* 
     const int cg = d->cin / d->groups;
     p.g = make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0);
     p.x = x; p.f = w; p.bias = nullptr; p.y = y; p.Ng = d->cout / d->groups; p.ldy = d->cout; p.ldf = p.g.K;
+    p.x_bytes = (int64_t)d->n * d->h * d->w * d->cin * 4; p.f_bytes = (int64_t)d->cout * p.g.K * 4;
     p.stats = nullptr; p.stat_gx = 0; p.stat_cout = 0;
     p.scale = scale; p.shift = shift; p.residual = residual; p.act = act; p.res_mode = residual ? (residual_after_act ? 2 : 1) : 0;
     const bool vec4 = (cg % 4 == 0) && (d->cin % 4 == 0) && aligned16(x) && aligned16(w);
@@ -1065,6 +1073,7 @@ int suhpe_conv2d_fwd_stats(const suhpe_conv_t* d, const float* x, const float* w
     const int cg = d->cin / d->groups;
     p.g = make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0);
     p.x = x; p.f = w; p.bias = nullptr; p.y = y; p.Ng = d->cout / d->groups; p.ldy = d->cout; p.ldf = p.g.K;
+    p.x_bytes = (int64_t)d->n * d->h * d->w * d->cin * 4; p.f_bytes = (int64_t)d->cout * p.g.K * 4;
     p.stats = stats; p.stat_gx = suhpe_conv2d_fwd_stats_tiles(d); p.stat_cout = d->cout; p.scale = p.shift = p.residual = nullptr; p.act = 0; p.res_mode = 0;
     const bool vec4 = (cg % 4 == 0) && (d->cin % 4 == 0);
     SUHPE_REQUIRE(!vec4 || (aligned16(x) && aligned16(w)), "suhpe_conv2d_fwd_stats: x / w must be 16-byte aligned");
@@ -1093,6 +1102,7 @@ int suhpe_conv2d_dgrad(const suhpe_conv_t* d, const float* dy, const float* wt, 
     if (d->stride == 1) {
         p.g = make_geom(d->n, d->ho, d->wo, d->h, d->w, d->cout, ng, d->r, d->s, d->stride, d->pad, 1);
         p.x = dy; p.f = wt; p.bias = nullptr; p.y = dx; p.Ng = cg; p.ldy = d->cin; p.ldf = p.g.K;
+        p.x_bytes = (int64_t)d->n * d->ho * d->wo * d->cout * 4; p.f_bytes = (int64_t)d->cout * cg * d->r * d->s * 4;
         p.stats = nullptr; p.stat_gx = 0; p.stat_cout = 0; p.scale = p.shift = p.residual = nullptr; p.act = 0; p.res_mode = 0;
         dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 1));
     } else {
@@ -1111,6 +1121,7 @@ int suhpe_conv2d_dgrad(const suhpe_conv_t* d, const float* dy, const float* wt, 
                 g.off_h = (ph + d->pad - r0) / st; g.off_w = (pw + d->pad - s0) / st;
                 p.g = g;
                 p.x = dy; p.f = wt; p.bias = nullptr; p.y = dx; p.Ng = cg; p.ldy = d->cin; p.ldf = d->r * d->s * ng;
+                p.x_bytes = (int64_t)d->n * d->ho * d->wo * d->cout * 4; p.f_bytes = (int64_t)d->cout * cg * d->r * d->s * 4;
                 p.stats = nullptr; p.stat_gx = 0; p.stat_cout = 0; p.scale = p.shift = p.residual = nullptr; p.act = 0; p.res_mode = 0;
                 dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 1));
             }
@@ -1200,6 +1211,7 @@ int suhpe_conv2d_wgrad_partial(const suhpe_conv_t* d, const float* x, const floa
     TnParams p;
     p.g = make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0);
     p.dy = dy; p.x = x; p.slab = static_cast<float*>(workspace); p.Ng = ng; p.lddy = d->cout;
+    p.dy_bytes = (int64_t)d->n * d->ho * d->wo * d->cout * 4; p.x_bytes = (int64_t)d->n * d->h * d->w * d->cin * 4;
     p.m_per_split = ceil_div(ceil_div(p.g.M, splits), BK) * BK;
     p.tiles_n = (int)ceil_div(p.g.K, bn);
     p.tiles_m = (int)ceil_div(ng, bm);
