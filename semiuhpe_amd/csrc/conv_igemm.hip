@@ -767,17 +767,31 @@ void igemm_tn_kernel(const TnParams p) {
         for (int64_t mb = mbeg; mb < mend; mb += BK) {
             const bool more = mb + BK < mend;
             if (more) load_tiles(mb + BK);
+            // fragments in groups of four k-pairs, two register sets: the LDS reads of group q+1 are in flight under the
+            // MFMAs of group q (with one set the compiler waits for every pair of reads right before its two MFMAs)
+            constexpr int GQ = 4;
+            float af[2][GQ][TM], bf[2][GQ][TN];
+            auto read_group = [&](int q, int set) __attribute__((always_inline)) {
 #pragma unroll
-            for (int kk = 0; kk < BK / 2; ++kk) {
-                float af[TM], bf[TN];
+                for (int u = 0; u < GQ; ++u) {
+                    const int kk = q * GQ + u;
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = As[(kk * 2 + h) * BM + wm * WM + i * 32 + r32];
+                    for (int i = 0; i < TM; ++i) af[set][u][i] = As[(kk * 2 + h) * BM + wm * WM + i * 32 + r32];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = Bs[(kk * 2 + h) * BN + wn * WN + j * 32 + r32];
+                    for (int j = 0; j < TN; ++j) bf[set][u][j] = Bs[(kk * 2 + h) * BN + wn * WN + j * 32 + r32];
+                }
+            };
+            read_group(0, 0);
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+            for (int q = 0; q < BK / 2 / GQ; ++q) {
+                const int cur = q & 1;
+                if (q + 1 < BK / 2 / GQ) read_group(q + 1, cur ^ 1);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int u = 0; u < GQ; ++u)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][u][i], bf[cur][u][j], acc[i][j], 0, 0, 0);
             }
             __syncthreads();
             if (more) {
