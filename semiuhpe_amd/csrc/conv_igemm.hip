@@ -94,29 +94,6 @@ struct NtParams {
     int stat_gx;         // row tiles = ceil(M / BM)
 };
 
-// Predicated loads go through buffer descriptors: a lane that must read zero (padding tap, row beyond M, column beyond N)
-// gets an out-of-range offset and the hardware bounds check returns 0.  With a plain load + select the select sits right
-// behind the load, and the compiler then waits for the data there (before the MFMAs of the current slab) instead of at
-// the LDS store one or two slabs later: that wait alone cost the pointwise GEMM a third of its rate.
-using BufRsrc = __amdgpu_buffer_rsrc_t;
-constexpr unsigned kOob = 0x80000000u;          // beyond any descriptor (tensors are < 2 GiB, checked by the host)
-__device__ __forceinline__ BufRsrc make_rsrc(const float* base, int64_t bytes) {
-    // readfirstlane makes the descriptor inputs provably wave-uniform (otherwise every buffer op gets a waterfall loop)
-    const uint64_t addr = reinterpret_cast<uint64_t>(base);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)addr), hi = __builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32));
-    const int nb = __builtin_amdgcn_readfirstlane((int)(bytes > 0x7fffffff ? 0x7fffffff : bytes));
-    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((uint64_t)hi << 32) | lo), 0, nb, 0x00020000);
-}
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-template <int VEC> __device__ __forceinline__ void buf_load(BufRsrc r, unsigned byte_off, float* dst) {
-    if constexpr (VEC == 4) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
-        dst[0] = __uint_as_float(v.x); dst[1] = __uint_as_float(v.y); dst[2] = __uint_as_float(v.z); dst[3] = __uint_as_float(v.w);
-    } else {
-        dst[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
-    }
-}
-
 // ---------------------------------------------------------------------------------------------- igemm_nt
 // MODE 0: generic gather (any stride, dgrad with stride > 1: per-tap divisibility test)
 // MODE 1: pointwise (1x1, stride 1, no padding): the gathered row IS row m

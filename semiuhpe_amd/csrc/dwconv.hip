@@ -143,6 +143,75 @@ __global__ __launch_bounds__(256) void dw3x3_row_kernel(const float* __restrict_
     }
 }
 
+// Stride-1 variant: a thread produces FOUR vertically adjacent outputs per column step from a 6 x 3 register window, so an
+// input row is fetched 1.5 times instead of 3 (with one output row per thread the halo rows came back from L2 / MALL:
+// FETCH_SIZE measured 2.7x the input).  Padding taps read zero through the buffer descriptor's bounds check, and the
+// column ahead is loaded one step early (the wait lands at its first use).
+constexpr int kDwRows = 4;
+__global__ __launch_bounds__(256) void dw3x3_s1_kernel(const float* __restrict__ src, int64_t src_bytes, const float* __restrict__ w,
+                                                       float* __restrict__ dst, int N, int H, int W, int C, int flip, int cw, int rp) {
+    __shared__ __attribute__((aligned(16))) float wl[9 * 256 * 4];
+    const int t = threadIdx.x, col = t % cw, rsub = t / cw;
+    const int cv = C / 4, col0 = blockIdx.y * cw;
+    for (int i = t; i < 9 * cw * 4; i += 256) {
+        const int tap = i / (cw * 4), cc = i - tap * cw * 4;
+        const int ch = col0 * 4 + cc;
+        wl[i] = ch < C ? w[(int64_t)ch * 9 + (flip ? 8 - tap : tap)] : 0.f;
+    }
+    __syncthreads();
+    if (rsub >= rp || col0 + col >= cv) return;
+    float4 wv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wv[k] = *reinterpret_cast<const float4*>(&wl[(k * cw + col) * 4]);
+    const BufRsrc sr = make_rsrc(src, src_bytes);
+    const unsigned coff = (unsigned)(col0 + col) * 16u, pix = (unsigned)C * 4u;       // byte offsets
+    const int groups_h = (H + kDwRows - 1) / kDwRows;                                  // row groups per image
+    for (int rg = blockIdx.x * rp + rsub; rg < N * groups_h; rg += gridDim.x * rp) {
+        const int n = rg / groups_h, oh0 = (rg - n * groups_h) * kDwRows;
+        unsigned rbase[kDwRows + 2];
+        bool rok[kDwRows + 2];
+#pragma unroll
+        for (int r = 0; r < kDwRows + 2; ++r) {
+            const int ih = oh0 - 1 + r;
+            rok[r] = (unsigned)ih < (unsigned)H;
+            rbase[r] = (unsigned)((n * H + ih) * W) * pix + coff;
+        }
+        float x[kDwRows + 2][4][4];                          // window columns ow-1, ow, ow+1 and the prefetched ow+2
+        auto ld = [&](int r, int p, int c) __attribute__((always_inline)) {
+            buf_load<4>(sr, (rok[r] & ((unsigned)c < (unsigned)W)) ? rbase[r] + (unsigned)c * pix : kOob, x[r][p]);
+        };
+#pragma unroll
+        for (int r = 0; r < kDwRows + 2; ++r) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) x[r][1][v] = 0.f;    // becomes column -1 after the first shift
+            ld(r, 2, 0);
+            ld(r, 3, 1);
+        }
+        for (int ow = 0; ow < W; ++ow) {
+#pragma unroll
+            for (int r = 0; r < kDwRows + 2; ++r) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { x[r][0][v] = x[r][1][v]; x[r][1][v] = x[r][2][v]; x[r][2][v] = x[r][3][v]; }
+                ld(r, 3, ow + 2);                            // needed at the next step
+            }
+#pragma unroll
+            for (int j = 0; j < kDwRows; ++j) {
+                if (oh0 + j >= H) break;
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float4 wk = wv[r * 3 + c];
+                        acc[0] += x[j + r][c][0] * wk.x; acc[1] += x[j + r][c][1] * wk.y;
+                        acc[2] += x[j + r][c][2] * wk.z; acc[3] += x[j + r][c][3] * wk.w;
+                    }
+                *reinterpret_cast<float4*>(dst + (((int64_t)n * H + oh0 + j) * W + ow) * C + (col0 + col) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            }
+        }
+    }
+}
+
 // filter-gradient partials with the same sliding window: part[bx][tap][c]
 __global__ __launch_bounds__(256) void dw3x3_wgrad_row_kernel(const float* __restrict__ x_, const float* __restrict__ dy, float* __restrict__ part,
                                                               int N, int H, int W, int OH, int OW, int C, int stride, int cw, int rp) {
@@ -321,9 +390,16 @@ int suhpe_dwconv_fwd(const suhpe_conv_t* d, const float* x, const float* w, floa
     SUHPE_REQUIRE(x && w && y, "suhpe_dwconv_fwd: null pointer");
     if (dw_fast(d) && (d->stride == 1 || d->stride == 2)) {
         int cw, rp, gx, ny;
-        dw_row_grid(d->cin, d->n * d->ho, 4096, &cw, &rp, &gx, &ny);
-        hipLaunchKernelGGL(dw3x3_row_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), x, w, y, d->n, d->h, d->w, d->ho, d->wo, d->cin,
-                           d->stride, 0, cw, rp);
+        // the four-row kernel needs enough row groups to fill the chip; small batches keep one output row per thread
+        const bool s1 = d->stride == 1 && (int64_t)d->n * d->h * d->w * d->cin * 4 < ((int64_t)1 << 31) &&
+                        (int64_t)d->n * ((d->h + kDwRows - 1) / kDwRows) * (d->cin / 4) >= 65536;
+        dw_row_grid(d->cin, s1 ? d->n * ((d->h + kDwRows - 1) / kDwRows) : d->n * d->ho, 4096, &cw, &rp, &gx, &ny);
+        if (s1)
+            hipLaunchKernelGGL(dw3x3_s1_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), x, (int64_t)d->n * d->h * d->w * d->cin * 4, w, y,
+                               d->n, d->h, d->w, d->cin, 0, cw, rp);
+        else
+            hipLaunchKernelGGL(dw3x3_row_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), x, w, y, d->n, d->h, d->w, d->ho, d->wo, d->cin,
+                               d->stride, 0, cw, rp);
         return check_launch("suhpe_dwconv_fwd");
     }
     const DwGeom g = dw_geom(d, 0, 2048);
@@ -338,9 +414,15 @@ int suhpe_dwconv_dgrad(const suhpe_conv_t* d, const float* dy, const float* w, f
     SUHPE_REQUIRE(dy && w && dx, "suhpe_dwconv_dgrad: null pointer");
     if (dw_fast(d) && d->stride == 1) {             // same conv on dy with the 180-degree rotated filter
         int cw, rp, gx, ny;
-        dw_row_grid(d->cin, d->n * d->h, 4096, &cw, &rp, &gx, &ny);
-        hipLaunchKernelGGL(dw3x3_row_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), dy, w, dx, d->n, d->ho, d->wo, d->h, d->w, d->cin, 1, 1,
-                           cw, rp);
+        const bool s1 = (int64_t)d->n * d->h * d->w * d->cin * 4 < ((int64_t)1 << 31) &&
+                        (int64_t)d->n * ((d->h + kDwRows - 1) / kDwRows) * (d->cin / 4) >= 65536;
+        dw_row_grid(d->cin, s1 ? d->n * ((d->h + kDwRows - 1) / kDwRows) : d->n * d->h, 4096, &cw, &rp, &gx, &ny);
+        if (s1)
+            hipLaunchKernelGGL(dw3x3_s1_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), dy, (int64_t)d->n * d->h * d->w * d->cin * 4, w, dx,
+                               d->n, d->h, d->w, d->cin, 1, cw, rp);
+        else
+            hipLaunchKernelGGL(dw3x3_row_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), dy, w, dx, d->n, d->ho, d->wo, d->h, d->w, d->cin, 1, 1,
+                               cw, rp);
         return check_launch("suhpe_dwconv_dgrad");
     }
     const DwGeom g = dw_geom(d, 1, 2048);
