@@ -257,20 +257,33 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
         sc[v] = rstd[ch + v] * g;
         sh[v] = b - mean[ch + v] * sc[v];
     }
-    for (int r = r0 + rsub; r < r1; r += rp) {
-        const int64_t off = ((int64_t)r * cv + vc) * VEC;
-        float xv[VEC], rv[VEC], o[VEC];
-        vload<VEC>(x + off, xv);
-        if (residual) vload<VEC>(residual + off, rv);
-        const float rsc = (post && rowscale) ? rowscale[r / hw] : 1.f;
+    // four rows per round: every load of the round is issued before the first use (one row at a time the loop waits for
+    // each load right behind it and only occupancy hides the latency); rows past the slab read a clamped address
+    constexpr int U = 4;
+    for (int r = r0 + rsub; r < r1; r += U * rp) {
+        float xv[U][VEC], rv[U][VEC];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            float u = xv[v] * sc[v] + sh[v];
-            if (residual && !post) u += rv[v];
-            o[v] = act_apply(u, act);
-            if (post) o[v] = rv[v] + rsc * o[v];
+        for (int u = 0; u < U; ++u) {
+            const int rr = r + u * rp < r1 ? r + u * rp : r1 - 1;
+            const int64_t off = ((int64_t)rr * cv + vc) * VEC;
+            vload<VEC>(x + off, xv[u]);
+            if (residual) vload<VEC>(residual + off, rv[u]);
         }
-        vstore<VEC>(y + off, o);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rr = r + u * rp;
+            if (rr >= r1) break;
+            const float rsc = (post && rowscale) ? rowscale[rr / hw] : 1.f;
+            float o[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                float uu = xv[u][v] * sc[v] + sh[v];
+                if (residual && !post) uu += rv[u][v];
+                o[v] = act_apply(uu, act);
+                if (post) o[v] = rv[u][v] + rsc * o[v];
+            }
+            vstore<VEC>(y + ((int64_t)rr * cv + vc) * VEC, o);
+        }
     }
 }
 
@@ -361,23 +374,34 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ x,
         m0[v] = train_stats ? sums[2 * (ch + v)] * inv_rows : 0.f;
         m1[v] = train_stats ? sums[2 * (ch + v) + 1] * inv_rows : 0.f;
     }
-    for (int r = r0 + rsub; r < r1; r += rp) {
-        const int64_t off = ((int64_t)r * cv + vc) * VEC;
-        float xv[VEC], dv[VEC], yv[VEC], o[VEC];
-        vload<VEC>(x + off, xv);
-        vload<VEC>(dy + off, dv);
-        if (yout) vload<VEC>(yout + off, yv);
-        const float rsc = rowscale ? rowscale[r / hw] : 1.f;
+    constexpr int U = 4;                                 // four rows of loads in flight per round (see bn_act_fwd_kernel)
+    for (int r = r0 + rsub; r < r1; r += U * rp) {
+        float xv[U][VEC], dv[U][VEC], yv[U][VEC];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            const float xh = (xv[v] - mu[v]) * rs[v];
-            float g;
-            if (yout) g = yv[v] > 0.f ? dv[v] : 0.f;
-            else g = dv[v] * rsc * act_grad(xh * ga[v] + be[v], act);
-            g = g - m0[v] - xh * m1[v];
-            o[v] = ga[v] * rs[v] * g;
+        for (int u = 0; u < U; ++u) {
+            const int rr = r + u * rp < r1 ? r + u * rp : r1 - 1;
+            const int64_t off = ((int64_t)rr * cv + vc) * VEC;
+            vload<VEC>(x + off, xv[u]);
+            vload<VEC>(dy + off, dv[u]);
+            if (yout) vload<VEC>(yout + off, yv[u]);
         }
-        vstore<VEC>(dx + off, o);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rr = r + u * rp;
+            if (rr >= r1) break;
+            const float rsc = rowscale ? rowscale[rr / hw] : 1.f;
+            float o[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const float xh = (xv[u][v] - mu[v]) * rs[v];
+                float g;
+                if (yout) g = yv[u][v] > 0.f ? dv[u][v] : 0.f;
+                else g = dv[u][v] * rsc * act_grad(xh * ga[v] + be[v], act);
+                g = g - m0[v] - xh * m1[v];
+                o[v] = ga[v] * rs[v] * g;
+            }
+            vstore<VEC>(dx + ((int64_t)rr * cv + vc) * VEC, o);
+        }
     }
 }
 
@@ -462,13 +486,19 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ 
     float bv[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) bv[v] = bias ? bias[ch + v] : 0.f;
-    for (int r = r0 + rsub; r < r1; r += rp) {
-        const int64_t off = ((int64_t)r * cv + vc) * VEC;
-        float xv[VEC], o[VEC];
-        vload<VEC>(x + off, xv);
+    constexpr int U = 4;
+    for (int r = r0 + rsub; r < r1; r += U * rp) {
+        float xv[U][VEC];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) o[v] = act_apply(xv[v] + bv[v], act);
-        vstore<VEC>(y + off, o);
+        for (int u = 0; u < U; ++u) vload<VEC>(x + ((int64_t)(r + u * rp < r1 ? r + u * rp : r1 - 1) * cv + vc) * VEC, xv[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (r + u * rp >= r1) break;
+            float o[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) o[v] = act_apply(xv[u][v] + bv[v], act);
+            vstore<VEC>(y + ((int64_t)(r + u * rp) * cv + vc) * VEC, o);
+        }
     }
 }
 template <int VEC>
@@ -479,14 +509,23 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     float bv[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) bv[v] = bias ? bias[ch + v] : 0.f;
-    for (int r = r0 + rsub; r < r1; r += rp) {
-        const int64_t off = ((int64_t)r * cv + vc) * VEC;
-        float xv[VEC], dv[VEC], o[VEC];
-        vload<VEC>(x + off, xv);
-        vload<VEC>(dy + off, dv);
+    constexpr int U = 4;
+    for (int r = r0 + rsub; r < r1; r += U * rp) {
+        float xv[U][VEC], dv[U][VEC];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) o[v] = dv[v] * act_grad(xv[v] + bv[v], act);
-        vstore<VEC>(dx + off, o);
+        for (int u = 0; u < U; ++u) {
+            const int64_t off = ((int64_t)(r + u * rp < r1 ? r + u * rp : r1 - 1) * cv + vc) * VEC;
+            vload<VEC>(x + off, xv[u]);
+            vload<VEC>(dy + off, dv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (r + u * rp >= r1) break;
+            float o[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) o[v] = dv[u][v] * act_grad(xv[u][v] + bv[v], act);
+            vstore<VEC>(dx + ((int64_t)(r + u * rp) * cv + vc) * VEC, o);
+        }
     }
 }
 
@@ -503,16 +542,21 @@ __global__ __launch_bounds__(256) void pool_sum_kernel(const float* __restrict__
 #pragma unroll
     for (int v = 0; v < VEC; ++v) s[v] = 0.f;
     if (rsub < rp && col0 + col < cv) {
-        for (int p = rsub; p < hw; p += rp) {
-            float xv[VEC], wv[VEC];
-            const int64_t off = ((n * hw + p) * cv + col0 + col) * VEC;
-            vload<VEC>(x + off, xv);
-            if (w) { vload<VEC>(w + off, wv);
+        constexpr int U = 4;                             // four pixels of loads in flight per round
+        for (int p = rsub; p < hw; p += U * rp) {
+            float xv[U][VEC], wv[U][VEC];
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) s[v] += xv[v] * wv[v];
-            } else {
+            for (int u = 0; u < U; ++u) {
+                const int pp = p + u * rp < hw ? p + u * rp : hw - 1;
+                const int64_t off = ((n * hw + pp) * cv + col0 + col) * VEC;
+                vload<VEC>(x + off, xv[u]);
+                if (w) vload<VEC>(w + off, wv[u]);
+            }
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) s[v] += xv[v];
+            for (int u = 0; u < U; ++u) {
+                const float m = p + u * rp < hw ? 1.f : 0.f;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) s[v] += m * (w ? xv[u][v] * wv[u][v] : xv[u][v]);
             }
         }
     }
@@ -549,18 +593,21 @@ __global__ __launch_bounds__(256) void per_sample_scale_kernel(const float* __re
     if (dpool) vload<VEC>(dpool + (n * cv + vc) * VEC, pv);
 #pragma unroll
     for (int v = 0; v < VEC; ++v) { pv[v] *= inv_hw; if (mode == 1) sv[v] *= inv_hw; }
-    for (int r = r0 + rsub; r < r1; r += rp) {
-        const int64_t off = ((n * hw + r) * cv + vc) * VEC;
-        float xv[VEC], o[VEC];
+    constexpr int U = 4;
+    for (int r = r0 + rsub; r < r1; r += U * rp) {
+        float xv[U][VEC];
         if (mode == 0) {
-            vload<VEC>(x + off, xv);
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) o[v] = xv[v] * sv[v] + pv[v];
-        } else {
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) o[v] = sv[v];
+            for (int u = 0; u < U; ++u) vload<VEC>(x + ((n * hw + (r + u * rp < r1 ? r + u * rp : r1 - 1)) * cv + vc) * VEC, xv[u]);
         }
-        vstore<VEC>(y + off, o);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (r + u * rp >= r1) break;
+            float o[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) o[v] = mode == 0 ? xv[u][v] * sv[v] + pv[v] : sv[v];
+            vstore<VEC>(y + ((n * hw + r + u * rp) * cv + vc) * VEC, o);
+        }
     }
 }
 
@@ -569,11 +616,22 @@ __global__ __launch_bounds__(256) void add_rowscale_kernel(const float* __restri
                                                            const float* __restrict__ rowscale, int per_vec, float* __restrict__ y) {
     const int64_t base = (int64_t)blockIdx.y * per_vec;
     const float sc = rowscale ? rowscale[blockIdx.y] : 1.f;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per_vec; i += gridDim.x * blockDim.x) {
-        const float4 bv = reinterpret_cast<const float4*>(b)[base + i];
-        float4 o = make_float4(bv.x * sc, bv.y * sc, bv.z * sc, bv.w * sc);
-        if (a) { const float4 av = reinterpret_cast<const float4*>(a)[base + i]; o.x += av.x; o.y += av.y; o.z += av.z; o.w += av.w; }
-        reinterpret_cast<float4*>(y)[base + i] = o;
+    const int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per_vec; i += 4 * stride) {
+        float4 bv[4], av[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ii = i + u * stride < per_vec ? i + u * stride : per_vec - 1;
+            bv[u] = reinterpret_cast<const float4*>(b)[base + ii];
+            if (a) av[u] = reinterpret_cast<const float4*>(a)[base + ii];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i + u * stride >= per_vec) break;
+            float4 o = make_float4(bv[u].x * sc, bv[u].y * sc, bv[u].z * sc, bv[u].w * sc);
+            if (a) { o.x += av[u].x; o.y += av[u].y; o.z += av[u].z; o.w += av[u].w; }
+            reinterpret_cast<float4*>(y)[base + i + u * stride] = o;
+        }
     }
 }
 
@@ -581,10 +639,21 @@ __global__ __launch_bounds__(256) void add_rowscale_kernel(const float* __restri
 __global__ __launch_bounds__(256) void binary_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t count,
                                                      int op, float* __restrict__ y) {
     const int64_t nvec = count / 4;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-        const float4 av = reinterpret_cast<const float4*>(a)[i], bv = reinterpret_cast<const float4*>(b)[i];
-        reinterpret_cast<float4*>(y)[i] = op == 0 ? make_float4(av.x + bv.x, av.y + bv.y, av.z + bv.z, av.w + bv.w)
-                                                  : make_float4(av.x * bv.x, av.y * bv.y, av.z * bv.z, av.w * bv.w);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += 4 * stride) {
+        float4 av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t ii = i + u * stride < nvec ? i + u * stride : nvec - 1;
+            av[u] = reinterpret_cast<const float4*>(a)[ii];
+            bv[u] = reinterpret_cast<const float4*>(b)[ii];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i + u * stride >= nvec) break;
+            reinterpret_cast<float4*>(y)[i + u * stride] = op == 0 ? make_float4(av[u].x + bv[u].x, av[u].y + bv[u].y, av[u].z + bv[u].z, av[u].w + bv[u].w)
+                                                                   : make_float4(av[u].x * bv[u].x, av[u].y * bv[u].y, av[u].z * bv[u].z, av[u].w * bv[u].w);
+        }
     }
     for (int64_t i = nvec * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
         y[i] = op == 0 ? a[i] + b[i] : a[i] * b[i];
