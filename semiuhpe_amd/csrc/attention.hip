@@ -106,6 +106,148 @@ __global__ __launch_bounds__(256) void window_attn_fwd_kernel(const AttnGeom g, 
     }
 }
 
+// ---- forward on the matrix cores.  A wavefront owns 32 query rows: S = Q K^T for the whole window stays in registers
+// (NP/32 tiles of 32x32, `v_mfma_f32_32x32x2_f32`), the softmax is exact (row max / sum by xor-shuffles over the 32 lanes
+// that share a row in the MFMA C layout), and each probability tile goes through a wave-private LDS tile to become the A
+// operand of P V.  K rows sit in LDS as [key][32+4] (B operand of Q K^T, one ds_read_b128 per 4 MFMAs), V transposed as
+// [d][NP+4] (B operand of P V).  NP = window tokens padded to a multiple of 32 (64 or 224); padded keys get probability 0.
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+constexpr int KP = DH + 4;      // row pitch of the K tile and of the probability staging tile (conflict-free b128 reads)
+constexpr int PP = 40;          // row pitch of the staging tile: the two lane halves (rows +4) land 32 banks apart
+
+template <int NP>
+__global__ __launch_bounds__(NP == 64 ? 128 : 256) void window_attn_fwd_mfma(const AttnGeom g, const float* __restrict__ qkv,
+                                                                            const float* __restrict__ bias_table,
+                                                                            const int32_t* __restrict__ bias_idx, float* __restrict__ out,
+                                                                            float* __restrict__ probs) {
+    constexpr int QB = NP / 32;                         // query / key tiles
+    constexpr int NW = NP == 64 ? 2 : 4;                // wavefronts
+    constexpr int VP = NP + 4;                          // row pitch of V^T
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;                                   // [NP][KP]
+    float* Vt = Ks + NP * KP;                           // [DH][VP]
+    float* Pst = Vt + DH * VP;                          // [NW][32][PP]
+    const int win = blockIdx.x / g.heads, hd = blockIdx.x - win * g.heads;
+    const int ld = g.heads * 3 * DH, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r32 = lane & 31, h = lane >> 5;
+    // K rows and V^T; tokens beyond the window are zero
+    for (int e = t; e < NP * (DH / 4); e += NW * 64) {
+        const int tok = e / (DH / 4), c4 = (e - tok * (DH / 4)) * 4;
+        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+        if (tok < g.N) {
+            const float* base = qkv + token_row(g, win, tok) * ld + hd * 3 * DH;
+            kv = *reinterpret_cast<const float4*>(base + DH + c4);
+            vv = *reinterpret_cast<const float4*>(base + 2 * DH + c4);
+        }
+        *reinterpret_cast<float4*>(&Ks[tok * KP + c4]) = kv;
+        Vt[(c4 + 0) * VP + tok] = vv.x; Vt[(c4 + 1) * VP + tok] = vv.y; Vt[(c4 + 2) * VP + tok] = vv.z; Vt[(c4 + 3) * VP + tok] = vv.w;
+    }
+    __syncthreads();
+    const float* bt = bias_table + (int64_t)hd * g.noff;
+    float* pst = Pst + wave * 32 * PP;
+    for (int qb = wave; qb < QB; qb += NW) {
+        // A operand of Q K^T straight from global memory: lane (row r32, half h) holds k = 8*kg + 4*h .. +3
+        const int qrow = qb * 32 + r32;
+        float4 qf[DH / 8];
+        {
+            const bool ok = qrow < g.N;
+            const float* base = qkv + (ok ? token_row(g, win, qrow) : 0) * ld + hd * 3 * DH;
+#pragma unroll
+            for (int kg = 0; kg < DH / 8; ++kg) {
+                qf[kg] = *reinterpret_cast<const float4*>(base + kg * 8 + h * 4);
+                if (!ok) qf[kg] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        floatx16 sc[QB];
+#pragma unroll
+        for (int kt = 0; kt < QB; ++kt) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sc[kt][e] = 0.f;
+#pragma unroll
+            for (int kg = 0; kg < DH / 8; ++kg) {
+                const float4 kf = *reinterpret_cast<const float4*>(&Ks[(kt * 32 + r32) * KP + kg * 8 + h * 4]);
+                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[kg].x, kf.x, sc[kt], 0, 0, 0);
+                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[kg].y, kf.y, sc[kt], 0, 0, 0);
+                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[kg].z, kf.z, sc[kt], 0, 0, 0);
+                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[kg].w, kf.w, sc[kt], 0, 0, 0);
+            }
+        }
+        // C layout: column (key) = kt*32 + r32, row (query) = qb*32 + (e&3) + 8*(e>>2) + 4*h.  Scale, bias, mask, row max.
+        float rmax[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rmax[e] = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < QB; ++kt) {
+            const int j = kt * 32 + r32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                float v = -3.0e38f;
+                if (i < g.N && j < g.N) v = sc[kt][e] * g.scale + bt[bias_idx[i * g.N + j]];
+                sc[kt][e] = v;
+                rmax[e] = fmaxf(rmax[e], v);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) rmax[e] = fmaxf(rmax[e], __shfl_xor(rmax[e], m, 64));
+        }
+        float rsum[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rsum[e] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < QB; ++kt) {
+            const int j = kt * 32 + r32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pv = j < g.N ? expf(sc[kt][e] - rmax[e]) : 0.f;      // rows beyond N: exp(0) = 1, never stored
+                sc[kt][e] = pv;
+                rsum[e] += pv;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) rsum[e] += __shfl_xor(rsum[e], m, 64);
+            rsum[e] = 1.f / rsum[e];
+        }
+        // P V: tile by tile through the wave's staging tile
+        floatx16 oacc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[e] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < QB; ++kt) {
+            const int j = kt * 32 + r32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rl = (e & 3) + 8 * (e >> 2) + 4 * h;
+                const float pv = sc[kt][e] * rsum[e];
+                pst[rl * PP + r32] = pv;
+                const int i = qb * 32 + rl;
+                if (probs && i < g.N && j < g.N) probs[((int64_t)blockIdx.x * g.N + i) * g.N + j] = pv;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);         // lgkmcnt(0): the wave's own LDS writes have landed (one wave owns the tile)
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+                const float4 pf = *reinterpret_cast<const float4*>(&pst[r32 * PP + kg * 8 + h * 4]);
+                const float4 vf = *reinterpret_cast<const float4*>(&Vt[r32 * VP + kt * 32 + kg * 8 + h * 4]);
+                oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(pf.x, vf.x, oacc, 0, 0, 0);
+                oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(pf.y, vf.y, oacc, 0, 0, 0);
+                oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(pf.z, vf.z, oacc, 0, 0, 0);
+                oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(pf.w, vf.w, oacc, 0, 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);         // reads done before the next tile overwrites the staging tile
+        }
+        // O in C layout: column = channel r32, row = query
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (i < g.N) out[token_row(g, win, i) * (g.heads * DH) + hd * DH + r32] = oacc[e];
+        }
+    }
+}
+
 // Backward.  Phase A (wave per query row): dP = dO V^T, dS = P*(dP - sum(P*dP)), dQ = scale dS K; dS is written to the
 // scratch matrix.  Phase B (wave per key): dK = scale dS^T Q, dV = P^T dO from the columns of dS / P.
 __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const AttnGeom g, const float* __restrict__ qkv,
@@ -187,6 +329,164 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const AttnGeom g, 
     }
 }
 
+// ---- backward on the matrix cores (probabilities P from the forward pass).
+//   dP = dO V^T,  delta_i = sum_j P_ij dP_ij,  dS = P o (dP - delta),  dQ = scale dS K,  dK = scale dS^T Q,  dV = P^T dO
+// Phase A, a wavefront per 32 query rows: dP tiles for the whole window in registers, delta by xor-shuffles, dS written to the
+// scratch matrix (for the bias gradient) and, tile by tile through a wave-private LDS tile, used as the A operand of dS K.
+// Phase B, a wavefront per 32 keys: the dP / dS tiles are recomputed (16 MFMAs) and dK, dV accumulate in the "TN" form
+// (reduction index = query = row index of both operands, read from LDS one value per lane: A[k][m] = dS[query][key]).
+// LDS: V, dO and (K, then Q in the same buffer) as [token][32+4]; two staging tiles per wavefront; delta.
+template <int NP>
+__global__ __launch_bounds__(NP == 64 ? 128 : 256) void window_attn_bwd_mfma(const AttnGeom g, const float* __restrict__ qkv,
+                                                                            const float* __restrict__ probs, const float* __restrict__ dout,
+                                                                            float* __restrict__ dS_out, float* __restrict__ dqkv) {
+    constexpr int QB = NP / 32;
+    constexpr int NW = NP == 64 ? 2 : 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* KQ = smem;                                   // [NP][KP]: K during phase A, Q during phase B
+    float* Vs = KQ + NP * KP;                           // [NP][KP]
+    float* Os = Vs + NP * KP;                           // [NP][KP]  dO
+    float* stP = Os + NP * KP;                          // [NW][32][PP]
+    float* stS = stP + NW * 32 * PP;                    // [NW][32][PP]
+    float* delta = stS + NW * 32 * PP;                  // [NP]
+    const int win = blockIdx.x / g.heads, hd = blockIdx.x - win * g.heads;
+    const int ld = g.heads * 3 * DH, lo = g.heads * DH, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r32 = lane & 31, h = lane >> 5;
+    const float* P = probs + (int64_t)blockIdx.x * g.N * g.N;
+    float* S = dS_out + (int64_t)blockIdx.x * g.N * g.N;
+    auto load_rows = [&](const float* src, int ldsrc, int off, float* dst) __attribute__((always_inline)) {
+        for (int e = t; e < NP * (DH / 4); e += NW * 64) {
+            const int tok = e / (DH / 4), c4 = (e - tok * (DH / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tok < g.N) v = *reinterpret_cast<const float4*>(src + token_row(g, win, tok) * ldsrc + off + c4);
+            *reinterpret_cast<float4*>(&dst[tok * KP + c4]) = v;
+        }
+    };
+    load_rows(qkv, ld, hd * 3 * DH + DH, KQ);           // K
+    load_rows(qkv, ld, hd * 3 * DH + 2 * DH, Vs);
+    load_rows(dout, lo, hd * DH, Os);
+    __syncthreads();
+    float* sS = stS + wave * 32 * PP;
+    float* sP = stP + wave * 32 * PP;
+
+    // ---------------- phase A: query blocks
+    for (int qb = wave; qb < QB; qb += NW) {
+        float4 of[DH / 8];
+#pragma unroll
+        for (int kg = 0; kg < DH / 8; ++kg) of[kg] = *reinterpret_cast<const float4*>(&Os[(qb * 32 + r32) * KP + kg * 8 + h * 4]);
+        floatx16 dp[QB], pt[QB];
+        float dl[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dl[e] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < QB; ++kt) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dp[kt][e] = 0.f;
+#pragma unroll
+            for (int kg = 0; kg < DH / 8; ++kg) {
+                const float4 vf = *reinterpret_cast<const float4*>(&Vs[(kt * 32 + r32) * KP + kg * 8 + h * 4]);
+                dp[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(of[kg].x, vf.x, dp[kt], 0, 0, 0);
+                dp[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(of[kg].y, vf.y, dp[kt], 0, 0, 0);
+                dp[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(of[kg].z, vf.z, dp[kt], 0, 0, 0);
+                dp[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(of[kg].w, vf.w, dp[kt], 0, 0, 0);
+            }
+            const int j = kt * 32 + r32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const float pv = (i < g.N && j < g.N) ? P[i * g.N + j] : 0.f;
+                pt[kt][e] = pv;
+                dl[e] += pv * dp[kt][e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) dl[e] += __shfl_xor(dl[e], m, 64);
+            if (r32 == 0) delta[qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] = dl[e];
+        }
+        floatx16 dq;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dq[e] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < QB; ++kt) {
+            const int j = kt * 32 + r32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rl = (e & 3) + 8 * (e >> 2) + 4 * h, i = qb * 32 + rl;
+                const float ds = pt[kt][e] * (dp[kt][e] - dl[e]);
+                sS[rl * PP + r32] = ds;
+                if (i < g.N && j < g.N) S[i * g.N + j] = ds;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+                const float4 sf = *reinterpret_cast<const float4*>(&sS[r32 * PP + kg * 8 + h * 4]);
+                const int key = kt * 32 + kg * 8 + h * 4;
+                dq = __builtin_amdgcn_mfma_f32_32x32x2f32(sf.x, KQ[(key + 0) * KP + r32], dq, 0, 0, 0);
+                dq = __builtin_amdgcn_mfma_f32_32x32x2f32(sf.y, KQ[(key + 1) * KP + r32], dq, 0, 0, 0);
+                dq = __builtin_amdgcn_mfma_f32_32x32x2f32(sf.z, KQ[(key + 2) * KP + r32], dq, 0, 0, 0);
+                dq = __builtin_amdgcn_mfma_f32_32x32x2f32(sf.w, KQ[(key + 3) * KP + r32], dq, 0, 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (i < g.N) dqkv[token_row(g, win, i) * ld + hd * 3 * DH + r32] = dq[e] * g.scale;
+        }
+    }
+    __syncthreads();                                    // every wave is done with K; delta is complete
+    load_rows(qkv, ld, hd * 3 * DH, KQ);                // Q
+    __syncthreads();
+
+    // ---------------- phase B: key tiles
+    for (int kt = wave; kt < QB; kt += NW) {
+        floatx16 dk, dv;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dk[e] = 0.f; dv[e] = 0.f; }
+        const int j = kt * 32 + r32;
+        for (int qb = 0; qb < QB; ++qb) {
+            floatx16 dp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dp[e] = 0.f;
+#pragma unroll
+            for (int kg = 0; kg < DH / 8; ++kg) {
+                const float4 of = *reinterpret_cast<const float4*>(&Os[(qb * 32 + r32) * KP + kg * 8 + h * 4]);
+                const float4 vf = *reinterpret_cast<const float4*>(&Vs[(kt * 32 + r32) * KP + kg * 8 + h * 4]);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(of.x, vf.x, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(of.y, vf.y, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(of.z, vf.z, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(of.w, vf.w, dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rl = (e & 3) + 8 * (e >> 2) + 4 * h, i = qb * 32 + rl;
+                const float pv = (i < g.N && j < g.N) ? P[i * g.N + j] : 0.f;
+                sP[rl * PP + r32] = pv;
+                sS[rl * PP + r32] = pv * (dp[e] - delta[i]);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const int q = 2 * kk + h;               // query inside the block = reduction index
+                dk = __builtin_amdgcn_mfma_f32_32x32x2f32(sS[q * PP + r32], KQ[(qb * 32 + q) * KP + r32], dk, 0, 0, 0);
+                dv = __builtin_amdgcn_mfma_f32_32x32x2f32(sP[q * PP + r32], Os[(qb * 32 + q) * KP + r32], dv, 0, 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (key < g.N) {
+                const int64_t row = token_row(g, win, key);
+                dqkv[row * ld + hd * 3 * DH + DH + r32] = dk[e] * g.scale;
+                dqkv[row * ld + hd * 3 * DH + 2 * DH + r32] = dv[e];
+            }
+        }
+    }
+}
+
 // dbias_table[h][bias_idx[i][j]] += sum over windows of dS[w][h][i][j]
 __global__ __launch_bounds__(256) void window_attn_dbias_kernel(const float* __restrict__ dS, const int32_t* __restrict__ bias_idx, int nwin,
                                                                 int heads, int N, int noff, float* __restrict__ dbias) {
@@ -220,9 +520,22 @@ int suhpe_window_attn_fwd(const float* qkv, const float* bias_table, const int32
     int rc = attn_geom(&g, B, H, W, ws, heads, dh, noff, scale, "suhpe_window_attn_fwd");
     if (rc) return rc;
     SUHPE_REQUIRE(qkv && bias_table && bias_idx && out, "suhpe_window_attn_fwd: null pointer");
-    const size_t lds = (size_t)(2 * g.N * PITCH + 4 * DH + 4 * MAXN) * sizeof(float);
-    hipLaunchKernelGGL(window_attn_fwd_kernel, dim3(B * g.nwy * g.nwx * heads), dim3(256), lds, as_stream(stream), g, qkv, bias_table, bias_idx,
-                       out, probs);
+    const dim3 grid(B * g.nwy * g.nwx * heads);
+    if (g.N <= 64) {
+        const size_t lds = (size_t)(64 * KP + DH * (64 + 4) + 2 * 32 * PP) * sizeof(float);
+        hipLaunchKernelGGL(window_attn_fwd_mfma<64>, grid, dim3(128), lds, as_stream(stream), g, qkv, bias_table, bias_idx, out, probs);
+    } else if (g.N <= 224) {
+        const size_t lds = (size_t)(224 * KP + DH * (224 + 4) + 4 * 32 * PP) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_fwd_mfma<224>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(window_attn_fwd_mfma<224>, grid, dim3(256), lds, as_stream(stream), g, qkv, bias_table, bias_idx, out, probs);
+    } else {
+        const size_t lds = (size_t)(2 * g.N * PITCH + 4 * DH + 4 * MAXN) * sizeof(float);
+        hipLaunchKernelGGL(window_attn_fwd_kernel, grid, dim3(256), lds, as_stream(stream), g, qkv, bias_table, bias_idx, out, probs);
+    }
     return check_launch("suhpe_window_attn_fwd");
 }
 
@@ -245,7 +558,20 @@ int suhpe_window_attn_bwd(const float* qkv, const float* probs, const float* dou
     }
     float* dS = static_cast<float*>(workspace);
     const int nwin = B * g.nwy * g.nwx;
-    hipLaunchKernelGGL(window_attn_bwd_kernel, dim3(nwin * heads), dim3(256), lds, as_stream(stream), g, qkv, probs, dout, dS, dqkv);
+    if (g.N <= 64) {
+        const size_t l2 = (size_t)(3 * 64 * KP + 2 * 2 * 32 * PP + 64) * sizeof(float);
+        hipLaunchKernelGGL(window_attn_bwd_mfma<64>, dim3(nwin * heads), dim3(128), l2, as_stream(stream), g, qkv, probs, dout, dS, dqkv);
+    } else if (g.N <= 224) {
+        const size_t l2 = (size_t)(3 * 224 * KP + 2 * 4 * 32 * PP + 224) * sizeof(float);
+        static bool attr2 = false;
+        if (!attr2) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_bwd_mfma<224>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr2 = true;
+        }
+        hipLaunchKernelGGL(window_attn_bwd_mfma<224>, dim3(nwin * heads), dim3(256), l2, as_stream(stream), g, qkv, probs, dout, dS, dqkv);
+    } else {
+        hipLaunchKernelGGL(window_attn_bwd_kernel, dim3(nwin * heads), dim3(256), lds, as_stream(stream), g, qkv, probs, dout, dS, dqkv);
+    }
     if (dbias_table) {
         const int64_t total = (int64_t)heads * g.N * g.N;
         hipLaunchKernelGGL(window_attn_dbias_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(stream), dS, bias_idx, nwin, heads,
