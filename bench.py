@@ -81,14 +81,17 @@ def gpu_leg(args, rank, world, device):
 
     # ---- roofline of the dominant kernel: same step, every dense-conv launch bracketed by HIP events on the
     # launch stream (torch's current stream is the stream the C ABI launches on)
+    # Every rank runs the instrumented steps (train_func all-reduces gradients: a rank stepping alone would deadlock the
+    # others at their barrier); only rank 0 records and reports.
     roof = None
+    nprof = 2
     if rank == 0:
         K.PROFILE = []
-        nprof = 2
-        for _ in range(nprof):
-            agent.train_func(data, ulb)
-            agent.clock.tick()
-        torch.cuda.synchronize()
+    for _ in range(nprof):
+        agent.train_func(data, ulb)
+        agent.clock.tick()
+    torch.cuda.synchronize()
+    if rank == 0:
         recs, K.PROFILE = K.PROFILE, None
         agg = {}
         for name, flops, nbytes, e0, e1, _shape in recs:
@@ -167,11 +170,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    local %= max(1, torch.cuda.device_count())             # (a single-GPU box can rehearse --gpus 2 with SUHPE_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         from semiuhpe_amd.src.distributed import init_from_env
-        init_from_env("nccl")
+        init_from_env(os.environ.get("SUHPE_DIST_BACKEND", "nccl"))
     dt, info, roof = gpu_leg(args, rank, world, device)
     if rank == 0:
         ms = dt / args.steps * 1e3

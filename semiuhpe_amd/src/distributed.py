@@ -28,7 +28,7 @@ def init_from_env(backend="nccl"):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     kw = {}
     if backend == "nccl":
-        local = int(os.environ.get("LOCAL_RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local)
         kw["device_id"] = torch.device("cuda", local)
     dist.init_process_group(backend, **kw)
@@ -44,7 +44,11 @@ def allreduce_sum_(t):
 def allreduce_avg_(t):
     """Average across ranks inside the collective (RCCL implements AVG); only used on device tensors."""
     if world()[1] > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.AVG)
+        if dist.get_backend() == "gloo":          # gloo has no AVG (CPU tests, and the single-box rehearsal of bench.py --gpus 2)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            t.div_(world()[1])
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.AVG)
     return t
 
 

@@ -78,3 +78,24 @@ def test_checkpoint_roundtrip_is_exact(tmp_path):
     a.net.eval(); b.net.eval()
     with torch.no_grad():
         assert torch.equal(a.net(data["img"]), b.net(data["img"]))
+
+
+def test_bench_two_rank_flow_on_one_gpu(tmp_path):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), rehearsed on a single GPU
+    with the gloo backend: both ranks must reach the end (the instrumented roofline steps all-reduce too) and rank 0 must
+    print exactly one JSON line with the contract's keys."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SUHPE_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline"):
+        assert key in out, key
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 320
+    assert "cpu_baseline" not in out                       # reported at N=1 only
