@@ -133,6 +133,24 @@ int suhpe_dwconv_wgrad(const suhpe_conv_t* d, const float* x, const float* dy, f
 int suhpe_bias_grad(const float* dy, int64_t rows, int c, float* db, int accumulate, void* workspace,
                     suhpe_stream_t stream);   /* workspace >= suhpe_bn_workspace_bytes(c) */
 
+/* ------------------------------------------------------------------ data-side augmentation ---- */
+/* The per-sample PIL / torchvision chain of src/datasets/dataset_300WLP.py:103-161 (process_annotated_image;
+ * dataset_WildHead.py:76-124 is the same chain) for n decoded 224x224 RGB crops in device memory, src (n,224,224,3) uint8:
+ *   flags[n]      bit 0 = flip left-right, bit 1 = ImageFilter.BLUR (applied after the flip)
+ *   weak_box[n][4], strong_box[n][4] = (top, left, height, width) of RandomResizedCrop (height, width <= 224)
+ *   rot_coef[n][8] = 16.16 fixed-point affine coefficients a0..a5 of Image.rotate(angle, center=(112,112), expand=True)
+ *                    followed by the centre 224 crop origin (x0, y0); NULL = no rotation
+ *   tables        device copy of suhpe_augment_build_tables' output (Pillow's bilinear resize coefficients)
+ * Outputs: weak_out / strong_out (n,224,224,3) fp32 = Normalize(ToTensor(view)) in the pixel-major layout of the backbone
+ * (strong_* may be NULL together); weak_u8 / strong_u8 optional uint8 copies of the views (debug / parity).
+ * Every pixel operation reproduces Pillow bit for bit.  workspace >= suhpe_augment_workspace_bytes(n). */
+int64_t suhpe_augment_tables_bytes(void);
+int suhpe_augment_build_tables(int32_t* host_tables);
+int64_t suhpe_augment_workspace_bytes(int n);
+int suhpe_augment_views(const uint8_t* src, int n, const int32_t* flags, const int32_t* weak_box, const int64_t* rot_coef,
+                        const int32_t* strong_box, const int32_t* tables, void* workspace, float* weak_out, float* strong_out,
+                        uint8_t* weak_u8, uint8_t* strong_u8, suhpe_stream_t stream);
+
 /* ------------------------------------------------------------------ normalisation + activation ----------- */
 /* BatchNorm (train): per-channel statistics of x (rows, c).  Writes mean/rstd (c each) and updates
  * running_mean / running_var (unbiased) / num_batches_tracked (int64, +1) when running_mean != NULL.
