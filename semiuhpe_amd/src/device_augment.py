@@ -93,28 +93,40 @@ def _device_tables(device):
     return _tables[key]
 
 
-def augment_views(images_u8, params, rotate_aug=True, return_u8=False):
-    """images_u8: (N, 224, 224, 3) uint8 CUDA tensor; params: list of draw_params dicts.
-    -> (img, img_strong or None[, weak_u8, strong_u8]) with img (N, 224, 224, 3) fp32 normalised, pixel-major."""
-    assert images_u8.is_cuda and images_u8.dtype == torch.uint8 and images_u8.is_contiguous() and tuple(images_u8.shape[1:]) == (SIZE, SIZE, 3)
-    n, dev = images_u8.shape[0], images_u8.device
-    assert len(params) == n
+def pack_params(params, device, rotate_aug=True):
+    """Host decisions of a batch -> the small device arrays of suhpe_augment_views: (flags, weak_box, strong_box, rot_coef)"""
     strong = params[0]["strong"] is not None
-    flags = torch.tensor([int(p["flip"]) | (int(p["blur"]) << 1) for p in params], dtype=torch.int32).to(dev, non_blocking=True)
-    wbox = torch.tensor([p["weak"] for p in params], dtype=torch.int32).to(dev, non_blocking=True)
+    flags = torch.tensor([int(p["flip"]) | (int(p["blur"]) << 1) for p in params], dtype=torch.int32).to(device, non_blocking=True)
+    wbox = torch.tensor([p["weak"] for p in params], dtype=torch.int32).to(device, non_blocking=True)
     sbox = coef = None
     if strong:
-        sbox = torch.tensor([p["strong"] for p in params], dtype=torch.int32).to(dev, non_blocking=True)
+        sbox = torch.tensor([p["strong"] for p in params], dtype=torch.int32).to(device, non_blocking=True)
         if rotate_aug:
-            coef = torch.tensor([rotate_coefficients(p["angle"]) for p in params], dtype=torch.int64).to(dev, non_blocking=True)
+            coef = torch.tensor([rotate_coefficients(p["angle"]) for p in params], dtype=torch.int64).to(device, non_blocking=True)
+    return flags, wbox, sbox, coef
+
+
+def augment_views_packed(images_u8, packed, return_u8=False):
+    """The device part alone: images (N, 224, 224, 3) uint8 + pack_params(...) -> normalised fp32 views, pixel-major."""
+    assert images_u8.is_cuda and images_u8.dtype == torch.uint8 and images_u8.is_contiguous() and tuple(images_u8.shape[1:]) == (SIZE, SIZE, 3)
+    flags, wbox, sbox, coef = packed
+    n, dev = images_u8.shape[0], images_u8.device
+    assert flags.numel() == n
     img = torch.empty((n, SIZE, SIZE, 3), dtype=torch.float32, device=dev)
-    img_s = torch.empty_like(img) if strong else None
+    img_s = torch.empty_like(img) if sbox is not None else None
     u8w = torch.empty((n, SIZE, SIZE, 3), dtype=torch.uint8, device=dev) if return_u8 else None
-    u8s = torch.empty_like(u8w) if (return_u8 and strong) else None
+    u8s = torch.empty_like(u8w) if (return_u8 and sbox is not None) else None
     ws = workspace("augment", _lib.load().suhpe_augment_workspace_bytes(n), dev)
     call("suhpe_augment_views", ptr(images_u8), n, ptr(flags), ptr(wbox), ptr(coef), ptr(sbox), ptr(_device_tables(dev)), ptr(ws), ptr(img),
          ptr(img_s), ptr(u8w), ptr(u8s))
     return (img, img_s, u8w, u8s) if return_u8 else (img, img_s)
+
+
+def augment_views(images_u8, params, rotate_aug=True, return_u8=False):
+    """images_u8: (N, 224, 224, 3) uint8 CUDA tensor; params: list of draw_params dicts.
+    -> (img, img_strong or None[, weak_u8, strong_u8]) with img (N, 224, 224, 3) fp32 normalised, pixel-major."""
+    assert len(params) == images_u8.shape[0]
+    return augment_views_packed(images_u8, pack_params(params, images_u8.device, rotate_aug), return_u8)
 
 
 def get_6DRepNet_Rot(x, y, z):

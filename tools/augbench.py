@@ -8,15 +8,16 @@ n = 288                                            # images one C2 step consumes
 images = torch.randint(0, 256, (n, 224, 224, 3), dtype=torch.uint8, device="cuda")
 np.random.seed(0); torch.manual_seed(0)
 t0 = time.perf_counter(); params = [D.draw_params(True, True) for _ in range(n)]; t_draw = time.perf_counter() - t0
-D.augment_views(images, params, True); torch.cuda.synchronize()
+t0 = time.perf_counter(); packed = D.pack_params(params, images.device, True); torch.cuda.synchronize(); t_pack = time.perf_counter() - t0
+D.augment_views_packed(images, packed); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(20):
-    D.augment_views(images, params, True)
+    D.augment_views_packed(images, packed)
 e1.record(); torch.cuda.synchronize()
 dt = e0.elapsed_time(e1) / 20 * 1e-3
 nbytes = n * 224 * 224 * 3 * (1 + 4) * 2          # uint8 in + fp32 out, two views (intermediates stay in L2 / MALL)
-print(f"device: {n} images x 2 views in {dt*1e6:.0f} us = {n/dt:,.0f} img/s ({nbytes/dt/1e9:.0f} GB/s algorithmic); host draw of the decisions {t_draw*1e3:.1f} ms")
+print(f"device: {n} images x 2 views in {dt*1e6:.0f} us = {n/dt:,.0f} img/s ({nbytes/dt/1e9:.0f} GB/s algorithmic); host: draw of the decisions {t_draw*1e3:.1f} ms, packing + upload {t_pack*1e3:.1f} ms")
 try:
     from PIL import Image, ImageFilter
     host = images[:32].cpu().numpy()
