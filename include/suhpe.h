@@ -163,6 +163,12 @@ int suhpe_bn_stats(const float* x, int64_t rows, int c, float eps, float momentu
 int suhpe_bn_stats_from_partials(const float* part, int gx, int64_t rows, int c, float eps, float momentum, float* mean,
                                  float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                  suhpe_stream_t stream);
+/* RepVGG re-parameterisation for eval (src/repvgg.py:104-142 get_equivalent_kernel_bias): 3x3 branch + 1x1 branch + identity
+ * BatchNorm -> one 3x3 filter w_eq (layout of w3) and bias b_eq; `ones` (cout) is filled with 1 so that
+ * suhpe_conv2d_fwd_affine(d, x, w_eq, ones, b_eq, RELU, ...) is the deploy-mode block.  bn3 / bn1 / bnid are arrays of four
+ * device pointers (gamma, beta, running_mean, running_var); bnid = NULL when the block has no identity branch. */
+int suhpe_repvgg_fuse(const float* w3, const float* w1, const float* const* bn3, const float* const* bn1, const float* const* bnid,
+                      float eps, int cout, int cin_per_group, float* w_eq, float* ones, float* b_eq, suhpe_stream_t stream);
 /* eval: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale (gamma / beta may be NULL) */
 int suhpe_bn_eval_affine(const float* running_mean, const float* running_var, const float* gamma, const float* beta, int c,
                          float eps, float* scale, float* shift, suhpe_stream_t stream);

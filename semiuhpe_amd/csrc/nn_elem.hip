@@ -239,6 +239,34 @@ __global__ void bn_eval_affine_kernel(const float* __restrict__ rm, const float*
     shift[ch] = (beta ? beta[ch] : 0.f) - rm[ch] * sc;
 }
 
+// RepVGG structural re-parameterisation for eval (src/repvgg.py:104-142, get_equivalent_kernel_bias): the 3x3 branch, the
+// 1x1 branch and the identity BatchNorm collapse into one 3x3 filter and a bias,
+//   W[co][r][s][ci] = W3[co][r][s][ci] t3[co] + [r = s = 1] (W1[co][ci] t1[co] + [ci = co mod Cg] tid[co]),   t = gamma / sqrt(var + eps)
+//   b[co] = sum over branches of beta - mean t.        Filters are in the physical layout [Cout][R][S][Cin/g].
+struct BnRef { const float* gamma; const float* beta; const float* mean; const float* var; float eps; };
+__global__ __launch_bounds__(256) void repvgg_fuse_kernel(const float* __restrict__ w3, const float* __restrict__ w1, BnRef b3, BnRef b1,
+                                                          BnRef bid, int has_id, int cout, int cg, float* __restrict__ w_eq,
+                                                          float* __restrict__ ones, float* __restrict__ b_eq) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, total = (int64_t)cout * 9 * cg;
+    if (idx >= total) return;
+    const int co = (int)(idx / (9 * cg)), rem = (int)(idx - (int64_t)co * 9 * cg), tap = rem / cg, ci = rem - tap * cg;
+    const float t3 = b3.gamma[co] / sqrtf(b3.var[co] + b3.eps);
+    const float t1 = b1.gamma[co] / sqrtf(b1.var[co] + b1.eps);
+    const float tid = has_id ? bid.gamma[co] / sqrtf(bid.var[co] + bid.eps) : 0.f;
+    float v = w3[idx] * t3;
+    if (tap == 4) {
+        v += w1[(int64_t)co * cg + ci] * t1;
+        if (has_id && ci == co % cg) v += tid;
+    }
+    w_eq[idx] = v;
+    if (rem == 0) {
+        float b = (b3.beta[co] - b3.mean[co] * t3) + (b1.beta[co] - b1.mean[co] * t1);
+        if (has_id) b += bid.beta[co] - bid.mean[co] * tid;
+        b_eq[co] = b;
+        ones[co] = 1.f;
+    }
+}
+
 // y = act(gamma*(x-mean)*rstd + beta + residual)                       (post == 0: pre-activation residual)
 // y = residual + rowscale[row / hw] * act(gamma*(x-mean)*rstd + beta)   (post == 1: the block's skip connection with
 //                                                                        StochasticDepth('row') folded in; rowscale may be NULL)
@@ -825,6 +853,18 @@ int suhpe_bn_eval_stats(const float* rm, const float* rv, int c, float eps, floa
     SUHPE_REQUIRE(rm && rv && mean && rstd && c > 0, "suhpe_bn_eval_stats: bad arguments");
     LAUNCH(bn_eval_stats_kernel, dim3((c + 255) / 256), dim3(256), stream, rm, rv, c, eps, mean, rstd);
     return check_launch("suhpe_bn_eval_stats");
+}
+
+int suhpe_repvgg_fuse(const float* w3, const float* w1, const float* const* bn3, const float* const* bn1, const float* const* bnid,
+                      float eps, int cout, int cin_per_group, float* w_eq, float* ones, float* b_eq, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(w3 && w1 && bn3 && bn1 && w_eq && ones && b_eq && cout > 0 && cin_per_group > 0, "suhpe_repvgg_fuse: bad arguments");
+    for (int k = 0; k < 4; ++k) SUHPE_REQUIRE(bn3[k] && bn1[k] && (!bnid || bnid[k]), "suhpe_repvgg_fuse: BatchNorm arrays are (gamma, beta, running_mean, running_var)");
+    const BnRef b3{bn3[0], bn3[1], bn3[2], bn3[3], eps}, b1{bn1[0], bn1[1], bn1[2], bn1[3], eps};
+    const BnRef bi = bnid ? BnRef{bnid[0], bnid[1], bnid[2], bnid[3], eps} : BnRef{nullptr, nullptr, nullptr, nullptr, eps};
+    const int64_t total = (int64_t)cout * 9 * cin_per_group;
+    LAUNCH(repvgg_fuse_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), stream, w3, w1, b3, b1, bi, bnid ? 1 : 0, cout, cin_per_group, w_eq,
+           ones, b_eq);
+    return check_launch("suhpe_repvgg_fuse");
 }
 
 int suhpe_bn_eval_affine(const float* rm, const float* rv, const float* gamma, const float* beta, int c, float eps, float* scale,

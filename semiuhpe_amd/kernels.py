@@ -246,6 +246,18 @@ def conv2d_fwd_affine(x, w, scale, shift, act, residual=None, residual_after_act
     return y
 
 
+def repvgg_fuse(w3, w1, bn3, bn1, bnid, eps):
+    """RepVGG deploy-mode filter and bias of one block (src/repvgg.py:104-142); bn* = (gamma, beta, running_mean, running_var)
+    tensors, bnid None without an identity branch.  -> (w_eq like w3, ones (cout), b_eq (cout))"""
+    assert filter_is_physical(w3) and filter_is_physical(w1)
+    cout, cg = w3.shape[0], w3.shape[1]
+    w_eq = torch.empty_strided(tuple(w3.shape), w3.stride(), dtype=torch.float32, device=w3.device)
+    vec = torch.empty(2, cout, dtype=torch.float32, device=w3.device)
+    arr = lambda bn: (ctypes.c_void_p * 4)(*[t.data_ptr() for t in bn]) if bn is not None else None
+    call("suhpe_repvgg_fuse", ptr(w3), ptr(w1), arr(bn3), arr(bn1), arr(bnid), float(eps), cout, cg, ptr(w_eq), ptr(vec[0]), ptr(vec[1]))
+    return w_eq, vec[0], vec[1]
+
+
 def bn_eval_affine(running_mean, running_var, gamma, beta, eps):
     c = running_mean.numel()
     out = torch.empty(2, c, dtype=torch.float32, device=running_mean.device)

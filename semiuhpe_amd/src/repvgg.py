@@ -33,10 +33,17 @@ class RepVGGBlock(Layer):
     def fwd(self, x, tape):
         train = self.rbr_dense.bn.training
         if not train and tape is None and self.rbr_dense.conv.fuses_stats():
-            # eval without a tape: each branch's BatchNorm rides in its conv's epilogue, the branch sum and the ReLU in the last one
-            u = self.rbr_identity.fwd(x, None) if self.rbr_identity is not None else None
-            u = conv_bn_fwd(self.rbr_1x1.conv, self.rbr_1x1.bn, x, None, residual=u)
-            return conv_bn_fwd(self.rbr_dense.conv, self.rbr_dense.bn, x, None, residual=u)          # relu(bn(t3) + u)
+            # eval without a tape (teacher threshold scan, validation, eval.py): the reference's structural re-parameterisation
+            # (repvgg.py:104-142) — both conv branches and the identity BatchNorm collapse into ONE 3x3 conv + bias + ReLU;
+            # the equivalent filter is rebuilt per call (the weights move every training step), one small kernel
+            c3, c1 = self.rbr_dense.conv, self.rbr_1x1.conv
+            for c in (c3, c1):
+                if not K.filter_is_physical(c.weight):
+                    c.weight.data = K.to_filter_layout(c.weight.data)
+            bn = lambda b: (b.weight, b.bias, b.running_mean, b.running_var)
+            w_eq, ones, b_eq = K.repvgg_fuse(c3.weight, c1.weight, bn(self.rbr_dense.bn), bn(self.rbr_1x1.bn),
+                                             bn(self.rbr_identity) if self.rbr_identity is not None else None, self.rbr_dense.bn.eps)
+            return K.conv2d_fwd_affine(x, w_eq, ones, b_eq, "relu", None, False, c3.stride, c3.padding, c3.groups)
         t3, p3 = self.rbr_dense.conv.fwd_stats(x, tape) if train else (self.rbr_dense.conv.fwd(x, tape), None)
         t1, p1 = self.rbr_1x1.conv.fwd_stats(x, tape) if train else (self.rbr_1x1.conv.fwd(x, tape), None)
         u = self.rbr_1x1.bn.fwd(t1, tape, partials=p1)

@@ -188,6 +188,31 @@ def test_conv_fwd_folded_eval_batchnorm(K, cfg, act, res):
     assert rel(from_nhwc(y), ref) < 2e-5
 
 
+@pytest.mark.parametrize("c,groups,identity,stride", [(64, 1, True, 1), (128, 2, True, 1), (64, 2, False, 2), (48, 1, False, 1)])
+def test_repvgg_reparameterised_block(K, c, groups, identity, stride):
+    """suhpe_repvgg_fuse + one conv(+bias, ReLU) == relu(bn3(conv3 x) + bn1(conv1 x) + bn_id(x)) in eval mode (repvgg.py:67-77, 104-142)"""
+    g = torch.Generator().manual_seed(c + groups)
+    cout = c if identity else c * 2
+    x = torch.randn(3, c, 14, 14, generator=g)
+    w3 = torch.randn(cout, c // groups, 3, 3, generator=g) / (3 * (c // groups) ** 0.5)
+    w1 = torch.randn(cout, c // groups, 1, 1, generator=g) / ((c // groups) ** 0.5)
+
+    def bn(ch):
+        return [torch.rand(ch, generator=g) + 0.5, torch.randn(ch, generator=g) * 0.2, torch.randn(ch, generator=g) * 0.3, torch.rand(ch, generator=g) + 0.4]
+    b3, b1, bi = bn(cout), bn(cout), (bn(c) if identity else None)
+    eps = 1e-5
+    xd = x.double()
+    f = lambda t, b: F.batch_norm(t, b[2].double(), b[3].double(), b[0].double(), b[1].double(), False, 0.0, eps)
+    ref = f(F.conv2d(xd, w3.double(), None, stride, 1, 1, groups), b3) + f(F.conv2d(xd, w1.double(), None, stride, 0, 1, groups), b1)
+    if identity:
+        ref = ref + f(xd, bi)
+    ref = F.relu(ref)
+    cu = lambda b: [t.cuda() for t in b] if b is not None else None
+    w_eq, ones, b_eq = K.repvgg_fuse(K.to_filter_layout(w3.cuda()), K.to_filter_layout(w1.cuda()), cu(b3), cu(b1), cu(bi), eps)
+    y = K.conv2d_fwd_affine(nhwc(x), w_eq, ones, b_eq, "relu", None, False, stride, 1, groups)
+    assert rel(from_nhwc(y), ref) < 2e-5
+
+
 @pytest.mark.parametrize("n,cin,cout", [(160, 1280, 512), (32, 512, 128), (160, 128, 9), (7, 576, 128), (160, 40, 960)])
 def test_linear(K, n, cin, cout):
     g = torch.Generator().manual_seed(n + cin)
