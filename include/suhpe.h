@@ -123,6 +123,13 @@ int suhpe_conv2d_wgrad_partial(const suhpe_conv_t* d, const float* x, const floa
                                int64_t workspace_bytes, suhpe_stream_t stream);
 int suhpe_conv2d_wgrad_reduce(const suhpe_conv_t* d, const void* workspace, float* dw, int accumulate,
                               suhpe_stream_t stream);
+/* Deferred form for a whole backward pass: every layer runs suhpe_conv2d_wgrad_partial into its own slab buffer, then ONE
+ * launch reduces them all (dw[i] += sum over splits, same fixed order: bit-identical to suhpe_conv2d_wgrad_reduce with
+ * accumulate = 1).  jobs_dev: njobs records of four 64-bit words (slab pointer, dw pointer, element count, splits =
+ * suhpe_conv2d_wgrad_splits(d)); chunk_start_dev[njobs + 1]: prefix sum of ceil(count / 1024) per job. */
+int suhpe_conv2d_wgrad_splits(const suhpe_conv_t* d);
+int suhpe_wgrad_reduce_batched(const void* jobs_dev, const int64_t* chunk_start_dev, int njobs, int64_t total_chunks,
+                               suhpe_stream_t stream);
 /* depthwise 3x3 (groups == cin == cout, cin % 4 == 0); w in torch layout [c][r*s] */
 int suhpe_dwconv_fwd(const suhpe_conv_t* d, const float* x, const float* w, float* y, suhpe_stream_t stream);
 int suhpe_dwconv_dgrad(const suhpe_conv_t* d, const float* dy, const float* w, float* dx, suhpe_stream_t stream);

@@ -793,13 +793,50 @@ void igemm_tn_kernel(const TnParams p) {
     }
 }
 
+// sum_z slab[z][i] in the fixed order z = 0, 1, 2, ...; eight loads are issued before the first add (the adds stay sequential)
+__device__ __forceinline__ float slab_sum(const float* __restrict__ slab, int64_t splits, int64_t count, int64_t i) {
+    float s = 0.f;
+    int64_t z = 0;
+    for (; z + 8 <= splits; z += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = slab[(z + u) * count + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; z < splits; ++z) s += slab[z * count + i];
+    return s;
+}
+
 // dw[i] (+)= sum_z slab[z][i], fixed order
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int splits, int64_t count, float* __restrict__ dw,
                                                           int accumulate) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int z = 0; z < splits; ++z) s += slab[(int64_t)z * count + i];
+        const float s = slab_sum(slab, splits, count, i);
         dw[i] = accumulate ? dw[i] + s : s;
+    }
+}
+
+// The same reduction for a whole backward pass in one launch: jobs[j] = (slab, dw, count, splits), chunk_start[j] = first
+// 1024-element chunk of job j (chunk_start[njobs] = total).  A workgroup takes one chunk: binary search for its job, then
+// dw[i] += sum_z slab[z][i] in the same fixed order as slab_reduce_kernel (bit-identical to reducing layer by layer).
+struct SlabJob { const float* slab; float* dw; int64_t count; int64_t splits; };
+constexpr int kSlabChunk = 1024;
+__global__ __launch_bounds__(256) void slab_reduce_batched_kernel(const SlabJob* __restrict__ jobs, const int64_t* __restrict__ chunk_start,
+                                                                  int njobs) {
+    const int64_t chunk = blockIdx.x;
+    int lo = 0, hi = njobs;                         // largest j with chunk_start[j] <= chunk
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (chunk_start[mid] <= chunk) lo = mid; else hi = mid;
+    }
+    const SlabJob jb = jobs[lo];
+    const int64_t base = (chunk - chunk_start[lo]) * kSlabChunk;
+#pragma unroll
+    for (int u = 0; u < kSlabChunk / 256; ++u) {
+        const int64_t i = base + u * 256 + threadIdx.x;
+        if (i >= jb.count) break;
+        jb.dw[i] += slab_sum(jb.slab, jb.splits, jb.count, i);
     }
 }
 
@@ -1124,7 +1161,8 @@ static int wgrad_splits(const suhpe_conv_t* d, int bm, int bn) {
     const int ng = d->cout / d->groups, K = d->r * d->s * (d->cin / d->groups);
     const int64_t M = (int64_t)d->n * d->ho * d->wo;
     const int64_t tiles = ceil_div(ng, bm) * ceil_div(K, bn) * d->groups;
-    int64_t splits = ceil_div(768, tiles);
+    static const int target_blocks = getenv("SUHPE_WGRAD_BLOCKS") ? atoi(getenv("SUHPE_WGRAD_BLOCKS")) : 768;   // experiment knob
+    int64_t splits = ceil_div(target_blocks, tiles);
     const int64_t max_by_m = ceil_div(M, 16 * BK);          // at least 512 rows per split
     if (splits > max_by_m) splits = max_by_m;
     const int64_t slab = (int64_t)d->cout * K * 4;
@@ -1239,6 +1277,20 @@ int suhpe_conv2d_wgrad_reduce(const suhpe_conv_t* d, const void* workspace, floa
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(count, 256)), dim3(256), 0, as_stream(stream), static_cast<const float*>(workspace),
                        splits, count, dw, accumulate);
     return check_launch("suhpe_conv2d_wgrad_reduce");
+}
+
+int suhpe_conv2d_wgrad_splits(const suhpe_conv_t* d) {
+    if (!d || d->groups <= 0) return 0;
+    int bm, bn;
+    wgrad_tile(d, &bm, &bn);
+    return wgrad_splits(d, bm, bn);
+}
+
+int suhpe_wgrad_reduce_batched(const void* jobs_dev, const int64_t* chunk_start_dev, int njobs, int64_t total_chunks, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(jobs_dev && chunk_start_dev && njobs > 0 && total_chunks > 0 && total_chunks < (1LL << 31), "suhpe_wgrad_reduce_batched: bad arguments");
+    hipLaunchKernelGGL(slab_reduce_batched_kernel, dim3((unsigned)total_chunks), dim3(256), 0, as_stream(stream), static_cast<const SlabJob*>(jobs_dev),
+                       chunk_start_dev, njobs);
+    return check_launch("suhpe_wgrad_reduce_batched");
 }
 
 int suhpe_conv2d_wgrad(const suhpe_conv_t* d, const float* x, const float* dy, float* dw, int accumulate, void* workspace,

@@ -305,6 +305,57 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, groups=1):
     return dx
 
 
+# Deferred filter-gradient reduction: inside `with deferred_wgrads():` (one backward pass, layers.NetFunction) every dense
+# wgrad keeps its split-K slabs in a buffer of its own and ONE launch at the end adds them all into the gradients
+# (162 small reductions per step become 2).  Same summation order as the immediate form: bit-identical results.
+_DEFER = None
+
+
+class deferred_wgrads:
+    def __enter__(self):
+        global _DEFER
+        self.outer, _DEFER = _DEFER, (_DEFER if _DEFER is not None else [])
+        return self
+
+    def __exit__(self, *exc):
+        global _DEFER
+        jobs, _DEFER = _DEFER, self.outer
+        if self.outer is None and jobs and exc[0] is None:
+            flush_wgrads(jobs)
+
+
+_flush_ring = []          # pinned staging buffers for the job tables: (table, starts, event), used round-robin
+_flush_turn = 0
+
+
+def flush_wgrads(jobs):
+    global _flush_turn
+    dev = jobs[0][0].device
+    n = len(jobs)
+    if len(_flush_ring) < 4:
+        _flush_ring.append([torch.empty((1024, 4), dtype=torch.int64).pin_memory(), torch.empty(1025, dtype=torch.int64).pin_memory(), None])
+    slot = _flush_ring[_flush_turn % len(_flush_ring)]
+    _flush_turn += 1
+    if slot[2] is not None:
+        slot[2].synchronize()                       # the upload that last used this staging buffer has run (normally long ago)
+    assert n <= 1024
+    table, starts = slot[0], slot[1]
+    total = 0
+    rows, st = [], []
+    for slab, out, count, splits in jobs:
+        rows.append((slab.data_ptr(), out.data_ptr(), count, splits))
+        st.append(total)
+        total += (count + 1023) // 1024
+    st.append(total)
+    table[:n] = torch.tensor(rows, dtype=torch.int64)
+    starts[:n + 1] = torch.tensor(st, dtype=torch.int64)
+    table_d, starts_d = table[:n].to(dev, non_blocking=True), starts[:n + 1].to(dev, non_blocking=True)
+    slot[2] = torch.cuda.Event()
+    slot[2].record()
+    call("suhpe_wgrad_reduce_batched", ptr(table_d), ptr(starts_d), n, total)
+    jobs.clear()                                     # the slabs go back to the caching allocator (same stream: safe to reuse)
+
+
 def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, groups=1, out=None, accumulate=False):
     """Filter gradient in the filter's physical layout.  out: tensor with the filter's shape/strides."""
     _chk(x, "x"); _chk(dy, "dy")
@@ -327,10 +378,14 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, groups=1, out=None, accumulate
                      ptr(workspace("wgrad", nb, x.device)), nb)
             _autotune(d, 2, trial)
         nbytes = lib.suhpe_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
-        ws = workspace("wgrad", nbytes, x.device)
+        defer = _DEFER is not None and accumulate
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if defer else workspace("wgrad", nbytes, x.device)
         with _Prof(d, 2):           # the profile brackets the split-K GEMM launch alone
             call("suhpe_conv2d_wgrad_partial", ctypes.byref(d), ptr(x), ptr(dy), ptr(ws), nbytes)
-        call("suhpe_conv2d_wgrad_reduce", ctypes.byref(d), ptr(ws), ptr(out), int(accumulate))
+        if defer:
+            _DEFER.append((ws, out, out.numel(), lib.suhpe_conv2d_wgrad_splits(ctypes.byref(d))))
+        else:
+            call("suhpe_conv2d_wgrad_reduce", ctypes.byref(d), ptr(ws), ptr(out), int(accumulate))
     return out
 
 

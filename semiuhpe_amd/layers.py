@@ -410,7 +410,8 @@ class NetFunction(torch.autograd.Function):
     def backward(ctx, dy):
         net, tape = ctx.net, ctx.tape
         ctx.tape = None
-        net.bwd(dy.contiguous(), tape)
+        with K.deferred_wgrads():               # the split-K slabs of every layer are reduced by one launch at the end
+            net.bwd(dy.contiguous(), tape)
         assert len(tape) == 0, "backward did not consume the whole tape"
         return None, None, None
 

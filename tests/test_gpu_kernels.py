@@ -124,6 +124,30 @@ def test_tile_menu_every_pinned_tile_matches(K, cfg):
             lib.suhpe_conv2d_set_tile(ctypes.byref(d), pid, -1)
 
 
+def test_deferred_wgrad_reduction_is_bit_identical(K):
+    """kernels.deferred_wgrads: one batched slab reduction at the end of a backward pass == the layer-by-layer reductions"""
+    g = torch.Generator().manual_seed(3)
+    cases = []
+    for (n, cin, cout, k, stride, pad, groups, h, w) in [(6, 48, 192, 3, 1, 1, 1, 28, 28), (40, 160, 960, 1, 1, 0, 1, 14, 14), (4, 64, 128, 3, 2, 1, 1, 30, 30),
+                                                         (2, 128, 128, 3, 1, 1, 2, 14, 14), (16, 512, 128, 1, 1, 0, 1, 1, 1)]:
+        x = nhwc(torch.randn(n, cin, h, w, generator=g))
+        wshape = (cout, cin // groups, k, k)
+        ho = (h + 2 * pad - k) // stride + 1
+        dy = torch.randn(n, ho, ho, cout, generator=g).cuda()
+        g0 = K.to_filter_layout(torch.randn(wshape, generator=g).cuda())
+        cases.append((x, dy, wshape, stride, pad, groups, g0))
+    ref = []
+    for x, dy, wshape, stride, pad, groups, g0 in cases:
+        ref.append(K.conv2d_wgrad(x, dy, wshape, stride, pad, groups, out=g0.clone(), accumulate=True))
+    outs = [c[6].clone() for c in cases]
+    with K.deferred_wgrads():
+        for (x, dy, wshape, stride, pad, groups, _), o in zip(cases, outs):
+            K.conv2d_wgrad(x, dy, wshape, stride, pad, groups, out=o, accumulate=True)
+        assert not torch.equal(outs[0], ref[0])            # nothing reduced yet
+    for o, r in zip(outs, ref):
+        assert torch.equal(o, r)
+
+
 STAT_CONVS = [c for c in CONVS if not (c[6] > 1 and c[6] == c[1] == c[2])] + [
     (1, 24, 24, 3, 1, 1, 1, 5, 5),         # a single ragged row tile
     (160, 24, 24, 3, 1, 1, 1, 28, 28),     # many row tiles, narrow output (256x32 / 128x32 tiles)
