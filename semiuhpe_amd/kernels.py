@@ -289,6 +289,23 @@ def bn_stats_from_partials(part, tiles, rows, c, eps, momentum, running_mean=Non
     return mean, rstd
 
 
+# Transposed filters for the input-gradient GEMM are rebuilt per call, unless the caller declares the weights constant for a
+# while: inside `with filter_cache():` (SSLAgent wraps the backward of a step, where two student passes share the weights)
+# a layer's transposed filter is built once and reused.
+_WT_CACHE = None
+
+
+class filter_cache:
+    def __enter__(self):
+        global _WT_CACHE
+        self.outer, _WT_CACHE = _WT_CACHE, (_WT_CACHE if _WT_CACHE is not None else {})
+        return self
+
+    def __exit__(self, *exc):
+        global _WT_CACHE
+        _WT_CACHE = self.outer
+
+
 def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, groups=1):
     _chk(dy, "dy")
     d = conv_desc(x_shape, w.shape, stride, pad, groups)
@@ -296,8 +313,14 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, groups=1):
     if _is_depthwise(d) and d.cin % 4 == 0:
         _dw_dgrad(d, dy, w, dx)
     else:
-        wt = workspace("wt", w.numel() * 4, dy.device)
-        call("suhpe_conv2d_transpose_filter", ctypes.byref(d), ptr(w), ptr(wt))
+        key = (w.data_ptr(), d.cin, d.cout, d.r, d.s, d.groups)
+        wt = _WT_CACHE.get(key) if _WT_CACHE is not None else None
+        if wt is None:
+            if _WT_CACHE is not None:
+                wt = _WT_CACHE[key] = torch.empty(w.numel() * 4, dtype=torch.uint8, device=dy.device)
+            else:
+                wt = workspace("wt", w.numel() * 4, dy.device)
+            call("suhpe_conv2d_transpose_filter", ctypes.byref(d), ptr(w), ptr(wt))
         if AUTOTUNE:
             _autotune(d, 1, lambda: call("suhpe_conv2d_dgrad", ctypes.byref(d), ptr(dy), ptr(wt), ptr(dx)))
         with _Prof(d, 1):

@@ -216,7 +216,8 @@ class SSLAgent:
         SSL_lambda = self.config.SSL_lambda
         loss_all = _Axpby.apply(fisher_dict["loss"].reshape(1), fisher_dict_unsuper["unsuper_loss"].reshape(1),
                                 float(SSL_lambda)).squeeze(0)
-        loss_all.backward(self._grad_seed)
+        with K.filter_cache():                      # both student passes differentiate through the same weights
+            loss_all.backward(self._grad_seed)
         self._exchange()
         self.optimizer.step()
         return fisher_dict, fisher_dict_unsuper, dict(SSL_lambda=SSL_lambda, loss_all=loss_all.detach())
