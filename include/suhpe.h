@@ -136,6 +136,15 @@ int suhpe_dwconv_dgrad(const suhpe_conv_t* d, const float* dy, const float* w, f
 int64_t suhpe_dwconv_wgrad_workspace_bytes(const suhpe_conv_t* d);
 int suhpe_dwconv_wgrad(const suhpe_conv_t* d, const float* x, const float* dy, float* dw, int accumulate,
                        void* workspace, int64_t workspace_bytes, suhpe_stream_t stream);
+/* The same depthwise forward / filter gradient with the producer's BatchNorm + activation applied while loading the input:
+ * x is the raw output of the preceding conv, the kernels use act(gamma*(x-mean)*rstd + beta) (zero at padding taps), so the
+ * normalised tensor of an MBConv's expand conv never exists in memory (torchvision MBConv: Conv2dNormActivation 1x1 ->
+ * Conv2dNormActivation depthwise).  gamma / beta may be NULL. */
+int suhpe_dwconv_bnact_fwd(const suhpe_conv_t* d, const float* x, const float* mean, const float* rstd, const float* gamma,
+                           const float* beta, int act, const float* w, float* y, suhpe_stream_t stream);
+int suhpe_dwconv_bnact_wgrad(const suhpe_conv_t* d, const float* x, const float* mean, const float* rstd, const float* gamma,
+                             const float* beta, int act, const float* dy, float* dw, int accumulate, void* workspace,
+                             int64_t workspace_bytes, suhpe_stream_t stream);
 /* db[c] (+)= sum over rows of dy (rows, c) */
 int suhpe_bias_grad(const float* dy, int64_t rows, int c, float* db, int accumulate, void* workspace,
                     suhpe_stream_t stream);   /* workspace >= suhpe_bn_workspace_bytes(c) */

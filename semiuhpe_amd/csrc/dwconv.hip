@@ -22,6 +22,31 @@ struct DwGeom {
     int64_t pix_per_block;
 };
 
+// Optional input transform of the forward / filter-gradient kernels: the depthwise conv of an MBConv reads the expand
+// conv's raw output x and applies that conv's BatchNorm + activation while loading, v -> act(v*sc[c] + sh[c]) with
+// sc = gamma*rstd, sh = beta - mean*sc, so the normalised tensor is never written to or read from HBM.  Padding taps stay 0
+// (the padding is applied to the activated tensor).  mean == NULL: no transform.
+struct DwXform { const float* mean; const float* rstd; const float* gamma; const float* beta; int act; };
+struct DwXf4 { float sc[4], sh[4]; int act; bool on; };
+__device__ __forceinline__ DwXf4 dw_xf_load(const DwXform& xf, int ch) {
+    DwXf4 r;
+    r.on = xf.mean != nullptr;
+    r.act = xf.act;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const float g = (r.on && xf.gamma) ? xf.gamma[ch + v] : 1.f, b = (r.on && xf.beta) ? xf.beta[ch + v] : 0.f;
+        r.sc[v] = r.on ? xf.rstd[ch + v] * g : 1.f;
+        r.sh[v] = r.on ? b - xf.mean[ch + v] * r.sc[v] : 0.f;
+    }
+    return r;
+}
+template <bool XF>
+__device__ __forceinline__ float4 dw_xf(const DwXf4& t, float4 v) {
+    if (!XF) return v;
+    return make_float4(act_apply(v.x * t.sc[0] + t.sh[0], t.act), act_apply(v.y * t.sc[1] + t.sh[1], t.act),
+                       act_apply(v.z * t.sc[2] + t.sh[2], t.act), act_apply(v.w * t.sc[3] + t.sh[3], t.act));
+}
+
 __device__ __forceinline__ bool dw_coord(const DwGeom& g, int o, int tap, int extent, int* out) {
     if (g.mode == 0) {
         const int v = o * g.stride - g.pad + tap;
@@ -37,8 +62,9 @@ __device__ __forceinline__ bool dw_coord(const DwGeom& g, int o, int tap, int ex
 }
 
 // y[p][c] = sum_taps G[gather(p,tap)][c] * w[c][tap]
+template <bool XF>
 __global__ __launch_bounds__(256) void dw_conv_kernel(const DwGeom g, const float* __restrict__ src, const float* __restrict__ w,
-                                                      float* __restrict__ dst) {
+                                                      float* __restrict__ dst, const DwXform xform) {
     __shared__ __attribute__((aligned(16))) float wl[kMaxTaps * 256 * 4];
     const int t = threadIdx.x, col = t % g.cw, rsub = t / g.cw;
     const int cv = g.C / 4, col0 = blockIdx.y * g.cw;
@@ -51,6 +77,7 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const DwGeom g, const floa
     }
     __syncthreads();
     if (rsub >= g.rp || col0 + col >= cv) return;
+    const DwXf4 xf = dw_xf_load(xform, (col0 + col) * 4);
     const int64_t p0 = (int64_t)blockIdx.x * g.pix_per_block;
     int64_t p1 = p0 + g.pix_per_block;
     if (p1 > g.P) p1 = g.P;
@@ -65,7 +92,7 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const DwGeom g, const floa
             for (int s = 0; s < g.S; ++s) {
                 int gw;
                 if (!dw_coord(g, ow, s, g.GW, &gw)) continue;
-                const float4 xv = *reinterpret_cast<const float4*>(src + (((int64_t)n * g.GH + gh) * g.GW + gw) * g.C + (col0 + col) * 4);
+                const float4 xv = dw_xf<XF>(xf, *reinterpret_cast<const float4*>(src + (((int64_t)n * g.GH + gh) * g.GW + gw) * g.C + (col0 + col) * 4));
                 const float4 wv = *reinterpret_cast<const float4*>(&wl[((r * g.S + s) * g.cw + col) * 4]);
                 acc.x += xv.x * wv.x; acc.y += xv.y * wv.y; acc.z += xv.z * wv.z; acc.w += xv.w * wv.w;
             }
@@ -86,8 +113,18 @@ __device__ __forceinline__ void fma4(float4& a, const float4& x, const float4& w
     a.x += x.x * w.x; a.y += x.y * w.y; a.z += x.z * w.z; a.w += x.w * w.w;
 }
 
+template <bool XF>
+__device__ __forceinline__ float4 ld4_xf(const float* __restrict__ base, bool ok, int64_t off, const DwXf4& xf) {
+    float4 v = *reinterpret_cast<const float4*>(base + (ok ? off : 0));
+    v = dw_xf<XF>(xf, v);
+    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    return v;
+}
+
+template <bool XF>
 __global__ __launch_bounds__(256) void dw3x3_row_kernel(const float* __restrict__ src, const float* __restrict__ w, float* __restrict__ dst,
-                                                        int N, int H, int W, int OH, int OW, int C, int stride, int flip, int cw, int rp) {
+                                                        int N, int H, int W, int OH, int OW, int C, int stride, int flip, int cw, int rp,
+                                                        const DwXform xform) {
     __shared__ __attribute__((aligned(16))) float wl[9 * 256 * 4];
     const int t = threadIdx.x, col = t % cw, rsub = t / cw;
     const int cv = C / 4, col0 = blockIdx.y * cw;
@@ -102,6 +139,7 @@ __global__ __launch_bounds__(256) void dw3x3_row_kernel(const float* __restrict_
 #pragma unroll
     for (int k = 0; k < 9; ++k) wv[k] = *reinterpret_cast<const float4*>(&wl[(k * cw + col) * 4]);
     const int coff = (col0 + col) * 4;
+    const DwXf4 xf = dw_xf_load(xform, coff);
     for (int row = blockIdx.x * rp + rsub; row < N * OH; row += gridDim.x * rp) {
         const int n = row / OH, oh = row - n * OH;
         const int ih0 = oh * stride - 1;
@@ -114,7 +152,7 @@ __global__ __launch_bounds__(256) void dw3x3_row_kernel(const float* __restrict_
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             x[r][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-            x[r][2] = ld4_or_zero(src, rok[r], rbase[r]);                      // iw = 0
+            x[r][2] = ld4_xf<XF>(src, rok[r], rbase[r], xf);                      // iw = 0
         }
         for (int ow = 0; ow < OW; ++ow) {
             const int iw0 = ow * stride - 1;                                    // window columns iw0, iw0+1, iw0+2
@@ -122,15 +160,15 @@ __global__ __launch_bounds__(256) void dw3x3_row_kernel(const float* __restrict_
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     x[r][0] = x[r][1]; x[r][1] = x[r][2];
-                    x[r][2] = ld4_or_zero(src, rok[r] && iw0 + 2 < W, rbase[r] + (int64_t)(iw0 + 2) * C);
+                    x[r][2] = ld4_xf<XF>(src, rok[r] && iw0 + 2 < W, rbase[r] + (int64_t)(iw0 + 2) * C, xf);
                 }
             } else {
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     x[r][0] = ow == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : x[r][2];
-                    if (ow > 0) x[r][1] = ld4_or_zero(src, rok[r] && iw0 + 1 < W, rbase[r] + (int64_t)(iw0 + 1) * C);
+                    if (ow > 0) x[r][1] = ld4_xf<XF>(src, rok[r] && iw0 + 1 < W, rbase[r] + (int64_t)(iw0 + 1) * C, xf);
                     else x[r][1] = x[r][2];
-                    x[r][2] = ld4_or_zero(src, rok[r] && iw0 + 2 < W, rbase[r] + (int64_t)(iw0 + 2) * C);
+                    x[r][2] = ld4_xf<XF>(src, rok[r] && iw0 + 2 < W, rbase[r] + (int64_t)(iw0 + 2) * C, xf);
                 }
             }
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -148,8 +186,9 @@ __global__ __launch_bounds__(256) void dw3x3_row_kernel(const float* __restrict_
 // FETCH_SIZE measured 2.7x the input).  Padding taps read zero through the buffer descriptor's bounds check, and the
 // column ahead is loaded one step early (the wait lands at its first use).
 constexpr int kDwRows = 4;
+template <bool XF>
 __global__ __launch_bounds__(256) void dw3x3_s1_kernel(const float* __restrict__ src, int64_t src_bytes, const float* __restrict__ w,
-                                                       float* __restrict__ dst, int N, int H, int W, int C, int flip, int cw, int rp) {
+                                                       float* __restrict__ dst, int N, int H, int W, int C, int flip, int cw, int rp, const DwXform xform) {
     __shared__ __attribute__((aligned(16))) float wl[9 * 256 * 4];
     const int t = threadIdx.x, col = t % cw, rsub = t / cw;
     const int cv = C / 4, col0 = blockIdx.y * cw;
@@ -165,6 +204,7 @@ __global__ __launch_bounds__(256) void dw3x3_s1_kernel(const float* __restrict__
     for (int k = 0; k < 9; ++k) wv[k] = *reinterpret_cast<const float4*>(&wl[(k * cw + col) * 4]);
     const BufRsrc sr = make_rsrc(src, src_bytes);
     const unsigned coff = (unsigned)(col0 + col) * 16u, pix = (unsigned)C * 4u;       // byte offsets
+    const DwXf4 xf = dw_xf_load(xform, (col0 + col) * 4);
     const int groups_h = (H + kDwRows - 1) / kDwRows;                                  // row groups per image
     for (int rg = blockIdx.x * rp + rsub; rg < N * groups_h; rg += gridDim.x * rp) {
         const int n = rg / groups_h, oh0 = (rg - n * groups_h) * kDwRows;
@@ -180,6 +220,14 @@ __global__ __launch_bounds__(256) void dw3x3_s1_kernel(const float* __restrict__
         auto ld = [&](int r, int p, int c) __attribute__((always_inline)) {
             buf_load<4>(sr, (rok[r] & ((unsigned)c < (unsigned)W)) ? rbase[r] + (unsigned)c * pix : kOob, x[r][p]);
         };
+        // the input transform is applied when a loaded column enters the window (one step after its load was issued, so the
+        // wait still lands late); padding taps (row or column outside) stay zero
+        auto enter = [&](int r, int p, int c) __attribute__((always_inline)) {
+            if (!XF) return;
+            const bool ok = rok[r] & ((unsigned)c < (unsigned)W);
+            const float4 v = dw_xf<XF>(xf, make_float4(x[r][p][0], x[r][p][1], x[r][p][2], x[r][p][3]));
+            x[r][p][0] = ok ? v.x : 0.f; x[r][p][1] = ok ? v.y : 0.f; x[r][p][2] = ok ? v.z : 0.f; x[r][p][3] = ok ? v.w : 0.f;
+        };
 #pragma unroll
         for (int r = 0; r < kDwRows + 2; ++r) {
 #pragma unroll
@@ -187,11 +235,14 @@ __global__ __launch_bounds__(256) void dw3x3_s1_kernel(const float* __restrict__
             ld(r, 2, 0);
             ld(r, 3, 1);
         }
+#pragma unroll
+        for (int r = 0; r < kDwRows + 2; ++r) enter(r, 2, 0);
         for (int ow = 0; ow < W; ++ow) {
 #pragma unroll
             for (int r = 0; r < kDwRows + 2; ++r) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v) { x[r][0][v] = x[r][1][v]; x[r][1][v] = x[r][2][v]; x[r][2][v] = x[r][3][v]; }
+                enter(r, 2, ow + 1);
                 ld(r, 3, ow + 2);                            // needed at the next step
             }
 #pragma unroll
@@ -213,8 +264,9 @@ __global__ __launch_bounds__(256) void dw3x3_s1_kernel(const float* __restrict__
 }
 
 // filter-gradient partials with the same sliding window: part[bx][tap][c]
+template <bool XF>
 __global__ __launch_bounds__(256) void dw3x3_wgrad_row_kernel(const float* __restrict__ x_, const float* __restrict__ dy, float* __restrict__ part,
-                                                              int N, int H, int W, int OH, int OW, int C, int stride, int cw, int rp) {
+                                                              int N, int H, int W, int OH, int OW, int C, int stride, int cw, int rp, const DwXform xform) {
     __shared__ __attribute__((aligned(16))) float red[kMaxTaps * 256 * 4];
     const int t = threadIdx.x, col = t % cw, rsub = t / cw;
     const int cv = C / 4, col0 = blockIdx.y * cw;
@@ -223,6 +275,7 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_row_kernel(const float* __res
     for (int k = 0; k < 9; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (rsub < rp && col0 + col < cv) {
         const int coff = (col0 + col) * 4;
+        const DwXf4 xf = dw_xf_load(xform, coff);
         for (int row = blockIdx.x * rp + rsub; row < N * OH; row += gridDim.x * rp) {
             const int n = row / OH, oh = row - n * OH;
             const int ih0 = oh * stride - 1;
@@ -232,22 +285,22 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_row_kernel(const float* __res
             for (int r = 0; r < 3; ++r) { const int ih = ih0 + r; rok[r] = ih >= 0 && ih < H; rbase[r] = ((int64_t)n * H + ih) * W * C + coff; }
             float4 x[3][3];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) { x[r][1] = make_float4(0.f, 0.f, 0.f, 0.f); x[r][2] = ld4_or_zero(x_, rok[r], rbase[r]); }
+            for (int r = 0; r < 3; ++r) { x[r][1] = make_float4(0.f, 0.f, 0.f, 0.f); x[r][2] = ld4_xf<XF>(x_, rok[r], rbase[r], xf); }
             for (int ow = 0; ow < OW; ++ow) {
                 const int iw0 = ow * stride - 1;
                 if (stride == 1) {
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
                         x[r][0] = x[r][1]; x[r][1] = x[r][2];
-                        x[r][2] = ld4_or_zero(x_, rok[r] && iw0 + 2 < W, rbase[r] + (int64_t)(iw0 + 2) * C);
+                        x[r][2] = ld4_xf<XF>(x_, rok[r] && iw0 + 2 < W, rbase[r] + (int64_t)(iw0 + 2) * C, xf);
                     }
                 } else {
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
                         x[r][0] = ow == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : x[r][2];
-                        if (ow > 0) x[r][1] = ld4_or_zero(x_, rok[r] && iw0 + 1 < W, rbase[r] + (int64_t)(iw0 + 1) * C);
+                        if (ow > 0) x[r][1] = ld4_xf<XF>(x_, rok[r] && iw0 + 1 < W, rbase[r] + (int64_t)(iw0 + 1) * C, xf);
                         else x[r][1] = x[r][2];
-                        x[r][2] = ld4_or_zero(x_, rok[r] && iw0 + 2 < W, rbase[r] + (int64_t)(iw0 + 2) * C);
+                        x[r][2] = ld4_xf<XF>(x_, rok[r] && iw0 + 2 < W, rbase[r] + (int64_t)(iw0 + 2) * C, xf);
                     }
                 }
                 const float4 dv = *reinterpret_cast<const float4*>(dy + ((int64_t)row * OW + ow) * C + coff);
@@ -274,8 +327,9 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_row_kernel(const float* __res
 }
 
 // partial filter gradient: part[bx][tap][c] = sum over the block's pixels of dy[p][c] * x[gather(p,tap)][c]
+template <bool XF>
 __global__ __launch_bounds__(256) void dw_wgrad_partial(const DwGeom g, const float* __restrict__ x, const float* __restrict__ dy,
-                                                        float* __restrict__ part) {
+                                                        float* __restrict__ part, const DwXform xform) {
     __shared__ __attribute__((aligned(16))) float red[kMaxTaps * 256 * 4];
     const int t = threadIdx.x, col = t % g.cw, rsub = t / g.cw;
     const int cv = g.C / 4, col0 = blockIdx.y * g.cw;
@@ -284,6 +338,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_partial(const DwGeom g, const fl
 #pragma unroll
     for (int i = 0; i < kMaxTaps; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (rsub < g.rp && col0 + col < cv) {
+        const DwXf4 xf = dw_xf_load(xform, (col0 + col) * 4);
         const int64_t p0 = (int64_t)blockIdx.x * g.pix_per_block;
         int64_t p1 = p0 + g.pix_per_block;
         if (p1 > g.P) p1 = g.P;
@@ -298,7 +353,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_partial(const DwGeom g, const fl
                 int gh = 0, gw = 0;
                 const bool ok = tap < taps && dw_coord(g, oh, r, g.GH, &gh) && dw_coord(g, ow, s, g.GW, &gw);
                 if (ok) {
-                    const float4 xv = *reinterpret_cast<const float4*>(x + (((int64_t)n * g.GH + gh) * g.GW + gw) * g.C + (col0 + col) * 4);
+                    const float4 xv = dw_xf<XF>(xf, *reinterpret_cast<const float4*>(x + (((int64_t)n * g.GH + gh) * g.GW + gw) * g.C + (col0 + col) * 4));
                     acc[tap].x += dv.x * xv.x; acc[tap].y += dv.y * xv.y; acc[tap].z += dv.z * xv.z; acc[tap].w += dv.w * xv.w;
                 }
             }
@@ -382,12 +437,20 @@ static void dw_row_grid(int C, int rows, int max_gx, int* cw, int* rp, int* gx, 
 
 using namespace suhpe;
 
+// the input transform is a template flag: the plain kernels carry none of its registers or code
+#define DW_LAUNCH(kern, grid, block, lds, st, ...)                                                       \
+    do {                                                                                                 \
+        if (DW_XF_ON) hipLaunchKernelGGL((kern<true>), grid, block, lds, st, __VA_ARGS__);               \
+        else hipLaunchKernelGGL((kern<false>), grid, block, lds, st, __VA_ARGS__);                       \
+    } while (0)
+
 extern "C" {
 
-int suhpe_dwconv_fwd(const suhpe_conv_t* d, const float* x, const float* w, float* y, suhpe_stream_t stream) {
+static int dwconv_fwd_impl(const suhpe_conv_t* d, const float* x, const float* w, float* y, const DwXform& xf, suhpe_stream_t stream) {
     int rc = dw_check(d, "suhpe_dwconv_fwd");
     if (rc) return rc;
     SUHPE_REQUIRE(x && w && y, "suhpe_dwconv_fwd: null pointer");
+    const bool DW_XF_ON = xf.mean != nullptr;
     if (dw_fast(d) && (d->stride == 1 || d->stride == 2)) {
         int cw, rp, gx, ny;
         // the four-row kernel needs enough row groups to fill the chip; small batches keep one output row per thread
@@ -395,39 +458,52 @@ int suhpe_dwconv_fwd(const suhpe_conv_t* d, const float* x, const float* w, floa
                         (int64_t)d->n * ((d->h + kDwRows - 1) / kDwRows) * (d->cin / 4) >= 65536;
         dw_row_grid(d->cin, s1 ? d->n * ((d->h + kDwRows - 1) / kDwRows) : d->n * d->ho, 4096, &cw, &rp, &gx, &ny);
         if (s1)
-            hipLaunchKernelGGL(dw3x3_s1_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), x, (int64_t)d->n * d->h * d->w * d->cin * 4, w, y,
-                               d->n, d->h, d->w, d->cin, 0, cw, rp);
+            DW_LAUNCH(dw3x3_s1_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), x, (int64_t)d->n * d->h * d->w * d->cin * 4, w, y,
+                               d->n, d->h, d->w, d->cin, 0, cw, rp, xf);
         else
-            hipLaunchKernelGGL(dw3x3_row_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), x, w, y, d->n, d->h, d->w, d->ho, d->wo, d->cin,
-                               d->stride, 0, cw, rp);
+            DW_LAUNCH(dw3x3_row_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), x, w, y, d->n, d->h, d->w, d->ho, d->wo, d->cin,
+                               d->stride, 0, cw, rp, xf);
         return check_launch("suhpe_dwconv_fwd");
     }
     const DwGeom g = dw_geom(d, 0, 2048);
     const int gx = (int)ceil_div(g.P, g.pix_per_block), ny = (int)ceil_div(g.C / 4, g.cw);
-    hipLaunchKernelGGL(dw_conv_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), g, x, w, y);
+    DW_LAUNCH(dw_conv_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), g, x, w, y, xf);
     return check_launch("suhpe_dwconv_fwd");
+}
+
+static const DwXform kNoXform{nullptr, nullptr, nullptr, nullptr, 0};
+
+int suhpe_dwconv_fwd(const suhpe_conv_t* d, const float* x, const float* w, float* y, suhpe_stream_t stream) {
+    return dwconv_fwd_impl(d, x, w, y, kNoXform, stream);
+}
+
+int suhpe_dwconv_bnact_fwd(const suhpe_conv_t* d, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                           int act, const float* w, float* y, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(mean && rstd, "suhpe_dwconv_bnact_fwd: mean / rstd required");
+    return dwconv_fwd_impl(d, x, w, y, DwXform{mean, rstd, gamma, beta, act}, stream);
 }
 
 int suhpe_dwconv_dgrad(const suhpe_conv_t* d, const float* dy, const float* w, float* dx, suhpe_stream_t stream) {
     int rc = dw_check(d, "suhpe_dwconv_dgrad");
     if (rc) return rc;
     SUHPE_REQUIRE(dy && w && dx, "suhpe_dwconv_dgrad: null pointer");
+    const bool DW_XF_ON = false;
     if (dw_fast(d) && d->stride == 1) {             // same conv on dy with the 180-degree rotated filter
         int cw, rp, gx, ny;
         const bool s1 = (int64_t)d->n * d->h * d->w * d->cin * 4 < ((int64_t)1 << 31) &&
                         (int64_t)d->n * ((d->h + kDwRows - 1) / kDwRows) * (d->cin / 4) >= 65536;
         dw_row_grid(d->cin, s1 ? d->n * ((d->h + kDwRows - 1) / kDwRows) : d->n * d->h, 4096, &cw, &rp, &gx, &ny);
         if (s1)
-            hipLaunchKernelGGL(dw3x3_s1_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), dy, (int64_t)d->n * d->h * d->w * d->cin * 4, w, dx,
-                               d->n, d->h, d->w, d->cin, 1, cw, rp);
+            DW_LAUNCH(dw3x3_s1_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), dy, (int64_t)d->n * d->h * d->w * d->cin * 4, w, dx,
+                               d->n, d->h, d->w, d->cin, 1, cw, rp, kNoXform);
         else
-            hipLaunchKernelGGL(dw3x3_row_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), dy, w, dx, d->n, d->ho, d->wo, d->h, d->w, d->cin, 1, 1,
-                               cw, rp);
+            DW_LAUNCH(dw3x3_row_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), dy, w, dx, d->n, d->ho, d->wo, d->h, d->w, d->cin, 1, 1,
+                               cw, rp, kNoXform);
         return check_launch("suhpe_dwconv_dgrad");
     }
     const DwGeom g = dw_geom(d, 1, 2048);
     const int gx = (int)ceil_div(g.P, g.pix_per_block), ny = (int)ceil_div(g.C / 4, g.cw);
-    hipLaunchKernelGGL(dw_conv_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), g, dy, w, dx);
+    DW_LAUNCH(dw_conv_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), g, dy, w, dx, kNoXform);
     return check_launch("suhpe_dwconv_dgrad");
 }
 
@@ -436,27 +512,40 @@ int64_t suhpe_dwconv_wgrad_workspace_bytes(const suhpe_conv_t* d) {
     return (int64_t)kDwMaxRowBlocks * d->r * d->s * d->cin * sizeof(float);
 }
 
-int suhpe_dwconv_wgrad(const suhpe_conv_t* d, const float* x, const float* dy, float* dw, int accumulate, void* workspace,
-                       int64_t workspace_bytes, suhpe_stream_t stream) {
+static int dwconv_wgrad_impl(const suhpe_conv_t* d, const float* x, const float* dy, float* dw, int accumulate, void* workspace,
+                             int64_t workspace_bytes, const DwXform& xf, suhpe_stream_t stream) {
     int rc = dw_check(d, "suhpe_dwconv_wgrad");
     if (rc) return rc;
     SUHPE_REQUIRE(x && dy && dw && workspace, "suhpe_dwconv_wgrad: null pointer");
+    const bool DW_XF_ON = xf.mean != nullptr;
     if (workspace_bytes < suhpe_dwconv_wgrad_workspace_bytes(d)) { set_error("suhpe_dwconv_wgrad: workspace too small"); return SUHPE_EWORKSPACE; }
     float* part = static_cast<float*>(workspace);
     const int taps = d->r * d->s;
     if (dw_fast(d) && (d->stride == 1 || d->stride == 2)) {
         int cw, rp, gx, ny;
         dw_row_grid(d->cin, d->n * d->ho, kDwMaxRowBlocks, &cw, &rp, &gx, &ny, 32);
-        hipLaunchKernelGGL(dw3x3_wgrad_row_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), x, dy, part, d->n, d->h, d->w, d->ho, d->wo,
-                           d->cin, d->stride, cw, rp);
+        DW_LAUNCH(dw3x3_wgrad_row_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), x, dy, part, d->n, d->h, d->w, d->ho, d->wo,
+                           d->cin, d->stride, cw, rp, xf);
         hipLaunchKernelGGL(dw_wgrad_finalize, dim3((taps * d->cin + 63) / 64), dim3(256), 0, as_stream(stream), part, gx, taps, d->cin, dw, accumulate);
         return check_launch("suhpe_dwconv_wgrad");
     }
     const DwGeom g = dw_geom(d, 0, kDwMaxRowBlocks, 32);      // narrow channel chunks: more workgroups per slab
     const int gx = (int)ceil_div(g.P, g.pix_per_block), ny = (int)ceil_div(g.C / 4, g.cw);
-    hipLaunchKernelGGL(dw_wgrad_partial, dim3(gx, ny), dim3(256), 0, as_stream(stream), g, x, dy, part);
+    DW_LAUNCH(dw_wgrad_partial, dim3(gx, ny), dim3(256), 0, as_stream(stream), g, x, dy, part, xf);
     hipLaunchKernelGGL(dw_wgrad_finalize, dim3((taps * g.C + 63) / 64), dim3(256), 0, as_stream(stream), part, gx, taps, g.C, dw, accumulate);
     return check_launch("suhpe_dwconv_wgrad");
+}
+
+int suhpe_dwconv_wgrad(const suhpe_conv_t* d, const float* x, const float* dy, float* dw, int accumulate, void* workspace,
+                       int64_t workspace_bytes, suhpe_stream_t stream) {
+    return dwconv_wgrad_impl(d, x, dy, dw, accumulate, workspace, workspace_bytes, kNoXform, stream);
+}
+
+int suhpe_dwconv_bnact_wgrad(const suhpe_conv_t* d, const float* x, const float* mean, const float* rstd, const float* gamma,
+                             const float* beta, int act, const float* dy, float* dw, int accumulate, void* workspace,
+                             int64_t workspace_bytes, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(mean && rstd, "suhpe_dwconv_bnact_wgrad: mean / rstd required");
+    return dwconv_wgrad_impl(d, x, dy, dw, accumulate, workspace, workspace_bytes, DwXform{mean, rstd, gamma, beta, act}, stream);
 }
 
 }  // extern "C"

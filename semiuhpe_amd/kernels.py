@@ -222,6 +222,36 @@ def _dw_fwd(d, x, w, y):
 
 
 @_memop
+def dwconv_bnact_fwd(x, mean, rstd, gamma, beta, act, w, stride=1, pad=1):
+    """depthwise conv of act(BN(x)) without materialising it: x is the producer conv's raw output (N,H,W,C)"""
+    _chk(x, "x")
+    c = x.shape[-1]
+    d = conv_desc(x.shape, w.shape, stride, pad, c)
+    assert _is_depthwise(d) and c % 4 == 0
+    y = torch.empty((d.n, d.ho, d.wo, d.cout), dtype=torch.float32, device=x.device)
+    call("suhpe_dwconv_bnact_fwd", ctypes.byref(d), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ACT[act], ptr(w), ptr(y))
+    return y
+
+
+@_memop
+def dwconv_bnact_wgrad(x, mean, rstd, gamma, beta, act, dy, w_shape, stride=1, pad=1, out=None, accumulate=False):
+    """filter gradient of the depthwise conv whose input is act(BN(x)), recomputed from x while loading"""
+    _chk(x, "x"); _chk(dy, "dy")
+    c = x.shape[-1]
+    d = conv_desc(x.shape, w_shape, stride, pad, c)
+    assert _is_depthwise(d) and c % 4 == 0
+    if out is None:
+        out = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
+        accumulate = False
+    lib = _lib.load()
+    nbytes = lib.suhpe_dwconv_wgrad_workspace_bytes(ctypes.byref(d))
+    ws = workspace("wgrad", nbytes, x.device)
+    call("suhpe_dwconv_bnact_wgrad", ctypes.byref(d), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ACT[act], ptr(dy), ptr(out),
+         int(accumulate), ptr(ws), nbytes)
+    return out
+
+
+@_memop
 def _dw_dgrad(d, dy, w, dx):
     call("suhpe_dwconv_dgrad", ctypes.byref(d), ptr(dy), ptr(w), ptr(dx))
 

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from .. import kernels as K
-from ..layers import (conv_bn_fwd, draw_mask, BatchNorm1d, Conv2d, ConvNormActivation, Dropout, GlobalAvgPool, Identity, Layer, Linear, Network,
+from ..layers import (conv_bn_fwd, draw_mask, grad_of, BatchNorm1d, Conv2d, ConvNormActivation, Dropout, GlobalAvgPool, Identity, Layer, Linear, Network,
                       Sequential, SqueezeExcitation, StochasticDepth)
 
 # (block, expand_ratio, kernel, stride, in, out, layers) — torchvision `_efficientnet_conf("efficientnet_v2_s")`
@@ -24,6 +24,10 @@ V2_S = [
 ]
 LAST_CHANNEL = 1280
 BN_EPS = 1e-3           # torchvision: partial(nn.BatchNorm2d, eps=1e-03) for the V2 family
+# Folding the expand conv's BatchNorm + SiLU into the depthwise loaders removes two passes over the largest activation but
+# makes the depthwise kernels recompute the SiLU 1.5x (forward) to 3x (filter gradient) per element: measured 84.1 vs 79.7
+# ms/step on C2, so it is off; the kernels and their tests stay (memory-saving mode: the expanded tensor is never stored).
+FUSE_EXPAND_BN_INTO_DW = False
 STOCHASTIC_DEPTH_PROB = 0.2
 
 
@@ -38,12 +42,21 @@ class _ResidualBlock(Layer):
     """Shared tail: x + StochasticDepth('row')(block(x)).  The add and the per-sample keep scale run inside the last
     BatchNorm's apply kernel (and its backward), so the skip costs no pass of its own."""
 
+    def _front_fwd(self, x, tape):
+        """every layer of the block but the last"""
+        for layer in list(self.block)[:-1]:
+            x = layer.fwd(x, tape)
+        return x
+
+    def _front_bwd(self, dy, tape):
+        for layer in reversed(list(self.block)[:-1]):
+            dy = layer.bwd(dy, tape)
+        return dy
+
     def fwd(self, x, tape):
         if not self.use_res_connect:
-            return self.block.fwd(x, tape)
-        y = x
-        for layer in list(self.block)[:-1]:
-            y = layer.fwd(y, tape)
+            return self.block[-1].fwd(self._front_fwd(x, tape), tape)
+        y = self._front_fwd(x, tape)
         last = self.block[-1]
         sd = self.stochastic_depth
         rowscale = None
@@ -52,9 +65,8 @@ class _ResidualBlock(Layer):
         return conv_bn_fwd(last[0], last[1], y, tape, residual=x, residual_after_act=True, rowscale=rowscale)
 
     def bwd(self, dy, tape):
-        if not self.use_res_connect:
-            return self.block.bwd(dy, tape)
-        return K.add(self.block.bwd(dy, tape), dy)           # the last BatchNorm's backward applies the keep scale
+        d = self._front_bwd(self.block[-1].bwd(dy, tape), tape)
+        return K.add(d, dy) if self.use_res_connect else d  # (the last BatchNorm's backward applies the keep scale)
 
 
 class FusedMBConv(_ResidualBlock):
@@ -84,6 +96,46 @@ class MBConv(_ResidualBlock):
         layers.append(ConvNormActivation(exp, cout, 1, 1, act="none", bn_eps=BN_EPS))
         self.block = Sequential(*layers)
         self.stochastic_depth = StochasticDepth(sd_prob, "row")
+        self.has_expand = exp != cin
+
+    # The expand conv's BatchNorm + SiLU is applied by the depthwise kernels while they load (suhpe_dwconv_bnact_fwd /
+    # _wgrad): the normalised, 4-6x expanded tensor — the largest activation of the block — is never written or re-read.
+    # Its BatchNorm still gets exact statistics (from the expand conv's epilogue) and an exact backward (from x and dy).
+    def _fusable(self, tape):
+        exp_bn = self.block[0][1]
+        return FUSE_EXPAND_BN_INTO_DW and self.has_expand and self.block[1][0].in_channels % 4 == 0 and self.block[1][0].kernel_size == 3 and (exp_bn.training or tape is not None)
+
+    def _front_fwd(self, x, tape):
+        if not self._fusable(tape):
+            return super()._front_fwd(x, tape)
+        (conv_e, bn_e), (conv_d, bn_d), se = self.block[0], self.block[1], self.block[2]
+        c = bn_e.num_features
+        if bn_e.training:
+            y0, partials = conv_e.fwd_stats(x, tape)
+            mean, rstd = K.bn_stats_from_partials(partials[0], partials[1], y0.numel() // c, c, bn_e.eps, bn_e.momentum, bn_e.running_mean,
+                                                  bn_e.running_var, bn_e.num_batches_tracked)
+        else:
+            y0 = conv_e.fwd(x, tape)
+            mean, rstd = K.bn_eval_stats(bn_e.running_mean, bn_e.running_var, bn_e.eps)
+        if not K.filter_is_physical(conv_d.weight):
+            conv_d.weight.data = K.to_filter_layout(conv_d.weight.data)
+        z = K.dwconv_bnact_fwd(y0, mean, rstd, bn_e.weight, bn_e.bias, bn_e.act, conv_d.weight, conv_d.stride, conv_d.padding)
+        if tape is not None:
+            tape.append((y0, mean, rstd, bn_e.training))
+        return se.fwd(bn_d.fwd(z, tape), tape)
+
+    def _front_bwd(self, dy, tape):
+        if not self._fusable(tape):
+            return super()._front_bwd(dy, tape)
+        (conv_e, bn_e), (conv_d, bn_d), se = self.block[0], self.block[1], self.block[2]
+        dz = bn_d.bwd(se.bwd(dy, tape), tape)
+        y0, mean, rstd, train_stats = tape.pop()
+        K.dwconv_bnact_wgrad(y0, mean, rstd, bn_e.weight, bn_e.bias, bn_e.act, dz, conv_d.weight.shape, conv_d.stride, conv_d.padding,
+                             out=grad_of(conv_d.weight), accumulate=True)
+        d_act = K.conv2d_dgrad(dz, conv_d.weight, y0.shape, conv_d.stride, conv_d.padding, conv_d.groups)
+        dy0 = K.bn_act_bwd(y0, d_act, bn_e.num_features, mean, rstd, bn_e.weight, bn_e.bias, bn_e.act, train_stats, grad_of(bn_e.weight),
+                           grad_of(bn_e.bias), True)
+        return conv_e.bwd(dy0, tape)
 
 
 def regression_head(in_dim, hidden1, hidden2, num_classes):

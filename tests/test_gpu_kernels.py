@@ -124,6 +124,25 @@ def test_tile_menu_every_pinned_tile_matches(K, cfg):
             lib.suhpe_conv2d_set_tile(ctypes.byref(d), pid, -1)
 
 
+@pytest.mark.parametrize("n,c,hw,stride,act", [(8, 96, 14, 1, "silu"), (40, 64, 14, 1, "silu"), (3, 32, 15, 2, "silu"), (2, 24, 9, 1, "gelu"), (64, 128, 7, 1, "silu")])
+def test_depthwise_with_folded_batchnorm_input(K, n, c, hw, stride, act):
+    """suhpe_dwconv_bnact_fwd / _wgrad: depthwise conv (and its filter gradient) of act(BN(x)) computed from x while loading
+    == the unfused bn_act_fwd -> depthwise chain (zero padding applied after the activation)"""
+    g = torch.Generator().manual_seed(n + c)
+    x = (torch.randn(n, hw, hw, c, generator=g) * 1.3 + 0.2).cuda()
+    mean, rstd = K.bn_stats(x, c, 1e-3, 0.1)
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).cuda(), (torch.randn(c, generator=g) * 0.3).cuda()
+    w = K.to_filter_layout((torch.randn(c, 1, 3, 3, generator=g) / 3).cuda())
+    y_act = K.bn_act_fwd(x, c, mean, rstd, gamma, beta, act)
+    ref = K.conv2d_fwd(y_act, w, None, stride, 1, c)
+    out = K.dwconv_bnact_fwd(x, mean, rstd, gamma, beta, act, w, stride, 1)
+    assert rel(out, ref.cpu()) < 2e-6
+    dy = torch.randn(ref.shape, generator=g).cuda()
+    dw_ref = K.conv2d_wgrad(y_act, dy, w.shape, stride, 1, c)
+    dw = K.dwconv_bnact_wgrad(x, mean, rstd, gamma, beta, act, dy, w.shape, stride, 1)
+    assert rel(dw, dw_ref.cpu()) < 2e-5
+
+
 def test_deferred_wgrad_reduction_is_bit_identical(K):
     """kernels.deferred_wgrads: one batched slab reduction at the end of a backward pass == the layer-by-layer reductions"""
     g = torch.Generator().manual_seed(3)
