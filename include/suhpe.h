@@ -102,6 +102,15 @@ int suhpe_conv2d_fwd_affine(const suhpe_conv_t* d, const float* x, const float* 
 int suhpe_conv2d_fwd_stats_tiles(const suhpe_conv_t* d);
 int suhpe_conv2d_fwd_stats(const suhpe_conv_t* d, const float* x, const float* w, float* y, float* stats,
                            suhpe_stream_t stream);
+/* Batch segments: when one launch carries two sub-batches that BatchNorm must normalise separately (the labeled and the
+ * strong-view batch of a training step run as ONE student pass), rows [0, seg_row) are the first segment.  The row tile that
+ * contains the boundary writes its first-segment rows to stats[tile] and the remaining rows to stats_extra[channel]
+ * (cout records); suhpe_conv2d_fwd_stats_tile_rows(d) is the tile height, so the first segment owns records
+ * [0, ceil(seg_row / tile_rows)) and the second stats_extra (if seg_row is not a multiple of the tile height) plus the
+ * records from ceil(seg_row / tile_rows) on: finish each with suhpe_bn_stats_from_partials_range. */
+int suhpe_conv2d_fwd_stats_tile_rows(const suhpe_conv_t* d);
+int suhpe_conv2d_fwd_stats_seg(const suhpe_conv_t* d, const float* x, const float* w, float* y, float* stats, float* stats_extra,
+                               int64_t seg_row, suhpe_stream_t stream);
 /* Tile menu of the GEMM kernels.  pass: 0 forward, 1 input gradient, 2 filter gradient.  A caller that has timed the
  * menu on a shape pins the winner with suhpe_conv2d_set_tile (tile = -1 unpins: back to the built-in heuristic); the
  * pin is process-wide and keyed by the whole descriptor.  Results of pass 0 / 1 do not depend on the tile; pass 2
@@ -179,6 +188,10 @@ int suhpe_bn_stats(const float* x, int64_t rows, int c, float eps, float momentu
 int suhpe_bn_stats_from_partials(const float* part, int gx, int64_t rows, int c, float eps, float momentum, float* mean,
                                  float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                  suhpe_stream_t stream);
+/* the same over records [first, first + count) plus one optional extra record per channel (extra: c records or NULL) */
+int suhpe_bn_stats_from_partials_range(const float* part, int first, int count, const float* extra, int64_t rows, int c, float eps,
+                                       float momentum, float* mean, float* rstd, float* running_mean, float* running_var,
+                                       int64_t* num_batches_tracked, suhpe_stream_t stream);
 /* RepVGG re-parameterisation for eval (src/repvgg.py:104-142 get_equivalent_kernel_bias): 3x3 branch + 1x1 branch + identity
  * BatchNorm -> one 3x3 filter w_eq (layout of w3) and bias b_eq; `ones` (cout) is filled with 1 so that
  * suhpe_conv2d_fwd_affine(d, x, w_eq, ones, b_eq, RELU, ...) is the deploy-mode block.  bn3 / bn1 / bnid are arrays of four

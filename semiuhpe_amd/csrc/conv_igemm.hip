@@ -90,6 +90,9 @@ struct NtParams {
     const float* residual;
     int act, res_mode;
     float* stats;        // optional BatchNorm statistics from the epilogue: records [stat_gx][stat_cout][4] = (S, Q, k, n)
+    float* stats_extra;  // [stat_cout][4]: second record of the one row tile that straddles seg_row (see below), or NULL
+    int64_t seg_row;     // batch segments (two sub-batches normalised separately): rows < seg_row belong to the first; a tile
+                         // that contains the boundary emits its first-segment rows to `stats` and the rest to `stats_extra`
     int stat_cout;       // channels of the whole output (record pitch)
     int stat_gx;         // row tiles = ceil(M / BM)
 };
@@ -343,38 +346,49 @@ void igemm_nt_kernel(const NtParams p) {
             for (int j = 0; j < TN; ++j) kk[wn * WN + j * 32 + r32] = acc[0][j][0];     // row m0 (always valid)
         }
         __syncthreads();
-        const int64_t rows_left = g.M - (m0 + wm * WM);
+        // rows [lo, hi) of the tile (tile-local) -> one record per column at dst0[col]
+        auto emit = [&](int64_t lo, int64_t hi, float4* dst0) __attribute__((always_inline)) {
+            const int64_t wlo = lo - wm * WM, whi = hi - wm * WM;          // in this wave's rows
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const float k = kk[wn * WN + j * 32 + r32];
-            float a = 0.f, q = 0.f;
+            for (int j = 0; j < TN; ++j) {
+                const float k = kk[wn * WN + j * 32 + r32];
+                float a = 0.f, q = 0.f;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int lr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    const float v = lr < rows_left ? acc[i][j][e] - k : 0.f;
-                    a += v;
-                    q += v * v;
+                    for (int e = 0; e < 16; ++e) {
+                        const int lr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        const float v = (lr >= wlo && lr < whi) ? acc[i][j][e] - k : 0.f;
+                        a += v;
+                        q += v * v;
+                    }
+                a += __shfl_xor(a, 32, 64);
+                q += __shfl_xor(q, 32, 64);
+                if (h == 0) {
+                    const int idx = wm * BN + wn * WN + j * 32 + r32;
+                    red[idx * 2] = a;
+                    red[idx * 2 + 1] = q;
                 }
-            a += __shfl_xor(a, 32, 64);
-            q += __shfl_xor(q, 32, 64);
-            if (h == 0) {
-                const int idx = wm * BN + wn * WN + j * 32 + r32;
-                red[idx * 2] = a;
-                red[idx * 2 + 1] = q;
             }
-        }
-        __syncthreads();
-        const int64_t nrows = g.M - m0 < BM ? g.M - m0 : BM;
-        for (int idx = t; idx < BN; idx += NT) {
-            const int col = n0 + idx;
-            if (col >= p.Ng) continue;
-            float a = 0.f, q = 0.f;
+            __syncthreads();
+            for (int idx = t; idx < BN; idx += NT) {
+                const int col = n0 + idx;
+                if (col >= p.Ng) continue;
+                float a = 0.f, q = 0.f;
 #pragma unroll
-            for (int w = 0; w < BM / WM; ++w) { a += red[(w * BN + idx) * 2]; q += red[(w * BN + idx) * 2 + 1]; }
-            float4* dst = reinterpret_cast<float4*>(p.stats) + (int64_t)row_tile * p.stat_cout + grp * p.Ng + col;
-            *dst = make_float4(a, q, kk[idx], (float)nrows);
+                for (int w = 0; w < BM / WM; ++w) { a += red[(w * BN + idx) * 2]; q += red[(w * BN + idx) * 2 + 1]; }
+                dst0[grp * p.Ng + col] = make_float4(a, q, kk[idx], (float)(hi - lo));
+            }
+            __syncthreads();
+        };
+        const int64_t nrows = g.M - m0 < BM ? g.M - m0 : BM;
+        float4* rec = reinterpret_cast<float4*>(p.stats) + (int64_t)row_tile * p.stat_cout;
+        const int64_t cut = p.seg_row - m0;                                 // segment boundary inside this tile?
+        if (p.stats_extra && cut > 0 && cut < nrows) {
+            emit(0, cut, rec);
+            emit(cut, nrows, reinterpret_cast<float4*>(p.stats_extra));
+        } else {
+            emit(0, nrows, rec);
         }
     }
 }
@@ -550,40 +564,49 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM * BN >= 128 * 128) 
                 for (int j = 0; j < TN; ++j) kk[wn * WN + j * 32 + r32] = acc[0][j][0];
             }
             __syncthreads();
-            const int rows_left = M - (m0 + wm * WM);
+            auto emit = [&](int lo, int hi, float4* dst0) __attribute__((always_inline)) {
+                const int wlo = lo - wm * WM, whi = hi - wm * WM;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const float k = kk[wn * WN + j * 32 + r32];
-                float a = 0.f, q = 0.f;
+                for (int j = 0; j < TN; ++j) {
+                    const float k = kk[wn * WN + j * 32 + r32];
+                    float a = 0.f, q = 0.f;
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int lr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        const float v = lr < rows_left ? acc[i][j][e] - k : 0.f;
-                        a += v;
-                        q += v * v;
+                        for (int e = 0; e < 16; ++e) {
+                            const int lr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                            const float v = (lr >= wlo && lr < whi) ? acc[i][j][e] - k : 0.f;
+                            a += v;
+                            q += v * v;
+                        }
+                    a += __shfl_xor(a, 32, 64);
+                    q += __shfl_xor(q, 32, 64);
+                    if (h == 0) {
+                        const int idx = wm * BN + wn * WN + j * 32 + r32;
+                        red[idx * 2] = a;
+                        red[idx * 2 + 1] = q;
                     }
-                a += __shfl_xor(a, 32, 64);
-                q += __shfl_xor(q, 32, 64);
-                if (h == 0) {
-                    const int idx = wm * BN + wn * WN + j * 32 + r32;
-                    red[idx * 2] = a;
-                    red[idx * 2 + 1] = q;
                 }
-            }
-            __syncthreads();
-            const int nrows = M - m0 < BM ? M - m0 : BM;
-            for (int idx = t; idx < BN; idx += NT) {
-                const int col = n0 + idx;
-                if (col >= p.Ng) continue;
-                float a = 0.f, q = 0.f;
+                __syncthreads();
+                for (int idx = t; idx < BN; idx += NT) {
+                    const int col = n0 + idx;
+                    if (col >= p.Ng) continue;
+                    float a = 0.f, q = 0.f;
 #pragma unroll
-                for (int w = 0; w < BM / WM; ++w) { a += red[(w * BN + idx) * 2]; q += red[(w * BN + idx) * 2 + 1]; }
-                float4* dst = reinterpret_cast<float4*>(p.stats) + (int64_t)c_rt * p.stat_cout + grp * p.Ng + col;
-                if (nrows > 0) *dst = make_float4(a, q, kk[idx], (float)nrows);
+                    for (int w = 0; w < BM / WM; ++w) { a += red[(w * BN + idx) * 2]; q += red[(w * BN + idx) * 2 + 1]; }
+                    if (hi > lo) dst0[grp * p.Ng + col] = make_float4(a, q, kk[idx], (float)(hi - lo));
+                }
+                __syncthreads();                                // the scratch is tile storage again from here on
+            };
+            const int nrows = M - m0 < BM ? M - m0 : BM;
+            float4* rec = reinterpret_cast<float4*>(p.stats) + (int64_t)c_rt * p.stat_cout;
+            const int64_t cut = p.seg_row - m0;
+            if (p.stats_extra && cut > 0 && cut < nrows) {
+                emit(0, (int)cut, rec);
+                emit((int)cut, nrows, reinterpret_cast<float4*>(p.stats_extra));
+            } else {
+                emit(0, nrows > 0 ? nrows : 0, rec);
             }
-            __syncthreads();                                    // the scratch is tile storage again from here on
         }
     };
 
@@ -1062,7 +1085,7 @@ int suhpe_conv2d_fwd(const suhpe_conv_t* d, const float* x, const float* w, cons
     p.g = make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0);
     p.x = x; p.f = w; p.bias = bias; p.y = y; p.Ng = d->cout / d->groups; p.ldy = d->cout; p.ldf = p.g.K;
     p.x_bytes = (int64_t)d->n * d->h * d->w * d->cin * 4; p.f_bytes = (int64_t)d->cout * p.g.K * 4;
-    p.stats = nullptr; p.stat_gx = 0; p.stat_cout = 0; p.scale = p.shift = p.residual = nullptr; p.act = 0; p.res_mode = 0;
+    p.stats = nullptr; p.stats_extra = nullptr; p.seg_row = 0; p.stat_gx = 0; p.stat_cout = 0; p.scale = p.shift = p.residual = nullptr; p.act = 0; p.res_mode = 0;
     const bool vec4 = (cg % 4 == 0) && (d->cin % 4 == 0) && aligned16(x) && aligned16(w);
     dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 0));
     return check_launch("suhpe_conv2d_fwd");
@@ -1079,7 +1102,7 @@ int suhpe_conv2d_fwd_affine(const suhpe_conv_t* d, const float* x, const float* 
     p.g = make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0);
     p.x = x; p.f = w; p.bias = nullptr; p.y = y; p.Ng = d->cout / d->groups; p.ldy = d->cout; p.ldf = p.g.K;
     p.x_bytes = (int64_t)d->n * d->h * d->w * d->cin * 4; p.f_bytes = (int64_t)d->cout * p.g.K * 4;
-    p.stats = nullptr; p.stat_gx = 0; p.stat_cout = 0;
+    p.stats = nullptr; p.stats_extra = nullptr; p.seg_row = 0; p.stat_gx = 0; p.stat_cout = 0;
     p.scale = scale; p.shift = shift; p.residual = residual; p.act = act; p.res_mode = residual ? (residual_after_act ? 2 : 1) : 0;
     const bool vec4 = (cg % 4 == 0) && (d->cin % 4 == 0) && aligned16(x) && aligned16(w);
     dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 0));
@@ -1093,7 +1116,14 @@ int suhpe_conv2d_fwd_stats_tiles(const suhpe_conv_t* d) {
     return (int)ceil_div(M, nt_tile_bm(choose_nt(M, ng, cg % 4 == 0 && d->cin % 4 == 0, pinned_tile(d, 0))));
 }
 
-int suhpe_conv2d_fwd_stats(const suhpe_conv_t* d, const float* x, const float* w, float* y, float* stats, suhpe_stream_t stream) {
+int suhpe_conv2d_fwd_stats_tile_rows(const suhpe_conv_t* d) {
+    if (!d || d->groups <= 0) return 0;
+    const int cg = d->cin / d->groups, ng = d->cout / d->groups;
+    return nt_tile_bm(choose_nt((int64_t)d->n * d->ho * d->wo, ng, cg % 4 == 0 && d->cin % 4 == 0, pinned_tile(d, 0)));
+}
+
+static int conv2d_fwd_stats_impl(const suhpe_conv_t* d, const float* x, const float* w, float* y, float* stats, float* stats_extra,
+                                 int64_t seg_row, suhpe_stream_t stream) {
     int rc = check_desc(d, "suhpe_conv2d_fwd_stats");
     if (rc) return rc;
     SUHPE_REQUIRE(x && w && y && stats, "suhpe_conv2d_fwd_stats: null pointer");
@@ -1102,11 +1132,21 @@ int suhpe_conv2d_fwd_stats(const suhpe_conv_t* d, const float* x, const float* w
     p.g = make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0);
     p.x = x; p.f = w; p.bias = nullptr; p.y = y; p.Ng = d->cout / d->groups; p.ldy = d->cout; p.ldf = p.g.K;
     p.x_bytes = (int64_t)d->n * d->h * d->w * d->cin * 4; p.f_bytes = (int64_t)d->cout * p.g.K * 4;
-    p.stats = stats; p.stat_gx = suhpe_conv2d_fwd_stats_tiles(d); p.stat_cout = d->cout; p.scale = p.shift = p.residual = nullptr; p.act = 0; p.res_mode = 0;
+    p.stats = stats; p.stats_extra = stats_extra; p.seg_row = seg_row; p.stat_gx = suhpe_conv2d_fwd_stats_tiles(d); p.stat_cout = d->cout; p.scale = p.shift = p.residual = nullptr; p.act = 0; p.res_mode = 0;
     const bool vec4 = (cg % 4 == 0) && (d->cin % 4 == 0);
     SUHPE_REQUIRE(!vec4 || (aligned16(x) && aligned16(w)), "suhpe_conv2d_fwd_stats: x / w must be 16-byte aligned");
     dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 0));
     return check_launch("suhpe_conv2d_fwd_stats");
+}
+
+int suhpe_conv2d_fwd_stats(const suhpe_conv_t* d, const float* x, const float* w, float* y, float* stats, suhpe_stream_t stream) {
+    return conv2d_fwd_stats_impl(d, x, w, y, stats, nullptr, 0, stream);
+}
+
+int suhpe_conv2d_fwd_stats_seg(const suhpe_conv_t* d, const float* x, const float* w, float* y, float* stats, float* stats_extra,
+                               int64_t seg_row, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(stats_extra && seg_row > 0, "suhpe_conv2d_fwd_stats_seg: stats_extra and a positive seg_row are required");
+    return conv2d_fwd_stats_impl(d, x, w, y, stats, stats_extra, seg_row, stream);
 }
 
 int suhpe_conv2d_transpose_filter(const suhpe_conv_t* d, const float* w, float* wt, suhpe_stream_t stream) {
@@ -1131,7 +1171,7 @@ int suhpe_conv2d_dgrad(const suhpe_conv_t* d, const float* dy, const float* wt, 
         p.g = make_geom(d->n, d->ho, d->wo, d->h, d->w, d->cout, ng, d->r, d->s, d->stride, d->pad, 1);
         p.x = dy; p.f = wt; p.bias = nullptr; p.y = dx; p.Ng = cg; p.ldy = d->cin; p.ldf = p.g.K;
         p.x_bytes = (int64_t)d->n * d->ho * d->wo * d->cout * 4; p.f_bytes = (int64_t)d->cout * cg * d->r * d->s * 4;
-        p.stats = nullptr; p.stat_gx = 0; p.stat_cout = 0; p.scale = p.shift = p.residual = nullptr; p.act = 0; p.res_mode = 0;
+        p.stats = nullptr; p.stats_extra = nullptr; p.seg_row = 0; p.stat_gx = 0; p.stat_cout = 0; p.scale = p.shift = p.residual = nullptr; p.act = 0; p.res_mode = 0;
         dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 1));
     } else {
         // one launch per parity class of the input pixel: only the taps r = (ph+pad) mod stride (+ k*stride) reach it,
@@ -1150,7 +1190,7 @@ int suhpe_conv2d_dgrad(const suhpe_conv_t* d, const float* dy, const float* wt, 
                 p.g = g;
                 p.x = dy; p.f = wt; p.bias = nullptr; p.y = dx; p.Ng = cg; p.ldy = d->cin; p.ldf = d->r * d->s * ng;
                 p.x_bytes = (int64_t)d->n * d->ho * d->wo * d->cout * 4; p.f_bytes = (int64_t)d->cout * cg * d->r * d->s * 4;
-                p.stats = nullptr; p.stat_gx = 0; p.stat_cout = 0; p.scale = p.shift = p.residual = nullptr; p.act = 0; p.res_mode = 0;
+                p.stats = nullptr; p.stats_extra = nullptr; p.seg_row = 0; p.stat_gx = 0; p.stat_cout = 0; p.scale = p.shift = p.residual = nullptr; p.act = 0; p.res_mode = 0;
                 dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 1));
             }
     }

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
 __global__ __launch_bounds__(kFinThreads) void bn_stats_finalize(const float* __restrict__ part, int gx, int c, int64_t rows, float eps,
                                                          float momentum, float* __restrict__ mean, float* __restrict__ rstd,
                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                         int64_t* __restrict__ nbt) {
+                                                         int64_t* __restrict__ nbt, const float* __restrict__ extra = nullptr) {
     const int chl = threadIdx.x & (kFinCh - 1), sub = threadIdx.x / kFinCh;
     const int ch = blockIdx.x * kFinCh + chl;
     if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
@@ -196,10 +196,17 @@ __global__ __launch_bounds__(kFinThreads) void bn_stats_finalize(const float* __
     double a = 0.0, b = 0.0, k0 = 0.0;
     if (ch < c) {
         const float4* pr = reinterpret_cast<const float4*>(part) + ch;
-        k0 = (double)pr[0].z;
+        const float4* ex = extra ? reinterpret_cast<const float4*>(extra) + ch : nullptr;      // one more record (segment boundary tile)
+        k0 = gx > 0 ? (double)pr[0].z : (double)ex[0].z;
 #pragma unroll 8
         for (int i = sub; i < gx; i += kFinSub) {
             const float4 v = pr[(int64_t)i * c];
+            const double S = v.x, Q = v.y, k = v.z, n = v.w;
+            a += S + n * k;
+            b += Q + 2.0 * k * S + n * k * k;
+        }
+        if (ex && sub == 0) {
+            const float4 v = ex[0];
             const double S = v.x, Q = v.y, k = v.z, n = v.w;
             a += S + n * k;
             b += Q + 2.0 * k * S + n * k * k;
@@ -847,6 +854,15 @@ int suhpe_bn_stats_from_partials(const float* part, int gx, int64_t rows, int c,
     SUHPE_REQUIRE(part && mean && rstd && gx > 0 && rows > 0 && c > 0, "suhpe_bn_stats_from_partials: bad arguments");
     LAUNCH(bn_stats_finalize, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, gx, c, rows, eps, momentum, mean, rstd, running_mean, running_var, nbt);
     return check_launch("suhpe_bn_stats_from_partials");
+}
+
+int suhpe_bn_stats_from_partials_range(const float* part, int first, int count, const float* extra, int64_t rows, int c, float eps,
+                                       float momentum, float* mean, float* rstd, float* running_mean, float* running_var, int64_t* nbt,
+                                       suhpe_stream_t stream) {
+    SUHPE_REQUIRE(part && mean && rstd && first >= 0 && count >= 0 && (count > 0 || extra) && rows > 0 && c > 0, "suhpe_bn_stats_from_partials_range: bad arguments");
+    LAUNCH(bn_stats_finalize, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part + (int64_t)first * c * 4, count, c, rows, eps, momentum, mean,
+           rstd, running_mean, running_var, nbt, extra);
+    return check_launch("suhpe_bn_stats_from_partials_range");
 }
 
 int suhpe_bn_eval_stats(const float* rm, const float* rv, int c, float eps, float* mean, float* rstd, suhpe_stream_t stream) {

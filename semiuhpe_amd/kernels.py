@@ -295,8 +295,10 @@ def bn_eval_affine(running_mean, running_var, gamma, beta, eps):
     return out[0], out[1]
 
 
-def conv2d_fwd_stats(x, w, stride=1, pad=0, groups=1):
-    """Dense conv forward that also returns BatchNorm partial sums from its epilogue: (y, partials, tiles)."""
+def conv2d_fwd_stats(x, w, stride=1, pad=0, groups=1, seg=None):
+    """Dense conv forward that also returns BatchNorm partial sums from its epilogue: (y, partials, tiles).
+    seg = samples in the first batch segment: the statistics are kept per segment and the result is
+    (y, partials, tiles, (first-segment records, boundary record or None))."""
     _chk(x, "x")
     assert filter_is_physical(w)
     d = conv_desc(x.shape, w.shape, stride, pad, groups)
@@ -304,6 +306,15 @@ def conv2d_fwd_stats(x, w, stride=1, pad=0, groups=1):
     if AUTOTUNE:
         _autotune(d, 0, lambda: call("suhpe_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(w), None, ptr(y)))
     tiles = _lib.load().suhpe_conv2d_fwd_stats_tiles(ctypes.byref(d))
+    if seg is not None and 0 < seg < d.n:
+        tile_rows = _lib.load().suhpe_conv2d_fwd_stats_tile_rows(ctypes.byref(d))
+        seg_row = seg * d.ho * d.wo
+        part = torch.empty(d.cout * (tiles + 1) * 4, dtype=torch.float32, device=x.device)
+        extra = part[d.cout * tiles * 4:]
+        with _Prof(d, 0):
+            call("suhpe_conv2d_fwd_stats_seg", ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(part), ptr(extra), seg_row)
+        straddle = seg_row % tile_rows != 0
+        return y, part, tiles, (seg_row // tile_rows + int(straddle), extra if straddle else None)
     part = torch.empty(d.cout * tiles * 4, dtype=torch.float32, device=x.device)
     with _Prof(d, 0):
         call("suhpe_conv2d_fwd_stats", ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(part))
@@ -316,6 +327,16 @@ def bn_stats_from_partials(part, tiles, rows, c, eps, momentum, running_mean=Non
     rstd = torch.empty(c, dtype=torch.float32, device=part.device)
     call("suhpe_bn_stats_from_partials", ptr(part), int(tiles), int(rows), c, float(eps), float(momentum), ptr(mean), ptr(rstd),
          ptr(running_mean), ptr(running_var), ptr(nbt))
+    return mean, rstd
+
+
+@_memop
+def bn_stats_from_partials_range(part, first, count, extra, rows, c, eps, momentum, running_mean=None, running_var=None, nbt=None):
+    """statistics over the epilogue records [first, first + count) plus the optional boundary record `extra`"""
+    mean = torch.empty(c, dtype=torch.float32, device=part.device)
+    rstd = torch.empty(c, dtype=torch.float32, device=part.device)
+    call("suhpe_bn_stats_from_partials_range", ptr(part), int(first), int(count), ptr(extra), int(rows), c, float(eps), float(momentum),
+         ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var), ptr(nbt))
     return mean, rstd
 
 
@@ -477,10 +498,10 @@ def bn_eval_stats(running_mean, running_var, eps):
 
 
 @_memop
-def bn_act_fwd(x, c, mean, rstd, gamma, beta, act, residual=None, post=False, rowscale=None, hw=1):
+def bn_act_fwd(x, c, mean, rstd, gamma, beta, act, residual=None, post=False, rowscale=None, hw=1, out=None):
     """post=False: act(BN(x) + residual).  post=True: residual + rowscale[sample] * act(BN(x)) (skip + StochasticDepth)."""
-    _chk(x, "x"); _chk(residual, "residual"); _chk(rowscale, "rowscale")
-    y = torch.empty_like(x)
+    _chk(x, "x"); _chk(residual, "residual"); _chk(rowscale, "rowscale"); _chk(out, "out")
+    y = torch.empty_like(x) if out is None else out
     if post:
         call("suhpe_bn_act_skip_fwd", ptr(x), x.numel() // c, c, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ACT[act],
              ptr(residual), ptr(rowscale), int(hw), ptr(y))
@@ -492,9 +513,9 @@ def bn_act_fwd(x, c, mean, rstd, gamma, beta, act, residual=None, post=False, ro
 
 @_memop
 def bn_act_bwd(x, dy, c, mean, rstd, gamma, beta, act, train_stats, dgamma=None, dbeta=None, accumulate=False, y_out=None,
-               rowscale=None, hw=1):
-    _chk(x, "x"); _chk(dy, "dy")
-    dx = torch.empty_like(x)
+               rowscale=None, hw=1, out=None):
+    _chk(x, "x"); _chk(dy, "dy"); _chk(out, "out")
+    dx = torch.empty_like(x) if out is None else out
     ws = workspace("bn", _lib.load().suhpe_bn_workspace_bytes(c), x.device)
     if rowscale is not None:
         call("suhpe_bn_act_skip_bwd", ptr(x), ptr(dy), x.numel() // c, c, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ACT[act],
@@ -697,22 +718,27 @@ def fill_(t, value):
     return t
 
 
-def nchw_to_nhwc(img):
-    _chk(img, "img")
+def nchw_to_nhwc(img, out=None):
+    _chk(img, "img"); _chk(out, "out")
     n, c, h, w = img.shape
-    out = torch.empty((n, h, w, c), dtype=torch.float32, device=img.device)
+    if out is None:
+        out = torch.empty((n, h, w, c), dtype=torch.float32, device=img.device)
+    assert tuple(out.shape) == (n, h, w, c)
     call("suhpe_nchw_to_nhwc", ptr(img), n, c, h, w, ptr(out))
     return out
 
 
-def strong_aug(src, cutout_boxes, cutmix_boxes, perm, holes, src_nhwc=False, dst_nhwc=True):
+def strong_aug(src, cutout_boxes, cutmix_boxes, perm, holes, src_nhwc=False, dst_nhwc=True, out=None):
     """CutOut + CutMix (+ layout change) out of place.  src (N,C,H,W) or (N,H,W,C)."""
     _chk(src, "src")
     if src_nhwc:
         n, h, w, c = src.shape
     else:
         n, c, h, w = src.shape
-    dst = torch.empty((n, h, w, c) if dst_nhwc else (n, c, h, w), dtype=torch.float32, device=src.device)
+    shape = (n, h, w, c) if dst_nhwc else (n, c, h, w)
+    _chk(out, "out")
+    dst = torch.empty(shape, dtype=torch.float32, device=src.device) if out is None else out
+    assert tuple(dst.shape) == shape
     call("suhpe_strong_aug", ptr(src), ptr(dst), n, c, h, w, int(src_nhwc), int(dst_nhwc), ptr(cutout_boxes),
          ptr(cutmix_boxes), ptr(perm), int(holes))
     return dst

@@ -86,13 +86,14 @@ class Conv2d(Layer):
         return y
 
     def fwd_stats(self, x, tape):
-        """forward + BatchNorm partial statistics from the GEMM epilogue (dense, bias-free convs only) -> (y, (part, tiles))"""
+        """forward + BatchNorm partial statistics from the GEMM epilogue (dense, bias-free convs only) -> (y, (part, tiles))
+        (with batch segments: (y, (part, tiles, records of the first segment, boundary record)))"""
         if not K.filter_is_physical(self.weight):
             self.weight.data = K.to_filter_layout(self.weight.data)
-        y, part, tiles = K.conv2d_fwd_stats(x, self.weight, self.stride, self.padding, self.groups)
+        out = K.conv2d_fwd_stats(x, self.weight, self.stride, self.padding, self.groups, seg=_segment_of(x))
         if tape is not None:
             tape.append(x)
-        return y, (part, tiles)
+        return out[0], out[1:]
 
     def fuses_stats(self):
         depthwise = self.groups > 1 and self.groups == self.in_channels == self.out_channels
@@ -144,6 +145,31 @@ class Linear(Layer):
         return dx.view(*shp[:-1], self.in_features)
 
 
+# Batch segments.  A training step runs the student on the labeled batch and on the strong views of the unlabeled batch
+# (reference src/agent.py: two self.net(...) calls); the weights are the same, so both can go through the network as ONE
+# batch -- every GEMM gets 160 instead of 32 / 128 images -- provided BatchNorm still normalises each sub-batch with its own
+# statistics and updates the running statistics twice, in the reference's order.  `with batch_segments(n):` declares that
+# the first n samples of every activation are one segment and the rest the other; all other layers are per-sample.
+_SEGMENT = None
+
+
+class batch_segments:
+    def __init__(self, first):
+        self.first = int(first) if first else None
+
+    def __enter__(self):
+        global _SEGMENT
+        self.prev, _SEGMENT = _SEGMENT, self.first
+
+    def __exit__(self, *exc):
+        global _SEGMENT
+        _SEGMENT = self.prev
+
+
+def _segment_of(x):
+    return _SEGMENT if (_SEGMENT is not None and 0 < _SEGMENT < x.shape[0]) else None
+
+
 class _BatchNorm(Layer):
     """BatchNorm fused with the activation that follows it (and an optional pre-activation residual)."""
 
@@ -160,6 +186,9 @@ class _BatchNorm(Layer):
         """residual, post=False: act(BN(x) + residual).  post=True: residual + rowscale[n] * act(BN(x)), the skip
         connection of a residual block with StochasticDepth('row') folded in (rowscale None = 1)."""
         c = self.num_features
+        seg = _segment_of(x) if self.training else None
+        if seg is not None:
+            return self._fwd_segments(x, tape, residual, partials, post, rowscale, seg)
         if self.training and partials is not None:          # statistics already accumulated by the producing conv's epilogue
             mean, rstd = K.bn_stats_from_partials(partials[0], partials[1], x.numel() // c, c, self.eps, self.momentum,
                                                   self.running_mean, self.running_var, self.num_batches_tracked)
@@ -174,8 +203,43 @@ class _BatchNorm(Layer):
             tape.append((x, mean, rstd, self.training, keep_y, rowscale if post else None, hw))
         return y
 
+    def _fwd_segments(self, x, tape, residual, partials, post, rowscale, seg):
+        """training forward with per-segment batch statistics: samples [0, seg) and [seg, n) are normalised separately and
+        the running statistics take two momentum updates, first segment first."""
+        c, n = self.num_features, x.shape[0]
+        hw = x.numel() // (c * n)
+        stats = []
+        for lo, hi in ((0, seg), (seg, n)):
+            rows = (hi - lo) * hw
+            if partials is not None:
+                part, tiles, (first_records, boundary) = partials
+                if lo == 0:
+                    first, count, extra = 0, first_records, None
+                else:
+                    first, count, extra = first_records, tiles - first_records, boundary
+                stats.append(K.bn_stats_from_partials_range(part, first, count, extra, rows, c, self.eps, self.momentum, self.running_mean,
+                                                            self.running_var, self.num_batches_tracked))
+            else:
+                stats.append(K.bn_stats(x[lo:hi], c, self.eps, self.momentum, self.running_mean, self.running_var, self.num_batches_tracked))
+        y = torch.empty_like(x)
+        for (lo, hi), (mean, rstd) in zip(((0, seg), (seg, n)), stats):
+            K.bn_act_fwd(x[lo:hi], c, mean, rstd, self.weight, self.bias, self.act, None if residual is None else residual[lo:hi], post,
+                         None if rowscale is None else rowscale[lo:hi], hw, out=y[lo:hi])
+        if tape is not None:
+            keep_y = y if (residual is not None and not post and self.act == "relu") else None
+            tape.append((x, stats, seg, True, keep_y, rowscale if post else None, hw))
+        return y
+
     def bwd(self, dy, tape):
         x, mean, rstd, train_stats, y_out, rowscale, hw = tape.pop()
+        if isinstance(mean, list):                           # per-segment statistics: (x, [(mean, rstd)] * 2, seg, ...)
+            stats, seg, n = mean, rstd, x.shape[0]
+            dx = torch.empty_like(x)
+            for (lo, hi), (m, r) in zip(((0, seg), (seg, n)), stats):
+                K.bn_act_bwd(x[lo:hi], dy[lo:hi], self.num_features, m, r, self.weight, self.bias, self.act, True, grad_of(self.weight),
+                             grad_of(self.bias), True, None if y_out is None else y_out[lo:hi],
+                             None if rowscale is None else rowscale[lo:hi], hw, out=dx[lo:hi])
+            return dx
         return K.bn_act_bwd(x, dy, self.num_features, mean, rstd, self.weight, self.bias, self.act, train_stats,
                             grad_of(self.weight), grad_of(self.bias), True, y_out, rowscale, hw)
 

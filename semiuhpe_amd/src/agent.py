@@ -20,6 +20,7 @@ import torch
 from .. import kernels as K
 from . import distributed as D
 from . import utils
+from ..layers import batch_segments
 from .augments import strong_view_nhwc
 from .fisher.fisher_utils import batch_torch_A_to_R, fisher_CE, fisher_entropy
 from .fisher.fisher_utils import vmf_loss as fisher_NLL
@@ -69,6 +70,7 @@ class SSLAgent:
         self.clock = utils.TrainClock()
         # time the GEMM tile menu on each new conv shape during the first steps and pin the winners (kernels._autotune)
         K.AUTOTUNE = bool(getattr(config, "autotune", True)) and os.environ.get("SUHPE_AUTOTUNE", "1") != "0"
+        self.merge_student_passes = bool(getattr(config, "merge_student_passes", True)) and os.environ.get("SUHPE_MERGE", "1") != "0"
         self.net = get_network(config)
         self.ema_net = get_network(config)
         for param in self.ema_net.parameters():      # reference :34-35: the teacher is never trained by gradients
@@ -129,7 +131,21 @@ class SSLAgent:
         gt = _dev(data.get("rot_mat"), dev).reshape(-1, 9).contiguous()
         gt_euler = _dev(data.get("euler_angles"), dev).contiguous() if "euler_angles" in data else None
         net = self.ema_net if eval_ema else self.net
-        fisher_out = net(img)
+        # The two student passes of a step (labeled batch, strong views) share the weights: run them as one batch whose
+        # BatchNorm statistics are kept per segment (layers.batch_segments) -- same arithmetic per sample, larger GEMMs.
+        merged = (self.merge_student_passes and ulb_data is not None and not eval_ema and net.training and torch.is_grad_enabled())
+        pred_strong = None
+        if merged:
+            strong = _dev(ulb_data.get("img_strong"), dev)
+            n_l, n_u = img.shape[0], strong.shape[0]
+            both = torch.empty((n_l + n_u, img.shape[2], img.shape[3], img.shape[1]), dtype=torch.float32, device=dev)
+            K.nchw_to_nhwc(img.contiguous(), out=both[:n_l])
+            strong_view_nhwc(strong, cfg.cutout_aug, cfg.cutmix_aug, 3, normal=True, out=both[n_l:])
+            with batch_segments(n_l):
+                both = net(both, nhwc=True)
+            fisher_out, pred_strong = both[:img.shape[0]], both[img.shape[0]:]
+        else:
+            fisher_out = net(img)
         if cfg.distribution == "RotationLaplace":
             from .laplace.rotation_laplace import NLL_loss as laplace_NLL
             losses, pred_orth = laplace_NLL("RLaplace", fisher_out, gt, self.grids)
@@ -143,7 +159,6 @@ class SSLAgent:
 
         ### 2. unsupervised loss (reference :98-192)
         ulb_img_weak = _dev(ulb_data.get("img"), dev)
-        ulb_img_strong = _dev(ulb_data.get("img_strong"), dev)
         ulb_gt = _dev(ulb_data.get("rot_mat"), dev).reshape(-1, 9).contiguous() if "rot_mat" in ulb_data else None
         with torch.no_grad():
             pred_weak = self.ema_net(ulb_img_weak)
@@ -159,8 +174,9 @@ class SSLAgent:
         else:
             pred_weak_adjusted = pred_weak
         # CutOut / CutMix on the strong view fused with the layout change (reference :125-126)
-        strong_nhwc = strong_view_nhwc(ulb_img_strong, cfg.cutout_aug, cfg.cutmix_aug, 3, normal=True)
-        pred_strong = self.net(strong_nhwc, nhwc=True)
+        if pred_strong is None:
+            strong_nhwc = strong_view_nhwc(_dev(ulb_data.get("img_strong"), dev), cfg.cutout_aug, cfg.cutmix_aug, 3, normal=True)
+            pred_strong = self.net(strong_nhwc, nhwc=True)
         entropy = fisher_entropy(pred_weak)
         mask, count = K.entropy_mask(entropy, self._conf_thres())
         mask_ratio = K.axpby(count, 1.0 / mu_b).squeeze(0)

@@ -49,7 +49,7 @@ def random_cutmix_tensor(image, mask_holes_num=3, normal=False):
     return image
 
 
-def strong_view_nhwc(image, cutout, cutmix, mask_holes_num=3, normal=True):
+def strong_view_nhwc(image, cutout, cutmix, mask_holes_num=3, normal=True, out=None):
     """Fused path used by the agent: CutOut then CutMix (same RNG order as calling the two functions above in
     sequence) while converting the NCHW loader batch to the backbone's NHWC layout; one read, one write."""
     N, _, width, height = image.shape
@@ -58,4 +58,4 @@ def strong_view_nhwc(image, cutout, cutmix, mask_holes_num=3, normal=True):
     if cutmix:
         cm = _to_dev(draw_boxes(N, width, height, mask_holes_num, normal), image.device)
         perm = _to_dev(torch.randperm(N).int(), image.device)
-    return K.strong_aug(image.contiguous(), co, cm, perm, mask_holes_num, src_nhwc=False, dst_nhwc=True)
+    return K.strong_aug(image.contiguous(), co, cm, perm, mask_holes_num, src_nhwc=False, dst_nhwc=True, out=out)

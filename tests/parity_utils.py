@@ -22,8 +22,23 @@ class MaskTape:
         self.cursor += 1
         return m
 
+    def replay_merged(self, kind, shape, keep):
+        """For an agent that runs its two student passes as one batch: the oracle drew [labeled pass | teacher pass | strong
+        pass], K masks each; the merged student asks for K masks over the concatenated batch, then the teacher for its K."""
+        k3 = len(self.masks) // 3
+        i = self.cursor
+        self.cursor += 1
+        self.end = 2 * k3
+        if i < k3:
+            (ka, sa, ma), (kb, sb, mb) = self.masks[i], self.masks[2 * k3 + i]
+            assert ka == kb == kind and (sa[0] + sb[0],) + sa[1:] == tuple(shape), f"merged mask mismatch at {i}: {ka}{sa}+{kb}{sb} vs {kind}{tuple(shape)}"
+            return torch.cat([ma, mb])
+        k, s, m = self.masks[i]
+        assert k == kind and s == tuple(shape), f"mask order mismatch: oracle drew {k}{s}, HIP asks {kind}{tuple(shape)}"
+        return m
+
     def done(self):
-        return self.cursor == len(self.masks)
+        return self.cursor == getattr(self, "end", len(self.masks))
 
 
 def rel_err(x, ref):

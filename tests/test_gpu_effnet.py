@@ -98,8 +98,10 @@ def _config(**kw):
     return SimpleNamespace(**base)
 
 
-def test_agent_ssl_step_matches_oracle(models):
-    """Two SSL steps (EMA copy at step 0, alpha=1/2 at step 1) of SSLAgent vs oracle.agent.OracleAgent."""
+@pytest.mark.parametrize("merge", [True, False])
+def test_agent_ssl_step_matches_oracle(models, merge):
+    """Two SSL steps (EMA copy at step 0, alpha=1/2 at step 1) of SSLAgent vs oracle.agent.OracleAgent; with the student's
+    labeled and strong passes run as one segmented batch (the default) and as the reference's two passes."""
     from oracle import networks as ON
     from oracle.agent import OracleAgent, synthetic_batches
     from semiuhpe_amd import layers as L
@@ -113,6 +115,7 @@ def test_agent_ssl_step_matches_oracle(models):
         return m
 
     cfg_o, cfg_h = _config(), _config()
+    cfg_h.merge_student_passes = merge
     oracle = OracleAgent(cfg_o, factory)
     agent = SSLAgent(cfg_h)
     agent.net.load_state_dict(sd0)
@@ -135,7 +138,7 @@ def test_agent_ssl_step_matches_oracle(models):
         fd_o, fu_o, out_o = oracle.train_func({k: v.clone() for k, v in data.items()}, {k: v.clone() for k, v in ulb.items()})
         ON.set_mask_hook(None)
         g_ref = {n: p.grad.clone() for n, p in oracle.net.named_parameters()}
-        L.set_mask_hook(tape.replay)
+        L.set_mask_hook(tape.replay_merged if merge else tape.replay)
         torch.manual_seed(50 + step)
         agent.clock.iteration = step
         fd, fu, out = agent.train_func({k: v.cuda() for k, v in data.items()}, {k: v.cuda() for k, v in ulb.items()})

@@ -1,0 +1,168 @@
+"""Batch segments: one training pass over cat[labeled; strong] with per-segment BatchNorm statistics must equal the
+reference's two separate student passes (src/agent.py: self.net(img) ... self.net(img_strong)) -- outputs, parameter
+gradients, BatchNorm running statistics (two momentum updates in the reference's order) -- on all three backbones, and
+the agent's merged step must equal its two-pass step.
+
+Tolerances: outputs 2e-4 relative, gradients 2e-3 relative to each tensor's max (the two paths tile and sum in different
+orders; everything is fp32), running statistics 1e-5 relative."""
+import copy
+import os
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from parity_utils import grad_mismatches, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+class SplitMasks:
+    """Records the masks of the two separate passes (own generator) and serves the merged pass their concatenation."""
+
+    def __init__(self, seed):
+        self.gen = torch.Generator().manual_seed(seed)
+        self.passes = [[], []]
+        self.which = 0
+        self.cursor = 0
+
+    def record(self, kind, shape, keep):
+        m = (torch.rand(shape, generator=self.gen) < keep).float() / keep
+        self.passes[self.which].append(m)
+        return m
+
+    def merged(self, kind, shape, keep):
+        a, b = self.passes[0][self.cursor], self.passes[1][self.cursor]
+        self.cursor += 1
+        m = torch.cat([a, b])
+        assert tuple(m.shape) == tuple(shape)
+        return m
+
+
+def build(name):
+    cfg = SimpleNamespace(network=name, num_classes=9)
+    from semiuhpe_amd.src.networks import get_network
+    torch.manual_seed(0)
+    net = get_network(cfg)
+    g = torch.Generator().manual_seed(1)
+    for m in net.modules():
+        if hasattr(m, "running_mean"):
+            m.running_mean.copy_((torch.randn(m.num_features, generator=g) * 0.1).cuda())
+            m.running_var.copy_((torch.rand(m.num_features, generator=g) * 0.5 + 0.75).cuda())
+    return net
+
+
+@pytest.mark.parametrize("name,size,na,nb", [("effinetv2", 96, 3, 5), ("repvgg", 64, 2, 7), ("tinyvit", 224, 2, 3),
+                                             ("effinetv2", 64, 4, 4)])
+def test_merged_pass_equals_two_passes(name, size, na, nb):
+    from semiuhpe_amd import layers as L
+    two = build(name).train()
+    one = copy.deepcopy(two).train()
+    g = torch.Generator().manual_seed(5)
+    xa = torch.randn(na, 3, size, size, generator=g).cuda()
+    xb = (torch.randn(nb, 3, size, size, generator=g) * 1.5 + 0.3).cuda()        # a different distribution per segment
+    dya, dyb = torch.randn(na, 9, generator=g).cuda(), torch.randn(nb, 9, generator=g).cuda()
+    masks = SplitMasks(9)
+    L.set_mask_hook(masks.record)
+    try:
+        masks.which = 0
+        ya = two(xa)
+        masks.which = 1
+        yb = two(xb)
+        torch.autograd.backward([ya, yb], [dya, dyb])
+        L.set_mask_hook(masks.merged)
+        with L.batch_segments(na):
+            y = one(torch.cat([xa, xb]))
+        y.backward(torch.cat([dya, dyb]))
+    finally:
+        L.set_mask_hook(None)
+    assert masks.cursor == len(masks.passes[0]) == len(masks.passes[1])
+    assert rel_err(y[:na], ya) < 2e-4 and rel_err(y[na:], yb) < 2e-4
+    ref = {n: p.grad.detach().cpu() for n, p in two.named_parameters()}
+    got = {n: p.grad for n, p in one.named_parameters()}
+    assert not grad_mismatches(ref, got, 2e-3)
+    for (n, b2), (_, b1) in zip(two.named_buffers(), one.named_buffers()):
+        if b2.dtype == torch.float32:
+            assert rel_err(b1, b2) < 1e-5, n
+        elif n.endswith("num_batches_tracked"):
+            assert int(b1) == int(b2) == 2, n                                   # two updates
+
+
+def test_segmented_conv_statistics_match_per_segment_sums():
+    """The conv epilogue's per-segment records, finished by the range finaliser, against BatchNorm statistics of the two halves
+    computed separately -- boundary inside a row tile, on a tile edge, and a first segment smaller than one tile."""
+    from semiuhpe_amd import kernels as K
+    g = torch.Generator().manual_seed(3)
+    for (n, h, cin, cout, k, seg) in [(6, 14, 32, 48, 1, 2), (5, 9, 16, 24, 3, 1), (8, 16, 64, 128, 1, 4), (3, 7, 24, 40, 3, 2)]:
+        x = (torch.randn(n, h, h, cin, generator=g) + 0.5).cuda()
+        w = K.to_filter_layout((torch.randn(cout, cin, k, k, generator=g) * 0.2).cuda())
+        y, part, tiles, (first_records, boundary) = K.conv2d_fwd_stats(x, w, 1, k // 2, 1, seg=seg)
+        assert rel_err(y, K.conv2d_fwd(x, w, None, 1, k // 2, 1)) == 0.0
+        hw = y.shape[1] * y.shape[2]
+        for lo, hi, first, count, extra in ((0, seg, 0, first_records, None), (seg, n, first_records, tiles - first_records, boundary)):
+            mean, rstd = K.bn_stats_from_partials_range(part, first, count, extra, (hi - lo) * hw, cout, 1e-5, 0.1)
+            ys = y[lo:hi].reshape(-1, cout).double()
+            assert rel_err(mean, ys.mean(0)) < 1e-5
+            assert rel_err(rstd, (ys.var(0, unbiased=False) + 1e-5).rsqrt()) < 1e-5
+
+
+@pytest.mark.parametrize("network", ["effinetv2"])
+def test_agent_merged_step_equals_two_pass_step(network, tmp_path, monkeypatch):
+    """SSLAgent.train_func with merge_student_passes on / off: same losses, same updated weights (dropout and stochastic depth
+    fed the same per-sample masks)."""
+    from semiuhpe_amd import layers as L
+    from semiuhpe_amd.src.agent import SSLAgent
+    from semiuhpe_amd.synthetic import synthetic_batches
+    monkeypatch.delenv("SUHPE_MERGE", raising=False)
+
+    def cfg(merge):
+        return SimpleNamespace(
+            lr=1e-4, log_dir=str(tmp_path), model_dir=str(tmp_path), distribution="matrixFisher", is_full_range=False,
+            rotate_aug=False, train_labeled="300WLP", train_unlabeled="300WLP", cutout_aug=False, cutmix_aug=False, conf_thres=1e9,
+            type_unsuper="ce", SSL_lambda=1.0, is_ema=True, ema_decay=0.999, eman=False, stage1_iteration=0, network=network,
+            num_classes=9, exp_name="t", date="t", left_ratio=0.95, save_feat=False, dynamic_thres=False, autotune=False,
+            merge_student_passes=merge)
+
+    torch.manual_seed(11)
+    a2 = SSLAgent(cfg(False))
+    a1 = SSLAgent(cfg(True))
+    a1.net.load_state_dict(a2.net.state_dict()); a1.ema_net.load_state_dict(a2.ema_net.state_dict())
+    assert a1.merge_student_passes and not a2.merge_student_passes
+    data, ulb = synthetic_batches(3, 6, size=96, seed=2, rotate_aug=False)
+    to = lambda d: {k: v.cuda().contiguous() for k, v in d.items()}
+    data, ulb = to(data), to(ulb)
+    masks = SplitMasks(4)
+    teacher, teacher_cursor = [], [0]
+
+    def record(kind, shape, keep):                     # two-pass agent: labeled pass, teacher pass (train mode), strong pass
+        if shape[0] == 6 and len(teacher) < len(masks.passes[0]):
+            teacher.append((torch.rand(shape, generator=masks.gen) < keep).float() / keep)
+            return teacher[-1]
+        masks.which = 0 if shape[0] == 3 else 1
+        return masks.record(kind, shape, keep)
+
+    def replay(kind, shape, keep):                     # merged agent: student pass over 3 + 6 samples, teacher pass
+        if shape[0] == 9:
+            return masks.merged(kind, shape, keep)
+        teacher_cursor[0] += 1
+        return teacher[teacher_cursor[0] - 1]
+
+    L.set_mask_hook(record)
+    try:
+        fd2, fu2, out2 = a2.train_func(data, ulb)
+        L.set_mask_hook(replay)
+        fd1, fu1, out1 = a1.train_func(data, ulb)
+    finally:
+        L.set_mask_hook(None)
+    assert rel_err(out1["loss_all"], out2["loss_all"]) < 2e-4
+    assert rel_err(fu1["unsuper_loss"], fu2["unsuper_loss"]) < 2e-4
+    assert rel_err(fd1["pred"], fd2["pred"]) < 2e-4
+    ref = {n: p.grad.detach().cpu() for n, p in a2.net.named_parameters()}
+    assert not grad_mismatches(ref, {n: p.grad for n, p in a1.net.named_parameters()}, 2e-3)
+    # Adam's first step is lr * g / (|g| + 1e-8): compare the updated weights where the gradient is neither rounding noise
+    # nor down at Adam's eps (there the step is a steep function of g)
+    for (n, p2), (_, p1) in zip(a2.net.named_parameters(), a1.net.named_parameters()):
+        g2 = p2.grad
+        big = (g2.abs() > 0.01 * g2.abs().max()) & (g2.abs() > 1e-5)
+        if bool(big.any()):
+            assert float((p1.data - p2.data)[big].abs().max()) < 2e-5, n
