@@ -127,6 +127,17 @@ def pmc_traffic(kernel):
     return rec["hbm_bytes_per_launch"] if rec else None
 
 
+def step_roofline(ms_per_step):
+    """Whole-step roofline of SURVEY.md §8d: T_roof = sum over layers of max(FLOP / 157.3 TF, bytes / 6.3 TB/s) for the
+    B + 2 muB image-forwards and B + muB image-backwards of one step (tools/count_work.py), against the measured step."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from count_work import step_work
+    s = step_work("effinetv2", B_LABELED, B_LABELED * MU)
+    return {"t_roof_ms": round(s["t_roof"] * 1e3, 2), "frac": round(s["t_roof"] * 1e3 / ms_per_step, 4),
+            "flop_per_step": s["flop"], "ideal_bytes_per_step": s["bytes"],
+            "achieved_tflops": round(s["flop"] / (ms_per_step * 1e-3) / 1e12, 2), "formula": "tools/count_work.py (SURVEY.md 8d)"}
+
+
 def cpu_leg():
     """The CPU oracle (our torch-CPU restatement of the reference step, kind="port") on this host's cores:
     one SSL step of the same shape (B=32 + muB=128, EfficientNetV2-S, 224x224), after a small warm-up step."""
@@ -188,6 +199,7 @@ def main():
                        "per_gpu_batch": "32+128", "parallelism": f"dp{world}", "global_batch": (B_LABELED + B_LABELED * MU) * world,
                        **info},
             "roofline": roof,
+            "step_roofline": step_roofline(ms),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_leg()

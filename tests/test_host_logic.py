@@ -81,3 +81,19 @@ def test_clock_and_ema_schedule():
     # alpha = min(1 - 1/(t+1), decay): 0, 1/2, 2/3, ... then the decay (reference agent.py:277-283)
     alphas = [min(1 - 1 / (t + 1), 0.999) for t in (0, 1, 2, 5000)]
     assert alphas[0] == 0 and abs(alphas[1] - 0.5) < 1e-12 and abs(alphas[2] - 2 / 3) < 1e-12 and alphas[3] == 0.999
+
+
+def test_count_work_reproduces_the_survey_totals():
+    """tools/count_work.py: MACs per image-forward, parameter counts and the step totals the roofline uses."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    import count_work as cw
+    want = {"effinetv2": (2.849e9, 20_901_465, 110), "repvgg": (9.787e9, 44_850_569, 56), "tinyvit": (4.250e9, 20_704_649, 27)}
+    for net, (macs, params, convs) in want.items():
+        t = cw.NETS[net]().totals()
+        assert abs(t["macs"] - macs) < 1e6 and t["params"] == params and t["convs"] == convs, (net, t)
+    assert abs(cw.NETS["tinyvit"]().totals()["attn_macs"] - 0.212e9) < 1e6
+    c2 = cw.step_work("effinetv2", 32, 128)
+    assert abs(c2["flop"] - 3.46e12) < 0.01e12 and abs(c2["t_flop"] - 22.0e-3) < 0.1e-3
+    assert abs(cw.step_work("repvgg", 64, 256)["flop"] - 23.8e12) < 0.05e12
+    assert abs(cw.step_work("tinyvit", 32, 128)["flop"] - 5.17e12) < 0.01e12
