@@ -294,9 +294,12 @@ int suhpe_fill(float* p, int64_t count, float value, suhpe_stream_t stream);
 /* src/tiny_vit.py:262-286 over windows addressed IN PLACE in a (B,H,W,C) token tensor (no window partition / reverse
  * copies, tiny_vit.py:356-366).  qkv: (B*H*W, heads*3*dh), per head [q(dh) k(dh) v(dh)] as the reference's
  * qkv.view(B,N,heads,-1).split; bias_table: (heads, noff); bias_idx: int32 (ws*ws, ws*ws); out: (B*H*W, heads*dh).
- * probs: (B*nwin*heads, N, N) saved for backward, NULL for inference.  dh must be 32, ws*ws <= 196, ws | H, ws | W. */
+ * probs: (B*nwin*heads, N, N) saved for backward, NULL for inference.  dh must be 32, ws*ws <= 196, ws | H, ws | W.
+ * workspace: suhpe_window_attn_fwd_workspace_bytes(ws, heads) bytes (the per-head bias expanded to a dense, padded
+ * (heads, NP, NP) matrix by a first small launch); qkv must be smaller than 2 GiB. */
+int64_t suhpe_window_attn_fwd_workspace_bytes(int ws, int heads);
 int suhpe_window_attn_fwd(const float* qkv, const float* bias_table, const int32_t* bias_idx, int B, int H, int W,
-                          int ws, int heads, int dh, int noff, float scale, float* out, float* probs,
+                          int ws, int heads, int dh, int noff, float scale, float* out, float* probs, void* workspace,
                           suhpe_stream_t stream);
 int64_t suhpe_window_attn_probs_elems(int B, int H, int W, int ws, int heads);
 /* dqkv gets every element written; dbias_table (+)= gradient (atomic accumulate); workspace: probs_elems floats */

@@ -115,10 +115,19 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 constexpr int KP = DH + 4;      // row pitch of the K tile and of the probability staging tile (conflict-free b128 reads)
 constexpr int PP = 40;          // row pitch of the staging tile: the two lane halves (rows +4) land 32 banks apart
 
+// Dense additive bias per head, padded to the tile grid: dense[h][i][j] = table[h][idx[i][j]] inside the window, -3e38 (the
+// softmax mask) in the padding, so that the score epilogue is one coalesced unconditional load per element.
+__global__ __launch_bounds__(256) void window_attn_dense_bias_kernel(const float* __restrict__ table, const int32_t* __restrict__ bias_idx, int heads,
+                                                                      int N, int NP, int noff, float* __restrict__ dense) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)heads * NP * NP) return;
+    const int h = (int)(e / (NP * NP)), ij = (int)(e - (int64_t)h * NP * NP), i = ij / NP, j = ij - i * NP;
+    dense[e] = (i < N && j < N) ? table[h * noff + bias_idx[i * N + j]] : -3.0e38f;
+}
+
 template <int NP>
 __global__ __launch_bounds__(NP == 64 ? 128 : 256) void window_attn_fwd_mfma(const AttnGeom g, const float* __restrict__ qkv,
-                                                                            const float* __restrict__ bias_table,
-                                                                            const int32_t* __restrict__ bias_idx, float* __restrict__ out,
+                                                                            const float* __restrict__ dense_bias, float* __restrict__ out,
                                                                             float* __restrict__ probs) {
     constexpr int QB = NP / 32;                         // query / key tiles
     constexpr int NW = NP == 64 ? 2 : 4;                // wavefronts
@@ -130,33 +139,31 @@ __global__ __launch_bounds__(NP == 64 ? 128 : 256) void window_attn_fwd_mfma(con
     const int win = blockIdx.x / g.heads, hd = blockIdx.x - win * g.heads;
     const int ld = g.heads * 3 * DH, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int r32 = lane & 31, h = lane >> 5;
+    // every qkv read is a buffer load whose offset is pushed out of range for tokens beyond the window (-> zeros): no
+    // branches around the loads, so they are all in flight together
+    const BufRsrc rq = make_rsrc(qkv, (int64_t)g.B * g.H * g.W * ld * 4);
     // K rows and V^T; tokens beyond the window are zero
+#pragma unroll
     for (int e = t; e < NP * (DH / 4); e += NW * 64) {
         const int tok = e / (DH / 4), c4 = (e - tok * (DH / 4)) * 4;
-        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-        if (tok < g.N) {
-            const float* base = qkv + token_row(g, win, tok) * ld + hd * 3 * DH;
-            kv = *reinterpret_cast<const float4*>(base + DH + c4);
-            vv = *reinterpret_cast<const float4*>(base + 2 * DH + c4);
-        }
+        float4 kv, vv;
+        const unsigned off = tok < g.N ? (unsigned)((token_row(g, win, tok) * ld + hd * 3 * DH + DH + c4) * 4) : kOob;
+        buf_load<4>(rq, off, &kv.x);
+        buf_load<4>(rq, off + (tok < g.N ? DH * 4u : 0u), &vv.x);
         *reinterpret_cast<float4*>(&Ks[tok * KP + c4]) = kv;
         Vt[(c4 + 0) * VP + tok] = vv.x; Vt[(c4 + 1) * VP + tok] = vv.y; Vt[(c4 + 2) * VP + tok] = vv.z; Vt[(c4 + 3) * VP + tok] = vv.w;
     }
     __syncthreads();
-    const float* bt = bias_table + (int64_t)hd * g.noff;
+    const float* bd = dense_bias + (int64_t)hd * NP * NP;
     float* pst = Pst + wave * 32 * PP;
     for (int qb = wave; qb < QB; qb += NW) {
         // A operand of Q K^T straight from global memory: lane (row r32, half h) holds k = 8*kg + 4*h .. +3
         const int qrow = qb * 32 + r32;
         float4 qf[DH / 8];
         {
-            const bool ok = qrow < g.N;
-            const float* base = qkv + (ok ? token_row(g, win, qrow) : 0) * ld + hd * 3 * DH;
+            const unsigned qoff = qrow < g.N ? (unsigned)((token_row(g, win, qrow) * ld + hd * 3 * DH + h * 4) * 4) : kOob;
 #pragma unroll
-            for (int kg = 0; kg < DH / 8; ++kg) {
-                qf[kg] = *reinterpret_cast<const float4*>(base + kg * 8 + h * 4);
-                if (!ok) qf[kg] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            for (int kg = 0; kg < DH / 8; ++kg) buf_load<4>(rq, qoff + (qrow < g.N ? kg * 32u : 0u), &qf[kg].x);
         }
         floatx16 sc[QB];
 #pragma unroll
@@ -182,8 +189,7 @@ __global__ __launch_bounds__(NP == 64 ? 128 : 256) void window_attn_fwd_mfma(con
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int i = qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                float v = -3.0e38f;
-                if (i < g.N && j < g.N) v = sc[kt][e] * g.scale + bt[bias_idx[i * g.N + j]];
+                const float v = sc[kt][e] * g.scale + bd[i * NP + j];         // padding: -3e38 swallows the (finite) score
                 sc[kt][e] = v;
                 rmax[e] = fmaxf(rmax[e], v);
             }
@@ -354,17 +360,22 @@ __global__ __launch_bounds__(NP == 64 ? 128 : 256) void window_attn_bwd_mfma(con
     const int r32 = lane & 31, h = lane >> 5;
     const float* P = probs + (int64_t)blockIdx.x * g.N * g.N;
     float* S = dS_out + (int64_t)blockIdx.x * g.N * g.N;
-    auto load_rows = [&](const float* src, int ldsrc, int off, float* dst) __attribute__((always_inline)) {
+    // buffer loads with the offset pushed out of range where the element does not exist (-> 0): no branches around loads
+    const BufRsrc rq = make_rsrc(qkv, (int64_t)g.B * g.H * g.W * ld * 4);
+    const BufRsrc ro = make_rsrc(dout, (int64_t)g.B * g.H * g.W * lo * 4);
+    const BufRsrc rp = make_rsrc(P, (int64_t)g.N * g.N * 4);
+    auto load_rows = [&](BufRsrc src, int ldsrc, int off, float* dst) __attribute__((always_inline)) {
+#pragma unroll
         for (int e = t; e < NP * (DH / 4); e += NW * 64) {
             const int tok = e / (DH / 4), c4 = (e - tok * (DH / 4)) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (tok < g.N) v = *reinterpret_cast<const float4*>(src + token_row(g, win, tok) * ldsrc + off + c4);
+            float4 v;
+            buf_load<4>(src, tok < g.N ? (unsigned)((token_row(g, win, tok) * ldsrc + off + c4) * 4) : kOob, &v.x);
             *reinterpret_cast<float4*>(&dst[tok * KP + c4]) = v;
         }
     };
-    load_rows(qkv, ld, hd * 3 * DH + DH, KQ);           // K
-    load_rows(qkv, ld, hd * 3 * DH + 2 * DH, Vs);
-    load_rows(dout, lo, hd * DH, Os);
+    load_rows(rq, ld, hd * 3 * DH + DH, KQ);            // K
+    load_rows(rq, ld, hd * 3 * DH + 2 * DH, Vs);
+    load_rows(ro, lo, hd * DH, Os);
     __syncthreads();
     float* sS = stS + wave * 32 * PP;
     float* sP = stP + wave * 32 * PP;
@@ -394,7 +405,8 @@ __global__ __launch_bounds__(NP == 64 ? 128 : 256) void window_attn_bwd_mfma(con
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int i = qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const float pv = (i < g.N && j < g.N) ? P[i * g.N + j] : 0.f;
+                float pv;
+                buf_load<1>(rp, (i < g.N) & (j < g.N) ? (unsigned)((i * g.N + j) * 4) : kOob, &pv);
                 pt[kt][e] = pv;
                 dl[e] += pv * dp[kt][e];
             }
@@ -437,7 +449,7 @@ __global__ __launch_bounds__(NP == 64 ? 128 : 256) void window_attn_bwd_mfma(con
         }
     }
     __syncthreads();                                    // every wave is done with K; delta is complete
-    load_rows(qkv, ld, hd * 3 * DH, KQ);                // Q
+    load_rows(rq, ld, hd * 3 * DH, KQ);                 // Q
     __syncthreads();
 
     // ---------------- phase B: key tiles
@@ -462,7 +474,8 @@ __global__ __launch_bounds__(NP == 64 ? 128 : 256) void window_attn_bwd_mfma(con
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int rl = (e & 3) + 8 * (e >> 2) + 4 * h, i = qb * 32 + rl;
-                const float pv = (i < g.N && j < g.N) ? P[i * g.N + j] : 0.f;
+                float pv;
+                buf_load<1>(rp, (i < g.N) & (j < g.N) ? (unsigned)((i * g.N + j) * 4) : kOob, &pv);
                 sP[rl * PP + r32] = pv;
                 sS[rl * PP + r32] = pv * (dp[e] - delta[i]);
             }
@@ -488,14 +501,17 @@ __global__ __launch_bounds__(NP == 64 ? 128 : 256) void window_attn_bwd_mfma(con
 }
 
 // dbias_table[h][bias_idx[i][j]] += sum over windows of dS[w][h][i][j]
+// (blockIdx.y selects a chunk of windows: more loads in flight, and the chunks' partial sums meet in the atomic)
 __global__ __launch_bounds__(256) void window_attn_dbias_kernel(const float* __restrict__ dS, const int32_t* __restrict__ bias_idx, int nwin,
                                                                 int heads, int N, int noff, float* __restrict__ dbias) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // (h, i*N + j)
     if (e >= (int64_t)heads * N * N) return;
     const int h = (int)(e / ((int64_t)N * N)), ij = (int)(e - (int64_t)h * N * N);
+    const int per = (nwin + gridDim.y - 1) / gridDim.y, w0 = blockIdx.y * per, w1 = min(nwin, w0 + per);
     float s = 0.f;
-    for (int w = 0; w < nwin; ++w) s += dS[((int64_t)w * heads + h) * N * N + ij];
-    atomicAdd(&dbias[h * noff + bias_idx[ij]], s);
+#pragma unroll 8
+    for (int w = w0; w < w1; ++w) s += dS[((int64_t)w * heads + h) * N * N + ij];
+    if (w1 > w0) atomicAdd(&dbias[h * noff + bias_idx[ij]], s);
 }
 
 static int attn_geom(AttnGeom* g, int B, int H, int W, int ws, int heads, int dh, int noff, float scale, const char* who) {
@@ -514,16 +530,29 @@ using namespace suhpe;
 
 extern "C" {
 
+int64_t suhpe_window_attn_fwd_workspace_bytes(int ws, int heads) {
+    const int n = ws * ws, np = n <= 64 ? 64 : 224;
+    return (n <= 224 && heads > 0) ? (int64_t)heads * np * np * (int64_t)sizeof(float) : 0;
+}
+
 int suhpe_window_attn_fwd(const float* qkv, const float* bias_table, const int32_t* bias_idx, int B, int H, int W, int ws, int heads, int dh,
-                          int noff, float scale, float* out, float* probs, suhpe_stream_t stream) {
+                          int noff, float scale, float* out, float* probs, void* workspace, suhpe_stream_t stream) {
     AttnGeom g;
     int rc = attn_geom(&g, B, H, W, ws, heads, dh, noff, scale, "suhpe_window_attn_fwd");
     if (rc) return rc;
     SUHPE_REQUIRE(qkv && bias_table && bias_idx && out, "suhpe_window_attn_fwd: null pointer");
     const dim3 grid(B * g.nwy * g.nwx * heads);
+    float* dense = static_cast<float*>(workspace);
+    if (g.N <= 224) {
+        SUHPE_REQUIRE(dense, "suhpe_window_attn_fwd: workspace of suhpe_window_attn_fwd_workspace_bytes() is required");
+        SUHPE_REQUIRE((int64_t)B * H * W * heads * 3 * DH * 4 < 0x7fffffffLL, "suhpe_window_attn_fwd: qkv must be smaller than 2 GiB");
+        const int np = g.N <= 64 ? 64 : 224;
+        hipLaunchKernelGGL(window_attn_dense_bias_kernel, dim3((unsigned)ceil_div((int64_t)heads * np * np, 256)), dim3(256), 0, as_stream(stream),
+                           bias_table, bias_idx, heads, g.N, np, noff, dense);
+    }
     if (g.N <= 64) {
         const size_t lds = (size_t)(64 * KP + DH * (64 + 4) + 2 * 32 * PP) * sizeof(float);
-        hipLaunchKernelGGL(window_attn_fwd_mfma<64>, grid, dim3(128), lds, as_stream(stream), g, qkv, bias_table, bias_idx, out, probs);
+        hipLaunchKernelGGL(window_attn_fwd_mfma<64>, grid, dim3(128), lds, as_stream(stream), g, qkv, dense, out, probs);
     } else if (g.N <= 224) {
         const size_t lds = (size_t)(224 * KP + DH * (224 + 4) + 4 * 32 * PP) * sizeof(float);
         static bool attr_set = false;
@@ -531,7 +560,7 @@ int suhpe_window_attn_fwd(const float* qkv, const float* bias_table, const int32
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_fwd_mfma<224>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        hipLaunchKernelGGL(window_attn_fwd_mfma<224>, grid, dim3(256), lds, as_stream(stream), g, qkv, bias_table, bias_idx, out, probs);
+        hipLaunchKernelGGL(window_attn_fwd_mfma<224>, grid, dim3(256), lds, as_stream(stream), g, qkv, dense, out, probs);
     } else {
         const size_t lds = (size_t)(2 * g.N * PITCH + 4 * DH + 4 * MAXN) * sizeof(float);
         hipLaunchKernelGGL(window_attn_fwd_kernel, grid, dim3(256), lds, as_stream(stream), g, qkv, bias_table, bias_idx, out, probs);
@@ -550,6 +579,7 @@ int suhpe_window_attn_bwd(const float* qkv, const float* probs, const float* dou
     int rc = attn_geom(&g, B, H, W, ws, heads, dh, noff, scale, "suhpe_window_attn_bwd");
     if (rc) return rc;
     SUHPE_REQUIRE(qkv && probs && dout && bias_idx && dqkv && workspace, "suhpe_window_attn_bwd: null pointer");
+    SUHPE_REQUIRE((int64_t)B * H * W * heads * 3 * DH * 4 < 0x7fffffffLL, "suhpe_window_attn_bwd: qkv must be smaller than 2 GiB");
     const size_t lds = (size_t)(4 * g.N * PITCH + 8 * MAXN) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -574,8 +604,9 @@ int suhpe_window_attn_bwd(const float* qkv, const float* probs, const float* dou
     }
     if (dbias_table) {
         const int64_t total = (int64_t)heads * g.N * g.N;
-        hipLaunchKernelGGL(window_attn_dbias_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(stream), dS, bias_idx, nwin, heads,
-                           g.N, noff, dbias_table);
+        const int chunks = nwin >= 64 ? 8 : (nwin >= 8 ? 2 : 1);
+        hipLaunchKernelGGL(window_attn_dbias_kernel, dim3((unsigned)ceil_div(total, 256), chunks), dim3(256), 0, as_stream(stream), dS, bias_idx, nwin,
+                           heads, g.N, noff, dbias_table);
     }
     return check_launch("suhpe_window_attn_bwd");
 }

@@ -842,8 +842,9 @@ def window_attn_fwd(qkv, bias_table, bias_idx, B, H, W, ws, heads, scale, save_p
     if save_probs:
         n = _lib.load().suhpe_window_attn_probs_elems(B, H, W, ws, heads)
         probs = torch.empty(n, dtype=torch.float32, device=qkv.device)
+    ws_buf = workspace("attn_bias", max(4, _lib.load().suhpe_window_attn_fwd_workspace_bytes(ws, heads)), qkv.device)
     call("suhpe_window_attn_fwd", ptr(qkv), ptr(bias_table), ptr(bias_idx), B, H, W, ws, heads, dh, bias_table.shape[1], float(scale),
-         ptr(out), ptr(probs))
+         ptr(out), ptr(probs), ptr(ws_buf))
     return out, probs
 
 
