@@ -97,7 +97,15 @@ def require_gpu():
                            "(the CPU oracle under oracle/ is test infrastructure only)")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_get_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream_ptr():
+    """hipStream_t of torch's current stream on the current device (the raw-handle query: building a torch.cuda.Stream
+    object per launch costs more host time than the launch itself)."""
+    if _raw_stream is not None and _get_device is not None:
+        return _raw_stream(_get_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -58,6 +58,12 @@ class _Axpby(torch.autograd.Function):
         return g, K.axpby(g, ctx.beta), None
 
 
+def _mode(net, training):
+    """net.train() / net.eval() without re-walking ~600 submodules every step when the mode is already set"""
+    if net.training != training:
+        net.train(training)
+
+
 def _dev(t, device):
     if t.device == device:
         return t
@@ -223,8 +229,8 @@ class SSLAgent:
 
     def train_func(self, data, ulb_data):
         """one SSL step (reference :194-218)"""
-        self.net.train()
-        self.ema_net.train()
+        _mode(self.net, True)
+        _mode(self.ema_net, True)
         stage2_iter = self.clock.iteration - self.config.stage1_iteration
         self.update_ema_variables(self.config.is_ema, self.config.ema_decay, stage2_iter)
         self.optimizer.zero_grad()
@@ -240,7 +246,7 @@ class SSLAgent:
 
     def train_func_s1(self, data):
         """supervised step (reference :254-266); the EMA teacher is not touched in stage 1"""
-        self.net.train()
+        _mode(self.net, True)
         self.optimizer.zero_grad()
         fisher_dict, _ = self.forward(data, None)
         fisher_dict["loss"].backward(self._grad_seed)
@@ -250,8 +256,8 @@ class SSLAgent:
 
     def val_func(self, data, eval_ema=False):
         """one validation step (reference :220-251); host syncs are fine here (the reference calls .item() too)"""
-        self.net.eval()
-        self.ema_net.eval()
+        _mode(self.net, False)
+        _mode(self.ema_net, False)
         with torch.no_grad():
             fisher_dict, fisher_dict_unsuper = self.forward(data, None, eval_ema=eval_ema)
             entropy = fisher_entropy(fisher_dict["pred"])
@@ -266,7 +272,7 @@ class SSLAgent:
             return fisher_dict, fisher_dict_unsuper, dict(mask_ratio=fisher_mask_ratio, err_pseudo_gt=fisher_err_pseudo_gt)
 
     def val_func_s1(self, data):
-        self.net.eval()
+        _mode(self.net, False)
         with torch.no_grad():
             fisher_dict, _ = self.forward(data, None)
             return fisher_dict
@@ -330,7 +336,7 @@ class SSLAgent:
     def compute_dynamic_entropy_threshold(self, ulb_train_bar):
         """reference :357-417: teacher (eval mode) entropies over the unlabeled set, sorted, left_ratio quantile.
         With world_size > 1 each rank scans its own loader shard and the entropy vectors are all-gathered."""
-        self.ema_net.eval()
+        _mode(self.ema_net, False)
         chunks = []
         with torch.no_grad():
             for ulb_data in ulb_train_bar:
