@@ -132,10 +132,10 @@ _ws = {}
 
 
 def workspace(tag, nbytes, device=None):
-    """Grow-only scratch buffer per (tag, device).  All launches are ordered on one stream per rank, so a tag can be
-    reused by consecutive kernels."""
+    """Grow-only scratch buffer per (tag, device, stream).  Launches on one stream are ordered, so a tag can be reused by
+    consecutive kernels; a second stream (the teacher pass runs beside the student's) gets its own buffers."""
     device = device if device is not None else torch.cuda.current_device()
-    key = (tag, torch.device("cuda", device) if isinstance(device, int) else device)
+    key = (tag, torch.device("cuda", device) if isinstance(device, int) else device, stream_ptr())
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=key[1])

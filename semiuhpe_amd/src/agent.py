@@ -77,6 +77,10 @@ class SSLAgent:
         # time the GEMM tile menu on each new conv shape during the first steps and pin the winners (kernels._autotune)
         K.AUTOTUNE = bool(getattr(config, "autotune", True)) and os.environ.get("SUHPE_AUTOTUNE", "1") != "0"
         self.merge_student_passes = bool(getattr(config, "merge_student_passes", True)) and os.environ.get("SUHPE_MERGE", "1") != "0"
+        # the teacher's forward pass does not depend on the student's: it is enqueued on a second stream so that the two
+        # passes fill each other's launch gaps and partial waves
+        self.overlap_teacher = bool(getattr(config, "overlap_teacher", True)) and os.environ.get("SUHPE_OVERLAP", "1") != "0"
+        self._teacher_stream = None
         self.net = get_network(config)
         self.ema_net = get_network(config)
         for param in self.ema_net.parameters():      # reference :34-35: the teacher is never trained by gradients
@@ -129,6 +133,16 @@ class SSLAgent:
         """sum(mask*x)/count as a 1-element device tensor (nan when nothing is selected, like mean of an empty tensor)"""
         return K.masked_mean(x, mask)
 
+    def _teacher_forward(self, img):
+        """teacher(weak view) on the side stream; the caller joins (wait_stream) before it reads the result"""
+        if self._teacher_stream is None:
+            self._teacher_stream = torch.cuda.Stream(device=self.device)
+        side = self._teacher_stream
+        side.wait_stream(torch.cuda.current_stream())       # EMA update and the input batch are ordered before the pass
+        with torch.cuda.stream(side), torch.no_grad():
+            img.record_stream(side)
+            return self.ema_net(img)
+
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self, data, ulb_data, eval_ema=False):
         cfg, dev = self.config, self.device
@@ -140,7 +154,9 @@ class SSLAgent:
         # The two student passes of a step (labeled batch, strong views) share the weights: run them as one batch whose
         # BatchNorm statistics are kept per segment (layers.batch_segments) -- same arithmetic per sample, larger GEMMs.
         merged = (self.merge_student_passes and ulb_data is not None and not eval_ema and net.training and torch.is_grad_enabled())
-        pred_strong = None
+        pred_strong = pred_weak = None
+        if ulb_data is not None and self.overlap_teacher:
+            pred_weak = self._teacher_forward(_dev(ulb_data.get("img"), dev))
         if merged:
             strong = _dev(ulb_data.get("img_strong"), dev)
             n_l, n_u = img.shape[0], strong.shape[0]
@@ -166,8 +182,13 @@ class SSLAgent:
         ### 2. unsupervised loss (reference :98-192)
         ulb_img_weak = _dev(ulb_data.get("img"), dev)
         ulb_gt = _dev(ulb_data.get("rot_mat"), dev).reshape(-1, 9).contiguous() if "rot_mat" in ulb_data else None
-        with torch.no_grad():
-            pred_weak = self.ema_net(ulb_img_weak)
+        if pred_weak is None:
+            with torch.no_grad():
+                pred_weak = self.ema_net(ulb_img_weak)
+        else:                                               # issued on the teacher stream before the student pass: join
+            main = torch.cuda.current_stream()
+            main.wait_stream(self._teacher_stream)
+            pred_weak.record_stream(main)
         mu_b = pred_weak.shape[0]
         if cfg.rotate_aug:
             aug = _dev(ulb_data.get("aug_rot_mat"), dev).reshape(-1, 9).contiguous()

@@ -24,21 +24,24 @@ class MaskTape:
 
     def replay_merged(self, kind, shape, keep):
         """For an agent that runs its two student passes as one batch: the oracle drew [labeled pass | teacher pass | strong
-        pass], K masks each; the merged student asks for K masks over the concatenated batch, then the teacher for its K."""
+        pass], K masks each.  The merged student asks for K masks over the concatenated batch; the teacher (which may be
+        enqueued before or after the student) for its K.  Requests are told apart by their batch dimension."""
         k3 = len(self.masks) // 3
-        i = self.cursor
-        self.cursor += 1
-        self.end = 2 * k3
-        if i < k3:
-            (ka, sa, ma), (kb, sb, mb) = self.masks[i], self.masks[2 * k3 + i]
-            assert ka == kb == kind and (sa[0] + sb[0],) + sa[1:] == tuple(shape), f"merged mask mismatch at {i}: {ka}{sa}+{kb}{sb} vs {kind}{tuple(shape)}"
+        if not hasattr(self, "cur_student"):
+            self.cur_student, self.cur_teacher = 0, 0
+        (ka, sa, ma), (kb, sb, mb) = self.masks[self.cur_student % k3], self.masks[2 * k3 + self.cur_student % k3]
+        if self.cur_student < k3 and tuple(shape) == (sa[0] + sb[0],) + sa[1:] and ka == kb == kind:
+            self.cur_student += 1
             return torch.cat([ma, mb])
-        k, s, m = self.masks[i]
-        assert k == kind and s == tuple(shape), f"mask order mismatch: oracle drew {k}{s}, HIP asks {kind}{tuple(shape)}"
+        k, s_, m = self.masks[k3 + self.cur_teacher]
+        assert k == kind and s_ == tuple(shape), f"mask order mismatch: oracle drew {k}{s_}, HIP asks {kind}{tuple(shape)}"
+        self.cur_teacher += 1
         return m
 
     def done(self):
-        return self.cursor == getattr(self, "end", len(self.masks))
+        if hasattr(self, "cur_student"):
+            return self.cur_student == self.cur_teacher == len(self.masks) // 3
+        return self.cursor == len(self.masks)
 
 
 def rel_err(x, ref):

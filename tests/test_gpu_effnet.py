@@ -116,6 +116,7 @@ def test_agent_ssl_step_matches_oracle(models, merge):
 
     cfg_o, cfg_h = _config(), _config()
     cfg_h.merge_student_passes = merge
+    cfg_h.overlap_teacher = merge           # (the strict replay of the two-pass flow needs the oracle's call order)
     oracle = OracleAgent(cfg_o, factory)
     agent = SSLAgent(cfg_h)
     agent.net.load_state_dict(sd0)

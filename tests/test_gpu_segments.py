@@ -121,7 +121,7 @@ def test_agent_merged_step_equals_two_pass_step(network, tmp_path, monkeypatch):
             rotate_aug=False, train_labeled="300WLP", train_unlabeled="300WLP", cutout_aug=False, cutmix_aug=False, conf_thres=1e9,
             type_unsuper="ce", SSL_lambda=1.0, is_ema=True, ema_decay=0.999, eman=False, stage1_iteration=0, network=network,
             num_classes=9, exp_name="t", date="t", left_ratio=0.95, save_feat=False, dynamic_thres=False, autotune=False,
-            merge_student_passes=merge)
+            merge_student_passes=merge, overlap_teacher=merge)
 
     torch.manual_seed(11)
     a2 = SSLAgent(cfg(False))
