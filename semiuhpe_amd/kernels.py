@@ -385,6 +385,50 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, groups=1):
 _DEFER = None
 
 
+# Inside a deferred_wgrads() region the filter-gradient GEMMs are also moved to a second stream: a layer's wgrad depends only
+# on its saved input and its output gradient, nothing on the backward chain waits for it, and it is MFMA-bound while the
+# BatchNorm / activation backward kernels it then runs beside are HBM-bound.  The region joins the stream at its end.
+WGRAD_OVERLAP = os.environ.get("SUHPE_WGRAD_OVERLAP", "1") != "0"
+_side_streams = {}
+_side_used = False
+
+
+def _side_stream(device):
+    key = torch.device(device)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=key)
+    return _side_streams[key]
+
+
+class _on_side_stream:
+    """run the body on the side stream after everything enqueued so far on the current stream; keeps the given tensors alive
+    for the side stream (allocator bookkeeping)"""
+
+    def __init__(self, device, *tensors):
+        self.side = _side_stream(device)
+        self.tensors = tensors
+
+    def __enter__(self):
+        global _side_used
+        _side_used = True
+        self.side.wait_stream(torch.cuda.current_stream())
+        for t in self.tensors:
+            t.record_stream(self.side)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        return self.ctx.__exit__(*exc)
+
+
+class _same_stream:
+    def __enter__(self):
+        pass
+
+    def __exit__(self, *exc):
+        return False
+
+
 class deferred_wgrads:
     def __enter__(self):
         global _DEFER
@@ -392,10 +436,20 @@ class deferred_wgrads:
         return self
 
     def __exit__(self, *exc):
-        global _DEFER
+        global _DEFER, _side_used
         jobs, _DEFER = _DEFER, self.outer
-        if self.outer is None and jobs and exc[0] is None:
-            flush_wgrads(jobs)
+        if self.outer is not None:
+            return
+        used, _side_used = _side_used, False
+        if exc[0] is None and jobs:
+            if used:
+                with torch.cuda.stream(_side_stream(jobs[0][0].device)):
+                    flush_wgrads(jobs)
+            else:
+                flush_wgrads(jobs)
+        if used:                                        # filter gradients are complete before anything that follows
+            for side in _side_streams.values():
+                torch.cuda.current_stream(side.device).wait_stream(side)
 
 
 _flush_ring = []          # pinned staging buffers for the job tables: (table, starts, event), used round-robin
@@ -440,6 +494,13 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, groups=1, out=None, accumulate
         accumulate = False
     assert filter_is_physical(out)
     lib = _lib.load()
+    side = _DEFER is not None and accumulate and WGRAD_OVERLAP
+    with (_on_side_stream(x.device, x, dy) if side else _same_stream()):
+        _conv2d_wgrad(lib, d, x, dy, out, accumulate)
+    return out
+
+
+def _conv2d_wgrad(lib, d, x, dy, out, accumulate):
     if _is_depthwise(d) and d.cin % 4 == 0:
         nbytes = lib.suhpe_dwconv_wgrad_workspace_bytes(ctypes.byref(d))
         ws = workspace("wgrad", nbytes, x.device)
