@@ -124,10 +124,17 @@ void igemm_nt_kernel(const NtParams p) {
     // XCD-aware tile order: workgroups b and b+8 share an XCD (round-robin dispatch, speed only).  Column tiles of one
     // row tile reuse the same gathered rows, so they are made consecutive on ONE XCD: xcd = b%8, j = b/8,
     // col tile = j % col_tiles, row tile = (j / col_tiles)*8 + xcd.  Row tiles are padded to a multiple of 8 by the host.
+    // Convolutions with a spatial footprint (every mode but the pointwise one) also share input rows BETWEEN neighbouring
+    // row tiles (the halo of the taps), so there each XCD takes one contiguous run of row tiles instead of every eighth.
     const int b = blockIdx.x;
     const int jx = b >> 3;
     const int col_tile = jx % p.col_tiles;
-    const int row_tile = (jx / p.col_tiles) * 8 + (b & 7);
+    int row_tile = (jx / p.col_tiles) * 8 + (b & 7);
+    if (MODE != 1) {
+        const int row_tiles = (int)((g.M + BM - 1) / BM), q = row_tiles >> 3, rem = row_tiles & 7, xcd = b & 7, jl = jx / p.col_tiles;
+        if (jl >= q + (xcd < rem ? 1 : 0)) return;      // padding workgroup
+        row_tile = xcd * q + (xcd < rem ? xcd : rem) + jl;
+    }
     const int64_t m0 = (int64_t)row_tile * BM;
     if (m0 >= g.M) return;                               // padding workgroup (whole block exits before any barrier)
     const int n0 = col_tile * BN;
