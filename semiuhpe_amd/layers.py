@@ -32,6 +32,8 @@ def draw_mask(kind, shape, keep, device):
     if _mask_hook is not None:
         m = _mask_hook(kind, tuple(shape), keep)
         if m is not None:
+            if tuple(m.shape) != tuple(shape):
+                raise ValueError(f"mask hook returned shape {tuple(m.shape)} for a {kind} mask of shape {tuple(shape)}")
             return m.to(device=device, dtype=torch.float32).contiguous()
     return K.dropout_mask(tuple(shape), keep, device)
 
