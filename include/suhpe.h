@@ -223,6 +223,28 @@ int suhpe_bn_act_skip_fwd(const float* x, int64_t rows, int c, const float* mean
 int suhpe_bn_act_skip_bwd(const float* x, const float* dy, int64_t rows, int c, const float* mean, const float* rstd,
                           const float* gamma, const float* beta, int act, int train_stats, const float* rowscale, int hw,
                           float* dx, float* dgamma, float* dbeta, int accumulate, void* workspace, suhpe_stream_t stream);
+/* Two batch segments in one launch: rows [0, rows_a) and [rows_a, rows) of x are normalised with separate statistics (the
+ * labeled and the strong batch of a step run through the network as one, layers.batch_segments).  mean / rstd are [2][c];
+ * the running statistics take the two momentum updates in order and num_batches_tracked += 2; dgamma / dbeta receive the sum
+ * over both segments.  Same arithmetic as calling the one-segment entry points on the two halves (tested).  The skip /
+ * rowscale forms need whole samples per segment (rows_a % hw == 0). */
+int suhpe_bn_stats_seg(const float* x, int64_t rows, int64_t rows_a, int c, float eps, float momentum, float* mean, float* rstd,
+                       float* running_mean, float* running_var, int64_t* num_batches_tracked, void* workspace,
+                       suhpe_stream_t stream);
+/* from the records of suhpe_conv2d_fwd_stats_seg: first_records = records of the first segment, boundary = stats_extra or NULL */
+int suhpe_bn_stats_from_partials_seg(const float* part, int tiles, int first_records, const float* boundary, int64_t rows,
+                                     int64_t rows_a, int c, float eps, float momentum, float* mean, float* rstd,
+                                     float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                     suhpe_stream_t stream);
+/* post = 0: act(BN(x) + residual); post = 1: residual + rowscale[sample] * act(BN(x)) */
+int suhpe_bn_act_fwd_seg(const float* x, int64_t rows, int64_t rows_a, int c, const float* mean, const float* rstd,
+                         const float* gamma, const float* beta, int act, const float* residual, int post,
+                         const float* rowscale, int hw, float* y, suhpe_stream_t stream);
+int suhpe_bn_act_bwd_seg(const float* x, const float* dy, const float* y_out, int64_t rows, int64_t rows_a, int c,
+                         const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                         const float* rowscale, int hw, float* dx, float* dgamma, float* dbeta, int accumulate,
+                         void* workspace, suhpe_stream_t stream);
+
 /* LayerNorm over the last dim (rows, c) (src/tiny_vit.py nn.LayerNorm) */
 int suhpe_layernorm_fwd(const float* x, int64_t rows, int c, float eps, const float* gamma, const float* beta,
                         float* y, float* mean, float* rstd, suhpe_stream_t stream);

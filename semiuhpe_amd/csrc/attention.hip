@@ -406,7 +406,7 @@ __global__ __launch_bounds__(NP == 64 ? 128 : 256) void window_attn_bwd_mfma(con
             for (int e = 0; e < 16; ++e) {
                 const int i = qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 float pv;
-                buf_load<1>(rp, (i < g.N) & (j < g.N) ? (unsigned)((i * g.N + j) * 4) : kOob, &pv);
+                buf_load<1>(rp, ((i < g.N) & (j < g.N)) ? (unsigned)((i * g.N + j) * 4) : kOob, &pv);
                 pt[kt][e] = pv;
                 dl[e] += pv * dp[kt][e];
             }
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(NP == 64 ? 128 : 256) void window_attn_bwd_mfma(con
             for (int e = 0; e < 16; ++e) {
                 const int rl = (e & 3) + 8 * (e >> 2) + 4 * h, i = qb * 32 + rl;
                 float pv;
-                buf_load<1>(rp, (i < g.N) & (j < g.N) ? (unsigned)((i * g.N + j) * 4) : kOob, &pv);
+                buf_load<1>(rp, ((i < g.N) & (j < g.N)) ? (unsigned)((i * g.N + j) * 4) : kOob, &pv);
                 sP[rl * PP + r32] = pv;
                 sS[rl * PP + r32] = pv * (dp[e] - delta[i]);
             }

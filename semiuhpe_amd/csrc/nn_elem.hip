@@ -58,14 +58,31 @@ static EwGeom ew_geom(int64_t rows, int c, int vec) {
     g.rows_per_block = (int)ceil_div(rows, gx);
     return g;
 }
+#define EW_BX blockIdx.x
 #define EW_THREAD_SETUP(VEC)                                                              \
     const int t = threadIdx.x, col = t % cw, rsub = t / cw;                               \
     const int cv = c / VEC, vc = blockIdx.y * cw + col;                                   \
     if (rsub >= rp || vc >= cv) return;                                                   \
     const int ch = vc * VEC; (void)ch;                                                    \
-    const int r0 = blockIdx.x * rows_per_block;                                           \
+    const int r0 = EW_BX * rows_per_block;                                                \
     int r1 = r0 + rows_per_block;                                                         \
     if (r1 > rows) r1 = rows;
+
+// Two batch segments in one launch.  Row blocks [0, nb_a) cover rows [0, rows_a) with the first statistics set, the blocks
+// after them the remaining rows with the second set: every per-channel array of statistics (mean, rstd, backward sums) is
+// then [2][c], and the reduction records of the two segments never mix.  nb_a == 0: ordinary single-segment launch.
+struct SegArgs { int64_t rows_a; int nb_a; };
+// -> the block's index inside its segment; `rows` becomes the segment's row count, row_off its first row, set its index
+__device__ __forceinline__ int seg_select(const SegArgs& sg, int64_t* rows, int64_t* row_off, int* set) {
+    int bx = blockIdx.x;
+    *row_off = 0;
+    *set = 0;
+    if (sg.nb_a > 0) {
+        if (bx >= sg.nb_a) { bx -= sg.nb_a; *row_off = sg.rows_a; *rows -= sg.rows_a; *set = 1; }
+        else *rows = sg.rows_a;
+    }
+    return bx;
+}
 
 template <int VEC> struct VecT;
 template <> struct VecT<4> { using type = float4; };
@@ -150,15 +167,19 @@ __device__ __forceinline__ void block_combine(const float* s0, const float* s1, 
 // shifted by k = the block's first-row value, so the variance is never the difference of two large sums.
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ x, int64_t rows, int c, int cw, int rp,
-                                                        int64_t rows_per_block, float* __restrict__ part) {
+                                                        int64_t rows_per_block, float* __restrict__ part, const SegArgs sg = SegArgs{0, 0}) {
     __shared__ float lds[256 * 2 * VEC];
+    int64_t row_off;
+    int set;
+    const int bx = seg_select(sg, &rows, &row_off, &set);
+    x += row_off * c;
     const int t = threadIdx.x, col = t % cw, rsub = t / cw;
     const int col0 = blockIdx.y * cw;
     const int cv = c / VEC;
     float s0[VEC], s1[VEC], k[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) { s0[v] = 0.f; s1[v] = 0.f; k[v] = 0.f; }
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r0 = (int64_t)bx * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > rows) r1 = rows;
     if (rsub < rp && col0 + col < cv && r0 < rows) {
@@ -185,13 +206,11 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
 }
 
 // pass 2: 8 channels per 1024-thread block; running-stat update as nn.BatchNorm does.  Records are [row block][channel] float4.
-__global__ __launch_bounds__(kFinThreads) void bn_stats_finalize(const float* __restrict__ part, int gx, int c, int64_t rows, float eps,
-                                                         float momentum, float* __restrict__ mean, float* __restrict__ rstd,
-                                                         float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                         int64_t* __restrict__ nbt, const float* __restrict__ extra = nullptr) {
+__device__ __forceinline__ void bn_stats_finish(const float* __restrict__ part, int gx, int c, int64_t rows, float eps, float momentum,
+                                                float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
+                                                float* __restrict__ running_var, const float* __restrict__ extra) {
     const int chl = threadIdx.x & (kFinCh - 1), sub = threadIdx.x / kFinCh;
     const int ch = blockIdx.x * kFinCh + chl;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
     // re-centre every record on zero in fp64 (exact to 1e-16) and add: sum x = S + n k, sum x^2 = Q + 2 k S + n k^2
     double a = 0.0, b = 0.0, k0 = 0.0;
     if (ch < c) {
@@ -225,6 +244,28 @@ __global__ __launch_bounds__(kFinThreads) void bn_stats_finalize(const float* __
         running_mean[ch] = (float)((1.0 - momentum) * (double)running_mean[ch] + momentum * m);
         running_var[ch] = (float)((1.0 - momentum) * (double)running_var[ch] + momentum * unb);
     }
+}
+
+__global__ __launch_bounds__(kFinThreads) void bn_stats_finalize(const float* __restrict__ part, int gx, int c, int64_t rows, float eps,
+                                                         float momentum, float* __restrict__ mean, float* __restrict__ rstd,
+                                                         float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                         int64_t* __restrict__ nbt, const float* __restrict__ extra = nullptr) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
+    bn_stats_finish(part, gx, c, rows, eps, momentum, mean, rstd, running_mean, running_var, extra);
+}
+
+// two segments: records [0, gx_a) then [gx_a, gx_a + gx_b) (+ the boundary record of a conv epilogue, which belongs to the
+// second segment); statistics to mean/rstd[0..c) and [c..2c); the running statistics take the two momentum updates in order
+// (the same thread owns a channel in both rounds).
+__global__ __launch_bounds__(kFinThreads) void bn_stats_finalize2(const float* __restrict__ part, int gx_a, int gx_b, int c, int64_t rows_a,
+                                                          int64_t rows_b, float eps, float momentum, float* __restrict__ mean,
+                                                          float* __restrict__ rstd, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, int64_t* __restrict__ nbt,
+                                                          const float* __restrict__ extra_b) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 2;
+    bn_stats_finish(part, gx_a, c, rows_a, eps, momentum, mean, rstd, running_mean, running_var, nullptr);
+    __syncthreads();                                     // the reduction scratch is reused
+    bn_stats_finish(part + (int64_t)gx_a * c * 4, gx_b, c, rows_b, eps, momentum, mean + c, rstd + c, running_mean, running_var, extra_b);
 }
 
 __global__ void bn_eval_stats_kernel(const float* __restrict__ rm, const float* __restrict__ rv, int c, float eps,
@@ -283,8 +324,20 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          int act, const float* __restrict__ residual, int post,
                                                          const float* __restrict__ rowscale, int hw,
-                                                         float* __restrict__ y) {
+                                                         float* __restrict__ y, const SegArgs sg = SegArgs{0, 0}) {
+    int64_t rows_s = rows, row_off;
+    int set;
+    const int bx = seg_select(sg, &rows_s, &row_off, &set);
+    rows = (int)rows_s;
+    x += row_off * c; y += row_off * c;
+    if (residual) residual += row_off * c;
+    if (rowscale) rowscale += row_off / hw;
+    mean += set * c; rstd += set * c;
+#undef EW_BX
+#define EW_BX bx
     EW_THREAD_SETUP(VEC)
+#undef EW_BX
+#define EW_BX blockIdx.x
     float sc[VEC], sh[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
@@ -329,8 +382,15 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
                                                       int64_t rows_per_block, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, int act, const float* __restrict__ rowscale,
-                                                      int hw, float* __restrict__ part) {
+                                                      int hw, float* __restrict__ part, const SegArgs sg = SegArgs{0, 0}) {
     __shared__ float lds[256 * 2 * VEC];
+    int64_t row_off;
+    int set;
+    const int bx = seg_select(sg, &rows, &row_off, &set);
+    x += row_off * c; dy += row_off * c;
+    if (yout) yout += row_off * c;
+    if (rowscale) rowscale += row_off / hw;
+    mean += set * c; rstd += set * c;
     const int t = threadIdx.x, col = t % cw, rsub = t / cw;
     const int col0 = blockIdx.y * cw;
     const int cv = c / VEC;
@@ -345,7 +405,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
             mu[v] = mean[ch + v]; rs[v] = rstd[ch + v];
             ga[v] = gamma ? gamma[ch + v] : 1.f; be[v] = beta ? beta[ch + v] : 0.f;
         }
-        const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+        const int64_t r0 = (int64_t)bx * rows_per_block;
         int64_t r1 = r0 + rows_per_block;
         if (r1 > rows) r1 = rows;
         // eight rows per round: 16-24 independent 16-byte loads in flight per thread, clamped + masked instead of branched
@@ -392,6 +452,23 @@ __global__ __launch_bounds__(kFinThreads) void bn_bwd_finalize(const float* __re
     if (dgamma) dgamma[ch] = accumulate ? dgamma[ch] + (float)q : (float)q;
 }
 
+// two segments: records [0, gx_a) and [gx_a, gx); sums[0..2c) / [2c..4c) for pass 3, one accumulation into dgamma / dbeta
+__global__ __launch_bounds__(kFinThreads) void bn_bwd_finalize2(const float* __restrict__ part, int gx_a, int gx, int c, float* __restrict__ sums,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+    double s0, q0, s1, q1;
+    const bool own0 = block_channel_sums(part, gx_a, c, &s0, &q0);
+    __syncthreads();                                     // the reduction scratch is reused
+    const bool own1 = block_channel_sums(part + (int64_t)gx_a * c * 2, gx - gx_a, c, &s1, &q1);
+    if (!(own0 && own1)) return;
+    const int ch = blockIdx.x * kFinCh + (threadIdx.x & (kFinCh - 1));
+    sums[2 * ch] = (float)s0;
+    sums[2 * ch + 1] = (float)q0;
+    sums[2 * c + 2 * ch] = (float)s1;
+    sums[2 * c + 2 * ch + 1] = (float)q1;
+    if (dbeta) dbeta[ch] = (accumulate ? dbeta[ch] : 0.f) + (float)s0 + (float)s1;
+    if (dgamma) dgamma[ch] = (accumulate ? dgamma[ch] : 0.f) + (float)q0 + (float)q1;
+}
+
 // pass 3: dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat))   [train]   or gamma*rstd*g [eval]
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ dy,
@@ -399,8 +476,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ x,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta, int act,
                                                     const float* __restrict__ sums, float inv_rows, int train_stats,
-                                                    const float* __restrict__ rowscale, int hw, float* __restrict__ dx) {
+                                                    const float* __restrict__ rowscale, int hw, float* __restrict__ dx,
+                                                    const SegArgs sg = SegArgs{0, 0}, float inv_rows_b = 0.f) {
+    int64_t rows_s = rows, row_off;
+    int set;
+    const int bx = seg_select(sg, &rows_s, &row_off, &set);
+    rows = (int)rows_s;
+    x += row_off * c; dy += row_off * c; dx += row_off * c;
+    if (yout) yout += row_off * c;
+    if (rowscale) rowscale += row_off / hw;
+    mean += set * c; rstd += set * c; sums += set * 2 * c;
+    if (set) inv_rows = inv_rows_b;
+#undef EW_BX
+#define EW_BX bx
     EW_THREAD_SETUP(VEC)
+#undef EW_BX
+#define EW_BX blockIdx.x
     float mu[VEC], rs[VEC], ga[VEC], be[VEC], m0[VEC], m1[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
@@ -829,7 +920,9 @@ using namespace suhpe;
 
 extern "C" {
 
-int64_t suhpe_bn_workspace_bytes(int c) { return (kPartFloats + (int64_t)c * 2) * sizeof(float); }
+// records (one spare row block for the two-segment launches) + per-channel backward sums of up to two segments
+int64_t suhpe_bn_workspace_bytes(int c) { return (kPartFloats + (int64_t)c * 4 + (int64_t)c * 4) * sizeof(float); }
+static float* bn_sums_of(void* workspace, int c) { return static_cast<float*>(workspace) + kPartFloats + (int64_t)c * 4; }
 
 int suhpe_bn_stats(const float* x, int64_t rows, int c, float eps, float momentum, float* mean, float* rstd,
                    float* running_mean, float* running_var, int64_t* nbt, void* workspace, suhpe_stream_t stream) {
@@ -926,7 +1019,7 @@ static int bn_act_bwd_impl(const float* x, const float* dy, const float* y_out, 
     if (y_out && act != SUHPE_ACT_RELU) { set_error("%s: y_out (pre-activation residual) needs act=RELU", who); return SUHPE_EINVAL; }
     if (rowscale && !(hw > 0 && rows % hw == 0 && !y_out)) { set_error("%s: rowscale needs rows %% hw == 0 and no y_out", who); return SUHPE_EINVAL; }
     float* part = static_cast<float*>(workspace);
-    float* sums = part + kPartFloats;
+    float* sums = bn_sums_of(workspace, c);
     const float inv_rows = 1.0f / (float)rows;
     if (vec4_ok(c, x, dy, dx) && vec4_ok(c, y_out)) {
         const ColGeom g = col_geom(rows, c, 4);
@@ -962,6 +1055,86 @@ int suhpe_bn_act_skip_bwd(const float* x, const float* dy, int64_t rows, int c, 
                            workspace, stream, "suhpe_bn_act_skip_bwd");
 }
 
+// ---- two batch segments per launch (rows [0, rows_a) and [rows_a, rows)); mean / rstd are [2][c]
+static bool seg_ok(int64_t rows, int64_t rows_a) { return rows_a > 0 && rows_a < rows; }
+
+int suhpe_bn_stats_seg(const float* x, int64_t rows, int64_t rows_a, int c, float eps, float momentum, float* mean, float* rstd,
+                       float* running_mean, float* running_var, int64_t* nbt, void* workspace, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(x && mean && rstd && workspace && c > 0 && seg_ok(rows, rows_a), "suhpe_bn_stats_seg: bad arguments (rows=%lld rows_a=%lld c=%d)",
+                  (long long)rows, (long long)rows_a, c);
+    float* part = static_cast<float*>(workspace);
+    const int vec = vec4_ok(c, x) ? 4 : 1;
+    const ColGeom g = col_geom(rows, c, vec);
+    const int gx_a = (int)ceil_div(rows_a, g.rows_per_block), gx_b = (int)ceil_div(rows - rows_a, g.rows_per_block);
+    const SegArgs sg{rows_a, gx_a};
+    if (vec == 4) LAUNCH(bn_stats_partial<4>, dim3(gx_a + gx_b, g.ny), dim3(256), stream, x, rows, c, g.cw, g.rp, g.rows_per_block, part, sg);
+    else LAUNCH(bn_stats_partial<1>, dim3(gx_a + gx_b, g.ny), dim3(256), stream, x, rows, c, g.cw, g.rp, g.rows_per_block, part, sg);
+    LAUNCH(bn_stats_finalize2, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, gx_a, gx_b, c, rows_a, rows - rows_a, eps, momentum,
+           mean, rstd, running_mean, running_var, nbt, static_cast<const float*>(nullptr));
+    return check_launch("suhpe_bn_stats_seg");
+}
+
+int suhpe_bn_stats_from_partials_seg(const float* part, int tiles, int first_records, const float* boundary, int64_t rows, int64_t rows_a,
+                                     int c, float eps, float momentum, float* mean, float* rstd, float* running_mean,
+                                     float* running_var, int64_t* nbt, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(part && mean && rstd && c > 0 && seg_ok(rows, rows_a) && first_records > 0 && first_records <= tiles &&
+                      (first_records < tiles || boundary),
+                  "suhpe_bn_stats_from_partials_seg: bad arguments");
+    LAUNCH(bn_stats_finalize2, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, first_records, tiles - first_records, c, rows_a,
+           rows - rows_a, eps, momentum, mean, rstd, running_mean, running_var, nbt, boundary);
+    return check_launch("suhpe_bn_stats_from_partials_seg");
+}
+
+int suhpe_bn_act_fwd_seg(const float* x, int64_t rows, int64_t rows_a, int c, const float* mean, const float* rstd, const float* gamma,
+                         const float* beta, int act, const float* residual, int post, const float* rowscale, int hw, float* y,
+                         suhpe_stream_t stream) {
+    SUHPE_REQUIRE(x && y && mean && rstd && rows < (1LL << 31) && c > 0 && seg_ok(rows, rows_a), "suhpe_bn_act_fwd_seg: bad arguments");
+    SUHPE_REQUIRE(!post || (residual && hw > 0 && rows % hw == 0 && rows_a % hw == 0), "suhpe_bn_act_fwd_seg: the skip form needs a skip tensor and whole samples per segment");
+    const int vec = vec4_ok(c, x, y, residual) ? 4 : 1;
+    const EwGeom g = ew_geom(rows, c, vec);
+    const int gx_a = (int)ceil_div(rows_a, (int64_t)g.rows_per_block), gx_b = (int)ceil_div(rows - rows_a, (int64_t)g.rows_per_block);
+    const SegArgs sg{rows_a, gx_a};
+    if (vec == 4)
+        LAUNCH(bn_act_fwd_kernel<4>, dim3(gx_a + gx_b, g.ny), dim3(256), stream, x, (int)rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta, act,
+               residual, post, rowscale, hw, y, sg);
+    else
+        LAUNCH(bn_act_fwd_kernel<1>, dim3(gx_a + gx_b, g.ny), dim3(256), stream, x, (int)rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta, act,
+               residual, post, rowscale, hw, y, sg);
+    return check_launch("suhpe_bn_act_fwd_seg");
+}
+
+int suhpe_bn_act_bwd_seg(const float* x, const float* dy, const float* y_out, int64_t rows, int64_t rows_a, int c, const float* mean,
+                         const float* rstd, const float* gamma, const float* beta, int act, const float* rowscale, int hw, float* dx,
+                         float* dgamma, float* dbeta, int accumulate, void* workspace, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(x && dy && dx && mean && rstd && workspace && rows < (1LL << 31) && c > 0 && seg_ok(rows, rows_a), "suhpe_bn_act_bwd_seg: bad arguments");
+    SUHPE_REQUIRE(!y_out || act == SUHPE_ACT_RELU, "suhpe_bn_act_bwd_seg: y_out (pre-activation residual) needs act=RELU");
+    SUHPE_REQUIRE(!rowscale || (hw > 0 && rows % hw == 0 && rows_a % hw == 0 && !y_out), "suhpe_bn_act_bwd_seg: rowscale needs whole samples per segment and no y_out");
+    float* part = static_cast<float*>(workspace);
+    float* sums = bn_sums_of(workspace, c);
+    const int vec = (vec4_ok(c, x, dy, dx) && vec4_ok(c, y_out)) ? 4 : 1;
+    const ColGeom g = col_geom(rows, c, vec);
+    const int gx_a = (int)ceil_div(rows_a, g.rows_per_block), gx_b = (int)ceil_div(rows - rows_a, g.rows_per_block);
+    const SegArgs sg{rows_a, gx_a};
+    const EwGeom e = ew_geom(rows, c, vec);
+    const int ex_a = (int)ceil_div(rows_a, (int64_t)e.rows_per_block), ex_b = (int)ceil_div(rows - rows_a, (int64_t)e.rows_per_block);
+    const SegArgs se{rows_a, ex_a};
+    const float inv_a = 1.0f / (float)rows_a, inv_b = 1.0f / (float)(rows - rows_a);
+    if (vec == 4) {
+        LAUNCH(bn_bwd_partial<4>, dim3(gx_a + gx_b, g.ny), dim3(256), stream, x, dy, y_out, rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta,
+               act, rowscale, hw, part, sg);
+        LAUNCH(bn_bwd_finalize2, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, gx_a, gx_a + gx_b, c, sums, dgamma, dbeta, accumulate);
+        LAUNCH(bn_bwd_apply<4>, dim3(ex_a + ex_b, e.ny), dim3(256), stream, x, dy, y_out, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd, gamma,
+               beta, act, sums, inv_a, 1, rowscale, hw, dx, se, inv_b);
+    } else {
+        LAUNCH(bn_bwd_partial<1>, dim3(gx_a + gx_b, g.ny), dim3(256), stream, x, dy, y_out, rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta,
+               act, rowscale, hw, part, sg);
+        LAUNCH(bn_bwd_finalize2, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, gx_a, gx_a + gx_b, c, sums, dgamma, dbeta, accumulate);
+        LAUNCH(bn_bwd_apply<1>, dim3(ex_a + ex_b, e.ny), dim3(256), stream, x, dy, y_out, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd, gamma,
+               beta, act, sums, inv_a, 1, rowscale, hw, dx, se, inv_b);
+    }
+    return check_launch("suhpe_bn_act_bwd_seg");
+}
+
 int suhpe_layernorm_fwd(const float* x, int64_t rows, int c, float eps, const float* gamma, const float* beta, float* y,
                         float* mean, float* rstd, suhpe_stream_t stream) {
     SUHPE_REQUIRE(x && y && mean && rstd && rows > 0 && c > 0, "suhpe_layernorm_fwd: bad arguments");
@@ -976,7 +1149,7 @@ int suhpe_layernorm_bwd(const float* x, const float* dy, int64_t rows, int c, co
     LAUNCH(layernorm_bwd_dx_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), stream, x, dy, rows, c, mean, rstd, gamma, dx);
     if (dgamma || dbeta) {
         float* part = static_cast<float*>(workspace);
-        float* sums = part + kPartFloats;
+        float* sums = bn_sums_of(workspace, c);
         if (vec4_ok(c, x, dy)) {
             const ColGeom g = col_geom(rows, c, 4);
             LAUNCH(layernorm_bwd_partial<4>, dim3(g.gx, g.ny), dim3(256), stream, x, dy, rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, part);

@@ -550,6 +550,45 @@ def bn_stats(x, c, eps, momentum, running_mean=None, running_var=None, nbt=None)
     return mean, rstd
 
 
+# ---- two batch segments per launch (layers.batch_segments): rows [0, rows_a) / [rows_a, rows); statistics are [2, c] tensors
+@_memop
+def bn_stats_seg(x, rows_a, c, eps, momentum, running_mean=None, running_var=None, nbt=None):
+    _chk(x, "x")
+    stats = torch.empty((2, 2, c), dtype=torch.float32, device=x.device)          # [mean | rstd][segment][c]
+    ws = workspace("bn", _lib.load().suhpe_bn_workspace_bytes(c), x.device)
+    call("suhpe_bn_stats_seg", ptr(x), x.numel() // c, int(rows_a), c, float(eps), float(momentum), ptr(stats[0]), ptr(stats[1]),
+         ptr(running_mean), ptr(running_var), ptr(nbt), ptr(ws))
+    return stats[0], stats[1]
+
+
+@_memop
+def bn_stats_from_partials_seg(part, tiles, first_records, boundary, rows, rows_a, c, eps, momentum, running_mean=None, running_var=None,
+                               nbt=None):
+    stats = torch.empty((2, 2, c), dtype=torch.float32, device=part.device)
+    call("suhpe_bn_stats_from_partials_seg", ptr(part), int(tiles), int(first_records), ptr(boundary), int(rows), int(rows_a), c, float(eps),
+         float(momentum), ptr(stats[0]), ptr(stats[1]), ptr(running_mean), ptr(running_var), ptr(nbt))
+    return stats[0], stats[1]
+
+
+@_memop
+def bn_act_fwd_seg(x, rows_a, c, mean, rstd, gamma, beta, act, residual=None, post=False, rowscale=None, hw=1):
+    _chk(x, "x"); _chk(residual, "residual"); _chk(rowscale, "rowscale")
+    y = torch.empty_like(x)
+    call("suhpe_bn_act_fwd_seg", ptr(x), x.numel() // c, int(rows_a), c, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ACT[act], ptr(residual),
+         int(bool(post)), ptr(rowscale), int(hw), ptr(y))
+    return y
+
+
+@_memop
+def bn_act_bwd_seg(x, dy, rows_a, c, mean, rstd, gamma, beta, act, dgamma=None, dbeta=None, accumulate=False, y_out=None, rowscale=None, hw=1):
+    _chk(x, "x"); _chk(dy, "dy")
+    dx = torch.empty_like(x)
+    ws = workspace("bn", _lib.load().suhpe_bn_workspace_bytes(c), x.device)
+    call("suhpe_bn_act_bwd_seg", ptr(x), ptr(dy), ptr(y_out), x.numel() // c, int(rows_a), c, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
+         ACT[act], ptr(rowscale), int(hw), ptr(dx), ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws))
+    return dx
+
+
 def bn_eval_stats(running_mean, running_var, eps):
     c = running_mean.numel()
     mean = torch.empty(c, dtype=torch.float32, device=running_mean.device)

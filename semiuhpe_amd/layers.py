@@ -11,6 +11,7 @@ reference's modules so released checkpoints load.
 Activations are (N, H, W, C) contiguous fp32; filters are (Cout, Cin/g, R, S) stored [Cout][R][S][Cin/g].
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -153,6 +154,7 @@ class Linear(Layer):
 # statistics and updates the running statistics twice, in the reference's order.  `with batch_segments(n):` declares that
 # the first n samples of every activation are one segment and the rest the other; all other layers are per-sample.
 _SEGMENT = None
+SEGMENT_LAUNCHES = os.environ.get("SUHPE_SEGMENT_LAUNCHES", "fused")     # "fused": one launch per kernel for both segments; "split"
 
 
 class batch_segments:
@@ -207,9 +209,22 @@ class _BatchNorm(Layer):
 
     def _fwd_segments(self, x, tape, residual, partials, post, rowscale, seg):
         """training forward with per-segment batch statistics: samples [0, seg) and [seg, n) are normalised separately and
-        the running statistics take two momentum updates, first segment first."""
+        the running statistics take two momentum updates, first segment first.  One launch per kernel covers both segments
+        (statistics are [2, c]); SEGMENT_LAUNCHES = "split" runs the one-segment kernels on the two halves instead."""
         c, n = self.num_features, x.shape[0]
         hw = x.numel() // (c * n)
+        if SEGMENT_LAUNCHES != "split":
+            if partials is not None:
+                part, tiles, (first_records, boundary) = partials
+                mean, rstd = K.bn_stats_from_partials_seg(part, tiles, first_records, boundary, n * hw, seg * hw, c, self.eps, self.momentum,
+                                                          self.running_mean, self.running_var, self.num_batches_tracked)
+            else:
+                mean, rstd = K.bn_stats_seg(x, seg * hw, c, self.eps, self.momentum, self.running_mean, self.running_var, self.num_batches_tracked)
+            y = K.bn_act_fwd_seg(x, seg * hw, c, mean, rstd, self.weight, self.bias, self.act, residual, post, rowscale, hw)
+            if tape is not None:
+                keep_y = y if (residual is not None and not post and self.act == "relu") else None
+                tape.append((x, (mean, rstd), seg, True, keep_y, rowscale if post else None, hw))
+            return y
         stats = []
         for lo, hi in ((0, seg), (seg, n)):
             rows = (hi - lo) * hw
@@ -234,7 +249,11 @@ class _BatchNorm(Layer):
 
     def bwd(self, dy, tape):
         x, mean, rstd, train_stats, y_out, rowscale, hw = tape.pop()
-        if isinstance(mean, list):                           # per-segment statistics: (x, [(mean, rstd)] * 2, seg, ...)
+        if isinstance(mean, tuple):                          # two segments, one launch: (x, (mean[2,c], rstd[2,c]), seg, ...)
+            (m2, r2), seg = mean, rstd
+            return K.bn_act_bwd_seg(x, dy, seg * hw, self.num_features, m2, r2, self.weight, self.bias, self.act, grad_of(self.weight),
+                                    grad_of(self.bias), True, y_out, rowscale, hw)
+        if isinstance(mean, list):                           # per-segment launches: (x, [(mean, rstd)] * 2, seg, ...)
             stats, seg, n = mean, rstd, x.shape[0]
             dx = torch.empty_like(x)
             for (lo, hi), (m, r) in zip(((0, seg), (seg, n)), stats):

@@ -166,3 +166,47 @@ def test_agent_merged_step_equals_two_pass_step(network, tmp_path, monkeypatch):
         big = (g2.abs() > 0.01 * g2.abs().max()) & (g2.abs() > 1e-5)
         if bool(big.any()):
             assert float((p1.data - p2.data)[big].abs().max()) < 2e-5, n
+
+
+@pytest.mark.parametrize("rows_hw,c,n,seg,act,form", [
+    (49, 1536, 6, 2, "silu", "plain"), (196, 96, 5, 1, "none", "skip"), (25, 24, 7, 3, "relu", "relu_res"), (9, 6, 4, 3, "relu6", "plain"),
+    (784, 192, 3, 1, "gelu", "plain"), (1, 512, 8, 4, "relu6", "plain")])
+def test_two_segment_batchnorm_kernels_equal_per_segment_calls(rows_hw, c, n, seg, act, form):
+    """suhpe_bn_stats_seg / _act_fwd_seg / _act_bwd_seg (one launch for both segments) against the one-segment entry points on
+    the two halves: statistics, running statistics (two ordered updates), outputs, dx, dgamma, dbeta."""
+    from semiuhpe_amd import kernels as K
+    g = torch.Generator().manual_seed(rows_hw + c)
+    x = torch.randn(n, rows_hw, c, generator=g).cuda()
+    x[seg:] = x[seg:] * 2.0 + 1.0
+    dy = torch.randn(n, rows_hw, c, generator=g).cuda()
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).cuda(), torch.randn(c, generator=g).cuda()
+    res = torch.randn(n, rows_hw, c, generator=g).cuda() if form != "plain" else None
+    rowscale = ((torch.rand(n, generator=g) < 0.7).float() / 0.7).cuda() if form == "skip" else None
+    post = form == "skip"
+    rm1, rv1, nb1 = torch.zeros(c).cuda(), torch.ones(c).cuda(), torch.zeros(1, dtype=torch.long).cuda()
+    rm2, rv2, nb2 = rm1.clone(), rv1.clone(), nb1.clone()
+    rows_a = seg * rows_hw
+    mean2, rstd2 = K.bn_stats_seg(x, rows_a, c, 1e-3, 0.1, rm1, rv1, nb1)
+    y = K.bn_act_fwd_seg(x, rows_a, c, mean2, rstd2, gamma, beta, act, res, post, rowscale, rows_hw)
+    y_out = y if form == "relu_res" else None
+    dg1, db1 = torch.zeros(c).cuda(), torch.zeros(c).cuda()
+    dx = K.bn_act_bwd_seg(x, dy, rows_a, c, mean2, rstd2, gamma, beta, act, dg1, db1, True, y_out, rowscale if post else None, rows_hw)
+    dg2, db2 = torch.zeros(c).cuda(), torch.zeros(c).cuda()
+    for s, (lo, hi) in enumerate(((0, seg), (seg, n))):
+        m, r = K.bn_stats(x[lo:hi], c, 1e-3, 0.1, rm2, rv2, nb2)
+        assert rel_err(mean2[s], m) < 5e-6 and rel_err(rstd2[s], r) < 5e-6
+        ys = K.bn_act_fwd(x[lo:hi], c, m, r, gamma, beta, act, None if res is None else res[lo:hi], post,
+                          None if rowscale is None else rowscale[lo:hi], rows_hw)
+        assert rel_err(y[lo:hi], ys) < 1e-5          # (the row-block partition of the statistics differs: last-bit differences)
+        dxs = K.bn_act_bwd(x[lo:hi], dy[lo:hi], c, m, r, gamma, beta, act, True, dg2, db2, True, None if y_out is None else y_out[lo:hi],
+                           None if not post else rowscale[lo:hi], rows_hw)
+        assert rel_err(dx[lo:hi], dxs) < 1e-5
+    assert rel_err(rm1, rm2) < 5e-6 and rel_err(rv1, rv2) < 5e-6 and int(nb1) == int(nb2) == 2
+    assert rel_err(dg1, dg2) < 1e-5 and rel_err(db1, db2) < 1e-5
+
+
+def test_merged_pass_with_per_segment_launches(monkeypatch):
+    """the fallback that runs the one-segment kernels on the two halves stays equivalent too"""
+    from semiuhpe_amd import layers as L
+    monkeypatch.setattr(L, "SEGMENT_LAUNCHES", "split")
+    test_merged_pass_equals_two_passes("effinetv2", 64, 3, 4)
