@@ -121,6 +121,10 @@ int suhpe_conv2d_set_tile(const suhpe_conv_t* d, int pass, int tile);
 /* input gradient; wt is the transposed+flipped filter made by suhpe_conv2d_transpose_filter */
 int suhpe_conv2d_dgrad(const suhpe_conv_t* d, const float* dy, const float* wt, float* dx, suhpe_stream_t stream);
 int suhpe_conv2d_transpose_filter(const suhpe_conv_t* d, const float* w, float* wt, suhpe_stream_t stream);
+/* The same for many filters in one launch: jobs_dev = device array of njobs records of six int64 (w, wt, groups, cout/groups,
+ * cin/groups, r*s), chunk_start_dev[j] = first 1024-element chunk of job j, chunk_start_dev[njobs] = total_chunks. */
+int suhpe_transpose_filters_batched(const void* jobs_dev, const int64_t* chunk_start_dev, int njobs, int64_t total_chunks,
+                                    suhpe_stream_t stream);
 /* name of the kernel instance a call dispatches to (pass 0 fwd, 1 dgrad, 2 wgrad) — for profiling/roofline reports */
 const char* suhpe_conv2d_kernel_name(const suhpe_conv_t* d, int pass);
 /* filter gradient; dw += sum (accumulate != 0) or dw = sum.  workspace: device scratch */

@@ -884,6 +884,33 @@ __global__ __launch_bounds__(256) void transpose_filter_kernel(const float* __re
     }
 }
 
+// All transposed filters of a network in one launch (the weights move every optimiser step, so the input-gradient GEMMs of a
+// backward pass need fresh transposes: ~80 launches of a few microseconds of work each otherwise).  jobs[j] = (w, wt, groups,
+// Ng, Cg, RS); chunk_start as in slab_reduce_batched_kernel.
+struct TransposeJob { const float* w; float* wt; int64_t groups, Ng, Cg, RS; };
+__global__ __launch_bounds__(256) void transpose_filters_batched_kernel(const TransposeJob* __restrict__ jobs, const int64_t* __restrict__ chunk_start,
+                                                                        int njobs) {
+    const int64_t chunk = blockIdx.x;
+    int lo = 0, hi = njobs;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (chunk_start[mid] <= chunk) lo = mid; else hi = mid;
+    }
+    const TransposeJob jb = jobs[lo];
+    const int Ng = (int)jb.Ng, Cg = (int)jb.Cg, RS = (int)jb.RS;
+    const int64_t total = jb.groups * Ng * RS * Cg, base = (chunk - chunk_start[lo]) * kSlabChunk;
+#pragma unroll
+    for (int u = 0; u < kSlabChunk / 256; ++u) {
+        const int64_t i = base + u * 256 + threadIdx.x;
+        if (i >= total) break;
+        const int co = (int)(i % Ng);
+        const int tap = (int)((i / Ng) % RS);
+        const int ci = (int)((i / ((int64_t)Ng * RS)) % Cg);
+        const int gq = (int)(i / ((int64_t)Ng * RS * Cg));
+        jb.wt[i] = jb.w[(((int64_t)gq * Ng + co) * RS + tap) * Cg + ci];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -1164,6 +1191,14 @@ int suhpe_conv2d_transpose_filter(const suhpe_conv_t* d, const float* w, float* 
     hipLaunchKernelGGL(transpose_filter_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), w, wt, d->groups,
                        d->cout / d->groups, d->cin / d->groups, d->r * d->s);
     return check_launch("suhpe_conv2d_transpose_filter");
+}
+
+int suhpe_transpose_filters_batched(const void* jobs_dev, const int64_t* chunk_start_dev, int njobs, int64_t total_chunks,
+                                    suhpe_stream_t stream) {
+    SUHPE_REQUIRE(jobs_dev && chunk_start_dev && njobs > 0 && total_chunks > 0 && total_chunks < (1LL << 31), "suhpe_transpose_filters_batched: bad arguments");
+    hipLaunchKernelGGL(transpose_filters_batched_kernel, dim3((unsigned)total_chunks), dim3(256), 0, as_stream(stream),
+                       static_cast<const TransposeJob*>(jobs_dev), chunk_start_dev, njobs);
+    return check_launch("suhpe_transpose_filters_batched");
 }
 
 int suhpe_conv2d_dgrad(const suhpe_conv_t* d, const float* dy, const float* wt, float* dx, suhpe_stream_t stream) {

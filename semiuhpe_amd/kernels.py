@@ -347,14 +347,56 @@ _WT_CACHE = None
 
 
 class filter_cache:
+    """`with filter_cache(owner):` -- transposed filters are built once inside the region.  With an owner (the agent) the
+    filters seen in one region are remembered on it, and from the next region on ALL of them are rebuilt by one batched launch
+    at the region's start instead of one small launch per layer."""
+
+    def __init__(self, owner=None):
+        self.owner = owner
+
     def __enter__(self):
         global _WT_CACHE
         self.outer, _WT_CACHE = _WT_CACHE, (_WT_CACHE if _WT_CACHE is not None else {})
+        if self.owner is not None and self.outer is None:
+            reg = getattr(self.owner, "_wt_registry", None)
+            if reg is None:
+                reg = self.owner._wt_registry = {"entries": {}, "table": None, "built_for": 0}
+            self.reg = reg
+            if reg["entries"]:
+                _transpose_registered(reg)
+                for key, (w, wt, dims) in reg["entries"].items():
+                    _WT_CACHE[key] = wt
+        else:
+            self.reg = None
         return self
 
     def __exit__(self, *exc):
         global _WT_CACHE
+        if self.reg is not None and exc[0] is None:
+            for key, wt in _WT_CACHE.items():              # filters transposed one by one in this region join the batch
+                if key not in self.reg["entries"] and key in _WT_SEEN:
+                    self.reg["entries"][key] = (_WT_SEEN[key][0], wt, _WT_SEEN[key][1])
+            _WT_SEEN.clear()
         _WT_CACHE = self.outer
+
+
+_WT_SEEN = {}          # key -> (weight tensor, (groups, Ng, Cg, RS)) of the transposes launched in the current region
+
+
+def _transpose_registered(reg):
+    entries = reg["entries"]
+    if reg["table"] is None or reg["built_for"] != len(entries):
+        rows, starts, total = [], [], 0
+        for key, (w, wt, dims) in entries.items():
+            rows.append((w.data_ptr(), wt.data_ptr()) + tuple(dims))
+            starts.append(total)
+            total += (w.numel() + 1023) // 1024
+        starts.append(total)
+        dev = next(iter(entries.values()))[1].device
+        reg["table"] = (torch.tensor(rows, dtype=torch.int64).to(dev), torch.tensor(starts, dtype=torch.int64).to(dev), len(rows), total)
+        reg["built_for"] = len(entries)
+    table, starts, n, total = reg["table"]
+    call("suhpe_transpose_filters_batched", ptr(table), ptr(starts), n, total)
 
 
 def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, groups=1):
@@ -369,6 +411,7 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, groups=1):
         if wt is None:
             if _WT_CACHE is not None:
                 wt = _WT_CACHE[key] = torch.empty(w.numel() * 4, dtype=torch.uint8, device=dy.device)
+                _WT_SEEN[key] = (w, (d.groups, d.cout // d.groups, d.cin // d.groups, d.r * d.s))
             else:
                 wt = workspace("wt", w.numel() * 4, dy.device)
             call("suhpe_conv2d_transpose_filter", ctypes.byref(d), ptr(w), ptr(wt))

@@ -259,7 +259,7 @@ class SSLAgent:
         SSL_lambda = self.config.SSL_lambda
         loss_all = _Axpby.apply(fisher_dict["loss"].reshape(1), fisher_dict_unsuper["unsuper_loss"].reshape(1),
                                 float(SSL_lambda)).squeeze(0)
-        with K.filter_cache():                      # both student passes differentiate through the same weights
+        with K.filter_cache(self):                  # transposed filters: one batched launch per step (and shared by both passes)
             loss_all.backward(self._grad_seed)
         self._exchange()
         self.optimizer.step()
