@@ -244,6 +244,10 @@ int suhpe_bn_stats_from_partials_seg(const float* part, int tiles, int first_rec
 int suhpe_bn_act_fwd_seg(const float* x, int64_t rows, int64_t rows_a, int c, const float* mean, const float* rstd,
                          const float* gamma, const float* beta, int act, const float* residual, int post,
                          const float* rowscale, int hw, float* y, suhpe_stream_t stream);
+/* y = act(BN(x)) and pool[sample][c] = mean over the sample's hw rows of y in the same pass (the squeeze of the
+ * SqueezeExcitation block behind a depthwise conv's BatchNorm); rows_a = 0: one segment (mean / rstd [c]), else two ([2][c]). */
+int suhpe_bn_act_pool_fwd(const float* x, int64_t rows, int64_t rows_a, int c, int hw, const float* mean, const float* rstd,
+                          const float* gamma, const float* beta, int act, float* y, float* pool, suhpe_stream_t stream);
 int suhpe_bn_act_bwd_seg(const float* x, const float* dy, const float* y_out, int64_t rows, int64_t rows_a, int c,
                          const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
                          const float* rowscale, int hw, float* dx, float* dgamma, float* dbeta, int accumulate,

@@ -375,6 +375,70 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
     }
 }
 
+// y = act(BN(x)) and, from the same pass, pool[sample][channel] = mean over the sample's hw rows of y (the squeeze of the
+// SqueezeExcitation block that follows the depthwise conv's BatchNorm: no second pass over y).  One row block = one sample,
+// so the pooled value is a fixed-order sum inside one workgroup (no atomics).
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __restrict__ x, int rows, int c, int cw, int rp, int hw,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                              float* __restrict__ y, float* __restrict__ pool, const SegArgs sg) {
+    __shared__ float pl[256 * VEC];
+    int64_t rows_s = rows, row_off;
+    int set;
+    const int bx = seg_select(sg, &rows_s, &row_off, &set);
+    x += row_off * c; y += row_off * c;
+    mean += set * c; rstd += set * c;
+    const int t = threadIdx.x, col = t % cw, rsub = t / cw;
+    const int cv = c / VEC, vc = blockIdx.y * cw + col;
+    const bool active = rsub < rp && vc < cv;
+    const int ch = vc * VEC;
+    const int r0 = bx * hw, r1 = r0 + hw;
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    if (active) {
+        float sc[VEC], sh[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const float g = gamma ? gamma[ch + v] : 1.f, b = beta ? beta[ch + v] : 0.f;
+            sc[v] = rstd[ch + v] * g;
+            sh[v] = b - mean[ch + v] * sc[v];
+        }
+        constexpr int U = 4;
+        for (int r = r0 + rsub; r < r1; r += U * rp) {
+            float xv[U][VEC];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int rr = r + u * rp < r1 ? r + u * rp : r1 - 1;
+                vload<VEC>(x + ((int64_t)rr * cv + vc) * VEC, xv[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int rr = r + u * rp;
+                if (rr >= r1) break;
+                float o[VEC];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) { o[v] = act_apply(xv[u][v] * sc[v] + sh[v], act); acc[v] += o[v]; }
+                vstore<VEC>(y + ((int64_t)rr * cv + vc) * VEC, o);
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) pl[t * VEC + v] = acc[v];
+    __syncthreads();
+    if (active && rsub == 0) {
+        const float inv = 1.f / (float)hw;
+        const int64_t sample = row_off / hw + bx;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            float a = 0.f;
+            for (int r = 0; r < rp; ++r) a += pl[(r * cw + col) * VEC + v];
+            pool[sample * c + ch + v] = a * inv;
+        }
+    }
+}
+
 // backward pass 1: partial sums of g and g*xhat, g = dy * act'(u)
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ x, const float* __restrict__ dy,
@@ -1101,6 +1165,20 @@ int suhpe_bn_act_fwd_seg(const float* x, int64_t rows, int64_t rows_a, int c, co
         LAUNCH(bn_act_fwd_kernel<1>, dim3(gx_a + gx_b, g.ny), dim3(256), stream, x, (int)rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta, act,
                residual, post, rowscale, hw, y, sg);
     return check_launch("suhpe_bn_act_fwd_seg");
+}
+
+int suhpe_bn_act_pool_fwd(const float* x, int64_t rows, int64_t rows_a, int c, int hw, const float* mean, const float* rstd, const float* gamma,
+                          const float* beta, int act, float* y, float* pool, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(x && y && pool && mean && rstd && rows > 0 && rows < (1LL << 31) && c > 0 && hw > 0 && rows % hw == 0 && rows_a >= 0 && rows_a < rows &&
+                      rows_a % hw == 0,
+                  "suhpe_bn_act_pool_fwd: bad arguments (whole samples per segment: rows %% hw == 0, rows_a %% hw == 0)");
+    const int vec = vec4_ok(c, x, y) ? 4 : 1;
+    const int cv = c / vec, cw = cv < 64 ? cv : 64, ny = (cv + cw - 1) / cw, rp = 256 / cw;
+    const SegArgs sg{rows_a, (int)(rows_a / hw)};
+    const dim3 grid((unsigned)(rows / hw), ny);
+    if (vec == 4) LAUNCH(bn_act_pool_fwd_kernel<4>, grid, dim3(256), stream, x, (int)rows, c, cw, rp, hw, mean, rstd, gamma, beta, act, y, pool, sg);
+    else LAUNCH(bn_act_pool_fwd_kernel<1>, grid, dim3(256), stream, x, (int)rows, c, cw, rp, hw, mean, rstd, gamma, beta, act, y, pool, sg);
+    return check_launch("suhpe_bn_act_pool_fwd");
 }
 
 int suhpe_bn_act_bwd_seg(const float* x, const float* dy, const float* y_out, int64_t rows, int64_t rows_a, int c, const float* mean,

@@ -623,6 +623,17 @@ def bn_act_fwd_seg(x, rows_a, c, mean, rstd, gamma, beta, act, residual=None, po
 
 
 @_memop
+def bn_act_pool_fwd(x, rows_a, c, mean, rstd, gamma, beta, act, hw):
+    """-> (act(BN(x)), per-sample channel means of it); rows_a = 0: one segment"""
+    _chk(x, "x")
+    y = torch.empty_like(x)
+    pool = torch.empty((x.numel() // (c * hw), c), dtype=torch.float32, device=x.device)
+    call("suhpe_bn_act_pool_fwd", ptr(x), x.numel() // c, int(rows_a), c, int(hw), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ACT[act], ptr(y),
+         ptr(pool))
+    return y, pool
+
+
+@_memop
 def bn_act_bwd_seg(x, dy, rows_a, c, mean, rstd, gamma, beta, act, dgamma=None, dbeta=None, accumulate=False, y_out=None, rowscale=None, hw=1):
     _chk(x, "x"); _chk(dy, "dy")
     dx = torch.empty_like(x)

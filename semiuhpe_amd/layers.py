@@ -186,11 +186,13 @@ class _BatchNorm(Layer):
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
-    def fwd(self, x, tape, residual=None, partials=None, post=False, rowscale=None):
+    def fwd(self, x, tape, residual=None, partials=None, post=False, rowscale=None, pool=False):
         """residual, post=False: act(BN(x) + residual).  post=True: residual + rowscale[n] * act(BN(x)), the skip
         connection of a residual block with StochasticDepth('row') folded in (rowscale None = 1)."""
         c = self.num_features
         seg = _segment_of(x) if self.training else None
+        if pool:                                            # -> (y, per-sample channel means of y), see _fwd_pool
+            return self._fwd_pool(x, tape, partials, seg)
         if seg is not None:
             return self._fwd_segments(x, tape, residual, partials, post, rowscale, seg)
         if self.training and partials is not None:          # statistics already accumulated by the producing conv's epilogue
@@ -206,6 +208,37 @@ class _BatchNorm(Layer):
             keep_y = y if (residual is not None and not post and self.act == "relu") else None
             tape.append((x, mean, rstd, self.training, keep_y, rowscale if post else None, hw))
         return y
+
+    def _fwd_pool(self, x, tape, partials, seg):
+        """act(BN(x)) together with the global average pool of it (the squeeze of the SqueezeExcitation block that follows):
+        one pass, the pooled means are fixed-order sums inside one workgroup per sample."""
+        c, n = self.num_features, x.shape[0]
+        hw = x.numel() // (c * n)
+        if seg is not None and SEGMENT_LAUNCHES == "split":
+            y = self._fwd_segments(x, tape, None, partials, False, None, seg)
+            return y, K.avgpool_fwd(y)
+        if seg is not None:
+            if partials is not None:
+                part, tiles, (first_records, boundary) = partials
+                mean, rstd = K.bn_stats_from_partials_seg(part, tiles, first_records, boundary, n * hw, seg * hw, c, self.eps, self.momentum,
+                                                          self.running_mean, self.running_var, self.num_batches_tracked)
+            else:
+                mean, rstd = K.bn_stats_seg(x, seg * hw, c, self.eps, self.momentum, self.running_mean, self.running_var, self.num_batches_tracked)
+            y, p = K.bn_act_pool_fwd(x, seg * hw, c, mean, rstd, self.weight, self.bias, self.act, hw)
+            if tape is not None:
+                tape.append((x, (mean, rstd), seg, True, None, None, hw))
+            return y, p
+        if self.training and partials is not None:
+            mean, rstd = K.bn_stats_from_partials(partials[0], partials[1], x.numel() // c, c, self.eps, self.momentum,
+                                                  self.running_mean, self.running_var, self.num_batches_tracked)
+        elif self.training:
+            mean, rstd = K.bn_stats(x, c, self.eps, self.momentum, self.running_mean, self.running_var, self.num_batches_tracked)
+        else:
+            mean, rstd = K.bn_eval_stats(self.running_mean, self.running_var, self.eps)
+        y, p = K.bn_act_pool_fwd(x, 0, c, mean, rstd, self.weight, self.bias, self.act, hw)
+        if tape is not None:
+            tape.append((x, mean, rstd, self.training, None, None, hw))
+        return y, p
 
     def _fwd_segments(self, x, tape, residual, partials, post, rowscale, seg):
         """training forward with per-segment batch statistics: samples [0, seg) and [seg, n) are normalised separately and
@@ -389,15 +422,16 @@ class SqueezeExcitation(Layer):
         return (self.act == "silu" and self.scale_act == "sigmoid" and self.c % 4 == 0 and self.c <= 2048 and self.csq % 4 == 0
                 and self.csq <= 64)
 
-    def fwd(self, z, tape):
+    def fwd(self, z, tape, pooled=None):
+        """pooled: the global average pool of z when the producer already has it (BatchNorm's apply kernel, conv_bn_fwd(pool=True))"""
         n = z.shape[0]
         if self._fused():                       # pool -> one micro-kernel for the whole MLP -> scale
-            p = K.avgpool_fwd(z)
+            p = pooled if pooled is not None else K.avgpool_fwd(z)
             a1, s = K.se_mlp_fwd(p, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
             if tape is not None:
                 tape.append((z, p, a1, None, None, s))
             return K.se_scale_fwd(z, s)
-        p = K.avgpool_fwd(z).view(n, 1, 1, self.c)
+        p = (pooled if pooled is not None else K.avgpool_fwd(z)).view(n, 1, 1, self.c)
         a1 = K.conv2d_fwd(p, self.fc1.weight, self.fc1.bias, 1, 0, 1)
         h = K.act_fwd(a1, self.csq, self.act)
         a2 = K.conv2d_fwd(h, self.fc2.weight, self.fc2.bias, 1, 0, 1)
@@ -454,9 +488,14 @@ class Sequential(Layer):
         return dy
 
 
-def conv_bn_fwd(conv, bn, x, tape, residual=None, residual_after_act=False, rowscale=None):
+def conv_bn_fwd(conv, bn, x, tape, residual=None, residual_after_act=False, rowscale=None, pool=False):
     """conv -> BatchNorm(+act): in training the statistics come out of the conv's epilogue when the conv is dense; in
     eval() without a tape (teacher pass, eval.py) BatchNorm, activation and the skip add are folded into that epilogue."""
+    if pool:                                                # depthwise conv -> BatchNorm + act + squeeze: (y, pooled)
+        if bn.training and conv.fuses_stats():
+            y, partials = conv.fwd_stats(x, tape)
+            return bn.fwd(y, tape, partials=partials, pool=True)
+        return bn.fwd(conv.fwd(x, tape), tape, pool=True)
     if not bn.training and tape is None and conv.fuses_stats() and rowscale is None:
         if not K.filter_is_physical(conv.weight):
             conv.weight.data = K.to_filter_layout(conv.weight.data)

@@ -107,7 +107,13 @@ class MBConv(_ResidualBlock):
 
     def _front_fwd(self, x, tape):
         if not self._fusable(tape):
-            return super()._front_fwd(x, tape)
+            # expand -> depthwise conv -> BatchNorm + SiLU + squeeze (one kernel) -> excitation
+            layers = list(self.block)[:-1]
+            if self.has_expand:
+                x = layers[0].fwd(x, tape)
+            dw, se = layers[-2], layers[-1]
+            z, pooled = conv_bn_fwd(dw[0], dw[1], x, tape, pool=True)
+            return se.fwd(z, tape, pooled=pooled)
         (conv_e, bn_e), (conv_d, bn_d), se = self.block[0], self.block[1], self.block[2]
         c = bn_e.num_features
         if bn_e.training:

@@ -210,3 +210,23 @@ def test_merged_pass_with_per_segment_launches(monkeypatch):
     from semiuhpe_amd import layers as L
     monkeypatch.setattr(L, "SEGMENT_LAUNCHES", "split")
     test_merged_pass_equals_two_passes("effinetv2", 64, 3, 4)
+
+
+@pytest.mark.parametrize("hw,c,n,seg,act", [(49, 1536, 6, 2, "silu"), (196, 96, 5, 0, "silu"), (25, 6, 4, 3, "relu"), (1, 512, 8, 0, "relu6")])
+def test_batchnorm_apply_with_fused_squeeze(hw, c, n, seg, act):
+    """suhpe_bn_act_pool_fwd: BatchNorm + activation and the per-sample channel means of the result from one pass, against
+    the apply kernel followed by the pooling kernel (one and two segments)."""
+    from semiuhpe_amd import kernels as K
+    g = torch.Generator().manual_seed(hw + c)
+    x = torch.randn(n, hw, c, generator=g).cuda()
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).cuda(), torch.randn(c, generator=g).cuda()
+    if seg:
+        mean, rstd = K.bn_stats_seg(x, seg * hw, c, 1e-3, 0.1)
+        want = K.bn_act_fwd_seg(x, seg * hw, c, mean, rstd, gamma, beta, act)
+    else:
+        mean, rstd = K.bn_stats(x, c, 1e-3, 0.1)
+        want = K.bn_act_fwd(x, c, mean, rstd, gamma, beta, act)
+    y, pool = K.bn_act_pool_fwd(x, seg * hw, c, mean, rstd, gamma, beta, act, hw)
+    assert torch.equal(y, want)
+    assert rel_err(pool, want.double().mean(1)) < 1e-6
+    assert rel_err(pool, K.avgpool_fwd(want.view(n, hw, 1, c))) < 1e-6
