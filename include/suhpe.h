@@ -227,6 +227,16 @@ int suhpe_bn_act_skip_fwd(const float* x, int64_t rows, int c, const float* mean
 int suhpe_bn_act_skip_bwd(const float* x, const float* dy, int64_t rows, int c, const float* mean, const float* rstd,
                           const float* gamma, const float* beta, int act, int train_stats, const float* rowscale, int hw,
                           float* dx, float* dgamma, float* dbeta, int accumulate, void* workspace, suhpe_stream_t stream);
+/* RepVGG block tail in training (src/repvgg.py:67-76): y = relu(BN(x[0]) + BN(x[1]) [+ BN(x[2])]) with per-branch batch
+ * statistics, one pass; nb = 2 or 3 branches, every array argument holds nb pointers.  mean / rstd are [c] (rows_a = 0) or
+ * [2][c] for two batch segments.  The backward shares g = dout * (y > 0): dx[j] = BatchNorm_j backward of g,
+ * dgamma[j] / dbeta[j] += (always accumulated).  workspace >= suhpe_bn_workspace_bytes(c). */
+int suhpe_repvgg_bn_fwd(const float* const* x, const float* const* mean, const float* const* rstd, const float* const* gamma,
+                        const float* const* beta, int nb, int64_t rows, int64_t rows_a, int c, float* y, suhpe_stream_t stream);
+int suhpe_repvgg_bn_bwd(const float* const* x, const float* const* mean, const float* const* rstd, const float* const* gamma, int nb,
+                        const float* dout, const float* y, int64_t rows, int64_t rows_a, int c, float* const* dx,
+                        float* const* dgamma, float* const* dbeta, void* workspace, suhpe_stream_t stream);
+
 /* Two batch segments in one launch: rows [0, rows_a) and [rows_a, rows) of x are normalised with separate statistics (the
  * labeled and the strong batch of a step run through the network as one, layers.batch_segments).  mean / rstd are [2][c];
  * the running statistics take the two momentum updates in order and num_batches_tracked += 2; dgamma / dbeta receive the sum

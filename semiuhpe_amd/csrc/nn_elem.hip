@@ -595,6 +595,263 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ x,
     }
 }
 
+// ------------------------------------------------------------------------------------------ RepVGG block tail
+// y = relu(BN_a(x_a) + BN_b(x_b) [+ BN_c(x_c)])  (src/repvgg.py:67-76: the 3x3 branch, the 1x1 branch and the identity
+// BatchNorm, train-mode statistics per branch) as ONE pass: 3-4 streams instead of the 8 of three chained apply kernels.
+// The backward shares g = dout * (y > 0) between the branches: one partial pass (sum g, sum g xhat_j), one finaliser, one
+// apply pass writing the three input gradients.  Segments as in the other BatchNorm kernels (statistics [2][c]).
+struct Bn3 {
+    const float* x[3];
+    const float* mean[3];
+    const float* rstd[3];
+    const float* gamma[3];
+    const float* beta[3];
+    int nb;                                              // 2 or 3 branches
+};
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bn3_act_fwd_kernel(Bn3 b, int rows, int c, int cw, int rp, int rows_per_block, float* __restrict__ y,
+                                                          const SegArgs sg) {
+    int64_t rows_s = rows, row_off;
+    int set;
+    const int bx = seg_select(sg, &rows_s, &row_off, &set);
+    rows = (int)rows_s;
+    y += row_off * c;
+#undef EW_BX
+#define EW_BX bx
+    EW_THREAD_SETUP(VEC)
+#undef EW_BX
+#define EW_BX blockIdx.x
+    float sc[3][VEC], sh[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) sh[v] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (j < b.nb) {
+            b.x[j] += row_off * c;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const float g = b.gamma[j][ch + v];
+                sc[j][v] = b.rstd[j][set * c + ch + v] * g;
+                sh[v] += b.beta[j][ch + v] - b.mean[j][set * c + ch + v] * sc[j][v];
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) sc[j][v] = 0.f;
+        }
+    }
+    constexpr int U = 4;
+    for (int r = r0 + rsub; r < r1; r += U * rp) {
+        float xv[3][U][VEC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rr = r + u * rp < r1 ? r + u * rp : r1 - 1;
+            const int64_t off = ((int64_t)rr * cv + vc) * VEC;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (j < b.nb) vload<VEC>(b.x[j] + off, xv[j][u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rr = r + u * rp;
+            if (rr >= r1) break;
+            float o[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                float a = sh[v];
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (j < b.nb) a += xv[j][u][v] * sc[j][v];
+                o[v] = a > 0.f ? a : 0.f;
+            }
+            vstore<VEC>(y + ((int64_t)rr * cv + vc) * VEC, o);
+        }
+    }
+}
+
+// records per (row block, channel): (sum g, sum g xhat_a, sum g xhat_b, sum g xhat_c)
+template <int VEC>
+__global__ __launch_bounds__(256) void bn3_bwd_partial(Bn3 b, const float* __restrict__ dout, const float* __restrict__ yout, int64_t rows, int c,
+                                                       int cw, int rp, int64_t rows_per_block, float* __restrict__ part, const SegArgs sg) {
+    __shared__ float lds[256 * 4 * VEC];
+    int64_t row_off;
+    int set;
+    const int bx = seg_select(sg, &rows, &row_off, &set);
+    dout += row_off * c; yout += row_off * c;
+    const int t = threadIdx.x, col = t % cw, rsub = t / cw;
+    const int col0 = blockIdx.y * cw;
+    const int cv = c / VEC;
+    float s[4][VEC];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) s[k][v] = 0.f;
+    if (rsub < rp && col0 + col < cv) {
+        const int ch = (col0 + col) * VEC;
+        float mu[3][VEC], rs[3][VEC];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (j < b.nb) {
+                b.x[j] += row_off * c;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) { mu[j][v] = b.mean[j][set * c + ch + v]; rs[j][v] = b.rstd[j][set * c + ch + v]; }
+            }
+        const int64_t r0 = (int64_t)bx * rows_per_block;
+        int64_t r1 = r0 + rows_per_block;
+        if (r1 > rows) r1 = rows;
+        constexpr int U = 4;
+        for (int64_t r = r0 + rsub; r < r1; r += U * (int64_t)rp) {
+            float xv[3][U][VEC], dv[U][VEC], yv[U][VEC];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t rr = r + u * (int64_t)rp;
+                const int64_t off = ((rr < r1 ? rr : r1 - 1) * cv + col0 + col) * VEC;
+                vload<VEC>(dout + off, dv[u]);
+                vload<VEC>(yout + off, yv[u]);
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (j < b.nb) vload<VEC>(b.x[j] + off, xv[j][u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool ok = r + u * (int64_t)rp < r1;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const float g = (ok && yv[u][v] > 0.f) ? dv[u][v] : 0.f;
+                    s[0][v] += g;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        if (j < b.nb) s[j + 1][v] += g * (xv[j][u][v] - mu[j][v]) * rs[j][v];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) lds[(t * 4 + k) * VEC + v] = s[k][v];
+    __syncthreads();
+    if (t < cw && (col0 + t) * VEC < c) {
+        float a[4][VEC];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) a[k][v] = 0.f;
+        for (int r = 0; r < rp; ++r) {
+            const int tt = r * cw + t;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) a[k][v] += lds[(tt * 4 + k) * VEC + v];
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+            reinterpret_cast<float4*>(part)[(int64_t)blockIdx.x * c + (col0 + t) * VEC + v] = make_float4(a[0][v], a[1][v], a[2][v], a[3][v]);
+    }
+}
+
+// sums[seg][k][c] (k = g, g xhat_a, g xhat_b, g xhat_c); dgamma_j += sum over segments of sums[.][j+1], dbeta_j += sums[.][0]
+struct Bn3Grads { float* dgamma[3]; float* dbeta[3]; int nb; };
+__global__ __launch_bounds__(kFinThreads) void bn3_bwd_finalize(const float* __restrict__ part, int gx_a, int gx, int c, float* __restrict__ sums,
+                                                        const Bn3Grads gr) {
+    const int chl = threadIdx.x & (kFinCh - 1), sub = threadIdx.x / kFinCh;
+    const int ch = blockIdx.x * kFinCh + chl;
+    double tot[2][4];
+    bool own = false;
+    for (int seg = 0; seg < 2; ++seg) {
+        const int first = seg == 0 ? 0 : gx_a, count = seg == 0 ? gx_a : gx - gx_a;
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        if (ch < c) {
+            const float4* p = reinterpret_cast<const float4*>(part) + (int64_t)first * c + ch;
+#pragma unroll 4
+            for (int i = sub; i < count; i += kFinSub) {
+                const float4 v = p[(int64_t)i * c];
+                a[0] += (double)v.x; a[1] += (double)v.y; a[2] += (double)v.z; a[3] += (double)v.w;
+            }
+        }
+        __syncthreads();
+        own = fin_reduce(&a[0], &a[1], ch, c);
+        __syncthreads();
+        fin_reduce(&a[2], &a[3], ch, c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tot[seg][k] = a[k];
+    }
+    if (!own) return;
+#pragma unroll
+    for (int seg = 0; seg < 2; ++seg)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sums[((int64_t)seg * 4 + k) * c + ch] = (float)tot[seg][k];
+    for (int j = 0; j < gr.nb; ++j) {
+        gr.dbeta[j][ch] += (float)tot[0][0] + (float)tot[1][0];
+        gr.dgamma[j][ch] += (float)tot[0][j + 1] + (float)tot[1][j + 1];
+    }
+}
+
+struct Bn3Out { float* dx[3]; };
+template <int VEC>
+__global__ __launch_bounds__(256) void bn3_bwd_apply(Bn3 b, const float* __restrict__ dout, const float* __restrict__ yout, int rows, int c, int cw,
+                                                     int rp, int rows_per_block, const float* __restrict__ sums, float inv_rows_a, float inv_rows_b,
+                                                     Bn3Out o, const SegArgs sg) {
+    int64_t rows_s = rows, row_off;
+    int set;
+    const int bx = seg_select(sg, &rows_s, &row_off, &set);
+    rows = (int)rows_s;
+    dout += row_off * c; yout += row_off * c;
+    const float inv_rows = set ? inv_rows_b : inv_rows_a;
+#undef EW_BX
+#define EW_BX bx
+    EW_THREAD_SETUP(VEC)
+#undef EW_BX
+#define EW_BX blockIdx.x
+    float mu[3][VEC], rs[3][VEC], ga[3][VEC], m1[3][VEC], m0[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) m0[v] = sums[((int64_t)set * 4 + 0) * c + ch + v] * inv_rows;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        if (j < b.nb) {
+            b.x[j] += row_off * c;
+            o.dx[j] += row_off * c;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                mu[j][v] = b.mean[j][set * c + ch + v];
+                rs[j][v] = b.rstd[j][set * c + ch + v];
+                ga[j][v] = b.gamma[j][ch + v] * rs[j][v];
+                m1[j][v] = sums[((int64_t)set * 4 + j + 1) * c + ch + v] * inv_rows;
+            }
+        }
+    constexpr int U = 4;
+    for (int r = r0 + rsub; r < r1; r += U * rp) {
+        float xv[3][U][VEC], dv[U][VEC], yv[U][VEC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rr = r + u * rp < r1 ? r + u * rp : r1 - 1;
+            const int64_t off = ((int64_t)rr * cv + vc) * VEC;
+            vload<VEC>(dout + off, dv[u]);
+            vload<VEC>(yout + off, yv[u]);
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (j < b.nb) vload<VEC>(b.x[j] + off, xv[j][u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rr = r + u * rp;
+            if (rr >= r1) break;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (j < b.nb) {
+                    float d[VEC];
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const float g = yv[u][v] > 0.f ? dv[u][v] : 0.f;
+                        const float xh = (xv[j][u][v] - mu[j][v]) * rs[j][v];
+                        d[v] = ga[j][v] * (g - m0[v] - xh * m1[j][v]);
+                    }
+                    vstore<VEC>(o.dx[j] + ((int64_t)rr * cv + vc) * VEC, d);
+                }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ LayerNorm (one wave per row)
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int64_t rows, int c, float eps,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -985,7 +1242,7 @@ using namespace suhpe;
 extern "C" {
 
 // records (one spare row block for the two-segment launches) + per-channel backward sums of up to two segments
-int64_t suhpe_bn_workspace_bytes(int c) { return (kPartFloats + (int64_t)c * 4 + (int64_t)c * 4) * sizeof(float); }
+int64_t suhpe_bn_workspace_bytes(int c) { return (kPartFloats + (int64_t)c * 4 + (int64_t)c * 8) * sizeof(float); }
 static float* bn_sums_of(void* workspace, int c) { return static_cast<float*>(workspace) + kPartFloats + (int64_t)c * 4; }
 
 int suhpe_bn_stats(const float* x, int64_t rows, int c, float eps, float momentum, float* mean, float* rstd,
@@ -1211,6 +1468,84 @@ int suhpe_bn_act_bwd_seg(const float* x, const float* dy, const float* y_out, in
                beta, act, sums, inv_a, 1, rowscale, hw, dx, se, inv_b);
     }
     return check_launch("suhpe_bn_act_bwd_seg");
+}
+
+// RepVGG block tail (train mode): x / mean / rstd / gamma / beta are arrays of nb (2 or 3) pointers, branch order as the sum is
+// written in the reference: 3x3 branch, 1x1 branch, identity BatchNorm; statistics [c] (rows_a = 0) or [2][c].
+static bool bn3_fill(Bn3* b, const float* const* x, const float* const* mean, const float* const* rstd, const float* const* gamma,
+                     const float* const* beta, int nb) {
+    if (!(x && mean && rstd && gamma && (nb == 2 || nb == 3))) return false;
+    b->nb = nb;
+    for (int j = 0; j < 3; ++j) {
+        const bool on = j < nb;
+        b->x[j] = on ? x[j] : nullptr; b->mean[j] = on ? mean[j] : nullptr; b->rstd[j] = on ? rstd[j] : nullptr;
+        b->gamma[j] = on ? gamma[j] : nullptr; b->beta[j] = (on && beta) ? beta[j] : nullptr;
+        if (on && !(b->x[j] && b->mean[j] && b->rstd[j] && b->gamma[j] && (!beta || b->beta[j]))) return false;
+    }
+    return true;
+}
+
+int suhpe_repvgg_bn_fwd(const float* const* x, const float* const* mean, const float* const* rstd, const float* const* gamma,
+                        const float* const* beta, int nb, int64_t rows, int64_t rows_a, int c, float* y, suhpe_stream_t stream) {
+    Bn3 b;
+    SUHPE_REQUIRE(bn3_fill(&b, x, mean, rstd, gamma, beta, nb) && beta && y && rows > 0 && rows < (1LL << 31) && c > 0 && rows_a >= 0 && rows_a < rows,
+                  "suhpe_repvgg_bn_fwd: bad arguments");
+    const int vec = (vec4_ok(c, b.x[0], b.x[1], y) && vec4_ok(c, b.x[2])) ? 4 : 1;
+    const EwGeom g = ew_geom(rows, c, vec);
+    int gx = g.gx;
+    SegArgs sg{0, 0};
+    if (rows_a > 0) {
+        const int gx_a = (int)ceil_div(rows_a, (int64_t)g.rows_per_block);
+        gx = gx_a + (int)ceil_div(rows - rows_a, (int64_t)g.rows_per_block);
+        sg = SegArgs{rows_a, gx_a};
+    }
+    if (vec == 4) LAUNCH(bn3_act_fwd_kernel<4>, dim3(gx, g.ny), dim3(256), stream, b, (int)rows, c, g.cw, g.rp, g.rows_per_block, y, sg);
+    else LAUNCH(bn3_act_fwd_kernel<1>, dim3(gx, g.ny), dim3(256), stream, b, (int)rows, c, g.cw, g.rp, g.rows_per_block, y, sg);
+    return check_launch("suhpe_repvgg_bn_fwd");
+}
+
+int suhpe_repvgg_bn_bwd(const float* const* x, const float* const* mean, const float* const* rstd, const float* const* gamma, int nb,
+                        const float* dout, const float* y, int64_t rows, int64_t rows_a, int c, float* const* dx, float* const* dgamma,
+                        float* const* dbeta, void* workspace, suhpe_stream_t stream) {
+    Bn3 b;
+    SUHPE_REQUIRE(bn3_fill(&b, x, mean, rstd, gamma, nullptr, nb) && dout && y && dx && dgamma && dbeta && workspace && rows > 0 && rows < (1LL << 31) &&
+                      c > 0 && rows_a >= 0 && rows_a < rows,
+                  "suhpe_repvgg_bn_bwd: bad arguments");
+    Bn3Grads gr;
+    Bn3Out out;
+    gr.nb = nb;
+    for (int j = 0; j < 3; ++j) {
+        gr.dgamma[j] = j < nb ? dgamma[j] : nullptr; gr.dbeta[j] = j < nb ? dbeta[j] : nullptr; out.dx[j] = j < nb ? dx[j] : nullptr;
+        SUHPE_REQUIRE(j >= nb || (gr.dgamma[j] && gr.dbeta[j] && out.dx[j]), "suhpe_repvgg_bn_bwd: null gradient pointer");
+    }
+    float* part = static_cast<float*>(workspace);
+    float* sums = bn_sums_of(workspace, c);
+    const int vec = (vec4_ok(c, b.x[0], b.x[1], dout) && vec4_ok(c, b.x[2], y) && vec4_ok(c, out.dx[0], out.dx[1], out.dx[2])) ? 4 : 1;
+    const ColGeom g = col_geom(rows, c, vec);
+    const EwGeom e = ew_geom(rows, c, vec);
+    int gx_a = g.gx, gx = g.gx, ex = e.gx;
+    SegArgs sg{0, 0}, se{0, 0};
+    float inv_a = 1.0f / (float)rows, inv_b = 0.f;
+    if (rows_a > 0) {
+        gx_a = (int)ceil_div(rows_a, g.rows_per_block);
+        gx = gx_a + (int)ceil_div(rows - rows_a, g.rows_per_block);
+        const int ex_a = (int)ceil_div(rows_a, (int64_t)e.rows_per_block);
+        ex = ex_a + (int)ceil_div(rows - rows_a, (int64_t)e.rows_per_block);
+        sg = SegArgs{rows_a, gx_a};
+        se = SegArgs{rows_a, ex_a};
+        inv_a = 1.0f / (float)rows_a;
+        inv_b = 1.0f / (float)(rows - rows_a);
+    }
+    if (vec == 4) {
+        LAUNCH(bn3_bwd_partial<4>, dim3(gx, g.ny), dim3(256), stream, b, dout, y, rows, c, g.cw, g.rp, g.rows_per_block, part, sg);
+        LAUNCH(bn3_bwd_finalize, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, gx_a, gx, c, sums, gr);
+        LAUNCH(bn3_bwd_apply<4>, dim3(ex, e.ny), dim3(256), stream, b, dout, y, (int)rows, c, e.cw, e.rp, e.rows_per_block, sums, inv_a, inv_b, out, se);
+    } else {
+        LAUNCH(bn3_bwd_partial<1>, dim3(gx, g.ny), dim3(256), stream, b, dout, y, rows, c, g.cw, g.rp, g.rows_per_block, part, sg);
+        LAUNCH(bn3_bwd_finalize, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, gx_a, gx, c, sums, gr);
+        LAUNCH(bn3_bwd_apply<1>, dim3(ex, e.ny), dim3(256), stream, b, dout, y, (int)rows, c, e.cw, e.rp, e.rows_per_block, sums, inv_a, inv_b, out, se);
+    }
+    return check_launch("suhpe_repvgg_bn_bwd");
 }
 
 int suhpe_layernorm_fwd(const float* x, int64_t rows, int c, float eps, const float* gamma, const float* beta, float* y,

@@ -643,6 +643,32 @@ def bn_act_bwd_seg(x, dy, rows_a, c, mean, rstd, gamma, beta, act, dgamma=None, 
     return dx
 
 
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+@_memop
+def repvgg_bn_fwd(xs, means, rstds, gammas, betas, rows_a, c):
+    """y = relu(sum_j BN_j(xs[j])) for the 2 or 3 branches of a RepVGG block in one pass; statistics [c] or [2, c] (rows_a > 0)"""
+    for t in xs:
+        _chk(t, "x")
+    y = torch.empty_like(xs[0])
+    call("suhpe_repvgg_bn_fwd", _ptr_array(xs), _ptr_array(means), _ptr_array(rstds), _ptr_array(gammas), _ptr_array(betas), len(xs),
+         xs[0].numel() // c, int(rows_a), c, ptr(y))
+    return y
+
+
+@_memop
+def repvgg_bn_bwd(xs, means, rstds, gammas, dout, y, rows_a, c, dgammas, dbetas):
+    """-> [dx_j]: BatchNorm backward of every branch on the shared g = dout * (y > 0); dgammas / dbetas are accumulated"""
+    _chk(dout, "dout"); _chk(y, "y")
+    dxs = [torch.empty_like(t) for t in xs]
+    ws = workspace("bn", _lib.load().suhpe_bn_workspace_bytes(c), dout.device)
+    call("suhpe_repvgg_bn_bwd", _ptr_array(xs), _ptr_array(means), _ptr_array(rstds), _ptr_array(gammas), len(xs), ptr(dout), ptr(y),
+         xs[0].numel() // c, int(rows_a), c, _ptr_array(dxs), _ptr_array(dgammas), _ptr_array(dbetas), ptr(ws))
+    return dxs
+
+
 def bn_eval_stats(running_mean, running_var, eps):
     c = running_mean.numel()
     mean = torch.empty(c, dtype=torch.float32, device=running_mean.device)

@@ -209,6 +209,27 @@ class _BatchNorm(Layer):
             tape.append((x, mean, rstd, self.training, keep_y, rowscale if post else None, hw))
         return y
 
+    def train_stats(self, x, partials=None):
+        """train-mode statistics of x (running statistics updated) -> (mean, rstd, rows of the first segment or 0); the
+        statistics are [2, c] tensors when the batch has two segments"""
+        c, n = self.num_features, x.shape[0]
+        hw = x.numel() // (c * n)
+        seg = _segment_of(x)
+        if seg is not None:
+            if partials is not None:
+                part, tiles, (first_records, boundary) = partials
+                mean, rstd = K.bn_stats_from_partials_seg(part, tiles, first_records, boundary, n * hw, seg * hw, c, self.eps, self.momentum,
+                                                          self.running_mean, self.running_var, self.num_batches_tracked)
+            else:
+                mean, rstd = K.bn_stats_seg(x, seg * hw, c, self.eps, self.momentum, self.running_mean, self.running_var, self.num_batches_tracked)
+            return mean, rstd, seg * hw
+        if partials is not None:
+            mean, rstd = K.bn_stats_from_partials(partials[0], partials[1], x.numel() // c, c, self.eps, self.momentum, self.running_mean,
+                                                  self.running_var, self.num_batches_tracked)
+        else:
+            mean, rstd = K.bn_stats(x, c, self.eps, self.momentum, self.running_mean, self.running_var, self.num_batches_tracked)
+        return mean, rstd, 0
+
     def _fwd_pool(self, x, tape, partials, seg):
         """act(BN(x)) together with the global average pool of it (the squeeze of the SqueezeExcitation block that follows):
         one pass, the pooled means are fixed-order sums inside one workgroup per sample."""

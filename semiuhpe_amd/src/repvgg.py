@@ -8,7 +8,11 @@ with per-branch batch statistics.  Blocks are Layers with explicit forward/backw
 import torch.nn as nn
 
 from .. import kernels as K
-from ..layers import BatchNorm2d, Conv2d, GlobalAvgPool, Layer, Network, Sequential, conv_bn_fwd
+from .. import layers as L
+from ..layers import BatchNorm2d, Conv2d, GlobalAvgPool, Layer, Network, Sequential, conv_bn_fwd, grad_of
+
+# training: the three BatchNorm applies + ReLU of a block (and their backward) run as one kernel each (suhpe_repvgg_bn_fwd / _bwd)
+FUSE_BLOCK_TAIL = True
 from .efficientnet_v2 import init_regression_head_, regression_head
 
 
@@ -44,6 +48,8 @@ class RepVGGBlock(Layer):
             w_eq, ones, b_eq = K.repvgg_fuse(c3.weight, c1.weight, bn(self.rbr_dense.bn), bn(self.rbr_1x1.bn),
                                              bn(self.rbr_identity) if self.rbr_identity is not None else None, self.rbr_dense.bn.eps)
             return K.conv2d_fwd_affine(x, w_eq, ones, b_eq, "relu", None, False, c3.stride, c3.padding, c3.groups)
+        if train and FUSE_BLOCK_TAIL and L.SEGMENT_LAUNCHES != "split":
+            return self._fwd_fused_tail(x, tape)
         t3, p3 = self.rbr_dense.conv.fwd_stats(x, tape) if train else (self.rbr_dense.conv.fwd(x, tape), None)
         t1, p1 = self.rbr_1x1.conv.fwd_stats(x, tape) if train else (self.rbr_1x1.conv.fwd(x, tape), None)
         u = self.rbr_1x1.bn.fwd(t1, tape, partials=p1)
@@ -51,7 +57,35 @@ class RepVGGBlock(Layer):
             u = self.rbr_identity.fwd(x, tape, residual=u)
         return self.rbr_dense.bn.fwd(t3, tape, residual=u, partials=p3)          # relu(bn(t3) + u)
 
+    def _fwd_fused_tail(self, x, tape):
+        """training: both convs emit their BatchNorm statistics, then ONE kernel forms relu(BN(t3) + BN(t1) [+ BN(x)])"""
+        bns = [self.rbr_dense.bn, self.rbr_1x1.bn] + ([self.rbr_identity] if self.rbr_identity is not None else [])
+        t3, p3 = self.rbr_dense.conv.fwd_stats(x, tape)
+        t1, p1 = self.rbr_1x1.conv.fwd_stats(x, tape)
+        xs = [t3, t1] + ([x] if self.rbr_identity is not None else [])
+        stats = [bns[0].train_stats(t3, p3), bns[1].train_stats(t1, p1)] + ([bns[2].train_stats(x)] if len(bns) == 3 else [])
+        means, rstds, rows_a = [s[0] for s in stats], [s[1] for s in stats], stats[0][2]
+        y = K.repvgg_bn_fwd(xs, means, rstds, [b.weight for b in bns], [b.bias for b in bns], rows_a, bns[0].num_features)
+        if tape is not None:
+            tape.append(("fused_tail", xs, means, rstds, rows_a, y))
+        return y
+
+    def _bwd_fused_tail(self, dout, tape):
+        _, xs, means, rstds, rows_a, y = tape.pop()
+        bns = [self.rbr_dense.bn, self.rbr_1x1.bn] + ([self.rbr_identity] if self.rbr_identity is not None else [])
+        dxs = K.repvgg_bn_bwd(xs, means, rstds, [b.weight for b in bns], dout.contiguous(), y, rows_a, bns[0].num_features,
+                              [grad_of(b.weight) for b in bns], [grad_of(b.bias) for b in bns])
+        self.rbr_1x1.conv.need_input_grad = self.rbr_dense.conv.need_input_grad = self.need_input_grad
+        dx1 = self.rbr_1x1.conv.bwd(dxs[1], tape)
+        dx3 = self.rbr_dense.conv.bwd(dxs[0], tape)
+        if not self.need_input_grad:
+            return None
+        dx = K.add(dx3, dx1)
+        return K.add(dx, dxs[2]) if len(dxs) == 3 else dx
+
     def bwd(self, dout, tape):
+        if isinstance(tape[-1], tuple) and len(tape[-1]) == 6 and tape[-1][0] == "fused_tail":
+            return self._bwd_fused_tail(dout, tape)
         out = tape[-1][4]                                           # forward output kept for the ReLU mask
         d_t3 = self.rbr_dense.bn.bwd(dout, tape)
         g = K.act_bwd(out, dout, out.shape[-1], "relu")             # dL/du = dout * (out > 0)

@@ -230,3 +230,41 @@ def test_batchnorm_apply_with_fused_squeeze(hw, c, n, seg, act):
     assert torch.equal(y, want)
     assert rel_err(pool, want.double().mean(1)) < 1e-6
     assert rel_err(pool, K.avgpool_fwd(want.view(n, hw, 1, c))) < 1e-6
+
+
+@pytest.mark.parametrize("hw,c,n,seg,nb", [(196, 512, 6, 2, 3), (49, 2048, 5, 0, 2), (25, 6, 4, 3, 3), (784, 128, 3, 0, 3)])
+def test_repvgg_block_tail_fused_batchnorms(hw, c, n, seg, nb):
+    """suhpe_repvgg_bn_fwd / _bwd (relu of the sum of 2-3 BatchNorm branches and its backward as one kernel each) against the
+    chain of one-branch kernels the block used before (and still uses in eval mode): outputs, dx per branch, dgamma, dbeta."""
+    from semiuhpe_amd import kernels as K
+    g = torch.Generator().manual_seed(hw + c + nb)
+    xs = [(torch.randn(n, hw, 1, c, generator=g) * (1 + j) + 0.3 * j).cuda() for j in range(nb)]
+    gam = [(torch.rand(c, generator=g) + 0.5).cuda() for _ in range(nb)]
+    bet = [torch.randn(c, generator=g).cuda() for _ in range(nb)]
+    dout = torch.randn(n, hw, 1, c, generator=g).cuda()
+    rows_a = seg * hw
+    if seg:
+        st = [K.bn_stats_seg(x, rows_a, c, 1e-5, 0.1) for x in xs]
+        fwd = lambda x, m, r, ga, be, act, res: K.bn_act_fwd_seg(x, rows_a, c, m, r, ga, be, act, res)
+        bwd = lambda x, dy, m, r, ga, be, act, dg, db, yo: K.bn_act_bwd_seg(x, dy, rows_a, c, m, r, ga, be, act, dg, db, True, yo)
+    else:
+        st = [K.bn_stats(x, c, 1e-5, 0.1) for x in xs]
+        fwd = lambda x, m, r, ga, be, act, res: K.bn_act_fwd(x, c, m, r, ga, be, act, res)
+        bwd = lambda x, dy, m, r, ga, be, act, dg, db, yo: K.bn_act_bwd(x, dy, c, m, r, ga, be, act, True, dg, db, True, yo)
+    means, rstds = [s[0] for s in st], [s[1] for s in st]
+    # the unfused chain: u = BN(x1) (+ BN(x2)); y = relu(BN(x0) + u)
+    u = fwd(xs[1], means[1], rstds[1], gam[1], bet[1], "none", None)
+    if nb == 3:
+        u = fwd(xs[2], means[2], rstds[2], gam[2], bet[2], "none", u)
+    want = fwd(xs[0], means[0], rstds[0], gam[0], bet[0], "relu", u)
+    y = K.repvgg_bn_fwd(xs, means, rstds, gam, bet, rows_a, c)
+    assert rel_err(y, want) < 1e-5
+    dg1 = [torch.zeros(c).cuda() for _ in range(nb)]; db1 = [torch.zeros(c).cuda() for _ in range(nb)]
+    dg2 = [torch.zeros(c).cuda() for _ in range(nb)]; db2 = [torch.zeros(c).cuda() for _ in range(nb)]
+    dxs = K.repvgg_bn_bwd(xs, means, rstds, gam, dout, y, rows_a, c, dg1, db1)
+    gmask = K.act_bwd(y, dout, c, "relu")
+    ref0 = bwd(xs[0], dout, means[0], rstds[0], gam[0], bet[0], "relu", dg2[0], db2[0], y)
+    refs = [ref0] + [bwd(xs[j], gmask, means[j], rstds[j], gam[j], bet[j], "none", dg2[j], db2[j], None) for j in range(1, nb)]
+    for j in range(nb):
+        assert rel_err(dxs[j], refs[j]) < 2e-5, j
+        assert rel_err(dg1[j], dg2[j]) < 2e-5 and rel_err(db1[j], db2[j]) < 2e-5, j
