@@ -302,6 +302,7 @@ int suhpe_mul_rowscale(const float* x, const float* rowscale, int n, int64_t per
 int suhpe_mul(const float* x, const float* m, int64_t count, float* y, suhpe_stream_t stream);
 /* out[i] = a[i] + b[i] */
 int suhpe_add(const float* a, const float* b, int64_t count, float* y, suhpe_stream_t stream);
+int suhpe_add3(const float* a, const float* b, const float* c, int64_t count, float* y, suhpe_stream_t stream);   /* (a + b) + c */
 /* Bernoulli(keep)/keep mask from a counter-based generator (Philox4x32-10).  Stream position = counter[1] (device,
  * 2 x uint64: seed, offset) + host_offset.  advance != 0 bumps the device offset after the draw (graph replays then
  * draw fresh numbers); with advance == 0 the caller tracks the position in host_offset and saves the extra launch. */

@@ -1106,6 +1106,31 @@ __global__ __launch_bounds__(256) void binary_kernel(const float* __restrict__ a
         y[i] = op == 0 ? a[i] + b[i] : a[i] * b[i];
 }
 
+// y = (a + b) + c: the three input-gradient paths of a RepVGG block in one pass (same rounding order as two binary adds)
+__global__ __launch_bounds__(256) void add3_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c3,
+                                                   int64_t count, float* __restrict__ y) {
+    const int64_t nvec = count / 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += 4 * stride) {
+        float4 av[4], bv[4], cv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t ii = i + u * stride < nvec ? i + u * stride : nvec - 1;
+            av[u] = reinterpret_cast<const float4*>(a)[ii];
+            bv[u] = reinterpret_cast<const float4*>(b)[ii];
+            cv[u] = reinterpret_cast<const float4*>(c3)[ii];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i + u * stride >= nvec) break;
+            reinterpret_cast<float4*>(y)[i + u * stride] = make_float4((av[u].x + bv[u].x) + cv[u].x, (av[u].y + bv[u].y) + cv[u].y,
+                                                                       (av[u].z + bv[u].z) + cv[u].z, (av[u].w + bv[u].w) + cv[u].w);
+        }
+    }
+    for (int64_t i = nvec * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = (a[i] + b[i]) + c3[i];
+}
+
 // ------------------------------------------------------------------------------------------ dropout mask (Philox4x32-10)
 __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
     const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
@@ -1659,6 +1684,12 @@ int suhpe_add(const float* a, const float* b, int64_t count, float* y, suhpe_str
     SUHPE_REQUIRE(a && b && y && count > 0 && vec4_ok(4, a, b, y), "suhpe_add: bad arguments");
     LAUNCH(binary_kernel, dim3(grid_for(count / 4 + 1, 256)), dim3(256), stream, a, b, count, 0, y);
     return check_launch("suhpe_add");
+}
+
+int suhpe_add3(const float* a, const float* b, const float* c, int64_t count, float* y, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(a && b && c && y && count > 0 && vec4_ok(4, a, b, y) && vec4_ok(4, c), "suhpe_add3: bad arguments");
+    LAUNCH(add3_kernel, dim3(grid_for(count / 4 + 1, 256)), dim3(256), stream, a, b, c, count, y);
+    return check_launch("suhpe_add3");
 }
 
 int suhpe_dropout_mask(uint64_t* counter, uint64_t host_offset, int advance, float keep, int64_t count, float* mask, suhpe_stream_t stream) {

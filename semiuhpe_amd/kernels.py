@@ -829,6 +829,14 @@ def add(a, b):
     return y
 
 
+def add3(a, b, c):
+    """(a + b) + c in one pass"""
+    _chk(a, "a"); _chk(b, "b"); _chk(c, "c")
+    y = torch.empty_like(a)
+    call("suhpe_add3", ptr(a), ptr(b), ptr(c), a.numel(), ptr(y))
+    return y
+
+
 @_memop
 def mul(a, b):
     _chk(a, "a"); _chk(b, "b")

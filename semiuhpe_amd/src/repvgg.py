@@ -80,8 +80,7 @@ class RepVGGBlock(Layer):
         dx3 = self.rbr_dense.conv.bwd(dxs[0], tape)
         if not self.need_input_grad:
             return None
-        dx = K.add(dx3, dx1)
-        return K.add(dx, dxs[2]) if len(dxs) == 3 else dx
+        return K.add3(dx3, dx1, dxs[2]) if len(dxs) == 3 else K.add(dx3, dx1)
 
     def bwd(self, dout, tape):
         if isinstance(tape[-1], tuple) and len(tape[-1]) == 6 and tape[-1][0] == "fused_tail":
@@ -96,8 +95,7 @@ class RepVGGBlock(Layer):
         dx3 = self.rbr_dense.conv.bwd(d_t3, tape)
         if not self.need_input_grad:
             return None
-        dx = K.add(dx3, dx1)
-        return K.add(dx, d_xid) if d_xid is not None else dx
+        return K.add3(dx3, dx1, d_xid) if d_xid is not None else K.add(dx3, dx1)
 
 
 def b1g2_stage_configs():
