@@ -75,6 +75,26 @@ def gather_varlen(t):
     return torch.cat([p[:s] for p, s in zip(parts, sizes)])
 
 
+def shard(iterable):
+    """This rank's share of an iterable of batches (round-robin: batch i goes to rank i % world).  Validation walks the test
+    loader through this and pools the per-sample results with gather_values, so N ranks validate N times faster and still
+    report the statistics of the whole set."""
+    rank, ws = world()
+    for i, item in enumerate(iterable):
+        if i % ws == rank:
+            yield item
+
+
+def gather_values(values, device="cpu"):
+    """1-D float array holding `values` (floats / arrays, flattened) of every rank, rank after rank, on every rank."""
+    import numpy as np
+    flat = np.concatenate([np.asarray(v, dtype=np.float64).reshape(-1) for v in values]) if len(values) else np.zeros(0)
+    if world()[1] == 1:
+        return flat
+    t = torch.from_numpy(flat).to(device)
+    return gather_varlen(t).cpu().numpy()
+
+
 def grad_seed(device):
     """d(loss_all)/d(loss_all) = 1/world: with per-rank mean losses this makes SUM(all-reduce) the global-batch mean."""
     return torch.full((), 1.0 / world()[1], dtype=torch.float32, device=device)

@@ -38,7 +38,10 @@ def _worker(rank, world, port, out):
     allent = D.gather_varlen(ent)
     b = torch.tensor([float(rank)])
     D.broadcast_(b, 0)
-    out[rank] = dict(flat=flat.numpy(), x=x.numpy(), ent=allent.numpy(), b=float(b))
+    # --- sharded validation: batches dealt round-robin, per-sample results pooled on every rank
+    mine = list(D.shard([np.arange(3) + 10 * i for i in range(5)]))
+    pooled = D.gather_values(mine)
+    out[rank] = dict(flat=flat.numpy(), x=x.numpy(), ent=allent.numpy(), b=float(b), mine=[m.tolist() for m in mine], pooled=pooled)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -61,3 +64,6 @@ def test_two_rank_exchange():
     from oracle.pose_utils import entropy_threshold
     assert entropy_threshold(r0["ent"], 0.75) == entropy_threshold(r1["ent"], 0.75) == np.sort(expect)[int(13 * 0.75)]
     assert r0["b"] == r1["b"] == 0.0
+    assert r0["mine"] == [[0, 1, 2], [20, 21, 22], [40, 41, 42]] and r1["mine"] == [[10, 11, 12], [30, 31, 32]]
+    whole = np.sort(np.concatenate([np.arange(3) + 10 * i for i in range(5)]).astype(np.float64))
+    assert np.array_equal(np.sort(r0["pooled"]), whole) and np.array_equal(r0["pooled"], r1["pooled"])

@@ -15,6 +15,7 @@ import torch.distributed as dist
 from semiuhpe_amd.src.agent import get_agent
 from semiuhpe_amd.src.config import get_config
 from semiuhpe_amd.src.datasets import build_loaders
+from semiuhpe_amd.src import distributed as D
 from semiuhpe_amd.src.distributed import init_from_env
 from semiuhpe_amd.src.utils import cycle, dict_get
 
@@ -29,9 +30,11 @@ def _log(agent, text):
 
 
 def validate(agent, test_loader, s1, eval_ema, tag):
-    """One pass over the test set -> mean test error (reference train.py:163-239); writes the `test*/...` log lines."""
+    """One pass over the test set -> mean test error (reference train.py:163-239); writes the `test*/...` log lines.
+    With several ranks every rank takes its share of the batches and the per-sample results are pooled, so all ranks see the
+    statistics of the whole set (and agree on the best checkpoint)."""
     losses, errs, ratios, pseudo = [], [], [], []
-    for data in test_loader:
+    for data in D.shard(test_loader):
         if s1:
             fisher_dict = agent.val_func_s1(data)
         else:
@@ -41,7 +44,11 @@ def validate(agent, test_loader, s1, eval_ema, tag):
                 pseudo.append(out["err_pseudo_gt"].detach().cpu().numpy())
         losses.append(fisher_dict["loss"].item())
         errs.append(fisher_dict["err_deg"].detach().cpu().numpy())
-    errs = np.concatenate(errs, 0)
+    dev = agent.device if D.world()[1] > 1 else "cpu"
+    errs, losses = D.gather_values(errs, dev), D.gather_values(losses, dev)
+    if not s1:
+        ratios, pseudo = D.gather_values([float(r) for r in ratios], dev), ([D.gather_values(pseudo, dev)] if D.world()[1] > 1 else pseudo)
+        pseudo = [p for p in pseudo if len(p)]
     _log(agent, _stamp(agent.clock) + " {0}/loss:{1:.6f} {0}/err_mean:{2:.6f}\n".format(tag, np.mean(losses), np.mean(errs)))
     if not s1:
         pseudo = [-1] if len(pseudo) == 0 else np.concatenate(pseudo, 0)
