@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void window_attn_dense_bias_kernel(const float
 }
 
 template <int NP>
-__global__ __launch_bounds__(NP == 64 ? 128 : 256) void window_attn_fwd_mfma(const AttnGeom g, const float* __restrict__ qkv,
+__global__ __launch_bounds__(NP == 64 ? 128 : 256, 2) void window_attn_fwd_mfma(const AttnGeom g, const float* __restrict__ qkv,
                                                                             const float* __restrict__ dense_bias, float* __restrict__ out,
                                                                             float* __restrict__ probs) {
     constexpr int QB = NP / 32;                         // query / key tiles
