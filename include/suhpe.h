@@ -276,6 +276,12 @@ int suhpe_act_bwd(const float* x, const float* dy, int64_t rows, int c, const fl
 
 /* ------------------------------------------------------------------ pooling, SE, residual, dropout ------- */
 /* mean over the hw axis: x (n,hw,c) -> y (n,c) */
+/* nn.MaxPool2d(k, stride, pad) on (N,H,W,C) (ResNet stem, torchvision resnet.py): ties go to the first window position, as
+ * in torch; idx (N,Ho,Wo,C) uint8 = position inside the window, kept for the backward (gather form, deterministic). */
+int suhpe_maxpool_fwd(const float* x, int n, int h, int w, int c, int k, int stride, int pad, float* y, uint8_t* idx,
+                      suhpe_stream_t stream);
+int suhpe_maxpool_bwd(const float* dy, const uint8_t* idx, int n, int h, int w, int c, int k, int stride, int pad, float* dx,
+                      suhpe_stream_t stream);
 int suhpe_avgpool_fwd(const float* x, int n, int hw, int c, float* y, suhpe_stream_t stream);
 int suhpe_avgpool_bwd(const float* dy, int n, int hw, int c, float* dx, suhpe_stream_t stream);
 /* squeeze-excite scale y[n,p,c] = x[n,p,c]*s[n,c] */

@@ -381,3 +381,56 @@ class TinyViT21M(nn.Module):
         for layer in self.layers:
             x = layer(x)
         return self.head(self.norm_head(x.mean(1)))
+
+
+# ------------------------------------------------------------------------------------------------ ResNet-50
+class Bottleneck(nn.Module):
+    """torchvision resnet.Bottleneck (v1.5: the stride sits on the 3x3 conv), expansion 4"""
+
+    def __init__(self, cin, planes, stride, downsample):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = downsample
+
+    def forward(self, x):
+        out = F.relu(self.bn1(self.conv1(x)))
+        out = F.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return F.relu(out + (x if self.downsample is None else self.downsample(x)))
+
+
+class ResNet50(nn.Module):
+    """torchvision 0.14.1 `resnet50` with `fc` replaced by the reference's regression head (src/networks.py:443-500; released
+    checkpoint DAD-COCOHead-ResNet50-best.pth).  torchvision is absent here: PARITY UNPINNED, restated from the published
+    architecture; sanity pin: 25,557,032 parameters with the 1000-class fc."""
+
+    def __init__(self, num_classes=9):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        cin = 64
+        for i, (planes, blocks, stride) in enumerate(((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)), start=1):
+            layers = []
+            for b in range(blocks):
+                s = stride if b == 0 else 1
+                down = None
+                if s != 1 or cin != planes * 4:
+                    down = nn.Sequential(nn.Conv2d(cin, planes * 4, 1, s, bias=False), nn.BatchNorm2d(planes * 4))
+                layers.append(Bottleneck(cin, planes, s, down))
+                cin = planes * 4
+            setattr(self, f"layer{i}", nn.Sequential(*layers))
+        self.fc = regression_head(2048, 512, 128, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out")
+
+    def forward(self, x):
+        x = self.maxpool(F.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return self.fc(x.mean((2, 3)))

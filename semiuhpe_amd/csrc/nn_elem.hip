@@ -976,6 +976,81 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------ max pooling (ResNet stem)
+// nn.MaxPool2d(k, stride, pad) on (N, H, W, C): the window is scanned kh, kw ascending and a value replaces the running
+// maximum only when it is greater (or NaN), so ties go to the FIRST position, as torch's kernels do; the position inside the
+// window (0 .. k*k-1) is kept for the backward.  One thread per (output pixel, channel vector).
+template <int VEC>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, int n, int h, int w, int c, int k, int stride, int pad,
+                                                          int oh, int ow, float* __restrict__ y, uint8_t* __restrict__ idx) {
+    const int cv = c / VEC;
+    const int64_t total = (int64_t)n * oh * ow * cv;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int vc = (int)(e % cv);
+        const int64_t pix = e / cv;
+        const int x0 = (int)(pix % ow), y0 = (int)((pix / ow) % oh), b = (int)(pix / ((int64_t)ow * oh));
+        float best[VEC];
+        int arg[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { best[v] = -INFINITY; arg[v] = 0; }
+        bool first = true;
+        for (int kh = 0; kh < k; ++kh) {
+            const int ih = y0 * stride - pad + kh;
+            if (ih < 0 || ih >= h) continue;
+            for (int kw = 0; kw < k; ++kw) {
+                const int iw = x0 * stride - pad + kw;
+                if (iw < 0 || iw >= w) continue;
+                float xv[VEC];
+                vload<VEC>(x + (((int64_t)b * h + ih) * w + iw) * c + vc * VEC, xv);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    if (first || xv[v] > best[v] || xv[v] != xv[v]) { best[v] = xv[v]; arg[v] = kh * k + kw; }
+                first = false;
+            }
+        }
+        vstore<VEC>(y + pix * c + vc * VEC, best);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) idx[pix * c + vc * VEC + v] = (uint8_t)arg[v];
+    }
+}
+
+// dx[b, ih, iw, c] = sum of dy over the output pixels whose window holds (ih, iw) at their recorded position (gather form:
+// deterministic, no atomics)
+template <int VEC>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx, int n, int h, int w, int c,
+                                                          int k, int stride, int pad, int oh, int ow, float* __restrict__ dx) {
+    const int cv = c / VEC;
+    const int64_t total = (int64_t)n * h * w * cv;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int vc = (int)(e % cv);
+        const int64_t pix = e / cv;
+        const int iw = (int)(pix % w), ih = (int)((pix / w) % h), b = (int)(pix / ((int64_t)w * h));
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        // window positions descending = output pixels ascending: the terms are added in the order torch's scatter visits them
+        for (int kh = k - 1; kh >= 0; --kh) {
+            const int num = ih + pad - kh;
+            if (num < 0 || num % stride) continue;
+            const int y0 = num / stride;
+            if (y0 >= oh) continue;
+            for (int kw = k - 1; kw >= 0; --kw) {
+                const int nw = iw + pad - kw;
+                if (nw < 0 || nw % stride) continue;
+                const int x0 = nw / stride;
+                if (x0 >= ow) continue;
+                const int64_t o = (((int64_t)b * oh + y0) * ow + x0) * c + vc * VEC;
+                float dv[VEC];
+                vload<VEC>(dy + o, dv);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    if (idx[o + v] == kh * k + kw) acc[v] += dv[v];
+            }
+        }
+        vstore<VEC>(dx + pix * c + vc * VEC, acc);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ pooling / SE
 // One block per (sample, column chunk): y[n,c] = scale * sum_p x[n,p,c] * (w ? w[n,p,c] : 1)
 template <int VEC>
@@ -1633,6 +1708,27 @@ static int per_sample_scale(const float* x, const float* s, const float* dpool, 
     if (v4) LAUNCH(per_sample_scale_kernel<4>, dim3(g.gx, g.ny, n), dim3(256), stream, x, s, dpool, hw, c, g.cw, g.rp, g.rows_per_block, inv_hw, mode, y);
     else LAUNCH(per_sample_scale_kernel<1>, dim3(g.gx, g.ny, n), dim3(256), stream, x, s, dpool, hw, c, g.cw, g.rp, g.rows_per_block, inv_hw, mode, y);
     return check_launch(who);
+}
+
+int suhpe_maxpool_fwd(const float* x, int n, int h, int w, int c, int k, int stride, int pad, float* y, uint8_t* idx, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(x && y && idx && n > 0 && h > 0 && w > 0 && c > 0 && k > 0 && k <= 15 && stride > 0 && pad >= 0 && 2 * pad <= k, "suhpe_maxpool_fwd: bad arguments");
+    const int oh = (h + 2 * pad - k) / stride + 1, ow = (w + 2 * pad - k) / stride + 1;
+    SUHPE_REQUIRE(oh > 0 && ow > 0, "suhpe_maxpool_fwd: empty output");
+    const int vec = vec4_ok(c, x, y) ? 4 : 1;
+    const int64_t total = (int64_t)n * oh * ow * (c / vec);
+    if (vec == 4) LAUNCH(maxpool_fwd_kernel<4>, dim3(grid_for(total, 256)), dim3(256), stream, x, n, h, w, c, k, stride, pad, oh, ow, y, idx);
+    else LAUNCH(maxpool_fwd_kernel<1>, dim3(grid_for(total, 256)), dim3(256), stream, x, n, h, w, c, k, stride, pad, oh, ow, y, idx);
+    return check_launch("suhpe_maxpool_fwd");
+}
+
+int suhpe_maxpool_bwd(const float* dy, const uint8_t* idx, int n, int h, int w, int c, int k, int stride, int pad, float* dx, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(dy && dx && idx && n > 0 && h > 0 && w > 0 && c > 0 && k > 0 && k <= 15 && stride > 0 && pad >= 0 && 2 * pad <= k, "suhpe_maxpool_bwd: bad arguments");
+    const int oh = (h + 2 * pad - k) / stride + 1, ow = (w + 2 * pad - k) / stride + 1;
+    const int vec = vec4_ok(c, dy, dx) ? 4 : 1;
+    const int64_t total = (int64_t)n * h * w * (c / vec);
+    if (vec == 4) LAUNCH(maxpool_bwd_kernel<4>, dim3(grid_for(total, 256)), dim3(256), stream, dy, idx, n, h, w, c, k, stride, pad, oh, ow, dx);
+    else LAUNCH(maxpool_bwd_kernel<1>, dim3(grid_for(total, 256)), dim3(256), stream, dy, idx, n, h, w, c, k, stride, pad, oh, ow, dx);
+    return check_launch("suhpe_maxpool_bwd");
 }
 
 int suhpe_avgpool_fwd(const float* x, int n, int hw, int c, float* y, suhpe_stream_t stream) {

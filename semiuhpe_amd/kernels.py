@@ -745,6 +745,27 @@ def act_bwd(x, dy, c, act, bias=None):
 
 # ---------------------------------------------------------------------------------------------- pooling / SE / misc
 @_memop
+def maxpool_fwd(x, k, stride, pad):
+    """nn.MaxPool2d(k, stride, pad) on (N, H, W, C) -> (y, window positions uint8 for the backward)"""
+    _chk(x, "x")
+    n, h, w, c = x.shape
+    oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    y = torch.empty((n, oh, ow, c), dtype=torch.float32, device=x.device)
+    idx = torch.empty((n, oh, ow, c), dtype=torch.uint8, device=x.device)
+    call("suhpe_maxpool_fwd", ptr(x), n, h, w, c, int(k), int(stride), int(pad), ptr(y), ptr(idx))
+    return y, idx
+
+
+@_memop
+def maxpool_bwd(dy, idx, x_shape, k, stride, pad):
+    _chk(dy, "dy")
+    n, h, w, c = x_shape
+    dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
+    call("suhpe_maxpool_bwd", ptr(dy), ptr(idx), n, h, w, c, int(k), int(stride), int(pad), ptr(dx))
+    return dx
+
+
+@_memop
 def avgpool_fwd(x):
     """(N,H,W,C) or (N,L,C) -> (N,C)"""
     _chk(x, "x")

@@ -418,6 +418,22 @@ class StochasticDepth(Layer):
         return (dy if rowscale is None else K.add_rowscale(None, dy, rowscale)), dy
 
 
+class MaxPool2d(Layer):
+    def __init__(self, kernel_size, stride, padding):
+        super().__init__()
+        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+
+    def fwd(self, x, tape):
+        y, idx = K.maxpool_fwd(x, self.kernel_size, self.stride, self.padding)
+        if tape is not None:
+            tape.append((idx, x.shape))
+        return y
+
+    def bwd(self, dy, tape):
+        idx, shape = tape.pop()
+        return K.maxpool_bwd(dy, idx, shape, self.kernel_size, self.stride, self.padding)
+
+
 class GlobalAvgPool(Layer):
     def fwd(self, x, tape):
         if tape is not None:

@@ -13,8 +13,11 @@ def get_network(config):
     elif config.network == "tinyvit":
         from .tiny_vit import get_TinyViT
         net = get_TinyViT(config, model_name="21m")
+    elif config.network == "resnet50":                  # src/networks.py:443-500 (released DAD-COCOHead-ResNet50 checkpoint)
+        from .resnet import ResNet50
+        net = ResNet50(num_classes=config.num_classes)
     else:
         raise NotImplementedError(f"network '{config.network}' is not part of the MI355X hot path "
-                                  "(supported: effinetv2, repvgg, tinyvit)")
+                                  "(supported: effinetv2, repvgg, tinyvit, resnet50)")
     net.cuda()
     return net

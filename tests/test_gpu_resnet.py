@@ -1,0 +1,142 @@
+"""ResNet-50 (the backbone of the released DAD-COCOHead-ResNet50 checkpoint) on the HIP path against the CPU
+oracle (oracle.networks.ResNet50, torchvision's architecture restated -- parity unpinned like EfficientNetV2-S), and the
+max-pool kernels against torch.
+
+Tolerances as for the other backbones: eval rotation matrices 1e-4 absolute, outputs 2e-4 relative, gradients 2e-3 of each
+tensor's max; max-pool forward and backward bit-exact (a selection and a fixed-order sum of at most four terms)."""
+import pytest
+import torch
+
+from parity_utils import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,h,w,c", [(2, 112, 112, 64), (3, 9, 7, 6), (1, 8, 8, 4)])
+def test_maxpool_matches_torch_including_ties(n, h, w, c):
+    from semiuhpe_amd import kernels as K
+    g = torch.Generator().manual_seed(h * w + c)
+    x = torch.randn(n, c, h, w, generator=g).clamp_(min=0.0)            # post-ReLU input: plenty of exact ties at zero
+    x.requires_grad_(True)
+    y_ref = torch.nn.functional.max_pool2d(x, 3, 2, 1)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    xh = x.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    y, idx = K.maxpool_fwd(xh, 3, 2, 1)
+    assert torch.equal(y.cpu(), y_ref.detach().permute(0, 2, 3, 1))
+    dx = K.maxpool_bwd(dy.permute(0, 2, 3, 1).contiguous().cuda(), idx, xh.shape, 3, 2, 1)
+    assert torch.equal(dx.cpu(), x.grad.permute(0, 2, 3, 1))
+
+
+@pytest.fixture(scope="module")
+def models():
+    from oracle import networks as ON
+    from semiuhpe_amd.src.resnet import ResNet50
+    torch.manual_seed(0)
+    ref = ON.ResNet50()
+    g = torch.Generator().manual_seed(1)
+    for m in ref.modules():
+        if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d)):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) * 0.5 + 0.75)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) * 0.5 + 0.75)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+    for m in ref.fc:
+        if isinstance(m, torch.nn.Linear):
+            m.weight.data.mul_(20.0)
+    hip = ResNet50()
+    hip.load_state_dict(ref.state_dict())
+    hip.cuda()
+    return ref, hip
+
+
+def test_state_dict_and_eval_forward(models):
+    from oracle import fisher as OF
+    from semiuhpe_amd import kernels as K
+    ref, hip = models
+    assert list(ref.state_dict().keys()) == list(hip.state_dict().keys())
+    assert sum(p.numel() for n, p in ref.named_parameters() if not n.startswith("fc.")) + 2048 * 1000 + 1000 == 25_557_032
+    ref.eval(); hip.eval()
+    x = torch.randn(3, 3, 224, 224, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        y_ref, y = ref(x), hip(x.cuda())
+    assert rel_err(y, y_ref) < 2e-4
+    assert float((K.fisher_svd_project(y).cpu() - OF.batch_torch_A_to_R(y_ref)).abs().max()) < 1e-4
+
+
+def test_train_forward_backward_and_running_stats(models):
+    """Through 53 train-mode BatchNorm + ReLU layers on a batch of 6 the fp32 gradients of ANY implementation deviate from the exact
+    ones at the percent level in the first layers (rounding moves ReLU masks), so -- as for RepVGG in test_gpu_backbones.py --
+    the HIP gradients must be as close to the float64 oracle as the fp32 oracle is (x4), or within 2e-3 of it."""
+    import copy
+    from oracle import networks as ON
+    from semiuhpe_amd import layers as L
+    ref, hip = models
+    ref.train(); hip.train()
+    for m in ref.modules():
+        if isinstance(m, ON.Dropout):
+            m.p = 0.0
+    for m in hip.modules():
+        if isinstance(m, L.Dropout):
+            m.p = 0.0
+    x = torch.randn(8, 3, 160, 160, generator=torch.Generator().manual_seed(3))      # layer4 at 5x5: 200 values per BN channel
+    dy = torch.randn(8, 9, generator=torch.Generator().manual_seed(4))
+    before = {k: v.clone() for k, v in ref.state_dict().items()}
+    exact = copy.deepcopy(ref).double()
+    exact(x.double()).backward(dy.double())
+    truth = {n: p.grad for n, p in exact.named_parameters()}
+    for p in ref.parameters():
+        p.grad = None
+    y_ref = ref(x)
+    y_ref.backward(dy)
+    hip.load_state_dict(before)
+    for p in hip.parameters():
+        p.grad = None
+    y = hip(x.cuda())
+    y.backward(dy.cuda())
+    assert rel_err(y, y_ref) < 2e-4
+    g_ref, g_hip = dict(ref.named_parameters()), dict(hip.named_parameters())
+    for n, t in truth.items():
+        scale = max(1e-6, float(t.abs().max()))
+        noise = float((g_ref[n].grad.double() - t).abs().max()) / scale
+        err = float((g_hip[n].grad.detach().cpu().double() - t).abs().max()) / scale
+        assert err <= max(2e-3, 6.0 * noise), (n, err, noise)
+    for (n, b_ref), (_, b) in zip(ref.named_buffers(), hip.named_buffers()):
+        if b_ref.dtype == torch.float32:
+            assert rel_err(b, b_ref) < 1e-4, n
+    ref.load_state_dict(before)
+
+
+@pytest.mark.parametrize("cin,planes,stride,down", [(64, 64, 1, True), (256, 64, 1, False), (256, 128, 2, True)])
+def test_bottleneck_block_forward_backward(cin, planes, stride, down):
+    """one Bottleneck (with / without the downsample branch) against the oracle block on a well-conditioned batch: outputs, input
+    gradient, parameter gradients, running statistics"""
+    from oracle import networks as ON
+    from semiuhpe_amd.layers import BatchNorm2d, Conv2d, Sequential
+    from semiuhpe_amd.src.resnet import Bottleneck
+    torch.manual_seed(cin + planes)
+    d_ref = torch.nn.Sequential(torch.nn.Conv2d(cin, planes * 4, 1, stride, bias=False), torch.nn.BatchNorm2d(planes * 4)) if down else None
+    ref = ON.Bottleneck(cin, planes, stride, d_ref).train()
+    for m in ref.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.2)
+    d_hip = Sequential(Conv2d(cin, planes * 4, 1, stride), BatchNorm2d(planes * 4)) if down else None
+    hip = Bottleneck(cin, planes, stride, d_hip)
+    hip.load_state_dict(ref.state_dict())
+    hip.cuda().train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(8, cin, 20, 20, generator=g).requires_grad_(True)
+    y_ref = ref(x)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    tape = []
+    y = hip.fwd(x.detach().permute(0, 2, 3, 1).contiguous().cuda(), tape)
+    dx = hip.bwd(dy.permute(0, 2, 3, 1).contiguous().cuda(), tape)
+    assert not tape
+    assert rel_err(y.permute(0, 3, 1, 2), y_ref) < 2e-4
+    assert rel_err(dx.permute(0, 3, 1, 2), x.grad) < 2e-3
+    for (n, p_ref), (_, p) in zip(ref.named_parameters(), hip.named_parameters()):
+        assert rel_err(p.grad, p_ref.grad) < 2e-3, n
+    for (n, b_ref), (_, b) in zip(ref.named_buffers(), hip.named_buffers()):
+        if b_ref.dtype == torch.float32:
+            assert rel_err(b, b_ref) < 1e-5, n

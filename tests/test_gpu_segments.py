@@ -53,7 +53,7 @@ def build(name):
 
 
 @pytest.mark.parametrize("name,size,na,nb", [("effinetv2", 96, 3, 5), ("repvgg", 64, 2, 7), ("tinyvit", 224, 2, 3),
-                                             ("effinetv2", 64, 4, 4)])
+                                             ("effinetv2", 64, 4, 4), ("resnet50", 64, 3, 4)])
 def test_merged_pass_equals_two_passes(name, size, na, nb):
     from semiuhpe_amd import layers as L
     two = build(name).train()

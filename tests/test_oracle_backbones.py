@@ -121,3 +121,15 @@ def test_efficientnet_v2_s_sanity_counts():
     for h in hs:
         h.remove()
     assert abs(macs / 1e9 - 2.849) < 0.02
+
+
+def test_resnet50_oracle_matches_the_published_size_and_the_module_tree_of_the_hip_model():
+    """ResNet-50 (torchvision architecture restated, parity unpinned): 25,557,032 parameters with the 1000-class fc, and the same
+    state-dict keys and shapes on both sides (released checkpoints load into either)."""
+    from oracle import networks as ON
+    from semiuhpe_amd.src.resnet import ResNet50
+    ref, hip = ON.ResNet50(), ResNet50()
+    assert sum(p.numel() for n, p in ref.named_parameters() if not n.startswith("fc.")) + 2048 * 1000 + 1000 == 25_557_032
+    a, b = ref.state_dict(), hip.state_dict()
+    assert list(a.keys()) == list(b.keys()) and all(tuple(a[k].shape) == tuple(b[k].shape) for k in a)
+    assert "layer1.0.downsample.0.weight" in a and "layer4.2.bn3.running_var" in a and "fc.7.bias" in a
