@@ -89,6 +89,8 @@ def test_count_work_reproduces_the_survey_totals():
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
     import count_work as cw
     want = {"effinetv2": (2.849e9, 20_901_465, 110), "repvgg": (9.787e9, 44_850_569, 56), "tinyvit": (4.250e9, 20_704_649, 27)}
+    r50 = cw.NETS["resnet50"]().totals()
+    assert r50["params"] == 24_625_225 and r50["convs"] == 53 and abs(r50["macs"] - 4.09e9) < 0.03e9      # torchvision: 4.09 GFLOPS
     for net, (macs, params, convs) in want.items():
         t = cw.NETS[net]().totals()
         assert abs(t["macs"] - macs) < 1e6 and t["params"] == params and t["convs"] == convs, (net, t)

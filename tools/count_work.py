@@ -158,7 +158,26 @@ def tinyvit_21m():
     return w
 
 
-NETS = {"effinetv2": effinetv2_s, "repvgg": repvgg_b1g2, "tinyvit": tinyvit_21m}
+def resnet50():
+    """torchvision resnet50 (Bottleneck v1.5) + the reference's regression head (src/networks.py:443-500)"""
+    w = Work()
+    h = w.conv("conv1", 224, 3, 64, 7, 2); bn(w, "bn1", 64)
+    h = (h + 2 - 3) // 2 + 1                                   # maxpool 3x3 s2 p1
+    cin = 64
+    for i, (planes, blocks, stride) in enumerate(((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)), start=1):
+        for b in range(blocks):
+            s, n = (stride if b == 0 else 1), f"layer{i}.{b}"
+            w.conv(n + ".conv1", h, cin, planes, 1); bn(w, n + ".bn1", planes)
+            h2 = w.conv(n + ".conv2", h, planes, planes, 3, s); bn(w, n + ".bn2", planes)
+            w.conv(n + ".conv3", h2, planes, planes * 4, 1); bn(w, n + ".bn3", planes * 4)
+            if s != 1 or cin != planes * 4:
+                w.conv(n + ".downsample", h, cin, planes * 4, 1, s); bn(w, n + ".downsample.bn", planes * 4)
+            h, cin = h2, planes * 4
+    head(w, 2048, 512, 128, 9)
+    return w
+
+
+NETS = {"effinetv2": effinetv2_s, "repvgg": repvgg_b1g2, "tinyvit": tinyvit_21m, "resnet50": resnet50}
 # per-GPU step shapes of the BASELINE configs (SURVEY.md §8): (network, B labeled, muB unlabeled)
 CONFIGS = {"C1": ("effinetv2", 32, 0), "C2": ("effinetv2", 32, 128), "C3": ("repvgg", 64, 256), "C5": ("tinyvit", 32, 128)}
 

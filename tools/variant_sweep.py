@@ -6,7 +6,7 @@ import torch, bench
 from semiuhpe_amd.src.agent import SSLAgent
 from semiuhpe_amd.synthetic import synthetic_batches
 for net, dist_, unsup, eman, rot in [("effinetv2","matrixFisher","nll",True,True), ("repvgg","RotationLaplace","ce",False,True), ("tinyvit","RotationLaplace","nll",True,False),
-                                     ("effinetv2","matrixFisher","ce",False,True)]:
+                                     ("effinetv2","matrixFisher","ce",False,True), ("resnet50","matrixFisher","ce",False,True)]:
     cfg = bench.make_config("/tmp/suhpe_var"); cfg.network = net; cfg.distribution = dist_; cfg.type_unsuper = unsup; cfg.eman = eman; cfg.rotate_aug = rot
     cfg.autotune = False
     full = net == "repvgg"; cfg.is_full_range = full; cfg.train_labeled = "DAD3DHeads" if full else "300WLP"
