@@ -94,18 +94,22 @@ def main():
 
             if clock.iteration % config.log_frequency == 0:             # the only host syncs of the training loop
                 agent.check_finite()
-                _log(agent, _stamp(clock) + " train/lr:{:.6f} train/loss:{:.6f} train/err_mean:{:.6f}\n".format(
-                    agent.optimizer.param_groups[0]["lr"], fisher_dict["loss"].item(), fisher_dict["err_deg"].mean().item()))
+                vals = [fisher_dict["loss"].reshape(1), fisher_dict["err_deg"].mean().reshape(1)]
                 if not s1:
                     u = fisher_dict_unsuper
                     ent = dict_get(u, "entropy", -1)
+                    vals += [dict_get(u, "unsuper_loss", -1).reshape(1), ent.mean().reshape(1), ent.std().reshape(1),
+                             dict_get(u, "mask_ratio", -1).reshape(1), dict_get(u, "err_weakAll_gt", -1).mean().reshape(1),
+                             dict_get(u, "err_weakPseudo_gt", -1).mean().reshape(1), dict_get(u, "err_strongSuper_pseudo", -1).mean().reshape(1)]
+                # one small all-reduce: the logged scalars are means over all ranks' shards
+                v = D.allreduce_avg_(torch.cat([t.detach().float() for t in vals])).tolist()
+                _log(agent, _stamp(clock) + " train/lr:{:.6f} train/loss:{:.6f} train/err_mean:{:.6f}\n".format(
+                    agent.optimizer.param_groups[0]["lr"], v[0], v[1]))
+                if not s1:
                     _log(agent, _stamp(clock) + " train_SSL/unsuper_loss:{:.6f} train_SSL/entropy_mean:{:.6f} train_SSL/entropy_std:{:.6f}"
-                         " train_SSL/mask_ratio:{:.6f}\n".format(dict_get(u, "unsuper_loss", -1).item(), ent.mean().item(),
-                                                                 ent.std().item(), dict_get(u, "mask_ratio", -1).item()))
+                         " train_SSL/mask_ratio:{:.6f}\n".format(v[2], v[3], v[4], v[5]))
                     _log(agent, _stamp(clock) + " train_SSL/err_weakAll_gt:{:.6f} train_SSL/err_weakPseudo_gt:{:.6f}"
-                         " train_SSL/err_strongSuper_pseudo:{:.6f}\n".format(dict_get(u, "err_weakAll_gt", -1).mean().item(),
-                                                                             dict_get(u, "err_weakPseudo_gt", -1).mean().item(),
-                                                                             dict_get(u, "err_strongSuper_pseudo", -1).mean().item()))
+                         " train_SSL/err_strongSuper_pseudo:{:.6f}\n".format(v[6], v[7], v[8]))
             clock.tick()
 
             if clock.iteration % config.val_frequency == 0:
