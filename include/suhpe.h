@@ -254,6 +254,16 @@ int suhpe_bn_stats_from_partials_seg(const float* part, int tiles, int first_rec
 int suhpe_bn_act_fwd_seg(const float* x, int64_t rows, int64_t rows_a, int c, const float* mean, const float* rstd,
                          const float* gamma, const float* beta, int act, const float* residual, int post,
                          const float* rowscale, int hw, float* y, suhpe_stream_t stream);
+/* The BatchNorm(+act) backward in two calls, for data-parallel callers that normalise over the GLOBAL batch (SyncBN, SURVEY.md
+ * 8e (2)): _sums leaves (sum g, sum g*xhat) per channel in sums[2c] (and accumulates dgamma / dbeta from the local rows); the
+ * caller all-reduces sums (SUM); _apply forms dx with the means over total_rows = rows of all ranks.  mean / rstd are the
+ * global-batch statistics. */
+int suhpe_bn_act_bwd_sums(const float* x, const float* dy, const float* y_out, int64_t rows, int c, const float* mean,
+                          const float* rstd, const float* gamma, const float* beta, int act, const float* rowscale, int hw,
+                          float* sums, float* dgamma, float* dbeta, int accumulate, void* workspace, suhpe_stream_t stream);
+int suhpe_bn_act_bwd_apply(const float* x, const float* dy, const float* y_out, int64_t rows, int64_t total_rows, int c,
+                           const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                           const float* sums, const float* rowscale, int hw, float* dx, suhpe_stream_t stream);
 /* y = act(BN(x)) and pool[sample][c] = mean over the sample's hw rows of y in the same pass (the squeeze of the
  * SqueezeExcitation block behind a depthwise conv's BatchNorm); rows_a = 0: one segment (mean / rstd [c]), else two ([2][c]). */
 int suhpe_bn_act_pool_fwd(const float* x, int64_t rows, int64_t rows_a, int c, int hw, const float* mean, const float* rstd,

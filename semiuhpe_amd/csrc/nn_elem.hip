@@ -1524,6 +1524,43 @@ int suhpe_bn_act_fwd_seg(const float* x, int64_t rows, int64_t rows_a, int c, co
     return check_launch("suhpe_bn_act_fwd_seg");
 }
 
+// ---- the two halves of the BatchNorm backward as separate calls, so that a data-parallel caller can all-reduce the per-channel
+// sums in between (SyncBN: statistics and gradient means over the global batch)
+int suhpe_bn_act_bwd_sums(const float* x, const float* dy, const float* y_out, int64_t rows, int c, const float* mean, const float* rstd,
+                          const float* gamma, const float* beta, int act, const float* rowscale, int hw, float* sums, float* dgamma,
+                          float* dbeta, int accumulate, void* workspace, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(x && dy && sums && mean && rstd && workspace && rows > 0 && rows < (1LL << 31) && c > 0, "suhpe_bn_act_bwd_sums: bad arguments");
+    SUHPE_REQUIRE(!y_out || act == SUHPE_ACT_RELU, "suhpe_bn_act_bwd_sums: y_out (pre-activation residual) needs act=RELU");
+    SUHPE_REQUIRE(!rowscale || (hw > 0 && rows % hw == 0 && !y_out), "suhpe_bn_act_bwd_sums: rowscale needs rows %% hw == 0 and no y_out");
+    float* part = static_cast<float*>(workspace);
+    const int vec = (vec4_ok(c, x, dy) && vec4_ok(c, y_out)) ? 4 : 1;
+    const ColGeom g = col_geom(rows, c, vec);
+    if (vec == 4)
+        LAUNCH(bn_bwd_partial<4>, dim3(g.gx, g.ny), dim3(256), stream, x, dy, y_out, rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta, act, rowscale,
+               hw, part);
+    else
+        LAUNCH(bn_bwd_partial<1>, dim3(g.gx, g.ny), dim3(256), stream, x, dy, y_out, rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta, act, rowscale,
+               hw, part);
+    LAUNCH(bn_bwd_finalize, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
+    return check_launch("suhpe_bn_act_bwd_sums");
+}
+
+int suhpe_bn_act_bwd_apply(const float* x, const float* dy, const float* y_out, int64_t rows, int64_t total_rows, int c, const float* mean,
+                           const float* rstd, const float* gamma, const float* beta, int act, const float* sums, const float* rowscale, int hw,
+                           float* dx, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(x && dy && dx && sums && mean && rstd && rows > 0 && rows < (1LL << 31) && total_rows >= rows && c > 0, "suhpe_bn_act_bwd_apply: bad arguments");
+    const int vec = (vec4_ok(c, x, dy, dx) && vec4_ok(c, y_out)) ? 4 : 1;
+    const EwGeom e = ew_geom(rows, c, vec);
+    const float inv = 1.0f / (float)total_rows;
+    if (vec == 4)
+        LAUNCH(bn_bwd_apply<4>, dim3(e.gx, e.ny), dim3(256), stream, x, dy, y_out, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd, gamma, beta, act, sums,
+               inv, 1, rowscale, hw, dx);
+    else
+        LAUNCH(bn_bwd_apply<1>, dim3(e.gx, e.ny), dim3(256), stream, x, dy, y_out, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd, gamma, beta, act, sums,
+               inv, 1, rowscale, hw, dx);
+    return check_launch("suhpe_bn_act_bwd_apply");
+}
+
 int suhpe_bn_act_pool_fwd(const float* x, int64_t rows, int64_t rows_a, int c, int hw, const float* mean, const float* rstd, const float* gamma,
                           const float* beta, int act, float* y, float* pool, suhpe_stream_t stream) {
     SUHPE_REQUIRE(x && y && pool && mean && rstd && rows > 0 && rows < (1LL << 31) && c > 0 && hw > 0 && rows % hw == 0 && rows_a >= 0 && rows_a < rows &&

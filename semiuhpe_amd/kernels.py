@@ -622,6 +622,24 @@ def bn_act_fwd_seg(x, rows_a, c, mean, rstd, gamma, beta, act, residual=None, po
     return y
 
 
+def bn_act_bwd_sums(x, dy, c, mean, rstd, gamma, beta, act, dgamma=None, dbeta=None, accumulate=False, y_out=None, rowscale=None, hw=1):
+    """first half of the BatchNorm backward: per-channel (sum g, sum g*xhat) of the local rows -> sums [2c] (interleaved)"""
+    _chk(x, "x"); _chk(dy, "dy")
+    sums = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+    ws = workspace("bn", _lib.load().suhpe_bn_workspace_bytes(c), x.device)
+    call("suhpe_bn_act_bwd_sums", ptr(x), ptr(dy), ptr(y_out), x.numel() // c, c, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ACT[act],
+         ptr(rowscale), int(hw), ptr(sums), ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws))
+    return sums
+
+
+def bn_act_bwd_apply(x, dy, c, mean, rstd, gamma, beta, act, sums, total_rows, y_out=None, rowscale=None, hw=1):
+    """second half: dx from the (possibly all-reduced) sums and the row count they cover"""
+    dx = torch.empty_like(x)
+    call("suhpe_bn_act_bwd_apply", ptr(x), ptr(dy), ptr(y_out), x.numel() // c, int(total_rows), c, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
+         ACT[act], ptr(sums), ptr(rowscale), int(hw), ptr(dx))
+    return dx
+
+
 @_memop
 def bn_act_pool_fwd(x, rows_a, c, mean, rstd, gamma, beta, act, hw):
     """-> (act(BN(x)), per-sample channel means of it); rows_a = 0: one segment"""

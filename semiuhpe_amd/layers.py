@@ -153,6 +153,12 @@ class Linear(Layer):
 # batch -- every GEMM gets 160 instead of 32 / 128 images -- provided BatchNorm still normalises each sub-batch with its own
 # statistics and updates the running statistics twice, in the reference's order.  `with batch_segments(n):` declares that
 # the first n samples of every activation are one segment and the rest the other; all other layers are per-sample.
+# SyncBN (optional): with several ranks, train-mode BatchNorm normalises over the GLOBAL batch -- one small
+# all-reduce of (mean, E[x^2]) per layer in the forward and one of (sum g, sum g*xhat) in the backward -- which reproduces
+# single-process global-batch BatchNorm exactly; the default is per-rank statistics (standard data-parallel semantics).
+# Set by SSLAgent from config.sync_bn; it implies two separate student passes (no batch segments).
+SYNC_BN = False
+
 _SEGMENT = None
 SEGMENT_LAUNCHES = os.environ.get("SUHPE_SEGMENT_LAUNCHES", "fused")     # "fused": one launch per kernel for both segments; "split"
 
@@ -190,6 +196,9 @@ class _BatchNorm(Layer):
         """residual, post=False: act(BN(x) + residual).  post=True: residual + rowscale[n] * act(BN(x)), the skip
         connection of a residual block with StochasticDepth('row') folded in (rowscale None = 1)."""
         c = self.num_features
+        if self.training and SYNC_BN:
+            y = self._fwd_sync(x, tape, residual, partials, post, rowscale)
+            return (y, K.avgpool_fwd(y)) if pool else y
         seg = _segment_of(x) if self.training else None
         if pool:                                            # -> (y, per-sample channel means of y), see _fwd_pool
             return self._fwd_pool(x, tape, partials, seg)
@@ -207,6 +216,32 @@ class _BatchNorm(Layer):
         if tape is not None:
             keep_y = y if (residual is not None and not post and self.act == "relu") else None
             tape.append((x, mean, rstd, self.training, keep_y, rowscale if post else None, hw))
+        return y
+
+    def _fwd_sync(self, x, tape, residual, partials, post, rowscale):
+        """training forward with statistics of the global batch (all ranks hold equally many rows)"""
+        from .src import distributed as D
+        c = self.num_features
+        rows = x.numel() // c
+        hw = x.numel() // (c * x.shape[0])
+        if partials is not None:
+            mean, rstd = K.bn_stats_from_partials(partials[0], partials[1], rows, c, self.eps, self.momentum)
+        else:
+            mean, rstd = K.bn_stats(x, c, self.eps, self.momentum)
+        world = D.world()[1]
+        buf = torch.stack([mean, rstd.pow(-2) - self.eps + mean * mean])          # (E[x], E[x^2]) of this rank's rows
+        D.allreduce_avg_(buf)
+        mean = buf[0].contiguous()
+        var = (buf[1] - mean * mean).clamp_(min=0.0)
+        rstd = (var + self.eps).rsqrt_()
+        n = rows * world
+        self.running_mean.mul_(1 - self.momentum).add_(mean, alpha=self.momentum)
+        self.running_var.mul_(1 - self.momentum).add_(var, alpha=self.momentum * n / max(1, n - 1))
+        self.num_batches_tracked += 1
+        y = K.bn_act_fwd(x, c, mean, rstd, self.weight, self.bias, self.act, residual, post, rowscale, hw)
+        if tape is not None:
+            keep_y = y if (residual is not None and not post and self.act == "relu") else None
+            tape.append((x, mean, rstd, ("sync", n), keep_y, rowscale if post else None, hw))
         return y
 
     def train_stats(self, x, partials=None):
@@ -303,6 +338,13 @@ class _BatchNorm(Layer):
 
     def bwd(self, dy, tape):
         x, mean, rstd, train_stats, y_out, rowscale, hw = tape.pop()
+        if isinstance(train_stats, tuple) and train_stats[0] == "sync":      # global-batch statistics: all-reduce the gradient sums
+            from .src import distributed as D
+            c = self.num_features
+            sums = K.bn_act_bwd_sums(x, dy, c, mean, rstd, self.weight, self.bias, self.act, grad_of(self.weight), grad_of(self.bias), True, y_out,
+                                     rowscale, hw)
+            D.allreduce_sum_(sums)
+            return K.bn_act_bwd_apply(x, dy, c, mean, rstd, self.weight, self.bias, self.act, sums, train_stats[1], y_out, rowscale, hw)
         if isinstance(mean, tuple):                          # two segments, one launch: (x, (mean[2,c], rstd[2,c]), seg, ...)
             (m2, r2), seg = mean, rstd
             return K.bn_act_bwd_seg(x, dy, seg * hw, self.num_features, m2, r2, self.weight, self.bias, self.act, grad_of(self.weight),

@@ -20,6 +20,7 @@ import torch
 from .. import kernels as K
 from . import distributed as D
 from . import utils
+from .. import layers as L
 from ..layers import batch_segments
 from .augments import strong_view_nhwc
 from .fisher.fisher_utils import batch_torch_A_to_R, fisher_CE, fisher_entropy
@@ -83,6 +84,12 @@ class SSLAgent:
         self._teacher_stream = None
         self.net = get_network(config)
         self.ema_net = get_network(config)
+        # optional SyncBN (global-batch BatchNorm statistics across ranks): exact global-batch semantics at the price of two small
+        # all-reduces per BatchNorm layer and pass; it uses the reference's two student passes
+        L.SYNC_BN = (bool(getattr(config, "sync_bn", False)) or os.environ.get("SUHPE_SYNC_BN") == "1") and D.world()[1] > 1
+        if L.SYNC_BN:
+            self.merge_student_passes = False
+            self.overlap_teacher = False              # the per-layer collectives of both networks stay in one stream's program order
         for param in self.ema_net.parameters():      # reference :34-35: the teacher is never trained by gradients
             param.detach_()
             param.requires_grad_(False)

@@ -1,6 +1,6 @@
 """Drop-in for the reference's src/config.py (configargparse) on argparse + PyYAML: same `--config` YAML keys, same
 CLI flags (config.py:88-163 of the reference), same derived `exp_detail` string and exps/<exp_name>/<exp_detail>/<date>/
-layout.  Additive flags (not in the reference): --synthetic (no datasets offline), --exp_root and --no_autotune.
+layout.  Additive flags (not in the reference): --synthetic (no datasets offline), --exp_root, --no_autotune and --sync_bn.
 """
 import argparse
 import os
@@ -103,6 +103,7 @@ class Config(object):
         ap.add_argument("--synthetic", action="store_true", help="synthetic 224x224 heads instead of dataset loaders")
         ap.add_argument("--exp_root", type=str, default=None, help="where exps/ lives (default: repo root)")
         ap.add_argument("--no_autotune", action="store_true", help="keep the built-in GEMM tile heuristics (no first-step timing)")
+        ap.add_argument("--sync_bn", action="store_true", help="data parallel: BatchNorm statistics over the global batch (default: per rank)")
         if not self.is_train:
             ap.add_argument("test_ckpt", type=str)
             ap.add_argument("--hist_low", type=int, default=10)
@@ -126,7 +127,7 @@ class Config(object):
         for k, v in ns.items():                   # the command line overrides the YAML
             if k == "config":
                 continue
-            is_flag = any(n == k and t == "flag" for n, t, _ in _OPTIONS) or k in ("synthetic", "no_autotune")
+            is_flag = any(n == k and t == "flag" for n, t, _ in _OPTIONS) or k in ("synthetic", "no_autotune", "sync_bn")
             if (is_flag and v) or (not is_flag and v is not None):
                 merged[k] = v
             elif k not in merged:

@@ -48,7 +48,7 @@ class RepVGGBlock(Layer):
             w_eq, ones, b_eq = K.repvgg_fuse(c3.weight, c1.weight, bn(self.rbr_dense.bn), bn(self.rbr_1x1.bn),
                                              bn(self.rbr_identity) if self.rbr_identity is not None else None, self.rbr_dense.bn.eps)
             return K.conv2d_fwd_affine(x, w_eq, ones, b_eq, "relu", None, False, c3.stride, c3.padding, c3.groups)
-        if train and FUSE_BLOCK_TAIL and L.SEGMENT_LAUNCHES != "split":
+        if train and FUSE_BLOCK_TAIL and L.SEGMENT_LAUNCHES != "split" and not L.SYNC_BN:
             return self._fwd_fused_tail(x, tape)
         t3, p3 = self.rbr_dense.conv.fwd_stats(x, tape) if train else (self.rbr_dense.conv.fwd(x, tape), None)
         t1, p1 = self.rbr_1x1.conv.fwd_stats(x, tape) if train else (self.rbr_1x1.conv.fwd(x, tape), None)
