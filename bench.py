@@ -19,6 +19,8 @@ import sys
 import time
 from types import SimpleNamespace
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC for RCCL between the ranks' processes (set before HIP starts)
+
 import torch
 import torch.distributed as dist
 

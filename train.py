@@ -8,6 +8,8 @@ RCCL all-reduce of the flat gradient; --batch_size is the GLOBAL labeled batch a
 import os
 from datetime import datetime
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC for RCCL between the ranks' processes (set before HIP starts)
+
 import numpy as np
 import torch
 import torch.distributed as dist
