@@ -268,3 +268,26 @@ def test_repvgg_block_tail_fused_batchnorms(hw, c, n, seg, nb):
     for j in range(nb):
         assert rel_err(dxs[j], refs[j]) < 2e-5, j
         assert rel_err(dg1[j], dg2[j]) < 2e-5 and rel_err(db1[j], db2[j]) < 2e-5, j
+
+
+def test_agent_step_with_no_pseudo_label_selected(tmp_path):
+    """Edge of the pseudo-label filter (reference src/agent.py:163-168): when no unlabeled sample passes the entropy threshold the
+    unsupervised loss is exactly 0 (not NaN), mask_ratio is 0, loss_all equals the supervised loss and every gradient stays finite."""
+    from semiuhpe_amd.src.agent import SSLAgent
+    from semiuhpe_amd.synthetic import synthetic_batches
+    cfg = SimpleNamespace(
+        lr=1e-4, log_dir=str(tmp_path), model_dir=str(tmp_path), distribution="matrixFisher", is_full_range=False, rotate_aug=True,
+        train_labeled="300WLP", train_unlabeled="300WLP", cutout_aug=True, cutmix_aug=True, conf_thres=-1e9, type_unsuper="ce", SSL_lambda=1.0,
+        is_ema=True, ema_decay=0.999, eman=False, stage1_iteration=0, network="effinetv2", num_classes=9, exp_name="t", date="t", left_ratio=0.95,
+        save_feat=False, dynamic_thres=False, autotune=False)
+    torch.manual_seed(5)
+    agent = SSLAgent(cfg)
+    data, ulb = synthetic_batches(4, 8, size=96, seed=1, rotate_aug=True)
+    to = lambda d: {k: v.cuda().contiguous() for k, v in d.items()}
+    fd, fu, out = agent.train_func(to(data), to(ulb))
+    assert float(fu["mask_ratio"]) == 0.0
+    assert float(fu["unsuper_loss"].detach()) == 0.0
+    assert float(out["loss_all"].detach()) == float(fd["loss"].detach())
+    agent.check_finite()
+    for n, p in agent.net.named_parameters():
+        assert bool(torch.isfinite(p.grad).all()) and bool(torch.isfinite(p).all()), n
