@@ -35,3 +35,38 @@ def test_input_tensor_and_experiment_name():
     name = lambda d: experiment_name(SimpleNamespace(network="repvgg", exp_detail=d))
     assert name("SSL1.0_r0.05_ce_tDyna0.75_b32") == "repvgg_SemiUHPE" and name("SSL1.0_r0.05_ce_t-4.3") == "repvgg_Baseline"
     assert name("SSL1.0_r1.0_ce_t-5.3") == "repvgg_Supervised"
+
+
+def test_submission_records_from_a_stub_agent(tmp_path):
+    """predict_rotations / write_submission: file layout in, JSON layout out (reference eval_DAD3DHeads.py:77-108), with a stub
+    network so that the host logic is covered without a GPU."""
+    import json
+    import torch
+    from make_golden_dad3d_crop import synthetic_image
+    from semiuhpe_amd.src import dad3d_eval as E
+    (tmp_path / "test" / "images").mkdir(parents=True)
+    items = []
+    for k in range(5):
+        Image.fromarray(synthetic_image(k, 200, 160)).save(tmp_path / "test" / "images" / f"id{k}.png")
+        items.append({"item_id": f"id{k}", "bbox": [30 + k, 20, 90, 100], "attributes": {}})
+    eye = torch.eye(3).reshape(1, 9)
+
+    class Net(torch.nn.Module):
+        def forward(self, x):
+            assert tuple(x.shape[1:]) == (3, 224, 224)
+            return eye.repeat(x.shape[0], 1) * (1.0 + x.mean((1, 2, 3)).reshape(-1, 1).abs())
+
+    agent = SimpleNamespace(net=Net(), device=torch.device("cpu"))
+    import semiuhpe_amd.src.fisher.fisher_utils as FU
+    saved = FU.batch_torch_A_to_R
+    FU.batch_torch_A_to_R = lambda A: A / A[:, :1]                      # scaled identities -> identities (no HIP kernel on the CPU)
+    try:
+        res = E.predict_rotations(agent, items, str(tmp_path), batch=2)
+    finally:
+        FU.batch_torch_A_to_R = saved
+    assert list(res) == [f"id{k}" for k in range(5)]
+    for rec in res.values():
+        assert set(rec) == {"68_landmarks_2d", "N_landmarks_3d", "7_landmarks_3d", "rotation_matrix"}
+        assert np.allclose(rec["rotation_matrix"], np.eye(3))
+    path = E.write_submission(res, SimpleNamespace(network="effinetv2", exp_detail="SSL1.0_r0.05_ce_effinetv2_tDyna0.75_b64"), str(tmp_path / "exps"))
+    assert path.endswith("testset_results_effinetv2_SemiUHPE.json") and json.load(open(path)).keys() == res.keys()
