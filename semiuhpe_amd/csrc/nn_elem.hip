@@ -1236,7 +1236,12 @@ __global__ __launch_bounds__(256) void weighted_sum_kernel(const float* __restri
                                                            float scale, float* __restrict__ out) {
     __shared__ double part[4];
     double s = 0.0;
-    for (int64_t i = threadIdx.x; i < count; i += blockDim.x) s += (double)x[i] * (w ? (double)w[i] : 1.0);
+    // a zero weight SELECTS the sample out (x may be nan / inf there: the reference compacts with pred[mask] and never
+    // evaluates those samples, src/agent.py:152-157)
+    for (int64_t i = threadIdx.x; i < count; i += blockDim.x) {
+        if (!w) s += (double)x[i];
+        else if (w[i] != 0.f) s += (double)x[i] * (double)w[i];
+    }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -1248,7 +1253,9 @@ __global__ __launch_bounds__(256) void masked_mean_kernel(const float* __restric
                                                           float* __restrict__ out) {
     __shared__ double part[8];
     double s = 0.0, c = 0.0;
-    for (int64_t i = threadIdx.x; i < count; i += blockDim.x) { s += (double)x[i] * (double)mask[i]; c += (double)mask[i]; }
+    for (int64_t i = threadIdx.x; i < count; i += blockDim.x) {
+        if (mask[i] != 0.f) { s += (double)x[i] * (double)mask[i]; c += (double)mask[i]; }      // select, not multiply (nan * 0)
+    }
     s = wave_sum(s);
     c = wave_sum(c);
     if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = s; part[4 + (threadIdx.x >> 6)] = c; }
@@ -1260,7 +1267,8 @@ __global__ void scale_rows_kernel(const float* __restrict__ x, const float* __re
                                   float* __restrict__ y) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * c) return;
-    y[i] = x[i] * (g ? g[i / c] : 1.f) * scale;
+    const float gv = g ? g[i / c] : 1.f;
+    y[i] = gv != 0.f ? x[i] * gv * scale : 0.f;      // a zero row gradient selects the row out (x may be nan / inf in unselected samples)
 }
 
 // out[i] = src[0]*scale (broadcast of a device scalar, e.g. d(mean)/dx) ; out = alpha*a + beta*b on short vectors

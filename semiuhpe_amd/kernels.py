@@ -178,6 +178,9 @@ def _autotune(d, pass_id, run):
     if known in names and lib.suhpe_conv2d_set_tile(ctypes.byref(d), pass_id, names.index(known)) == 0:
         return
     dev = torch.cuda.current_device()
+    # this shape really has to be measured: drain the device first, so the trials do not share the GPU with the teacher pass /
+    # filter-gradient GEMMs still running on the side streams (the host is inside this function: nothing new is enqueued)
+    torch.cuda.synchronize()
     if dev not in _flush:
         _flush[dev] = torch.empty(1 << 26, dtype=torch.float32, device="cuda")
     best = (float("inf"), -1)

@@ -339,11 +339,12 @@ class SSLAgent:
         def host(sd):
             return {k: v.detach().cpu().contiguous() for k, v in sd.items()}
 
-        opt = self.optimizer.state_dict()
-        for st in opt["state"].values():
-            for k, v in st.items():
-                if torch.is_tensor(v):
-                    st[k] = v.detach().cpu().contiguous().clone()
+        # Optimizer.state_dict() hands out the LIVE per-parameter dicts (sd["state"][i] is optimizer.state[p]): build a fresh
+        # dict of host copies and leave the live one -- views of the flat Adam buffers, shared step scalar -- untouched
+        sd = self.optimizer.state_dict()
+        opt = {"state": {i: {k: (v.detach().cpu().contiguous().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                         for i, st in sd["state"].items()},
+               "param_groups": [dict(g) for g in sd["param_groups"]]}
         torch.save({"clock": self.clock.make_checkpoint(), "model_state_dict": host(self.net.state_dict()),
                     "model_state_dict_ema": host(self.ema_net.state_dict()), "optimizer_state_dict": opt}, save_path)
 

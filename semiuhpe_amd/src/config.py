@@ -49,6 +49,22 @@ _OPTIONS = [
 _NETWORKS = ["mobilenet", "resnet18", "resnet50", "repvgg", "effinetv2", "effinet", "tinyvit"]
 
 
+def _shared_run_date():
+    """The run's time stamp -- the last component of log_dir / model_dir -- must be ONE value for all ranks of a job (only rank
+    0 writes best.pth; the others load it at the stage switch): SUHPE_RUN_DATE from the launcher if set, else rank 0's clock
+    broadcast over the process group (train.py initialises it before building the config)."""
+    date = os.environ.get("SUHPE_RUN_DATE") or datetime.now().strftime("%b%d_%H%M%S")
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            box = [date]
+            dist.broadcast_object_list(box, src=0)
+            date = box[0]
+    except ImportError:
+        pass
+    return date
+
+
 class Config(object):
     def __init__(self, phase, argv=None):
         self.is_train = phase == "train"
@@ -66,7 +82,7 @@ class Config(object):
                 self.exp_detail, self.date, self.ckpt = self.cont_ckpt.split("/")
             else:
                 self.exp_detail = self.get_exp_detail()
-                self.date = datetime.now().strftime("%b%d_%H%M%S")
+                self.date = _shared_run_date()
         else:
             self.exp_detail, self.date, self.ckpt = self.test_ckpt.split("/")
         print(f"exp name: {self.exp_name}, {self.exp_detail}")

@@ -53,6 +53,26 @@ def _reference_loaders(config):
     return train, ulb, test
 
 
+def shard_loader(loader, rank, world, seed=0):
+    """Data-parallel view of one of the reference's training DataLoaders: the same dataset / workers / collate function, the
+    per-rank share of the batch (--batch_size is the GLOBAL batch: lr is not rescaled, so world x B images per step would
+    silently change the recipe) and a DistributedSampler in place of the unseeded global shuffle, so the ranks draw disjoint
+    samples.  utils.cycle and train.py's epoch loop advance `sampler.set_epoch`."""
+    if world <= 1 or loader is None:
+        return loader
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+    bs = int(loader.batch_size)
+    if bs % world:
+        raise ValueError(f"data parallel: the global batch {bs} of a training loader is not divisible by {world} ranks")
+    sampler = DistributedSampler(loader.dataset, num_replicas=world, rank=rank, shuffle=True, seed=seed, drop_last=True)
+    kw = dict(batch_size=bs // world, sampler=sampler, num_workers=loader.num_workers, collate_fn=loader.collate_fn,
+              pin_memory=loader.pin_memory, drop_last=loader.drop_last, worker_init_fn=loader.worker_init_fn)
+    if loader.num_workers > 0:
+        kw.update(persistent_workers=loader.persistent_workers, prefetch_factor=loader.prefetch_factor)
+    return DataLoader(loader.dataset, **kw)
+
+
 def build_loaders(config, rank=0, world=1):
     """-> (train_loader, ulb_train_loader or None, test_loader); mirrors the selection logic of train.py:47-76."""
     name = str(config.exp_name)
@@ -62,7 +82,10 @@ def build_loaders(config, rank=0, world=1):
         assert config.is_full_range is True, "We only support full range for DAD3DHeads!!!"
     if not getattr(config, "synthetic", False):
         try:
-            return _reference_loaders(config)
+            train, ulb, test = _reference_loaders(config)
+            # training loaders: per-rank batch + disjoint shards; the test loader stays whole (train.validate deals its
+            # batches round-robin to the ranks, distributed.shard)
+            return shard_loader(train, rank, world, seed=1), shard_loader(ulb, rank, world, seed=2), test
         except ImportError as e:
             raise ImportError("dataset loaders (src.datasets.*) are not importable; put the reference's src/datasets on "
                               "PYTHONPATH or pass --synthetic") from e

@@ -43,10 +43,15 @@ def ensure_dirs(paths):
 
 
 def cycle(iterable):
-    """reference :175-178"""
+    """reference :175-178 (a DistributedSampler behind the loader gets a new epoch per pass, so every pass reshuffles)"""
+    epoch = 0
     while True:
+        sampler = getattr(iterable, "sampler", None)
+        if hasattr(sampler, "set_epoch"):
+            sampler.set_epoch(epoch)
         for x in iterable:
             yield x
+        epoch += 1
 
 
 def requires_grad(xs, req=False):

@@ -78,6 +78,20 @@ def test_checkpoint_roundtrip_is_exact(tmp_path):
     a.net.eval(); b.net.eval()
     with torch.no_grad():
         assert torch.equal(a.net(data["img"]), b.net(data["img"]))
+    # a save must not freeze the live optimiser state (Optimizer.state_dict() hands out the live dicts): train on, save again,
+    # reload -> the SECOND checkpoint carries the current Adam moments and step, and the live state entries are still device views
+    for _ in range(2):
+        a.train_func(data, ulb)
+        a.clock.tick()
+    a.save_ckpt("best")
+    st0 = a.optimizer.state[fa.params[0]]
+    assert st0["exp_avg"].is_cuda and st0["exp_avg"].data_ptr() == fa.exp_avg.data_ptr() and st0["step"] is fa.step_t
+    c = SSLAgent(SimpleNamespace(**cfg))
+    c.load_ckpt("best")
+    fc = c.optimizer.flat_buffers[0]
+    assert c.clock.iteration == 4 and fc.step == fa.step == 4
+    assert torch.equal(fa.exp_avg, fc.exp_avg) and torch.equal(fa.exp_avg_sq, fc.exp_avg_sq)
+    assert not torch.equal(fb.exp_avg, fc.exp_avg)            # (moments did move between the two saves)
 
 
 def test_bench_two_rank_flow_on_one_gpu(tmp_path):

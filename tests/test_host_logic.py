@@ -99,3 +99,30 @@ def test_count_work_reproduces_the_survey_totals():
     assert abs(c2["flop"] - 3.46e12) < 0.01e12 and abs(c2["t_flop"] - 22.0e-3) < 0.1e-3
     assert abs(cw.step_work("repvgg", 64, 256)["flop"] - 23.8e12) < 0.05e12
     assert abs(cw.step_work("tinyvit", 32, 128)["flop"] - 5.17e12) < 0.01e12
+
+
+def test_shard_loader_splits_batch_and_samples():
+    """data parallel over the reference's loaders: per-rank batch = global / world, disjoint shards, new order per epoch"""
+    import torch
+    from torch.utils.data import DataLoader, TensorDataset
+
+    from semiuhpe_amd.src.datasets import shard_loader
+    from semiuhpe_amd.src.utils import cycle
+    ds = TensorDataset(torch.arange(64))
+    base = DataLoader(ds, batch_size=8, shuffle=True, drop_last=True)
+    assert shard_loader(base, 0, 1) is base
+    shards = [shard_loader(base, r, 2, seed=3) for r in range(2)]
+    seen = []
+    for ld in shards:
+        assert ld.batch_size == 4 and ld.drop_last
+        batches = [b[0] for b in ld]
+        assert len(batches) == 8 and all(len(b) == 4 for b in batches)
+        seen.append(torch.cat(batches))
+    assert sorted(torch.cat(seen).tolist()) == list(range(64))          # disjoint and complete
+    it = cycle(shards[0])
+    first = torch.cat([next(it)[0] for _ in range(8)])
+    second = torch.cat([next(it)[0] for _ in range(8)])
+    assert not torch.equal(first, second)                                # set_epoch advanced by cycle
+    import pytest
+    with pytest.raises(ValueError):
+        shard_loader(DataLoader(ds, batch_size=9), 0, 2)

@@ -75,6 +75,8 @@ def main():
     best_mean_error = 360
     done = False
     while not done:
+        if hasattr(getattr(train_loader, "sampler", None), "set_epoch"):
+            train_loader.sampler.set_epoch(clock.epoch)
         for data in train_loader:
             if clock.iteration == config.stage1_iteration and ssl:      # stage switch: best stage-1 weights, lr x0.1
                 stage1_clock = clock.make_checkpoint()
