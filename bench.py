@@ -1,7 +1,11 @@
 #!/usr/bin/env python
 """bench.py — throughput of SemiUHPE's teacher-student training step on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]            (N>1: launched by torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1: one process per GPU over RCCL.  Under a launcher (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)
+this process is one rank; started bare (`python bench.py --gpus N`, no WORLD_SIZE) it spawns the N ranks itself as child
+processes -- before anything in the parent touches the GPU -- and exits with their status.
 
 Workload (BASELINE.json configs[1], "C2"): SemiUHPE 300WLP_AFLW2000, EfficientNetV2-S, per GPU B=32 labeled +
 muB=128 unlabeled 224x224 synthetic heads, dynamic threshold (left_ratio 0.95) + CutOut + CutMix, fp32.
@@ -81,7 +85,9 @@ def gpu_leg(args, rank, world, device):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     agent.check_finite()
-    info = dict(mask_ratio=float(fu["mask_ratio"]), loss_all=float(out["loss_all"]), conf_thres=float(cfg.conf_thres))
+    gib = 1.0 / (1 << 30)
+    info = dict(mask_ratio=float(fu["mask_ratio"]), loss_all=float(out["loss_all"]), conf_thres=float(cfg.conf_thres),
+                hbm_gib={"peak_allocated": round(torch.cuda.max_memory_allocated() * gib, 2), "reserved": round(torch.cuda.memory_reserved() * gib, 2)})
 
     # ---- roofline of the dominant kernel: same step, every dense-conv launch bracketed by HIP events on the
     # launch stream (torch's current stream is the stream the C ABI launches on)
@@ -156,8 +162,12 @@ def step_roofline(ms_per_step):
 
 
 def cpu_leg():
-    """The CPU oracle (our torch-CPU restatement of the reference step, kind="port") on this host's cores:
-    one SSL step of the same shape (B=32 + muB=128, EfficientNetV2-S, 224x224), after a small warm-up step."""
+    """The CPU oracle (our torch-CPU restatement of the reference step, kind="port") on this host's cores, SURVEY.md 8d:
+    C1 (the reference's own CPU-runnable config: supervised train_func_s1 steps, B=32) 2 warm-up + 5 timed, and the C2 step
+    shape (B=32 + muB=128 SSL step, the workload of `value`) 1 small warm-up + 2 timed -- a bounded sample (about a minute of
+    CPU work on 32 threads).  `value` is the C2 rate (same workload as the GPU line).  The same leg holds the Euler-MAE parity
+    check of the HIP path against this CPU path on a 256-image sample of the 8d evaluation set (tools/mae_parity.py; the full
+    1 964 images run in tests/test_gpu_mae_parity.py)."""
     from oracle import networks as ON
     from oracle.agent import OracleAgent, synthetic_batches
     ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -170,9 +180,19 @@ def cpu_leg():
     d0, u0 = synthetic_batches(2, 8, size=224, seed=0)
     agent.train_func(d0, u0)                                   # warm-up (allocator, thread pool)
     data, ulb = synthetic_batches(B_LABELED, B_LABELED * MU, size=224, seed=0)
-    t0 = time.perf_counter()
-    agent.train_func(data, ulb)
-    dt = time.perf_counter() - t0
+    c1_times = []
+    for i in range(7):                                         # C1: 2 warm-up + 5 timed supervised steps
+        t0 = time.perf_counter()
+        agent.train_func_s1(data)
+        if i >= 2:
+            c1_times.append(time.perf_counter() - t0)
+    c2_times = []
+    for _ in range(2):                                         # C2 step shape
+        t0 = time.perf_counter()
+        agent.train_func(data, ulb)
+        c2_times.append(time.perf_counter() - t0)
+    dt = sum(c2_times) / len(c2_times)
+    dt1 = sum(c1_times) / len(c1_times)
     model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -181,9 +201,55 @@ def cpu_leg():
                 break
     except OSError:
         pass
+    del agent
+    mae = None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import mae_parity
+        mae = mae_parity.run(n_images=256, warm_steps=3, train_batch=(8, 16), size=224, network="effinetv2")
+    except Exception as e:                                     # the throughput line must not die with the checker
+        mae = {"error": repr(e)}
     return {"value": round((B_LABELED + B_LABELED * MU) / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"1 SSL step B=32+muB=128 EfficientNetV2-S 224x224 fp32 ({dt:.1f} s), torch-CPU oracle",
-            "cpu": model}
+            "kind": "port", "sample": f"C2 step shape: {len(c2_times)} SSL steps B=32+muB=128 EfficientNetV2-S 224x224 fp32 ({dt:.1f} s/step) after a "
+                                      f"small warm-up step; C1: 5 supervised steps B=32 after 2 warm-up ({dt1:.2f} s/step); torch-CPU oracle",
+            "c1_supervised_bs32": {"value": round(B_LABELED / dt1, 3), "unit": "images/s", "s_per_step": round(dt1, 3), "steps": "2 warm-up + 5 timed"},
+            "host_threads": ncores, "cpu": model, "mae_parity": mae}
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (this parent never initialises the
+    GPU and never exec()s), wait for them, kill the rest when one fails, exit non-zero on any failure.  Rank 0 inherits stdout,
+    so its JSON line is this command's JSON line."""
+    import socket
+    import subprocess
+    n = args.gpus
+    have = torch.cuda.device_count()                        # counting devices does not initialise HIP
+    if have < n and os.environ.get("SUHPE_DIST_BACKEND", "nccl") == "nccl":
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible (set SUHPE_DIST_BACKEND=gloo to rehearse the {n}-rank flow on fewer)")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen(argv, env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for q in pending:
+                    procs[q].terminate()                    # exact child PIDs only
+        time.sleep(0.2)
+    raise SystemExit(rc)
 
 
 def main():
@@ -194,9 +260,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="one stream: no teacher / filter-gradient overlap (per-kernel profiling)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)                                   # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     local %= max(1, torch.cuda.device_count())             # (a single-GPU box can rehearse --gpus 2 with SUHPE_DIST_BACKEND=gloo)
@@ -221,7 +291,9 @@ def main():
             "step_roofline": step_roofline(ms),
         }
         if world == 1 and not args.no_cpu_baseline:
+            torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_leg()
+            out["mae_parity"] = out["cpu_baseline"].pop("mae_parity", None)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -65,9 +65,9 @@ def evaluate(config, test_loader, agent, eval_ema=False, dump_json=True):
         print(f"{ema_name}Euler MAE (pitch, yaw, roll, mean): {np.mean(p):.4f}, {np.mean(y):.4f}, {np.mean(r):.4f}, {np.mean(m):.4f}")
         result = dict(pitch=float(np.mean(p)), yaw=float(np.mean(y)), roll=float(np.mean(r)), mean=float(np.mean(m)))
         rows = [[float(a), float(b), float(c), float(d)] for a, b, c, d in zip(gt_yaw, p, y, r)]
-        os.makedirs("./exps", exist_ok=True)
         name = f"./exps/MAE_{config.exp_name}_{config.network}_{config.test_set}.json"
     if dump_json and not eval_ema:
+        os.makedirs(os.path.dirname(name) or ".", exist_ok=True)
         with open(name, "w") as fh:
             json.dump(rows, fh)
     return result

@@ -113,3 +113,33 @@ def test_bench_two_rank_flow_on_one_gpu(tmp_path):
         assert key in out, key
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 320
     assert "cpu_baseline" not in out                       # reported at N=1 only
+
+
+def _bench_line(cmd, env, timeout=900):
+    import json, subprocess
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher (how the driver's BENCH/SCALE commands look): the parent spawns the two ranks
+    itself before touching the GPU and forwards rank 0's line: n_gpus 2, global batch 320.  One GPU here -> gloo rehearsal."""
+    env = dict(os.environ, SUHPE_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = _bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 320 and out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0 and "cpu_baseline" not in out
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_bench_two_ranks_over_rccl():
+    """the same command on the backend it is written for (nccl = RCCL over xGMI)"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SUHPE_DIST_BACKEND"):
+        env.pop(k, None)
+    out = _bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2"], env)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 320

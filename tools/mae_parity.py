@@ -1,0 +1,164 @@
+"""AFLW2000 Euler-MAE parity of the HIP path against the CPU oracle (the second half of BASELINE.json's metric).
+
+Protocol (8d): identical seeded weights on both paths -> K identical SSL warm-up steps (same inputs, same Bernoulli masks:
+the oracle's draws are replayed to the HIP agent) -> the synthetic "AFLW2000-like" evaluation set (1 964 images = 2000 - 36,
+seed 4000, batch 32, drop_last=False, N(0,1) 224x224 images, front-range Euler labels) goes through `val_func` of both
+agents -> per image max |R_hip - R_cpu| (bar: 1e-4) and pitch / yaw / roll / mean MAE computed as the reference's eval.py:76-83,
+125-133 does (HIP: this repo's eval.evaluate; CPU: the same arithmetic on the oracle's rotation matrices) (bar: 0.05 degrees).
+
+Two comparisons are reported:
+  * "same_weights": both paths evaluate the weights the ORACLE holds after its K steps -- the statement about the eval path
+    (every conv/BN/SE/head kernel in eval mode) alone;
+  * "own_trajectory": the HIP agent evaluates the weights IT reached after its own K steps -- this adds the fp32 rounding
+    differences of K training steps (Adam's lr*sign(g) update turns gradient noise into +-lr parameter differences).
+
+Test infrastructure: imports oracle/ (only tests/ and bench.py's cpu_baseline leg call this).
+"""
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+EVAL_IMAGES, EVAL_BATCH, EVAL_SEED = 1964, 32, 4000
+
+
+def eval_batches(n_images=EVAL_IMAGES, batch=EVAL_BATCH, size=224, seed=EVAL_SEED):
+    """the evaluation set as a list-like of loader dicts (img, rot_mat, euler_angles), drop_last=False"""
+    from oracle.agent import synthetic_batches
+    out, i = [], 0
+    while i < n_images:
+        b = min(batch, n_images - i)
+        data, _ = synthetic_batches(b, 0, size=size, seed=seed + len(out))
+        out.append(data)
+        i += b
+    return out
+
+
+def _config(network, **kw):
+    base = dict(lr=1e-4, log_dir="/tmp/suhpe_mae", model_dir="/tmp/suhpe_mae", distribution="matrixFisher", is_full_range=False,
+                rotate_aug=False, train_labeled="300WLP", train_unlabeled="300WLP", cutout_aug=True, cutmix_aug=True, conf_thres=1e9,
+                type_unsuper="ce", SSL_lambda=1.0, is_ema=True, ema_decay=0.999, eman=False, stage1_iteration=0, network=network,
+                num_classes=9, exp_name="300WLP_AFLW2000", date="mae", left_ratio=0.95, save_feat=False, test_set="AFLW2000", autotune=False)
+    base.update(kw)
+    return SimpleNamespace(**base)
+
+
+def _mae(err):
+    p, y, r = err[:, 0], err[:, 1], err[:, 2]
+    return dict(pitch=float(p.mean()), yaw=float(y.mean()), roll=float(r.mean()), mean=float(((p + y + r) / 3).mean()))
+
+
+def _oracle_eval(oracle, batches, eval_ema=False):
+    """eval.py:76-83,125-133 on the oracle: -> (pred_orth (N,3,3), per-image |euler error| (N,3))"""
+    from oracle import pose_utils as OP
+    Rs, errs = [], []
+    for data in batches:
+        fd, _, _ = oracle.val_func(data, eval_ema=eval_ema)
+        R = fd["pred_orth"].reshape(-1, 3, 3)
+        pd_e = OP.compute_euler_angles_from_rotation_matrices(R, full_range=False) * 180 / np.pi
+        errs.append((data["euler_angles"] - pd_e).abs().numpy())
+        Rs.append(R.numpy())
+    return np.concatenate(Rs), np.concatenate(errs)
+
+
+def _hip_eval(agent, cfg, batches, eval_ema=False):
+    """-> (pred_orth (N,3,3), MAE dict from this repo's eval.evaluate)"""
+    import eval as EV
+    dev = agent.device
+    dev_batches = [{k: v.to(dev) for k, v in b.items()} for b in batches]
+    Rs = []
+    with torch.no_grad():
+        for data in dev_batches:
+            fd, _, _ = agent.val_func(data, eval_ema=eval_ema)
+            Rs.append(fd["pred_orth"].reshape(-1, 3, 3).cpu().numpy())
+        mae = EV.evaluate(cfg, dev_batches, agent, eval_ema=eval_ema, dump_json=False)
+    return np.concatenate(Rs), mae
+
+
+def run(n_images=EVAL_IMAGES, warm_steps=3, train_batch=(8, 16), size=224, network="effinetv2", threads=None, verbose=False):
+    from oracle import networks as ON
+    from oracle.agent import OracleAgent, synthetic_batches
+    from parity_utils import MaskTape
+    from semiuhpe_amd import layers as L
+    from semiuhpe_amd.src.agent import SSLAgent
+    if threads:
+        torch.set_num_threads(threads)
+    t_start = time.perf_counter()
+    torch.manual_seed(0)
+    make = {"effinetv2": ON.EfficientNetV2S, "repvgg": ON.RepVggNet, "tinyvit": ON.TinyViT21M}[network]
+    ref = make()
+    head = getattr(ref, "classifier", None) or getattr(ref, "linear_reg", None) or getattr(ref, "head", None)
+    for m in head:
+        if isinstance(m, torch.nn.Linear):
+            m.weight.data.mul_(20.0)      # random-init heads emit A ~ 0 (N(0, 0.01) weights): lift it so the SVD is well conditioned
+    sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
+
+    def factory():
+        m = make()
+        m.load_state_dict(sd0)
+        return m
+
+    cfg_o, cfg_h = _config(network), _config(network)
+    oracle = OracleAgent(cfg_o, factory)
+    agent = SSLAgent(cfg_h)
+    agent.net.load_state_dict(sd0)
+    agent.ema_net.load_state_dict(sd0)
+    B, muB = train_batch
+    for step in range(warm_steps):
+        data, ulb = synthetic_batches(B, muB, size=size, seed=step)
+        tape = MaskTape(900 + step)
+        ON.set_mask_hook(tape.record)
+        torch.manual_seed(50 + step)
+        oracle.iteration = step
+        oracle.train_func({k: v.clone() for k, v in data.items()}, {k: v.clone() for k, v in ulb.items()})
+        ON.set_mask_hook(None)
+        L.set_mask_hook(tape.replay_merged)
+        torch.manual_seed(50 + step)
+        agent.clock.iteration = step
+        agent.train_func({k: v.cuda() for k, v in data.items()}, {k: v.cuda() for k, v in ulb.items()})
+        L.set_mask_hook(None)
+        assert tape.done(), "the two paths drew different numbers of Bernoulli masks"
+    t_train = time.perf_counter()
+
+    batches = eval_batches(n_images, EVAL_BATCH, size)
+    R_cpu, err_cpu = _oracle_eval(oracle, batches)
+    t_cpu = time.perf_counter()
+    mae_cpu = _mae(err_cpu)
+    R_own, mae_own = _hip_eval(agent, cfg_h, batches)
+    # the oracle's post-training weights into a HIP agent: the eval path alone
+    agent.net.load_state_dict(oracle.net.state_dict())
+    agent.ema_net.load_state_dict(oracle.ema_net.state_dict())
+    R_same, mae_same = _hip_eval(agent, cfg_h, batches)
+    R_ema_cpu, err_ema_cpu = _oracle_eval(oracle, batches[:4], eval_ema=True)
+    R_ema, _ = _hip_eval(agent, cfg_h, batches[:4], eval_ema=True)
+    agent.logs_writer.close()
+
+    def cmp(R, mae):
+        return {"max_abs_dR": float(np.abs(R - R_cpu).max()), "mae_hip": {k: round(v, 5) for k, v in mae.items()},
+                "d_mae_deg": {k: round(abs(mae[k] - mae_cpu[k]), 6) for k in mae_cpu}}
+
+    out = {"protocol": f"SURVEY 8d: {n_images} synthetic images seed {EVAL_SEED}, batch {EVAL_BATCH}, {network}, {warm_steps} SSL warm-up steps "
+                       f"(B={B}+muB={muB}) on both paths from the same init, eval.py:76-83,125-133",
+           "images": int(n_images), "mae_cpu": {k: round(v, 5) for k, v in mae_cpu.items()},
+           "same_weights": cmp(R_same, mae_same), "own_trajectory": cmp(R_own, mae_own),
+           "ema_same_weights_max_abs_dR": float(np.abs(R_ema - R_ema_cpu).max()),
+           "tolerance": {"max_abs_dR": 1e-4, "d_mae_deg": 0.05},
+           "cpu_eval_s": round(t_cpu - t_train, 1), "train_s": round(t_train - t_start, 1)}
+    if verbose:
+        print(out)
+    return out
+
+
+if __name__ == "__main__":
+    import json
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else EVAL_IMAGES
+    net = sys.argv[2] if len(sys.argv) > 2 else "effinetv2"
+    print(json.dumps(run(n_images=n, network=net)))
