@@ -8,6 +8,7 @@ import numpy as np
 import torch
 
 from . import fisher as OF
+from . import laplace as OL
 from . import pose_utils as OP
 
 
@@ -20,6 +21,18 @@ class OracleAgent:
             p.detach_()
         self.optimizer = torch.optim.Adam(self.net.parameters(), config.lr)     # :37
         self.iteration = 0
+        self.grids = None
+        if getattr(config, "distribution", "matrixFisher") == "RotationLaplace":      # :43-58: eq_grids2.npy for both ranges
+            import os
+            path = getattr(config, "laplace_grids", None) or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "semiuhpe_amd", "src",
+                                                                          "laplace", "eq_grids2.npy")
+            self.grids = torch.from_numpy(np.load(path))
+
+    def _nll(self, pred, gt):
+        """src/agent.py:78-81 / :156-162: the NLL of the configured distribution"""
+        if getattr(self.config, "distribution", "matrixFisher") == "RotationLaplace":
+            return OL.NLL_loss("RLaplace", pred, gt, self.grids)
+        return OF.vmf_loss(pred, gt, overreg=1.025)
 
     # src/agent.py:61-192
     def forward(self, data, ulb_data, eval_ema=False):
@@ -28,7 +41,7 @@ class OracleAgent:
         gt_euler = data.get("euler_angles")
         net = self.ema_net if eval_ema else self.net
         fisher_out = net(img)
-        losses, pred_orth = OF.vmf_loss(fisher_out, gt, overreg=1.025)
+        losses, pred_orth = self._nll(fisher_out, gt)
         loss = losses.mean()
         err_deg = OP.compute_err_deg_from_matrices(pred_orth, gt, gt_euler)
         fisher_dict = dict(loss=loss, pred=fisher_out, pred_orth=pred_orth, err_deg=err_deg)
@@ -54,7 +67,7 @@ class OracleAgent:
                 ul = OF.fisher_CE(pred_weak_adjusted[mask], pred_strong[mask])
             else:
                 pseudo = OF.batch_torch_A_to_R(pred_weak_adjusted[mask])
-                ul, _ = OF.vmf_loss(pred_strong[mask], pseudo, overreg=1.025)
+                ul, _ = self._nll(pred_strong[mask], pseudo)
             unsuper_loss = ul.mean()
         else:
             unsuper_loss = torch.zeros(())
@@ -72,6 +85,14 @@ class OracleAgent:
     # src/agent.py:277-299
     def update_ema_variables(self, is_ema, alpha, global_step):
         alpha = min(1 - 1 / (global_step + 1), alpha) if is_ema else 0
+        if getattr(self.config, "eman", False):         # :285-297 EMAN: every state_dict entry (parameters AND BatchNorm buffers)
+            for (k, v_main), (k_ema, v_ema) in zip(self.net.state_dict().items(), self.ema_net.state_dict().items()):
+                assert k == k_ema and v_main.shape == v_ema.shape
+                if "num_batches_tracked" in k_ema:
+                    v_ema.copy_(v_main)
+                else:
+                    v_ema.copy_(v_ema * alpha + (1.0 - alpha) * v_main)
+            return
         for e, p in zip(self.ema_net.parameters(), self.net.parameters()):
             e.data.mul_(alpha).add_(p.detach(), alpha=1 - alpha)
 
@@ -95,6 +116,13 @@ class OracleAgent:
         fd["loss"].backward()
         self.optimizer.step()
         return fd
+
+    # src/agent.py:269-274
+    def val_func_s1(self, data):
+        self.net.eval()
+        with torch.no_grad():
+            fd, _ = self.forward(data, None)
+            return fd
 
     # src/agent.py:220-251
     def val_func(self, data, eval_ema=False):

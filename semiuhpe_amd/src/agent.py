@@ -362,23 +362,70 @@ class SSLAgent:
         self.clock.restore_checkpoint(checkpoint["clock"])
 
     # ------------------------------------------------------------------------------------------------ threshold
+    # the layer whose output the reference dumps for t-SNE (src/agent.py:376-379: the second Linear of the regression head);
+    # EfficientNetV2 / TinyViT have no entry there (the reference crashes on them): their head's layer 4 is used the same way
+    _FEAT_LAYER = {"mobilenet": "classifier.4", "resnet18": "fc.4", "resnet50": "fc.4", "repvgg": "linear_reg.4",
+                   "effinetv2": "classifier.4", "tinyvit": "head.4"}
+
     def compute_dynamic_entropy_threshold(self, ulb_train_bar):
         """reference :357-417: teacher (eval mode) entropies over the unlabeled set, sorted, left_ratio quantile.
-        With world_size > 1 each rank scans its own loader shard and the entropy vectors are all-gathered."""
+        With world_size > 1 each rank scans its own loader shard and the entropy vectors are all-gathered.
+        config.save_feat (:369-414): the head's 64/128-d feature of every unlabeled sample is written with its entropy to
+        <log_dir>/ulb_feats_iter<iteration>_thre<threshold>.json as {str(idx): [feature list, entropy]}."""
         _mode(self.ema_net, False)
-        chunks = []
-        with torch.no_grad():
-            for ulb_data in ulb_train_bar:
-                pred_weak = self.ema_net(_dev(ulb_data.get("img"), self.device))
-                chunks.append(fisher_entropy(pred_weak))
-        ent = torch.cat(chunks) if chunks else torch.zeros(0, device=self.device)
-        ent = D.gather_varlen(ent)
+        chunks, feats, idxs = [], [], []
+        hooked = None
+        if getattr(self.config, "save_feat", False):
+            name = self._FEAT_LAYER.get(self.config.network)
+            mods = dict(self.ema_net.named_modules())
+            if name not in mods:
+                raise NotImplementedError(f"--save_feat: no feature layer known for network '{self.config.network}'")
+            hooked, fmap = mods[name], {}
+            orig_fwd = hooked.fwd
+
+            def fwd_and_keep(x, tape):
+                y = orig_fwd(x, tape)
+                fmap["output"] = y
+                return y
+            hooked.fwd = fwd_and_keep
+        try:
+            with torch.no_grad():
+                seen = 0
+                for ulb_data in ulb_train_bar:
+                    pred_weak = self.ema_net(_dev(ulb_data.get("img"), self.device))
+                    chunks.append(fisher_entropy(pred_weak))
+                    if hooked is not None:
+                        feats.append(fmap["output"].reshape(pred_weak.shape[0], -1))
+                        idx = ulb_data.get("idx")
+                        n = pred_weak.shape[0]
+                        idxs += [str(i) for i in (idx.tolist() if torch.is_tensor(idx) else idx)] if idx is not None else \
+                            [f"r{self.rank}_{seen + i}" for i in range(n)]
+                        seen += n
+        finally:
+            if hooked is not None:
+                hooked.fwd = orig_fwd
+        ent_local = torch.cat(chunks) if chunks else torch.zeros(0, device=self.device)
+        ent = D.gather_varlen(ent_local)
         entropy_all = ent.cpu().numpy()
         entropy_all.sort()
         index = int(len(entropy_all) * self.config.left_ratio)
         entropy_thre = entropy_all[index]
         if self.rank == 0:
             print("The best dynamic entropy threshold is:", entropy_thre)
+        if hooked is not None:
+            import json
+            f = torch.cat(feats).cpu().numpy().tolist() if feats else []
+            e = ent_local.cpu().numpy().tolist()
+            table = {k: [fv, ev] for k, fv, ev in zip(idxs, f, e)}
+            if self.world_size > 1:
+                import torch.distributed as dist
+                parts = [None] * self.world_size
+                dist.all_gather_object(parts, table)
+                table = {k: v for part in parts for k, v in part.items()}
+            if self.rank == 0:
+                path = os.path.join(self.config.log_dir, "ulb_feats_iter%d_thre%s.json" % (self.clock.iteration, str(entropy_thre)))
+                with open(path, "w") as fh:
+                    json.dump(table, fh)
         self.config.conf_thres = entropy_thre
         return entropy_thre
 

@@ -1,0 +1,316 @@
+"""GPU: the rest of the agent surface against the CPU oracle (oracle/agent.py restates src/agent.py of the reference), one
+SSL / supervised / validation step each on the same weights, inputs and Bernoulli masks:
+
+  C5  TinyViT-21M + rotate_aug (300WLP convention) agent step        reference src/agent.py:110-122, src/tiny_vit.py
+  C4  EfficientNetV2-S, train_labeled='DAD3DHeads', is_full_range    :113-114 (DAD rotation convention), geodesic metric :447-455
+  C1  train_func_s1 at the BASELINE batch (32 labeled, 224x224)      :254-266
+      val_func(eval_ema=False / True), val_func_s1                   :220-251, :269-274
+      eman=True (buffers follow the EMA too)                         :285-297
+      type_unsuper='nll'                                             :156-157
+      distribution='RotationLaplace' (ce and nll)                    :78-81, :158-162
+
+Tolerances (as tests/test_gpu_effnet.py): rotation matrices 1e-4 absolute; losses / network outputs 2-3e-4 relative;
+gradients 5e-3 of each tensor's max.  The pseudo-label filter always selects a STRICT subset: the threshold is put into the
+widest gap of the teacher's entropies near the median, found by a dry run of the oracle step on a copy of the agent."""
+import copy
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from parity_utils import MaskTape, grad_mismatches, rel_err, seeded_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _config(**kw):
+    base = dict(lr=1e-4, log_dir="/tmp/suhpe_test_logs", model_dir="/tmp/suhpe_test_logs", distribution="matrixFisher",
+                is_full_range=False, rotate_aug=True, train_labeled="300WLP", train_unlabeled="300WLP", cutout_aug=True,
+                cutmix_aug=True, conf_thres=1e9, type_unsuper="ce", SSL_lambda=1.0, is_ema=True, ema_decay=0.999, eman=False,
+                stage1_iteration=0, network="effinetv2", num_classes=9, exp_name="t", date="t", left_ratio=0.95, save_feat=False,
+                autotune=False)
+    base.update(kw)
+    return base
+
+
+def _oracle_net(network):
+    from oracle import networks as ON
+    return {"effinetv2": ON.EfficientNetV2S, "repvgg": ON.RepVggNet, "tinyvit": ON.TinyViT21M}[network]
+
+
+def _pair(seed=23, **kw):
+    """(oracle agent, HIP agent, cfg_o, cfg_h) on the same seeded weights (non-trivial BatchNorm statistics, O(1) head output)"""
+    from oracle.agent import OracleAgent
+    from semiuhpe_amd.src.agent import SSLAgent
+    cfg_o, cfg_h = SimpleNamespace(**_config(**kw)), SimpleNamespace(**_config(**kw))
+    make = _oracle_net(cfg_o.network)
+    sd0 = seeded_state_dict(make().state_dict(), seed)
+
+    def factory():
+        m = make()
+        m.load_state_dict(sd0)
+        return m
+
+    oracle = OracleAgent(cfg_o, factory)
+    agent = SSLAgent(cfg_h)
+    agent.net.load_state_dict(sd0)
+    agent.ema_net.load_state_dict(sd0)
+    return oracle, agent, cfg_o, cfg_h
+
+
+def _batches(B, muB, size, seed, full_range=False, rotate_aug=True):
+    from oracle.agent import synthetic_batches
+    data, ulb = synthetic_batches(B, muB, size=size, seed=seed, full_range=full_range, rotate_aug=rotate_aug)
+    if ulb is not None:
+        ulb["rot_mat"] = synthetic_batches(muB, 0, size=8, seed=70 + seed, full_range=full_range)[0]["rot_mat"]
+    return data, ulb
+
+
+def _gap_threshold(entropy):
+    """a threshold inside the widest gap among the middle third of the sorted entropies -> a strict, noise-robust subset"""
+    e = np.sort(entropy.detach().cpu().double().numpy())
+    n = len(e)
+    lo, hi = max(1, n // 3), max(2, n - n // 3)
+    gaps = e[lo:hi] - e[lo - 1:hi - 1]
+    i = int(np.argmax(gaps)) + lo
+    return float(0.5 * (e[i - 1] + e[i])), i
+
+
+def _ssl_step(oracle, agent, cfg_o, cfg_h, data, ulb, step, strict=True):
+    from oracle import networks as ON
+    from semiuhpe_amd import layers as L
+    if strict:
+        dry = copy.deepcopy(oracle)
+        dry.config = copy.copy(cfg_o)
+        dry.config.conf_thres = 1e9
+        tape = MaskTape(100 + step)
+        ON.set_mask_hook(tape.record)
+        torch.manual_seed(50 + step)
+        dry.iteration = step
+        _, fu_dry, _ = dry.train_func({k: v.clone() for k, v in data.items()}, {k: v.clone() for k, v in ulb.items()})
+        ON.set_mask_hook(None)
+        thr, kept = _gap_threshold(fu_dry["entropy"])
+        cfg_o.conf_thres = cfg_h.conf_thres = thr
+    tape = MaskTape(100 + step)
+    ON.set_mask_hook(tape.record)
+    torch.manual_seed(50 + step)
+    oracle.iteration = step
+    fd_o, fu_o, out_o = oracle.train_func({k: v.clone() for k, v in data.items()}, {k: v.clone() for k, v in ulb.items()})
+    ON.set_mask_hook(None)
+    L.set_mask_hook(tape.replay_merged)
+    torch.manual_seed(50 + step)
+    agent.clock.iteration = step
+    fd, fu, out = agent.train_func({k: v.cuda() for k, v in data.items()}, {k: v.cuda() for k, v in ulb.items()})
+    L.set_mask_hook(None)
+    assert tape.done()
+    if strict:
+        assert 0 < int(fu_o["mask"].sum()) < len(fu_o["mask"])
+    return (fd_o, fu_o, out_o), (fd, fu, out)
+
+
+def _compare_step(o, h, oracle, agent, grad_tol=5e-3, loss_tol=3e-4):
+    (fd_o, fu_o, out_o), (fd, fu, out) = o, h
+    assert rel_err(fd["pred"], fd_o["pred"]) < 3e-4
+    assert float((fd["pred_orth"].cpu().reshape(-1, 3, 3) - fd_o["pred_orth"].reshape(-1, 3, 3)).abs().max()) < 1e-4
+    assert abs(float(fd["loss"]) - float(fd_o["loss"])) < loss_tol * max(1.0, abs(float(fd_o["loss"])))
+    assert rel_err(fd["err_deg"], fd_o["err_deg"]) < 2e-3
+    assert rel_err(fu["entropy"], fu_o["entropy"]) < 3e-4
+    assert abs(float(fu["mask_ratio"]) - float(fu_o["mask_ratio"])) < 1e-6
+    assert abs(float(fu["unsuper_loss"]) - float(fu_o["unsuper_loss"])) < 5e-4 * max(1.0, abs(float(fu_o["unsuper_loss"])))
+    assert abs(float(out["loss_all"]) - float(out_o["loss_all"])) < 5e-4 * max(1.0, abs(float(out_o["loss_all"])))
+    assert rel_err(fu["err_weakAll_gt"], fu_o["err_weakAll_gt"]) < 2e-3
+    m = fu_o["mask"]
+    assert abs(float(fu["err_weakPseudo_gt"]) - float(fu_o["err_weakPseudo_gt"].mean())) < 2e-3 * max(1.0, float(fu_o["err_weakPseudo_gt"].mean()))
+    assert abs(float(fu["err_strongSuper_pseudo"]) - float(fu_o["err_strongSuper_pseudo"].mean())) < 5e-3 * max(1.0, float(fu_o["err_strongSuper_pseudo"].mean()))
+    g_ref = {n: p.grad.clone() for n, p in oracle.net.named_parameters()}
+    bad = grad_mismatches(g_ref, {n: p.grad for n, p in agent.net.named_parameters()}, grad_tol)
+    assert not bad, f"{len(bad)} gradients off: {list(bad.items())[:8]}"
+    assert m.sum() > 0
+
+
+def _resync(oracle, agent):
+    agent.net.load_state_dict(oracle.net.state_dict())
+    agent.ema_net.load_state_dict(oracle.ema_net.state_dict())
+    agent.optimizer.load_state_dict(oracle.optimizer.state_dict())
+
+
+def test_c5_tinyvit_rotate_aug_step():
+    """TinyViT-21M agent step with the pose-altering rotation consistency (300WLP convention): merged student pass with per-segment
+    BatchNorm statistics + DropPath + window attention in ONE step, against the oracle (C5's per-GPU step at a small batch)."""
+    oracle, agent, cfg_o, cfg_h = _pair(network="tinyvit", rotate_aug=True, train_labeled="300WLP")
+    for step in range(2):
+        data, ulb = _batches(3, 6, 224, step)
+        o, h = _ssl_step(oracle, agent, cfg_o, cfg_h, data, ulb, step)
+        _compare_step(o, h, oracle, agent, grad_tol=1e-2)
+        for (n, pe), (_, po) in zip(agent.ema_net.named_parameters(), oracle.ema_net.named_parameters()):
+            assert rel_err(pe, po) < 1e-6, n
+        _resync(oracle, agent)
+
+
+def test_c4_effnet_dad3dheads_full_range_step():
+    """EfficientNetV2-S with train_labeled='DAD3DHeads', is_full_range (C4 per-rank form): DAD rotation convention in the
+    consistency adjust, no euler labels -> geodesic error metric"""
+    oracle, agent, cfg_o, cfg_h = _pair(network="effinetv2", rotate_aug=True, train_labeled="DAD3DHeads", train_unlabeled="WildHead",
+                                        is_full_range=True)
+    for step in range(2):
+        data, ulb = _batches(4, 8, 96, step, full_range=True)
+        assert "euler_angles" not in data
+        o, h = _ssl_step(oracle, agent, cfg_o, cfg_h, data, ulb, step)
+        _compare_step(o, h, oracle, agent)
+        _resync(oracle, agent)
+
+
+@pytest.mark.parametrize("variant", ["nll", "laplace_ce", "laplace_nll"])
+def test_unsupervised_loss_variants(variant):
+    kw = {"nll": dict(type_unsuper="nll"), "laplace_ce": dict(distribution="RotationLaplace", type_unsuper="ce"),
+          "laplace_nll": dict(distribution="RotationLaplace", type_unsuper="nll")}[variant]
+    oracle, agent, cfg_o, cfg_h = _pair(network="effinetv2", **kw)
+    data, ulb = _batches(4, 8, 96, 3)
+    o, h = _ssl_step(oracle, agent, cfg_o, cfg_h, data, ulb, 0)
+    _compare_step(o, h, oracle, agent)
+
+
+def test_eman_updates_buffers_too():
+    """eman=True: the teacher's BatchNorm buffers follow the EMA as well, num_batches_tracked is copied (reference :285-297)"""
+    oracle, agent, cfg_o, cfg_h = _pair(network="effinetv2", eman=True)
+    for step in range(3):                                   # alpha = 0, 1/2, 2/3
+        data, ulb = _batches(4, 8, 96, step)
+        o, h = _ssl_step(oracle, agent, cfg_o, cfg_h, data, ulb, step)
+        _compare_step(o, h, oracle, agent)
+        # the teacher right after its update at the start of this step is not observable any more (its own train-mode pass moved
+        # the buffers): compare the state both paths hold at the end of the step -- parameters exactly EMA'd, buffers EMA'd then
+        # updated by the teacher's pass
+        sd_o, sd_h = oracle.ema_net.state_dict(), agent.ema_net.state_dict()
+        for k, v in sd_o.items():
+            if "num_batches_tracked" in k:
+                assert int(sd_h[k]) == int(v), k
+            else:
+                assert rel_err(sd_h[k], v) < 2e-4, k
+        _resync(oracle, agent)
+    # and the update in isolation: alpha = 3/4 on diverged student / teacher states
+    with torch.no_grad():
+        for p in oracle.net.parameters():
+            p.add_(0.01)
+    agent.net.load_state_dict(oracle.net.state_dict())
+    oracle.update_ema_variables(True, 0.999, 3)
+    agent.update_ema_variables(True, 0.999, 3)
+    for k, v in oracle.ema_net.state_dict().items():
+        got = agent.ema_net.state_dict()[k]
+        if "num_batches_tracked" in k:
+            assert int(got) == int(v), k
+        else:
+            assert rel_err(got, v) < 1e-6, k
+
+
+def test_c1_train_func_s1_batch32():
+    """C1: the supervised stage-1 step at the BASELINE batch (32 labeled images, 224x224), two steps, values + gradients +
+    post-step parameters where the gradient is well resolved (Adam's first update is lr*sign(g))"""
+    from oracle import networks as ON
+    from semiuhpe_amd import layers as L
+    oracle, agent, cfg_o, cfg_h = _pair(network="effinetv2")
+    for step in range(2):
+        data, _ = _batches(32, 0, 224, 10 + step)
+        tape = MaskTape(300 + step)
+        ON.set_mask_hook(tape.record)
+        before = {n: p.detach().clone() for n, p in oracle.net.named_parameters()}
+        fd_o = oracle.train_func_s1({k: v.clone() for k, v in data.items()})
+        ON.set_mask_hook(None)
+        L.set_mask_hook(tape.replay)
+        fd = agent.train_func_s1({k: v.cuda() for k, v in data.items()})
+        L.set_mask_hook(None)
+        assert tape.done()
+        assert rel_err(fd["pred"], fd_o["pred"]) < 3e-4
+        assert float((fd["pred_orth"].cpu().reshape(-1, 3, 3) - fd_o["pred_orth"].reshape(-1, 3, 3)).abs().max()) < 1e-4
+        assert abs(float(fd["loss"]) - float(fd_o["loss"])) < 3e-4 * max(1.0, abs(float(fd_o["loss"])))
+        assert rel_err(fd["err_deg"], fd_o["err_deg"]) < 2e-3
+        g_ref = {n: p.grad.clone() for n, p in oracle.net.named_parameters()}
+        bad = grad_mismatches(g_ref, {n: p.grad for n, p in agent.net.named_parameters()}, 5e-3)
+        assert not bad, f"step {step}: {len(bad)} gradients off: {list(bad.items())[:8]}"
+        after_h = dict(agent.net.named_parameters())
+        for n, p in oracle.net.named_parameters():
+            g = g_ref[n].double()
+            solid = g.abs() > 0.25 * max(1e-30, float(g.abs().max()))
+            if solid.any():
+                d = (after_h[n].detach().cpu().double() - p.detach().double()).abs()[solid].max()
+                assert float(d) < 0.1 * cfg_o.lr + 1e-6 * float(p.abs().max()), (n, float(d))
+                assert float((p.detach() - before[n]).abs().max()) > 0
+        # the EMA teacher is untouched in stage 1
+        for (n, pe), (_, po) in zip(agent.ema_net.named_parameters(), oracle.ema_net.named_parameters()):
+            assert torch.equal(pe.cpu(), po), n
+        agent.net.load_state_dict(oracle.net.state_dict())
+        agent.optimizer.load_state_dict(oracle.optimizer.state_dict())
+
+
+@pytest.mark.parametrize("network", ["effinetv2", "repvgg"])
+def test_val_funcs_match_oracle(network):
+    """val_func(eval_ema=False/True) and val_func_s1 in eval mode: loss, rotation matrices, Euler / geodesic error, and the
+    out_dict {mask_ratio, err_pseudo_gt} with a strict subset selected by the entropy filter"""
+    from oracle import fisher as OF
+    full = network == "repvgg"
+    oracle, agent, cfg_o, cfg_h = _pair(network=network, is_full_range=full, train_labeled="DAD3DHeads" if full else "300WLP")
+    # make the teacher differ from the student so that eval_ema selects something else
+    with torch.no_grad():
+        for p in oracle.ema_net.parameters():
+            p.mul_(1.01)
+    agent.ema_net.load_state_dict(oracle.ema_net.state_dict())
+    data, _ = _batches(12, 0, 96, 5, full_range=full)
+    dev = {k: v.cuda() for k, v in data.items()}
+    for eval_ema in (False, True):
+        cfg_o.conf_thres = cfg_h.conf_thres = 1e9
+        fd_dry, _, _ = oracle.val_func(data, eval_ema=eval_ema)
+        thr, kept = _gap_threshold(OF.fisher_entropy(fd_dry["pred"]))
+        cfg_o.conf_thres = cfg_h.conf_thres = thr
+        fd_o, none_o, out_o = oracle.val_func(data, eval_ema=eval_ema)
+        fd, none_h, out = agent.val_func(dev, eval_ema=eval_ema)
+        assert none_o is None and none_h is None
+        assert not agent.net.training and not agent.ema_net.training
+        assert rel_err(fd["pred"], fd_o["pred"]) < 2e-4
+        assert float((fd["pred_orth"].cpu().reshape(-1, 3, 3) - fd_o["pred_orth"].reshape(-1, 3, 3)).abs().max()) < 1e-4
+        assert abs(float(fd["loss"]) - float(fd_o["loss"])) < 2e-4 * max(1.0, abs(float(fd_o["loss"])))
+        assert rel_err(fd["err_deg"], fd_o["err_deg"]) < 1e-3
+        assert 0 < out_o["mask_ratio"] < 1 and abs(out["mask_ratio"] - out_o["mask_ratio"]) < 1e-6
+        assert out["err_pseudo_gt"].shape == out_o["err_pseudo_gt"].shape == (kept,)
+        assert rel_err(out["err_pseudo_gt"], out_o["err_pseudo_gt"]) < 1e-3
+    # nothing selected -> err_pseudo_gt is None on both paths (reference :246-247)
+    cfg_o.conf_thres = cfg_h.conf_thres = -1e9
+    assert oracle.val_func(data)[2]["err_pseudo_gt"] is None and agent.val_func(dev)[2]["err_pseudo_gt"] is None
+    fd_o = oracle.val_func_s1(data)
+    fd = agent.val_func_s1(dev)
+    assert rel_err(fd["pred"], fd_o["pred"]) < 2e-4 and abs(float(fd["loss"]) - float(fd_o["loss"])) < 2e-4 * max(1.0, abs(float(fd_o["loss"])))
+
+
+def test_save_feat_dumps_head_features(tmp_path):
+    """--save_feat (reference src/agent.py:369-414): {str(idx): [head feature (128 for RepVGG: linear_reg.4), entropy]} next to the
+    logs, named after the iteration and the threshold; the hook is removed afterwards"""
+    import glob, json, os
+    from oracle import fisher as OF
+    oracle, agent, cfg_o, cfg_h = _pair(network="repvgg", save_feat=True, log_dir=str(tmp_path), model_dir=str(tmp_path), is_full_range=True,
+                                        train_labeled="DAD3DHeads", left_ratio=0.75)
+    batches = []
+    for i in range(2):
+        _, ulb = _batches(1, 6, 64, 20 + i, full_range=True)
+        ulb["idx"] = torch.arange(6) + 100 * i
+        batches.append(ulb)
+    agent.clock.iteration = 7
+    thr = agent.compute_dynamic_entropy_threshold([{k: (v.cuda() if k != "idx" else v) for k, v in b.items()} for b in batches])
+    thr_o = oracle.compute_dynamic_entropy_threshold(batches)
+    assert abs(float(thr) - float(thr_o)) < 2e-4 * max(1.0, abs(float(thr_o)))
+    files = glob.glob(os.path.join(str(tmp_path), "ulb_feats_iter7_thre*.json"))
+    assert len(files) == 1
+    table = json.load(open(files[0]))
+    assert sorted(table) == sorted(str(i) for i in list(range(6)) + list(range(100, 106)))
+    # features = output of linear_reg.4 of the teacher in eval mode; entropies as the oracle's
+    feats = {}
+    oracle.ema_net.eval()
+    hook = dict(oracle.ema_net.named_modules())["linear_reg.4"].register_forward_hook(lambda m, i, o: feats.__setitem__("o", o))
+    with torch.no_grad():
+        for b in batches:
+            ent = OF.fisher_entropy(oracle.ema_net(b["img"]))
+            for j, idx in enumerate(b["idx"].tolist()):
+                f, e = table[str(idx)]
+                assert len(f) == 128
+                assert float((torch.tensor(f) - feats["o"][j]).abs().max()) < 2e-4 * max(1.0, float(feats["o"][j].abs().max()))
+                assert abs(e - float(ent[j])) < 2e-4 * max(1.0, abs(float(ent[j])))
+    hook.remove()
+    assert "fwd" not in vars(dict(agent.ema_net.named_modules())["linear_reg.4"])
