@@ -268,6 +268,24 @@ int suhpe_bn_act_bwd_apply(const float* x, const float* dy, const float* y_out, 
  * SqueezeExcitation block behind a depthwise conv's BatchNorm); rows_a = 0: one segment (mean / rstd [c]), else two ([2][c]). */
 int suhpe_bn_act_pool_fwd(const float* x, int64_t rows, int64_t rows_a, int c, int hw, const float* mean, const float* rstd,
                           const float* gamma, const float* beta, int act, float* y, float* pool, suhpe_stream_t stream);
+/* MBConv middle section fused around the depthwise conv's BatchNorm (torchvision MBConv: dw conv -> BatchNorm -> SiLU ->
+ * SqueezeExcitation -> project conv; built by models.efficientnet_v2_s at reference src/networks.py:303).  x = the depthwise conv's
+ * raw output (rows = n*hw, c); z = act(BN(x)) is never stored.  Whole samples per segment (rows % hw == 0, rows_a % hw == 0).
+ *   suhpe_bn_act_pool_fwd with y == NULL   pool[n][c] = mean_hw z                         (the squeeze alone)
+ *   suhpe_bn_act_scale_fwd                 y = z * s[n][c]                                 (excitation applied)
+ *   suhpe_se_bn_bwd_reduce                 sums[5][n][c]: per-sample sums over hw of dout z | dout a' | dout a' xhat | a' | a' xhat
+ *                                          (a' = act'(u)); sums[0] is ds, the gradient of the excitation (input of suhpe_se_mlp_bwd)
+ *   suhpe_se_bn_bwd_combine                chan[segments][2c] = (sum g, sum g xhat), g = (dout s + dpool/hw) a'; dgamma / dbeta (+)=
+ *   suhpe_se_bn_bwd_apply                  dy = gamma rstd (g - mean g - xhat mean(g xhat))   (train_stats = 0: gamma rstd g) */
+int suhpe_bn_act_scale_fwd(const float* x, int64_t rows, int64_t rows_a, int c, int hw, const float* mean, const float* rstd,
+                           const float* gamma, const float* beta, int act, const float* s, float* y, suhpe_stream_t stream);
+int suhpe_se_bn_bwd_reduce(const float* x, const float* dout, int64_t rows, int64_t rows_a, int c, int hw, const float* mean,
+                           const float* rstd, const float* gamma, const float* beta, int act, float* sums, suhpe_stream_t stream);
+int suhpe_se_bn_bwd_combine(const float* sums, const float* s, const float* dpool, int n, int n_a, int c, int hw, float* chan,
+                            float* dgamma, float* dbeta, int accumulate, suhpe_stream_t stream);
+int suhpe_se_bn_bwd_apply(const float* x, const float* dout, int64_t rows, int64_t rows_a, int c, int hw, const float* mean,
+                          const float* rstd, const float* gamma, const float* beta, int act, const float* s, const float* dpool,
+                          const float* chan, int train_stats, float* dy, suhpe_stream_t stream);
 int suhpe_bn_act_bwd_seg(const float* x, const float* dy, const float* y_out, int64_t rows, int64_t rows_a, int c,
                          const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
                          const float* rowscale, int hw, float* dx, float* dgamma, float* dbeta, int accumulate,

@@ -387,7 +387,8 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __res
     int64_t rows_s = rows, row_off;
     int set;
     const int bx = seg_select(sg, &rows_s, &row_off, &set);
-    x += row_off * c; y += row_off * c;
+    x += row_off * c;
+    if (y) y += row_off * c;
     mean += set * c; rstd += set * c;
     const int t = threadIdx.x, col = t % cw, rsub = t / cw;
     const int cv = c / VEC, vc = blockIdx.y * cw + col;
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __res
                 float o[VEC];
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) { o[v] = act_apply(xv[u][v] * sc[v] + sh[v], act); acc[v] += o[v]; }
-                vstore<VEC>(y + ((int64_t)rr * cv + vc) * VEC, o);
+                if (y) vstore<VEC>(y + ((int64_t)rr * cv + vc) * VEC, o);           // y == NULL: the squeeze alone (no tensor written)
             }
         }
     }
@@ -1133,6 +1134,200 @@ __global__ __launch_bounds__(256) void per_sample_scale_kernel(const float* __re
     }
 }
 
+// ---- MBConv middle section fused around the depthwise conv's BatchNorm (torchvision MBConv: dw conv -> BatchNorm -> SiLU ->
+// SqueezeExcitation -> project conv).  With y = the depthwise conv's raw output, z = act(BN(y)), s = the excitation (n, c):
+//   forward   pool[n,c] = mean_hw z            (bn_act_pool_fwd_kernel with y == NULL: one read, nothing written)
+//             out = z * s[n,c]                  (bn_act_scale_fwd_kernel: z itself is never stored)
+//   backward  given dout = d loss / d out:   ds[n,c] = sum_hw dout z,   dz = dout s + dpool[n,c]/hw,   g = dz act'(u),
+//             and the BatchNorm backward needs sum g and sum g xhat over a whole segment.  Both are linear in (s, dpool):
+//               sum_hw g      = s A2 + dpool/hw A4,      sum_hw g xhat = s A3 + dpool/hw A5
+//             with the per-sample sums A1 = sum dout z, A2 = sum dout a', A3 = sum dout a' xhat, A4 = sum a', A5 = sum a' xhat
+//             (a' = act'(u)), so ONE pass over (y, dout) produces everything the excitation MLP's backward and the BatchNorm
+//             backward need (se_bn_bwd_reduce_kernel), a tiny kernel folds them per channel once dpool is known
+//             (se_bn_bwd_combine_kernel), and ONE more pass writes dy (se_bn_bwd_apply_kernel): 4 reads + 1 write of the
+//             expanded tensor instead of the 7 + 2 of scale-backward (two kernels) + BatchNorm backward (two passes).
+// Grids are per sample (a workgroup row never straddles samples), so the sums are fixed-order and s / dpool are per-thread
+// constants; batch segments only select the statistics set by the sample index.
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_act_scale_fwd_kernel(const float* __restrict__ x, int hw, int c, int cw, int rp, int rows_per_block,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                               const float* __restrict__ s, int n_a, float* __restrict__ y) {
+    const int rows = hw;
+    EW_THREAD_SETUP(VEC)
+    const int64_t n = blockIdx.z;
+    const int set = (n_a > 0 && n >= n_a) ? 1 : 0;
+    float sc[VEC], sh[VEC], sv[VEC];
+    vload<VEC>(s + (n * cv + vc) * VEC, sv);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        const float g = gamma ? gamma[ch + v] : 1.f, b = beta ? beta[ch + v] : 0.f;
+        sc[v] = rstd[set * c + ch + v] * g;
+        sh[v] = b - mean[set * c + ch + v] * sc[v];
+    }
+    constexpr int U = 4;
+    for (int r = r0 + rsub; r < r1; r += U * rp) {
+        float xv[U][VEC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) vload<VEC>(x + ((n * hw + (r + u * rp < r1 ? r + u * rp : r1 - 1)) * cv + vc) * VEC, xv[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (r + u * rp >= r1) break;
+            float o[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) o[v] = act_apply(xv[u][v] * sc[v] + sh[v], act) * sv[v];
+            vstore<VEC>(y + ((n * hw + r + u * rp) * cv + vc) * VEC, o);
+        }
+    }
+}
+
+// sums[k][n][c], k = 0..4 (A1..A5 above); one workgroup per (sample, column chunk)
+template <int VEC>
+__global__ __launch_bounds__(256) void se_bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dout, int nsamp, int hw, int c,
+                                                               int cw, int rp, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta, int act, int n_a,
+                                                               float* __restrict__ sums) {
+    __shared__ float lds[256 * 5 * VEC];
+    const int t = threadIdx.x, col = t % cw, rsub = t / cw;
+    const int col0 = blockIdx.y * cw, cv = c / VEC;
+    const int64_t n = blockIdx.x;
+    const int set = (n_a > 0 && n >= n_a) ? 1 : 0;
+    float a[5][VEC];
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) a[k][v] = 0.f;
+    if (rsub < rp && col0 + col < cv) {
+        const int ch = (col0 + col) * VEC;
+        float mu[VEC], rs[VEC], ga[VEC], be[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            mu[v] = mean[set * c + ch + v]; rs[v] = rstd[set * c + ch + v];
+            ga[v] = gamma ? gamma[ch + v] : 1.f; be[v] = beta ? beta[ch + v] : 0.f;
+        }
+        constexpr int U = 4;
+        for (int p = rsub; p < hw; p += U * rp) {
+            float xv[U][VEC], dv[U][VEC];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int pp = p + u * rp < hw ? p + u * rp : hw - 1;
+                const int64_t off = ((n * hw + pp) * cv + col0 + col) * VEC;
+                vload<VEC>(x + off, xv[u]);
+                vload<VEC>(dout + off, dv[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool ok = p + u * rp < hw;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const float xh = (xv[u][v] - mu[v]) * rs[v], uu = xh * ga[v] + be[v];
+                    const float z = ok ? act_apply(uu, act) : 0.f, ap = ok ? act_grad(uu, act) : 0.f, d = ok ? dv[u][v] : 0.f;
+                    a[0][v] += d * z;
+                    a[1][v] += d * ap;
+                    a[2][v] += d * ap * xh;
+                    a[3][v] += ap;
+                    a[4][v] += ap * xh;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) lds[(t * 5 + k) * VEC + v] = a[k][v];
+    __syncthreads();
+    if (t < cw && col0 + t < cv) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            float o[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) o[v] = 0.f;
+            for (int r = 0; r < rp; ++r)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) o[v] += lds[((r * cw + t) * 5 + k) * VEC + v];
+            vstore<VEC>(sums + (((int64_t)k * nsamp + n) * cv + col0 + t) * VEC, o);
+        }
+    }
+}
+
+// chan[set][2c] = (sum g, sum g xhat) over the samples of each segment, fixed order over n; dbeta / dgamma accumulate both segments
+__global__ __launch_bounds__(256) void se_bn_bwd_combine_kernel(const float* __restrict__ sums, const float* __restrict__ s,
+                                                                const float* __restrict__ dpool, int nsamp, int n_a, int c, float inv_hw,
+                                                                float* __restrict__ chan, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                int accumulate) {
+    const int ch = blockIdx.x * 256 + threadIdx.x;
+    if (ch >= c) return;
+    const int64_t plane = (int64_t)nsamp * c;
+    double tot_g = 0.0, tot_q = 0.0;
+    int lo = 0;
+    for (int set = 0; set < (n_a > 0 ? 2 : 1); ++set) {
+        const int hi = (n_a > 0 && set == 0) ? n_a : nsamp;
+        double g = 0.0, q = 0.0;
+        for (int n = lo; n < hi; ++n) {
+            const int64_t i = (int64_t)n * c + ch;
+            const double sv = s[i], dp = (double)dpool[i] * inv_hw;
+            g += sv * sums[plane + i] + dp * sums[3 * plane + i];
+            q += sv * sums[2 * plane + i] + dp * sums[4 * plane + i];
+        }
+        chan[set * 2 * c + 2 * ch] = (float)g;
+        chan[set * 2 * c + 2 * ch + 1] = (float)q;
+        tot_g += (double)(float)g;
+        tot_q += (double)(float)q;
+        lo = hi;
+    }
+    if (dbeta) dbeta[ch] = (accumulate ? dbeta[ch] : 0.f) + (float)tot_g;
+    if (dgamma) dgamma[ch] = (accumulate ? dgamma[ch] : 0.f) + (float)tot_q;
+}
+
+// dy = gamma rstd (g - mean(g) - xhat mean(g xhat)),  g = (dout s + dpool/hw) act'(u);   grid (row blocks of a sample, column chunks, n)
+template <int VEC>
+__global__ __launch_bounds__(256) void se_bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dout, int hw, int c, int cw, int rp,
+                                                              int rows_per_block, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                              const float* __restrict__ s, const float* __restrict__ dpool,
+                                                              const float* __restrict__ chan, int n_a, float inv_rows_a, float inv_rows_b,
+                                                              int train_stats, float* __restrict__ dy) {
+    const int rows = hw;
+    EW_THREAD_SETUP(VEC)
+    const int64_t n = blockIdx.z;
+    const int set = (n_a > 0 && n >= n_a) ? 1 : 0;
+    const float inv_rows = set ? inv_rows_b : inv_rows_a, inv_hw = 1.f / (float)hw;
+    float mu[VEC], rs[VEC], ga[VEC], be[VEC], m0[VEC], m1[VEC], sv[VEC], pv[VEC];
+    vload<VEC>(s + (n * cv + vc) * VEC, sv);
+    vload<VEC>(dpool + (n * cv + vc) * VEC, pv);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        mu[v] = mean[set * c + ch + v]; rs[v] = rstd[set * c + ch + v];
+        ga[v] = gamma ? gamma[ch + v] : 1.f; be[v] = beta ? beta[ch + v] : 0.f;
+        m0[v] = train_stats ? chan[set * 2 * c + 2 * (ch + v)] * inv_rows : 0.f;
+        m1[v] = train_stats ? chan[set * 2 * c + 2 * (ch + v) + 1] * inv_rows : 0.f;
+        pv[v] *= inv_hw;
+    }
+    constexpr int U = 4;
+    for (int r = r0 + rsub; r < r1; r += U * rp) {
+        float xv[U][VEC], dv[U][VEC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t off = ((n * hw + (r + u * rp < r1 ? r + u * rp : r1 - 1)) * cv + vc) * VEC;
+            vload<VEC>(x + off, xv[u]);
+            vload<VEC>(dout + off, dv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (r + u * rp >= r1) break;
+            float o[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const float xh = (xv[u][v] - mu[v]) * rs[v];
+                float g = (dv[u][v] * sv[v] + pv[v]) * act_grad(xh * ga[v] + be[v], act);
+                g = g - m0[v] - xh * m1[v];
+                o[v] = ga[v] * rs[v] * g;
+            }
+            vstore<VEC>(dy + ((n * hw + r + u * rp) * cv + vc) * VEC, o);
+        }
+    }
+}
+
 // y = a + b*rowscale[n]   (a may be NULL -> y = b*rowscale[n]); grid (chunks of a sample, n)
 __global__ __launch_bounds__(256) void add_rowscale_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                            const float* __restrict__ rowscale, int per_vec, float* __restrict__ y) {
@@ -1571,16 +1766,64 @@ int suhpe_bn_act_bwd_apply(const float* x, const float* dy, const float* y_out, 
 
 int suhpe_bn_act_pool_fwd(const float* x, int64_t rows, int64_t rows_a, int c, int hw, const float* mean, const float* rstd, const float* gamma,
                           const float* beta, int act, float* y, float* pool, suhpe_stream_t stream) {
-    SUHPE_REQUIRE(x && y && pool && mean && rstd && rows > 0 && rows < (1LL << 31) && c > 0 && hw > 0 && rows % hw == 0 && rows_a >= 0 && rows_a < rows &&
+    SUHPE_REQUIRE(x && pool && mean && rstd && rows > 0 && rows < (1LL << 31) && c > 0 && hw > 0 && rows % hw == 0 && rows_a >= 0 && rows_a < rows &&
                       rows_a % hw == 0,
                   "suhpe_bn_act_pool_fwd: bad arguments (whole samples per segment: rows %% hw == 0, rows_a %% hw == 0)");
-    const int vec = vec4_ok(c, x, y) ? 4 : 1;
+    const int vec = (vec4_ok(c, x, y) && vec4_ok(c, pool)) ? 4 : 1;
     const int cv = c / vec, cw = cv < 64 ? cv : 64, ny = (cv + cw - 1) / cw, rp = 256 / cw;
     const SegArgs sg{rows_a, (int)(rows_a / hw)};
     const dim3 grid((unsigned)(rows / hw), ny);
     if (vec == 4) LAUNCH(bn_act_pool_fwd_kernel<4>, grid, dim3(256), stream, x, (int)rows, c, cw, rp, hw, mean, rstd, gamma, beta, act, y, pool, sg);
     else LAUNCH(bn_act_pool_fwd_kernel<1>, grid, dim3(256), stream, x, (int)rows, c, cw, rp, hw, mean, rstd, gamma, beta, act, y, pool, sg);
     return check_launch("suhpe_bn_act_pool_fwd");
+}
+
+static bool se_bn_args_ok(const float* x, int64_t rows, int64_t rows_a, int c, int hw) {
+    return x && rows > 0 && rows < (1LL << 31) && c > 0 && hw > 0 && rows % hw == 0 && rows_a >= 0 && rows_a < rows && rows_a % hw == 0;
+}
+
+int suhpe_bn_act_scale_fwd(const float* x, int64_t rows, int64_t rows_a, int c, int hw, const float* mean, const float* rstd, const float* gamma,
+                           const float* beta, int act, const float* s, float* y, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(se_bn_args_ok(x, rows, rows_a, c, hw) && mean && rstd && s && y, "suhpe_bn_act_scale_fwd: bad arguments (whole samples per segment)");
+    const int n = (int)(rows / hw), n_a = (int)(rows_a / hw);
+    const bool v4 = vec4_ok(c, x, s, y);
+    const EwGeom g = ew_geom(hw, c, v4 ? 4 : 1);
+    if (v4) LAUNCH(bn_act_scale_fwd_kernel<4>, dim3(g.gx, g.ny, n), dim3(256), stream, x, hw, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta, act, s, n_a, y);
+    else LAUNCH(bn_act_scale_fwd_kernel<1>, dim3(g.gx, g.ny, n), dim3(256), stream, x, hw, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta, act, s, n_a, y);
+    return check_launch("suhpe_bn_act_scale_fwd");
+}
+
+int suhpe_se_bn_bwd_reduce(const float* x, const float* dout, int64_t rows, int64_t rows_a, int c, int hw, const float* mean, const float* rstd,
+                           const float* gamma, const float* beta, int act, float* sums, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(se_bn_args_ok(x, rows, rows_a, c, hw) && dout && mean && rstd && sums, "suhpe_se_bn_bwd_reduce: bad arguments (whole samples per segment)");
+    const int n = (int)(rows / hw), n_a = (int)(rows_a / hw);
+    const int vec = (vec4_ok(c, x, dout, sums)) ? 4 : 1;
+    const int cv = c / vec, cw = cv < 32 ? cv : 32, ny = (cv + cw - 1) / cw, rp = 256 / cw;
+    if (vec == 4) LAUNCH(se_bn_bwd_reduce_kernel<4>, dim3(n, ny), dim3(256), stream, x, dout, n, hw, c, cw, rp, mean, rstd, gamma, beta, act, n_a, sums);
+    else LAUNCH(se_bn_bwd_reduce_kernel<1>, dim3(n, ny), dim3(256), stream, x, dout, n, hw, c, cw, rp, mean, rstd, gamma, beta, act, n_a, sums);
+    return check_launch("suhpe_se_bn_bwd_reduce");
+}
+
+int suhpe_se_bn_bwd_combine(const float* sums, const float* s, const float* dpool, int n, int n_a, int c, int hw, float* chan, float* dgamma,
+                            float* dbeta, int accumulate, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(sums && s && dpool && chan && n > 0 && n_a >= 0 && n_a < n && c > 0 && hw > 0, "suhpe_se_bn_bwd_combine: bad arguments");
+    LAUNCH(se_bn_bwd_combine_kernel, dim3((c + 255) / 256), dim3(256), stream, sums, s, dpool, n, n_a, c, 1.0f / (float)hw, chan, dgamma, dbeta, accumulate);
+    return check_launch("suhpe_se_bn_bwd_combine");
+}
+
+int suhpe_se_bn_bwd_apply(const float* x, const float* dout, int64_t rows, int64_t rows_a, int c, int hw, const float* mean, const float* rstd,
+                          const float* gamma, const float* beta, int act, const float* s, const float* dpool, const float* chan, int train_stats,
+                          float* dy, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(se_bn_args_ok(x, rows, rows_a, c, hw) && dout && mean && rstd && s && dpool && chan && dy, "suhpe_se_bn_bwd_apply: bad arguments");
+    const int n = (int)(rows / hw), n_a = (int)(rows_a / hw);
+    const bool v4 = vec4_ok(c, x, dout, dy) && vec4_ok(c, s, dpool);
+    const EwGeom g = ew_geom(hw, c, v4 ? 4 : 1);
+    const float inv_a = 1.0f / (float)(rows_a > 0 ? rows_a : rows), inv_b = 1.0f / (float)(rows - rows_a);
+    if (v4) LAUNCH(se_bn_bwd_apply_kernel<4>, dim3(g.gx, g.ny, n), dim3(256), stream, x, dout, hw, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta, act,
+                   s, dpool, chan, n_a, inv_a, inv_b, train_stats, dy);
+    else LAUNCH(se_bn_bwd_apply_kernel<1>, dim3(g.gx, g.ny, n), dim3(256), stream, x, dout, hw, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta, act,
+                s, dpool, chan, n_a, inv_a, inv_b, train_stats, dy);
+    return check_launch("suhpe_se_bn_bwd_apply");
 }
 
 int suhpe_bn_act_bwd_seg(const float* x, const float* dy, const float* y_out, int64_t rows, int64_t rows_a, int c, const float* mean,

@@ -655,6 +655,50 @@ def bn_act_pool_fwd(x, rows_a, c, mean, rstd, gamma, beta, act, hw):
 
 
 @_memop
+def bn_act_pool(x, rows_a, c, mean, rstd, gamma, beta, act, hw):
+    """squeeze alone: per-sample channel means of act(BN(x)); nothing but the (n, c) means is written"""
+    _chk(x, "x")
+    pool = torch.empty((x.numel() // (c * hw), c), dtype=torch.float32, device=x.device)
+    call("suhpe_bn_act_pool_fwd", ptr(x), x.numel() // c, int(rows_a), c, int(hw), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ACT[act], None,
+         ptr(pool))
+    return pool
+
+
+@_memop
+def bn_act_scale_fwd(x, rows_a, c, mean, rstd, gamma, beta, act, s, hw):
+    """act(BN(x)) * s[n, c] (SqueezeExcitation's scale applied to a BatchNorm output that is never stored)"""
+    _chk(x, "x"); _chk(s, "s")
+    y = torch.empty_like(x)
+    call("suhpe_bn_act_scale_fwd", ptr(x), x.numel() // c, int(rows_a), c, int(hw), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ACT[act], ptr(s), ptr(y))
+    return y
+
+
+@_memop
+def se_bn_bwd_reduce(x, dout, rows_a, c, mean, rstd, gamma, beta, act, hw):
+    """-> sums (5, n, c): per-sample sums the excitation's and the BatchNorm's backward need (sums[0] = ds)"""
+    _chk(x, "x"); _chk(dout, "dout")
+    n = x.numel() // (c * hw)
+    sums = torch.empty((5, n, c), dtype=torch.float32, device=x.device)
+    call("suhpe_se_bn_bwd_reduce", ptr(x), ptr(dout), x.numel() // c, int(rows_a), c, int(hw), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ACT[act], ptr(sums))
+    return sums
+
+
+def se_bn_bwd_combine(sums, s, dpool, n_a, hw, dgamma, dbeta, accumulate=True):
+    n, c = s.shape
+    chan = torch.empty((2, 2 * c), dtype=torch.float32, device=s.device)
+    call("suhpe_se_bn_bwd_combine", ptr(sums), ptr(s), ptr(dpool), n, int(n_a), c, int(hw), ptr(chan), ptr(dgamma), ptr(dbeta), int(accumulate))
+    return chan
+
+
+@_memop
+def se_bn_bwd_apply(x, dout, rows_a, c, mean, rstd, gamma, beta, act, s, dpool, chan, train_stats, hw):
+    dy = torch.empty_like(x)
+    call("suhpe_se_bn_bwd_apply", ptr(x), ptr(dout), x.numel() // c, int(rows_a), c, int(hw), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ACT[act],
+         ptr(s), ptr(dpool), ptr(chan), int(bool(train_stats)), ptr(dy))
+    return dy
+
+
+@_memop
 def bn_act_bwd_seg(x, dy, rows_a, c, mean, rstd, gamma, beta, act, dgamma=None, dbeta=None, accumulate=False, y_out=None, rowscale=None, hw=1):
     _chk(x, "x"); _chk(dy, "dy")
     dx = torch.empty_like(x)

@@ -403,7 +403,7 @@ class SSLAgent:
                         seen += n
         finally:
             if hooked is not None:
-                hooked.fwd = orig_fwd
+                del hooked.fwd                      # drop the instance attribute: the class's fwd is back
         ent_local = torch.cat(chunks) if chunks else torch.zeros(0, device=self.device)
         ent = D.gather_varlen(ent_local)
         entropy_all = ent.cpu().numpy()

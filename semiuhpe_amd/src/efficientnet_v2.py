@@ -6,6 +6,8 @@ restated from its published definition — parity of this
 
 Blocks are Layers with explicit forward/backward over the HIP kernels (semiuhpe_amd/layers.py).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -28,6 +30,7 @@ BN_EPS = 1e-3           # torchvision: partial(nn.BatchNorm2d, eps=1e-03) for th
 # makes the depthwise kernels recompute the SiLU 1.5x (forward) to 3x (filter gradient) per element: measured 84.1 vs 79.7
 # ms/step on C2, so it is off; the kernels and their tests stay (memory-saving mode: the expanded tensor is never stored).
 FUSE_EXPAND_BN_INTO_DW = False
+FUSE_DW_BN_SE = os.environ.get("SUHPE_FUSE_DW_BN_SE", "1") != "0"     # depthwise BatchNorm + SiLU + SqueezeExcitation as one section (MBConv._dw_se_*)
 STOCHASTIC_DEPTH_PROB = 0.2
 
 
@@ -105,12 +108,50 @@ class MBConv(_ResidualBlock):
         exp_bn = self.block[0][1]
         return FUSE_EXPAND_BN_INTO_DW and self.has_expand and self.block[1][0].in_channels % 4 == 0 and self.block[1][0].kernel_size == 3 and (exp_bn.training or tape is not None)
 
+    # depthwise conv -> BatchNorm -> SiLU -> SqueezeExcitation as ONE section around the BatchNorm (kernels.bn_act_pool /
+    # bn_act_scale_fwd / se_bn_bwd_*): the activated tensor z = silu(BN(y)) is never stored; forward = squeeze pass (read y) +
+    # scale pass (read y, write z*s); backward = one reduction pass + one apply pass over (y, dout) instead of scale-backward
+    # (two kernels) + BatchNorm backward (two passes).  SyncBN keeps the layer-by-layer form (its statistics are all-reduced).
+    def _dw_se_fused(self):
+        from .. import layers as L
+        conv_d, se = self.block[-3][0], self.block[-2]
+        return FUSE_DW_BN_SE and not L.SYNC_BN and se._fused() and conv_d.in_channels % 4 == 0
+
+    def _dw_se_fwd(self, x, tape):
+        (conv_d, bn_d), se = self.block[-3], self.block[-2]
+        c = bn_d.num_features
+        y = conv_d.fwd(x, tape)
+        hw = y.shape[1] * y.shape[2]
+        if bn_d.training:
+            mean, rstd, rows_a = bn_d.train_stats(y)
+        else:
+            (mean, rstd), rows_a = K.bn_eval_stats(bn_d.running_mean, bn_d.running_var, bn_d.eps), 0
+        p = K.bn_act_pool(y, rows_a, c, mean, rstd, bn_d.weight, bn_d.bias, bn_d.act, hw)
+        a1, s = K.se_mlp_fwd(p, se.fc1.weight, se.fc1.bias, se.fc2.weight, se.fc2.bias)
+        out = K.bn_act_scale_fwd(y, rows_a, c, mean, rstd, bn_d.weight, bn_d.bias, bn_d.act, s, hw)
+        if tape is not None:
+            tape.append((y, mean, rstd, rows_a, bn_d.training, p, a1, s, hw))
+        return out
+
+    def _dw_se_bwd(self, dout, tape):
+        (conv_d, bn_d), se = self.block[-3], self.block[-2]
+        y, mean, rstd, rows_a, train_stats, p, a1, s, hw = tape.pop()
+        c = bn_d.num_features
+        sums = K.se_bn_bwd_reduce(y, dout, rows_a, c, mean, rstd, bn_d.weight, bn_d.bias, bn_d.act, hw)
+        dp = K.se_mlp_bwd(sums[0], s, a1, p, se.fc1.weight, se.fc2.weight, grad_of(se.fc1.weight), grad_of(se.fc1.bias),
+                          grad_of(se.fc2.weight), grad_of(se.fc2.bias))
+        chan = K.se_bn_bwd_combine(sums, s, dp, rows_a // hw, hw, grad_of(bn_d.weight), grad_of(bn_d.bias), True)
+        dy = K.se_bn_bwd_apply(y, dout, rows_a, c, mean, rstd, bn_d.weight, bn_d.bias, bn_d.act, s, dp, chan, train_stats, hw)
+        return conv_d.bwd(dy, tape)
+
     def _front_fwd(self, x, tape):
         if not self._fusable(tape):
-            # expand -> depthwise conv -> BatchNorm + SiLU + squeeze (one kernel) -> excitation
+            # expand -> depthwise conv -> BatchNorm + SiLU + squeeze -> excitation
             layers = list(self.block)[:-1]
             if self.has_expand:
                 x = layers[0].fwd(x, tape)
+            if self._dw_se_fused():
+                return self._dw_se_fwd(x, tape)
             dw, se = layers[-2], layers[-1]
             z, pooled = conv_bn_fwd(dw[0], dw[1], x, tape, pool=True)
             return se.fwd(z, tape, pooled=pooled)
@@ -132,6 +173,9 @@ class MBConv(_ResidualBlock):
 
     def _front_bwd(self, dy, tape):
         if not self._fusable(tape):
+            if self._dw_se_fused():
+                d = self._dw_se_bwd(dy, tape)
+                return self.block[0].bwd(d, tape) if self.has_expand else d
             return super()._front_bwd(dy, tape)
         (conv_e, bn_e), (conv_d, bn_d), se = self.block[0], self.block[1], self.block[2]
         dz = bn_d.bwd(se.bwd(dy, tape), tape)
