@@ -149,6 +149,13 @@ int suhpe_dwconv_dgrad(const suhpe_conv_t* d, const float* dy, const float* w, f
 int64_t suhpe_dwconv_wgrad_workspace_bytes(const suhpe_conv_t* d);
 int suhpe_dwconv_wgrad(const suhpe_conv_t* d, const float* x, const float* dy, float* dw, int accumulate,
                        void* workspace, int64_t workspace_bytes, suhpe_stream_t stream);
+/* Depthwise forward that also emits the BatchNorm statistics records of its OUTPUT (the depthwise conv of torchvision's MBConv and of
+ * tiny_vit.py:91-93,130-131,323-324 is always followed by a train-mode BatchNorm): stats = [segments][blocks][C] float4 (S, Q, k, n),
+ * blocks = suhpe_dwconv_fwd_stats_blocks(d) (0: this shape has no statistics epilogue, use suhpe_dwconv_fwd + suhpe_bn_stats);
+ * seg_n > 0: samples [0, seg_n) are the first batch segment (two record planes), seg_n = 0: one plane.  The records feed
+ * suhpe_bn_stats_from_partials / _seg like the GEMM epilogue's. */
+int suhpe_dwconv_fwd_stats_blocks(const suhpe_conv_t* d);
+int suhpe_dwconv_fwd_stats(const suhpe_conv_t* d, const float* x, const float* w, float* y, float* stats, int seg_n, suhpe_stream_t stream);
 /* The same depthwise forward / filter gradient with the producer's BatchNorm + activation applied while loading the input:
  * x is the raw output of the preceding conv, the kernels use act(gamma*(x-mean)*rstd + beta) (zero at padding taps), so the
  * normalised tensor of an MBConv's expand conv never exists in memory (torchvision MBConv: Conv2dNormActivation 1x1 ->

@@ -121,10 +121,68 @@ __device__ __forceinline__ float4 ld4_xf(const float* __restrict__ base, bool ok
     return v;
 }
 
-template <bool XF>
+
+// ---- BatchNorm statistics of the OUTPUT from the same pass (the depthwise conv of an MBConv block is followed by a train-mode
+// BatchNorm: a separate statistics pass would read the tensor once more).  A thread keeps shifted sums (S, Q, k, n) of the
+// output values it produces -- k = its first value, per channel -- for the current batch segment; when its rows cross into
+// the second segment (sample index >= seg_n) the sums move to the first segment's registers and restart.  At the end the
+// threads of a workgroup that share a channel vector are combined in LDS in a fixed order, re-centred on the first
+// contributing thread's shift, and ONE record per (workgroup, channel) and segment is written: stats[seg][blockIdx.x][C] as
+// float4 (S, Q, k, n), the format of the GEMM epilogue's records (conv_igemm.hip) and of bn_stats_partial (nn_elem.hip).
+struct DwStat {
+    float S[4], Q[4], k[4];
+    float n;
+};
+__device__ __forceinline__ void dw_stat_zero(DwStat& a) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { a.S[v] = 0.f; a.Q[v] = 0.f; a.k[v] = 0.f; }
+    a.n = 0.f;
+}
+__device__ __forceinline__ void dw_stat_add(DwStat& a, const float* o) {
+    if (a.n == 0.f) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) a.k[v] = o[v];
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { const float d = o[v] - a.k[v]; a.S[v] += d; a.Q[v] += d * d; }
+    a.n += 1.f;
+}
+// all 256 threads call this (no early exits before it); scratch: 256 * 13 floats of LDS
+__device__ __forceinline__ void dw_stat_emit(const DwStat& a, bool active, int cw, int rp, int col, int col0, int C, float* __restrict__ rec,
+                                             float* scratch) {
+    const int t = threadIdx.x;
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { scratch[t * 13 + v] = a.S[v]; scratch[t * 13 + 4 + v] = a.Q[v]; scratch[t * 13 + 8 + v] = a.k[v]; }
+    scratch[t * 13 + 12] = active ? a.n : 0.f;
+    __syncthreads();
+    if (t < cw && (col0 + t) * 4 < C) {
+        float S[4] = {0.f, 0.f, 0.f, 0.f}, Q[4] = {0.f, 0.f, 0.f, 0.f}, kb[4] = {0.f, 0.f, 0.f, 0.f}, n = 0.f;
+        for (int r = 0; r < rp; ++r) {
+            const float* e = &scratch[(r * cw + t) * 13];
+            const float nt = e[12];
+            if (nt == 0.f) continue;
+            if (n == 0.f) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) kb[v] = e[8 + v];
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float d = e[8 + v] - kb[v];
+                S[v] += e[v] + nt * d;
+                Q[v] += e[4 + v] + 2.f * d * e[v] + nt * d * d;
+            }
+            n += nt;
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) reinterpret_cast<float4*>(rec)[(col0 + t) * 4 + v] = make_float4(S[v], Q[v], kb[v], n);
+    }
+}
+
+template <bool XF, bool STATS = false>
 __global__ __launch_bounds__(256) void dw3x3_row_kernel(const float* __restrict__ src, const float* __restrict__ w, float* __restrict__ dst,
                                                         int N, int H, int W, int OH, int OW, int C, int stride, int flip, int cw, int rp,
-                                                        const DwXform xform) {
+                                                        const DwXform xform, float* __restrict__ stats = nullptr, int seg_n = 0) {
     __shared__ __attribute__((aligned(16))) float wl[9 * 256 * 4];
     const int t = threadIdx.x, col = t % cw, rsub = t / cw;
     const int cv = C / 4, col0 = blockIdx.y * cw;
@@ -134,14 +192,19 @@ __global__ __launch_bounds__(256) void dw3x3_row_kernel(const float* __restrict_
         wl[i] = ch < C ? w[(int64_t)ch * 9 + (flip ? 8 - tap : tap)] : 0.f;
     }
     __syncthreads();
-    if (rsub >= rp || col0 + col >= cv) return;
+    const bool active = rsub < rp && col0 + col < cv;
+    if (!STATS && !active) return;
     float4 wv[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) wv[k] = *reinterpret_cast<const float4*>(&wl[(k * cw + col) * 4]);
+    for (int k = 0; k < 9; ++k) wv[k] = *reinterpret_cast<const float4*>(&wl[(k * cw + (active ? col : 0)) * 4]);
     const int coff = (col0 + col) * 4;
-    const DwXf4 xf = dw_xf_load(xform, coff);
-    for (int row = blockIdx.x * rp + rsub; row < N * OH; row += gridDim.x * rp) {
+    const DwXf4 xf = dw_xf_load(xform, active ? coff : 0);
+    DwStat st_a, st;
+    bool crossed = false;
+    if (STATS) { dw_stat_zero(st_a); dw_stat_zero(st); }
+    for (int row = blockIdx.x * rp + rsub; active && row < N * OH; row += gridDim.x * rp) {
         const int n = row / OH, oh = row - n * OH;
+        if (STATS && seg_n > 0 && !crossed && n >= seg_n) { st_a = st; dw_stat_zero(st); crossed = true; }
         const int ih0 = oh * stride - 1;
         bool rok[3];
         int64_t rbase[3];
@@ -177,6 +240,19 @@ __global__ __launch_bounds__(256) void dw3x3_row_kernel(const float* __restrict_
 #pragma unroll
                 for (int c = 0; c < 3; ++c) fma4(acc, x[r][c], wv[r * 3 + c]);
             *reinterpret_cast<float4*>(dst + ((int64_t)row * OW + ow) * C + coff) = acc;
+            if (STATS) { const float o[4] = {acc.x, acc.y, acc.z, acc.w}; dw_stat_add(st, o); }
+        }
+    }
+    if (STATS) {
+        // rows of the first segment: st_a when the thread crossed the boundary, else st if it never left the first segment
+        const bool two = seg_n > 0;
+        if (two && !crossed) { st_a = st; dw_stat_zero(st); }          // everything this thread produced lies in the first segment
+        float* rec = stats + (int64_t)blockIdx.x * C * 4;
+        if (two) {
+            dw_stat_emit(st_a, active, cw, rp, col, col0, C, rec, wl);
+            dw_stat_emit(st, active, cw, rp, col, col0, C, rec + (int64_t)gridDim.x * C * 4, wl);
+        } else {
+            dw_stat_emit(st, active, cw, rp, col, col0, C, rec, wl);
         }
     }
 }
@@ -186,9 +262,10 @@ __global__ __launch_bounds__(256) void dw3x3_row_kernel(const float* __restrict_
 // FETCH_SIZE measured 2.7x the input).  Padding taps read zero through the buffer descriptor's bounds check, and the
 // column ahead is loaded one step early (the wait lands at its first use).
 constexpr int kDwRows = 4;
-template <bool XF>
+template <bool XF, bool STATS = false>
 __global__ __launch_bounds__(256) void dw3x3_s1_kernel(const float* __restrict__ src, int64_t src_bytes, const float* __restrict__ w,
-                                                       float* __restrict__ dst, int N, int H, int W, int C, int flip, int cw, int rp, const DwXform xform) {
+                                                       float* __restrict__ dst, int N, int H, int W, int C, int flip, int cw, int rp, const DwXform xform,
+                                                       float* __restrict__ stats = nullptr, int seg_n = 0) {
     __shared__ __attribute__((aligned(16))) float wl[9 * 256 * 4];
     const int t = threadIdx.x, col = t % cw, rsub = t / cw;
     const int cv = C / 4, col0 = blockIdx.y * cw;
@@ -198,16 +275,21 @@ __global__ __launch_bounds__(256) void dw3x3_s1_kernel(const float* __restrict__
         wl[i] = ch < C ? w[(int64_t)ch * 9 + (flip ? 8 - tap : tap)] : 0.f;
     }
     __syncthreads();
-    if (rsub >= rp || col0 + col >= cv) return;
+    const bool active = rsub < rp && col0 + col < cv;
+    if (!STATS && !active) return;
     float4 wv[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) wv[k] = *reinterpret_cast<const float4*>(&wl[(k * cw + col) * 4]);
+    for (int k = 0; k < 9; ++k) wv[k] = *reinterpret_cast<const float4*>(&wl[(k * cw + (active ? col : 0)) * 4]);
     const BufRsrc sr = make_rsrc(src, src_bytes);
     const unsigned coff = (unsigned)(col0 + col) * 16u, pix = (unsigned)C * 4u;       // byte offsets
-    const DwXf4 xf = dw_xf_load(xform, (col0 + col) * 4);
+    const DwXf4 xf = dw_xf_load(xform, active ? (col0 + col) * 4 : 0);
     const int groups_h = (H + kDwRows - 1) / kDwRows;                                  // row groups per image
-    for (int rg = blockIdx.x * rp + rsub; rg < N * groups_h; rg += gridDim.x * rp) {
+    DwStat st_a, st;
+    bool crossed = false;
+    if (STATS) { dw_stat_zero(st_a); dw_stat_zero(st); }
+    for (int rg = blockIdx.x * rp + rsub; active && rg < N * groups_h; rg += gridDim.x * rp) {
         const int n = rg / groups_h, oh0 = (rg - n * groups_h) * kDwRows;
+        if (STATS && seg_n > 0 && !crossed && n >= seg_n) { st_a = st; dw_stat_zero(st); crossed = true; }
         unsigned rbase[kDwRows + 2];
         bool rok[kDwRows + 2];
 #pragma unroll
@@ -258,7 +340,19 @@ __global__ __launch_bounds__(256) void dw3x3_s1_kernel(const float* __restrict__
                         acc[2] += x[j + r][c][2] * wk.z; acc[3] += x[j + r][c][3] * wk.w;
                     }
                 *reinterpret_cast<float4*>(dst + (((int64_t)n * H + oh0 + j) * W + ow) * C + (col0 + col) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                if (STATS) dw_stat_add(st, acc);
             }
+        }
+    }
+    if (STATS) {
+        const bool two = seg_n > 0;
+        if (two && !crossed) { st_a = st; dw_stat_zero(st); }          // everything this thread produced lies in the first segment
+        float* rec = stats + (int64_t)blockIdx.x * C * 4;
+        if (two) {
+            dw_stat_emit(st_a, active, cw, rp, col, col0, C, rec, wl);
+            dw_stat_emit(st, active, cw, rp, col, col0, C, rec + (int64_t)gridDim.x * C * 4, wl);
+        } else {
+            dw_stat_emit(st, active, cw, rp, col, col0, C, rec, wl);
         }
     }
 }
@@ -446,17 +540,35 @@ using namespace suhpe;
 
 extern "C" {
 
-static int dwconv_fwd_impl(const suhpe_conv_t* d, const float* x, const float* w, float* y, const DwXform& xf, suhpe_stream_t stream) {
+// grid of the fast 3x3 forward kernels (shared by the launch and by suhpe_dwconv_fwd_stats_blocks)
+static bool dw_fwd_fast_grid(const suhpe_conv_t* d, bool* s1, int* cw, int* rp, int* gx, int* ny) {
+    if (!(dw_fast(d) && (d->stride == 1 || d->stride == 2))) return false;
+    // the four-row kernel needs enough row groups to fill the chip; small batches keep one output row per thread
+    *s1 = d->stride == 1 && (int64_t)d->n * d->h * d->w * d->cin * 4 < ((int64_t)1 << 31) &&
+          (int64_t)d->n * ((d->h + kDwRows - 1) / kDwRows) * (d->cin / 4) >= 65536;
+    dw_row_grid(d->cin, *s1 ? d->n * ((d->h + kDwRows - 1) / kDwRows) : d->n * d->ho, 4096, cw, rp, gx, ny);
+    return true;
+}
+
+static int dwconv_fwd_impl(const suhpe_conv_t* d, const float* x, const float* w, float* y, const DwXform& xf, suhpe_stream_t stream,
+                           float* stats = nullptr, int seg_n = 0) {
     int rc = dw_check(d, "suhpe_dwconv_fwd");
     if (rc) return rc;
     SUHPE_REQUIRE(x && w && y, "suhpe_dwconv_fwd: null pointer");
     const bool DW_XF_ON = xf.mean != nullptr;
-    if (dw_fast(d) && (d->stride == 1 || d->stride == 2)) {
-        int cw, rp, gx, ny;
-        // the four-row kernel needs enough row groups to fill the chip; small batches keep one output row per thread
-        const bool s1 = d->stride == 1 && (int64_t)d->n * d->h * d->w * d->cin * 4 < ((int64_t)1 << 31) &&
-                        (int64_t)d->n * ((d->h + kDwRows - 1) / kDwRows) * (d->cin / 4) >= 65536;
-        dw_row_grid(d->cin, s1 ? d->n * ((d->h + kDwRows - 1) / kDwRows) : d->n * d->ho, 4096, &cw, &rp, &gx, &ny);
+    bool s1;
+    int cw, rp, gx, ny;
+    if (dw_fwd_fast_grid(d, &s1, &cw, &rp, &gx, &ny)) {
+        if (stats) {
+            SUHPE_REQUIRE(!DW_XF_ON, "suhpe_dwconv_fwd_stats: not combined with the input transform");
+            if (s1)
+                hipLaunchKernelGGL((dw3x3_s1_kernel<false, true>), dim3(gx, ny), dim3(256), 0, as_stream(stream), x, (int64_t)d->n * d->h * d->w * d->cin * 4, w, y,
+                                   d->n, d->h, d->w, d->cin, 0, cw, rp, xf, stats, seg_n);
+            else
+                hipLaunchKernelGGL((dw3x3_row_kernel<false, true>), dim3(gx, ny), dim3(256), 0, as_stream(stream), x, w, y, d->n, d->h, d->w, d->ho, d->wo, d->cin,
+                                   d->stride, 0, cw, rp, xf, stats, seg_n);
+            return check_launch("suhpe_dwconv_fwd_stats");
+        }
         if (s1)
             DW_LAUNCH(dw3x3_s1_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), x, (int64_t)d->n * d->h * d->w * d->cin * 4, w, y,
                                d->n, d->h, d->w, d->cin, 0, cw, rp, xf);
@@ -465,9 +577,10 @@ static int dwconv_fwd_impl(const suhpe_conv_t* d, const float* x, const float* w
                                d->stride, 0, cw, rp, xf);
         return check_launch("suhpe_dwconv_fwd");
     }
+    SUHPE_REQUIRE(!stats, "suhpe_dwconv_fwd_stats: only the 3x3 / pad 1 / stride 1-2 kernels emit statistics (suhpe_dwconv_fwd_stats_blocks returns 0 otherwise)");
     const DwGeom g = dw_geom(d, 0, 2048);
-    const int gx = (int)ceil_div(g.P, g.pix_per_block), ny = (int)ceil_div(g.C / 4, g.cw);
-    DW_LAUNCH(dw_conv_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), g, x, w, y, xf);
+    const int gxg = (int)ceil_div(g.P, g.pix_per_block), nyg = (int)ceil_div(g.C / 4, g.cw);
+    DW_LAUNCH(dw_conv_kernel, dim3(gxg, nyg), dim3(256), 0, as_stream(stream), g, x, w, y, xf);
     return check_launch("suhpe_dwconv_fwd");
 }
 
@@ -475,6 +588,18 @@ static const DwXform kNoXform{nullptr, nullptr, nullptr, nullptr, 0};
 
 int suhpe_dwconv_fwd(const suhpe_conv_t* d, const float* x, const float* w, float* y, suhpe_stream_t stream) {
     return dwconv_fwd_impl(d, x, w, y, kNoXform, stream);
+}
+
+int suhpe_dwconv_fwd_stats_blocks(const suhpe_conv_t* d) {
+    if (!d || dw_check(d, "suhpe_dwconv_fwd_stats_blocks")) return 0;
+    bool s1;
+    int cw, rp, gx, ny;
+    return dw_fwd_fast_grid(d, &s1, &cw, &rp, &gx, &ny) ? gx : 0;
+}
+
+int suhpe_dwconv_fwd_stats(const suhpe_conv_t* d, const float* x, const float* w, float* y, float* stats, int seg_n, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(stats && d && seg_n >= 0 && seg_n < d->n, "suhpe_dwconv_fwd_stats: stats required, 0 <= seg_n < n");
+    return dwconv_fwd_impl(d, x, w, y, kNoXform, stream, stats, seg_n);
 }
 
 int suhpe_dwconv_bnact_fwd(const suhpe_conv_t* d, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,

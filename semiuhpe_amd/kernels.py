@@ -324,6 +324,32 @@ def conv2d_fwd_stats(x, w, stride=1, pad=0, groups=1, seg=None):
     return y, part, tiles
 
 
+def dwconv_stats_blocks(x_shape, w_shape, stride, pad):
+    """record planes' height of the depthwise forward's statistics epilogue (0: this shape has none)"""
+    d = conv_desc(x_shape, w_shape, stride, pad, x_shape[-1])
+    if not (_is_depthwise(d) and d.cin % 4 == 0):
+        return 0
+    return _lib.load().suhpe_dwconv_fwd_stats_blocks(ctypes.byref(d))
+
+
+@_memop
+def dwconv_fwd_stats(x, w, stride=1, pad=1, seg=None):
+    """depthwise forward + BatchNorm statistics records of its output, in conv2d_fwd_stats's result format:
+    (y, part, tiles) or, with seg = samples of the first batch segment, (y, part, tiles, (first-segment records, None))"""
+    _chk(x, "x")
+    c = x.shape[-1]
+    d = conv_desc(x.shape, w.shape, stride, pad, c)
+    blocks = _lib.load().suhpe_dwconv_fwd_stats_blocks(ctypes.byref(d))
+    assert blocks > 0
+    y = torch.empty((d.n, d.ho, d.wo, d.cout), dtype=torch.float32, device=x.device)
+    two = seg is not None and 0 < seg < d.n
+    part = torch.empty((2 if two else 1) * blocks * c * 4, dtype=torch.float32, device=x.device)
+    call("suhpe_dwconv_fwd_stats", ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(part), int(seg) if two else 0)
+    if two:
+        return y, part, 2 * blocks, (blocks, None)
+    return y, part, blocks
+
+
 @_memop
 def bn_stats_from_partials(part, tiles, rows, c, eps, momentum, running_mean=None, running_var=None, nbt=None):
     mean = torch.empty(c, dtype=torch.float32, device=part.device)

@@ -93,14 +93,28 @@ class Conv2d(Layer):
         (with batch segments: (y, (part, tiles, records of the first segment, boundary record)))"""
         if not K.filter_is_physical(self.weight):
             self.weight.data = K.to_filter_layout(self.weight.data)
-        out = K.conv2d_fwd_stats(x, self.weight, self.stride, self.padding, self.groups, seg=_segment_of(x))
+        if self._depthwise():
+            out = K.dwconv_fwd_stats(x, self.weight, self.stride, self.padding, seg=_segment_of(x))
+        else:
+            out = K.conv2d_fwd_stats(x, self.weight, self.stride, self.padding, self.groups, seg=_segment_of(x))
         if tape is not None:
             tape.append(x)
         return out[0], out[1:]
 
+    def _depthwise(self):
+        return self.groups > 1 and self.groups == self.in_channels == self.out_channels
+
     def fuses_stats(self):
-        depthwise = self.groups > 1 and self.groups == self.in_channels == self.out_channels
-        return self.bias is None and not depthwise
+        """dense convs: statistics from the GEMM epilogue; depthwise 3x3 / pad 1 / stride 1-2: from the depthwise kernel's"""
+        if self.bias is not None:
+            return False
+        if not self._depthwise():
+            return True
+        return DW_STATS and self.kernel_size == 3 and self.padding == 1 and self.stride in (1, 2) and self.in_channels % 4 == 0
+
+    def fuses_affine(self):
+        """eval mode without a tape: BatchNorm + activation (+ skip) folded into the GEMM epilogue (dense convs only)"""
+        return self.bias is None and not self._depthwise()
 
     def bwd(self, dy, tape):
         x = tape.pop()
@@ -158,6 +172,7 @@ class Linear(Layer):
 # single-process global-batch BatchNorm exactly; the default is per-rank statistics (standard data-parallel semantics).
 # Set by SSLAgent from config.sync_bn; it implies two separate student passes (no batch segments).
 SYNC_BN = False
+DW_STATS = os.environ.get("SUHPE_DW_STATS", "1") != "0"      # depthwise convs emit their BatchNorm's statistics records themselves
 
 _SEGMENT = None
 SEGMENT_LAUNCHES = os.environ.get("SUHPE_SEGMENT_LAUNCHES", "fused")     # "fused": one launch per kernel for both segments; "split"
@@ -575,7 +590,7 @@ def conv_bn_fwd(conv, bn, x, tape, residual=None, residual_after_act=False, rows
             y, partials = conv.fwd_stats(x, tape)
             return bn.fwd(y, tape, partials=partials, pool=True)
         return bn.fwd(conv.fwd(x, tape), tape, pool=True)
-    if not bn.training and tape is None and conv.fuses_stats() and rowscale is None:
+    if not bn.training and tape is None and conv.fuses_affine() and rowscale is None:
         if not K.filter_is_physical(conv.weight):
             conv.weight.data = K.to_filter_layout(conv.weight.data)
         scale, shift = K.bn_eval_affine(bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps)

@@ -120,10 +120,14 @@ class MBConv(_ResidualBlock):
     def _dw_se_fwd(self, x, tape):
         (conv_d, bn_d), se = self.block[-3], self.block[-2]
         c = bn_d.num_features
-        y = conv_d.fwd(x, tape)
+        partials = None
+        if bn_d.training and conv_d.fuses_stats():
+            y, partials = conv_d.fwd_stats(x, tape)
+        else:
+            y = conv_d.fwd(x, tape)
         hw = y.shape[1] * y.shape[2]
         if bn_d.training:
-            mean, rstd, rows_a = bn_d.train_stats(y)
+            mean, rstd, rows_a = bn_d.train_stats(y, partials)
         else:
             (mean, rstd), rows_a = K.bn_eval_stats(bn_d.running_mean, bn_d.running_var, bn_d.eps), 0
         p = K.bn_act_pool(y, rows_a, c, mean, rstd, bn_d.weight, bn_d.bias, bn_d.act, hw)

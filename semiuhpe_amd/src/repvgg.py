@@ -36,7 +36,7 @@ class RepVGGBlock(Layer):
 
     def fwd(self, x, tape):
         train = self.rbr_dense.bn.training
-        if not train and tape is None and self.rbr_dense.conv.fuses_stats():
+        if not train and tape is None and self.rbr_dense.conv.fuses_affine():
             # eval without a tape (teacher threshold scan, validation, eval.py): the reference's structural re-parameterisation
             # (repvgg.py:104-142) — both conv branches and the identity BatchNorm collapse into ONE 3x3 conv + bias + ReLU;
             # the equivalent filter is rebuilt per call (the weights move every training step), one small kernel

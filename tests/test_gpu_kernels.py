@@ -552,3 +552,43 @@ def test_mbconv_dw_bn_se_section_fused_matches_layerwise(seg, stride, cin, cout)
     E.FUSE_DW_BN_SE = True
     ye1 = blk.fwd(x, None)
     assert rel(ye1, ye0) < 2e-5
+
+
+@pytest.mark.parametrize("n,h,c,stride,seg", [(6, 14, 64, 1, None), (6, 14, 64, 1, 2), (5, 15, 48, 2, 2), (160, 14, 512, 1, 32), (40, 28, 256, 2, 8),
+                                               (3, 7, 1536, 1, 1)])
+def test_dwconv_statistics_epilogue(n, h, c, stride, seg):
+    """suhpe_dwconv_fwd_stats: same output bits as suhpe_dwconv_fwd, and its (S, Q, k, n) records finalise to the BatchNorm
+    statistics (mean, rstd, running statistics) a separate statistics pass over the output gives -- one and two batch segments,
+    the four-row stride-1 kernel (large batches) and the row kernel (small batches, stride 2)."""
+    from semiuhpe_amd import kernels as K
+    g = torch.Generator().manual_seed(n * 100 + c)
+    x = (torch.randn(n, h, h, c, generator=g) * 1.5 + 0.7).cuda()
+    w = torch.randn(c, 1, 3, 3, generator=g).cuda()
+    w = K.to_filter_layout(w)
+    assert K.dwconv_stats_blocks(x.shape, w.shape, stride, 1) > 0
+    y0 = K.conv2d_fwd(x, w, None, stride, 1, c)
+    out = K.dwconv_fwd_stats(x, w, stride, 1, seg=seg)
+    y = out[0]
+    assert torch.equal(y, y0)
+    hw = y.shape[1] * y.shape[2]
+    rm0, rv0 = torch.zeros(c).cuda(), torch.ones(c).cuda()
+    rm1, rv1 = rm0.clone(), rv0.clone()
+    nbt0, nbt1 = torch.zeros((), dtype=torch.long).cuda(), torch.zeros((), dtype=torch.long).cuda()
+    if seg is None:
+        m0, r0 = K.bn_stats(y0, c, 1e-3, 0.1, rm0, rv0, nbt0)
+        m1, r1 = K.bn_stats_from_partials(out[1], out[2], y.numel() // c, c, 1e-3, 0.1, rm1, rv1, nbt1)
+    else:
+        m0, r0 = K.bn_stats_seg(y0, seg * hw, c, 1e-3, 0.1, rm0, rv0, nbt0)
+        first, boundary = out[3]
+        m1, r1 = K.bn_stats_from_partials_seg(out[1], out[2], first, boundary, n * hw, seg * hw, c, 1e-3, 0.1, rm1, rv1, nbt1)
+    ref = y0.double().reshape(n, hw, c)
+    segs = [(0, n)] if seg is None else [(0, seg), (seg, n)]
+    for i, (lo, hi) in enumerate(segs):
+        mu = ref[lo:hi].reshape(-1, c).mean(0)
+        var = ref[lo:hi].reshape(-1, c).var(0, unbiased=False)
+        mm = m1 if seg is None else m1[i]
+        rr = r1 if seg is None else r1[i]
+        assert float((mm.double().cpu() - mu.cpu()).abs().max()) < 2e-6 * max(1.0, float(mu.abs().max()))
+        assert float((rr.double().cpu() * (var.cpu() + 1e-3).sqrt() - 1).abs().max()) < 5e-6
+    assert float((m1 - m0).abs().max()) < 2e-6 * max(1.0, float(m0.abs().max())) and float((r1 / r0 - 1).abs().max()) < 5e-6
+    assert float((rm1 - rm0).abs().max()) < 1e-6 and float((rv1 / rv0 - 1).abs().max()) < 1e-5 and int(nbt1) == int(nbt0)
