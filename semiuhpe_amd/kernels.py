@@ -524,6 +524,27 @@ class deferred_wgrads:
                 torch.cuda.current_stream(side.device).wait_stream(side)
 
 
+def flush_deferred_now():
+    """Inside a deferred_wgrads() region: reduce the split-K slabs collected so far NOW (on the stream the filter-gradient GEMMs
+    run on), so that the gradients of the layers already walked are final -- the bucketed gradient exchange sends a bucket as soon
+    as the backward has left it.  Same per-layer summation order as the flush at the region's end: bit-identical results."""
+    if _DEFER:
+        if _side_used:
+            with torch.cuda.stream(_side_stream(_DEFER[0][0].device)):
+                flush_wgrads(_DEFER)
+        else:
+            flush_wgrads(_DEFER)
+
+
+def backward_streams(device):
+    """the streams gradient kernels of the running backward pass may be on (current stream + the filter-gradient side stream)"""
+    out = [torch.cuda.current_stream(device)]
+    side = _side_streams.get(torch.device(device))
+    if side is not None:
+        out.append(side)
+    return out
+
+
 _flush_ring = []          # pinned staging buffers for the job tables: (table, starts, event), used round-robin
 _flush_turn = 0
 

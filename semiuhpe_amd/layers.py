@@ -39,12 +39,24 @@ def draw_mask(kind, shape, keep, device):
     return K.dropout_mask(tuple(shape), keep, device)
 
 
+# Data-parallel gradient exchange in buckets: when set, called with every gradient buffer a layer is about to accumulate into
+# (SSLAgent points it at distributed.BucketedAllReduce through the buffer's offset in the flat gradient).
+_grad_watch = None
+
+
+def set_grad_watch(fn):
+    global _grad_watch
+    _grad_watch = fn
+
+
 def grad_of(p):
     """The accumulation buffer of a parameter (a view of the flat gradient buffer once the optimiser has
     flattened the model; allocated lazily otherwise)."""
     if p.grad is None:
         p.grad = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=p.device)
         K.fill_(p.grad, 0.0)
+    if _grad_watch is not None:
+        _grad_watch(p.grad)
     return p.grad
 
 

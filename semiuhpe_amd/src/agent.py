@@ -99,18 +99,27 @@ class SSLAgent:
         self._ema_flat = FlatBuffer(list(self.ema_net.parameters()), with_grad=False)
         self.rank, self.world_size = D.world()
         # BatchNorm running statistics of each network as one flat buffer (averaged across ranks once per step)
-        def bn_stats(net):
-            bufs = [b for n, b in net.named_buffers() if b.dtype == torch.float32]
-            return FlatBuffer(bufs, with_grad=False) if bufs else None
-        self._bn_flat, self._bn_flat_ema = bn_stats(self.net), bn_stats(self.ema_net)
+        bufs = [b for net in (self.net, self.ema_net) for n, b in net.named_buffers() if b.dtype == torch.float32]
+        self._bn_flat_all = FlatBuffer(bufs, with_grad=False) if bufs else None
         if self.world_size > 1:                       # identical replicas to start from (rank 0's init)
             for fb in self.optimizer.flat_buffers:
                 D.broadcast_(fb.data, 0)
             D.broadcast_(self._ema_flat.data, 0)
-            for fb in (self._bn_flat, self._bn_flat_ema):
-                if fb is not None:
-                    D.broadcast_(fb.data, 0)
+            if self._bn_flat_all is not None:
+                D.broadcast_(self._bn_flat_all.data, 0)
         self._grad_seed = D.grad_seed(self.device)
+        # gradient exchange in reverse-layer buckets, overlapped with the backward (one stream for RCCL beside the compute
+        # streams); SUHPE_GRAD_BUCKETS=1 (or config.grad_buckets) = one collective after the backward
+        self._buckets = None
+        nb = int(getattr(config, "grad_buckets", os.environ.get("SUHPE_GRAD_BUCKETS", "4")))
+        if self.world_size > 1 and nb > 1 and len(self.optimizer.flat_buffers) == 1:
+            fb = self.optimizer.flat_buffers[0]
+            names = [n for n, _ in self.net.named_parameters()]
+            bounds = D.bucket_boundaries(names, fb.offsets, fb.numel, nb)
+            if len(bounds) > 2:
+                self._buckets = D.BucketedAllReduce(fb.grad, bounds, ready=lambda k: K.flush_deferred_now(),
+                                                    streams=lambda: K.backward_streams(self.device))
+                self._grad_base = fb.grad.data_ptr()
         self._thres_host = None
         self._thres_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._finite_flag = None
@@ -161,6 +170,7 @@ class SSLAgent:
         # The two student passes of a step (labeled batch, strong views) share the weights: run them as one batch whose
         # BatchNorm statistics are kept per segment (layers.batch_segments) -- same arithmetic per sample, larger GEMMs.
         merged = (self.merge_student_passes and ulb_data is not None and not eval_ema and net.training and torch.is_grad_enabled())
+        self._merged_step = merged
         pred_strong = pred_weak = None
         if ulb_data is not None and self.overlap_teacher:
             pred_weak = self._teacher_forward(_dev(ulb_data.get("img"), dev))
@@ -245,15 +255,31 @@ class SSLAgent:
         return fisher_dict, fisher_dict_unsuper
 
     # ------------------------------------------------------------------------------------------------ steps
+    def _watch_grads(self, single_backward):
+        """arm the bucketed exchange for the backward that follows (only when ONE network backward produces the whole gradient:
+        the merged student pass or a supervised step; with two student passes the buckets are complete only after both)"""
+        if self._buckets is None:
+            return
+        self._buckets.begin()
+        if single_backward:
+            base = self._grad_base
+            L.set_grad_watch(lambda g: self._buckets.touched((g.data_ptr() - base) >> 2))
+        else:
+            self._buckets.active = False
+
     def _exchange(self):
-        """The one exchange step of data-parallel training: SUM all-reduce of the flat (pre-scaled) gradient, AVG of the
-        BatchNorm running statistics of student and teacher."""
+        """The exchange step of data-parallel training: SUM all-reduce of the flat (pre-scaled) gradient -- in buckets already
+        under way since the backward left them, see _watch_grads -- and AVG of the BatchNorm running statistics of student and
+        teacher (ONE collective: both networks' buffers live in one flat buffer)."""
         if self.world_size > 1:
-            for fb in self.optimizer.flat_buffers:
-                D.allreduce_sum_(fb.grad)
-            for fb in (self._bn_flat, self._bn_flat_ema):
-                if fb is not None:
-                    D.allreduce_avg_(fb.data)
+            if self._buckets is not None:
+                L.set_grad_watch(None)
+                self._buckets.finish()
+            else:
+                for fb in self.optimizer.flat_buffers:
+                    D.allreduce_sum_(fb.grad)
+            if self._bn_flat_all is not None:
+                D.allreduce_avg_(self._bn_flat_all.data)
 
     def train_func(self, data, ulb_data):
         """one SSL step (reference :194-218)"""
@@ -266,6 +292,7 @@ class SSLAgent:
         SSL_lambda = self.config.SSL_lambda
         loss_all = _Axpby.apply(fisher_dict["loss"].reshape(1), fisher_dict_unsuper["unsuper_loss"].reshape(1),
                                 float(SSL_lambda)).squeeze(0)
+        self._watch_grads(self._merged_step)
         with K.filter_cache(self):                  # transposed filters: one batched launch per step (and shared by both passes)
             loss_all.backward(self._grad_seed)
         self._exchange()
@@ -277,6 +304,7 @@ class SSLAgent:
         _mode(self.net, True)
         self.optimizer.zero_grad()
         fisher_dict, _ = self.forward(data, None)
+        self._watch_grads(True)
         fisher_dict["loss"].backward(self._grad_seed)
         self._exchange()
         self.optimizer.step()

@@ -98,3 +98,92 @@ def gather_values(values, device="cpu"):
 def grad_seed(device):
     """d(loss_all)/d(loss_all) = 1/world: with per-rank mean losses this makes SUM(all-reduce) the global-batch mean."""
     return torch.full((), 1.0 / world()[1], dtype=torch.float32, device=device)
+
+
+# ------------------------------------------------------------------------------------------------ bucketed gradient exchange
+def bucket_boundaries(names, offsets, numel, n_buckets):
+    """Flat-buffer offsets [0 = b0 < b1 < ... < numel] that cut the flat gradient into ~n_buckets buckets of similar size, each
+    cut at the start of a UNIT of the network: a unit is what the parameter names share up to their last leading numeric
+    component ('features.4.2', 'layer3.5', 'layers.1', 'classifier.4'), i.e. a block whose backward has finished before the
+    backward of the block in front of it starts.  Buckets are filled from the END of the buffer (the order the backward runs)."""
+    def unit(name):
+        parts = name.split(".")
+        key = [parts[0]]
+        for q in parts[1:]:
+            if not q.isdigit():
+                break
+            key.append(q)
+        return tuple(key)
+
+    starts, last = [], None
+    for name, off in zip(names, offsets):
+        u = unit(name)
+        if u != last:
+            starts.append(off)
+            last = u
+    target = max(1, numel // max(1, n_buckets))
+    cuts, hi = [], numel
+    for st in reversed(starts):
+        if st > 0 and hi - st >= target:
+            cuts.append(st)
+            hi = st
+    return [0] + sorted(cuts) + [numel]
+
+
+class BucketedAllReduce:
+    """SUM all-reduce of one flat gradient buffer in reverse-layer buckets, each issued as soon as the backward has moved past
+    it, so that the exchange over xGMI runs under the rest of the backward.
+
+    `touched(offset)` is called (semiuhpe_amd.layers.grad_of) with the flat offset of every gradient slice a layer is about to
+    accumulate into.  The backward visits the units of a network back to front, so the first touch below a bucket's start means
+    every kernel that writes into that bucket has been enqueued: `ready(k)` lets the owner flush what it defers (the split-K
+    slab reduction of the filter gradients), then bucket k's collective is enqueued on a communication stream behind the
+    compute streams.  `finish()` sends what is left (bucket 0 at least) and joins.  Elementwise sums do not depend on how the
+    buffer is cut: results are bit-identical to ONE all-reduce of the whole buffer (tests/test_distributed_cpu.py)."""
+
+    def __init__(self, flat, boundaries, ready=None, streams=None):
+        self.flat, self.bounds = flat, list(boundaries)
+        self.ready = ready                      # callback(k) before bucket k is sent (flush deferred work)
+        self.streams = streams                  # callable -> compute streams the collective has to wait for (CUDA only)
+        self.comm = None
+        self.begin()
+
+    def begin(self):
+        self.next = len(self.bounds) - 2        # highest bucket not yet sent
+        self.handles = []
+        self.active = True
+
+    def _send(self, k):
+        if self.ready is not None:
+            self.ready(k)
+        view = self.flat[self.bounds[k]:self.bounds[k + 1]]
+        if self.flat.is_cuda:
+            if self.comm is None:
+                self.comm = torch.cuda.Stream(device=self.flat.device)
+            for st in (self.streams() if self.streams else [torch.cuda.current_stream(self.flat.device)]):
+                self.comm.wait_stream(st)
+            with torch.cuda.stream(self.comm):
+                self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+
+    def touched(self, offset):
+        """a layer is about to write gradients at flat offset `offset`"""
+        while self.active and self.next > 0 and offset < self.bounds[self.next]:
+            self._send(self.next)
+            self.next -= 1
+
+    def finish(self):
+        while self.next >= 0:
+            self._send(self.next)
+            self.next -= 1
+        if self.flat.is_cuda and self.comm is not None:
+            with torch.cuda.stream(self.comm):
+                for h in self.handles:
+                    h.wait()
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.comm)
+        else:
+            for h in self.handles:
+                h.wait()
+        self.handles = []
+        self.active = False
