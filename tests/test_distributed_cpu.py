@@ -67,3 +67,53 @@ def test_two_rank_exchange():
     assert r0["mine"] == [[0, 1, 2], [20, 21, 22], [40, 41, 42]] and r1["mine"] == [[10, 11, 12], [30, 31, 32]]
     whole = np.sort(np.concatenate([np.arange(3) + 10 * i for i in range(5)]).astype(np.float64))
     assert np.array_equal(np.sort(r0["pooled"]), whole) and np.array_equal(r0["pooled"], r1["pooled"])
+
+
+def _bucket_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from semiuhpe_amd.src import distributed as D
+    D.init_from_env("gloo")
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(10_000, generator=g)
+    whole = flat.clone()
+    D.allreduce_sum_(whole)                                     # today's single collective
+    names = [f"features.{i // 3}.{i % 3}.block.0.weight" for i in range(12)] + ["classifier.1.weight", "classifier.4.weight"]
+    sizes = [500] * 12 + [3000, 1000]
+    offsets = [sum(sizes[:i]) for i in range(len(sizes))]
+    bounds = D.bucket_boundaries(names, offsets, 10_000, 4)
+    sent = []
+    br = D.BucketedAllReduce(flat, bounds, ready=lambda k: sent.append(k))
+    br.begin()
+    for off in reversed(offsets):                               # the backward touches the units back to front
+        br.touched(off)
+    in_flight = list(sent)
+    br.finish()
+    out[rank] = dict(whole=whole.numpy(), bucketed=flat.numpy(), bounds=bounds, in_flight=in_flight, sent=sent)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_is_bit_identical_and_early():
+    """reverse-layer buckets: cut at unit starts, sent as soon as the backward has left them, same bits as one collective"""
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_bucket_worker, args=(world, port, out), nprocs=world, join=True)
+    r0, r1 = out[0], out[1]
+    assert np.array_equal(r0["bucketed"], r0["whole"]) and np.array_equal(r1["bucketed"], r0["whole"])
+    b = r0["bounds"]
+    assert b[0] == 0 and b[-1] == 10_000 and b == sorted(b) and len(b) >= 4
+    assert all(x % 500 == 0 for x in b[1:-1])                   # cut at unit (parameter-block) starts only
+    assert r0["sent"] == list(range(len(b) - 2, -1, -1))        # back to front, every bucket once
+    assert len(r0["in_flight"]) == len(b) - 2                   # all but the first bucket were sent before finish()
+
+
+def test_bucket_boundaries_follow_network_units():
+    from semiuhpe_amd.src.distributed import bucket_boundaries
+    names = ["features.0.0.weight", "features.0.1.weight", "features.1.0.block.0.0.weight", "features.1.0.block.0.1.weight",
+             "features.1.1.block.0.0.weight", "layers.1.blocks.0.attn.qkv.weight", "layers.1.blocks.1.mlp.fc1.weight", "head.1.weight"]
+    offs = [0, 10, 20, 40, 60, 100, 140, 180]
+    b = bucket_boundaries(names, offs, 200, 3)
+    assert b[0] == 0 and b[-1] == 200
+    assert set(b[1:-1]) <= {10, 20, 60, 100, 180}               # never inside features.1.0 (40) nor inside layers.1 (140)
+    assert bucket_boundaries(names, offs, 200, 1) == [0, 200]

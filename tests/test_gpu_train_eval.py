@@ -143,3 +143,28 @@ def test_bench_two_ranks_over_rccl():
         env.pop(k, None)
     out = _bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2"], env)
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 320
+
+
+def test_bucketed_exchange_bit_identical(tmp_path):
+    """Two data-parallel ranks (gloo rehearsal on one GPU): the gradient exchange in reverse-layer buckets, issued while the
+    backward is still running, gives the SAME BITS as one all-reduce after the backward (SUHPE_GRAD_BUCKETS=1), and both ranks
+    hold identical parameters, teacher and BatchNorm buffers after two SSL steps + one supervised step."""
+    import subprocess
+    res = {}
+    for mode in ("4", "1"):
+        out = tmp_path / f"b{mode}"
+        out.mkdir()
+        env = dict(os.environ, SUHPE_GRAD_BUCKETS=mode, SUHPE_AUTOTUNE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29547", os.path.join(ROOT, "tests", "ddp_worker.py"), str(out)]
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        res[mode] = [torch.load(out / f"rank{k}.pt") for k in range(2)]
+    assert res["4"][0]["buckets"] is not None and len(res["4"][0]["buckets"]) >= 4 and res["1"][0]["buckets"] is None
+    for mode in res:
+        a, b = res[mode]
+        for k in ("params", "grads", "ema", "bn"):
+            assert torch.equal(a[k], b[k]), (mode, k)               # replicas stay identical
+    for k in ("params", "grads", "ema", "bn"):
+        assert torch.equal(res["4"][0][k], res["1"][0][k]), k       # bucketing does not change a bit
+    assert float(res["4"][0]["grads"].abs().max()) > 0
