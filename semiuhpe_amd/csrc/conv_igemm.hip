@@ -953,6 +953,8 @@ static GatherGeom make_geom(int N, int GH, int GW, int OH, int OW, int ldg, int 
     return g;
 }
 
+#include "conv_halo.inl"
+
 // fast-path selector: 1 = pointwise, 2 = affine taps, 3 = parity class of a strided dgrad, 0 = generic
 static int nt_mode(const GatherGeom& g) {
     if (g.om > 1) return 3;
@@ -988,11 +990,15 @@ static void launch_nt(const NtParams& p_in, int groups, hipStream_t st) {
 // first time a shape is seen).  Unpinned shapes use the heuristics below.
 // NT_P*: the persistent pointwise kernel (gemm_nt_persistent); on a shape that is not a plain GEMM (3x3, strided) a pinned
 // NT_P* tile falls back to the igemm tile of the same size
-enum NtTile { NT_64x64_S = 0, NT_64x64, NT_128x32, NT_128x128, NT_128x64, NT_256x32, NT_P64x64, NT_P128x32, NT_P128x64, NT_P128x128, NT_TILES };
+// NT_H*: the 3x3 / stride 1 halo-tile kernel (conv_halo.inl); on any other geometry a pinned NT_H* tile runs the igemm tile of the same size
+enum NtTile { NT_64x64_S = 0, NT_64x64, NT_128x32, NT_128x128, NT_128x64, NT_256x32, NT_P64x64, NT_P128x32, NT_P128x64, NT_P128x128,
+              NT_H64x64, NT_H128x32, NT_H128x64, NT_H128x128, NT_TILES };
 static const char* kNtNames[] = {"igemm_nt_kernel<64,64,32,32,1>", "igemm_nt_kernel<64,64,32,32,4>", "igemm_nt_kernel<128,32,32,32,4>",
                                  "igemm_nt_kernel<128,128,64,32,4>", "igemm_nt_kernel<128,64,32,32,4>", "igemm_nt_kernel<256,32,64,32,4>",
                                  "gemm_nt_persistent<64,64,32,32>", "gemm_nt_persistent<128,32,32,32>", "gemm_nt_persistent<128,64,32,32>",
-                                 "gemm_nt_persistent<128,128,64,32>"};
+                                 "gemm_nt_persistent<128,128,64,32>",
+                                 "igemm_nt3x3_kernel<64,64,32,32>", "igemm_nt3x3_kernel<128,32,32,32>", "igemm_nt3x3_kernel<128,64,32,32>",
+                                 "igemm_nt3x3_kernel<128,128,64,32>"};
 
 struct TnTile { int bm, bn; const char* name; };
 static const TnTile kTnTiles[] = {
@@ -1024,9 +1030,11 @@ static int pinned_tile(const suhpe_conv_t* d, int pass) {
     return it == tile_table().end() ? -1 : it->second;
 }
 
-static NtTile choose_nt(int64_t M, int ng, bool vec4, int pinned) {
+static const bool kHaloDefault = !(getenv("SUHPE_HALO") && atoi(getenv("SUHPE_HALO")) == 0);   // SUHPE_HALO=0: heuristics never pick the halo kernel
+static NtTile choose_nt(int64_t M, int ng, bool vec4, int pinned, bool halo = false) {
     if (!vec4) return NT_64x64_S;
     if (pinned >= 1 && pinned < (int)NT_TILES) return (NtTile)pinned;
+    if (halo && kHaloDefault && M >= 8192) return ng <= 32 ? NT_H128x32 : ((ng % 128 == 0 || ng > 256) ? NT_H128x128 : NT_H128x64);
     if (M < 2048) return ng > 32 ? NT_64x64 : NT_128x32;     // small row counts (Linear, SE): more, smaller tiles
     if (ng <= 32) return NT_256x32;                           // narrow outputs are operand-bandwidth bound anyway
     // measured on the EfficientNetV2-S / RepVGG layer shapes: 128x64 (8 waves of 32x32) wins or ties nearly everywhere
@@ -1034,7 +1042,9 @@ static NtTile choose_nt(int64_t M, int ng, bool vec4, int pinned) {
     return ceil_div(M, 128) * ceil_div(ng, 64) >= 512 ? NT_128x64 : NT_64x64;
 }
 
-static int nt_tile_bm(NtTile t) { return (t == NT_64x64_S || t == NT_64x64 || t == NT_P64x64) ? 64 : (t == NT_256x32 ? 256 : 128); }
+static int nt_tile_bm(NtTile t) { return (t == NT_64x64_S || t == NT_64x64 || t == NT_P64x64 || t == NT_H64x64) ? 64 : (t == NT_256x32 ? 256 : 128); }
+// the halo kernel runs 3x3 / stride 1 / pad 1 forward and input-gradient GEMMs whose channel counts chunk evenly
+static bool halo_ok(const GatherGeom& g, bool vec4) { return vec4 && halo_capable(g, 128) && halo_capable(g, 64); }
 
 template <int BM, int BN, int WM, int WN>
 static void launch_persistent(const NtParams& p_in, int groups, hipStream_t st) {
@@ -1060,13 +1070,27 @@ static void launch_persistent(const NtParams& p_in, int groups, hipStream_t st) 
 }
 
 // a pinned persistent tile on a shape that is not a plain GEMM runs the igemm tile of the same size
-static NtTile effective_nt(NtTile tile, bool plain) {
+static NtTile effective_nt(NtTile tile, bool plain, bool halo = false) {
+    if (tile >= NT_H64x64) {
+        if (halo) return tile;
+        return tile == NT_H64x64 ? NT_64x64 : (tile == NT_H128x32 ? NT_128x32 : (tile == NT_H128x64 ? NT_128x64 : NT_128x128));
+    }
     if (tile < NT_P64x64 || plain) return tile;
     return tile == NT_P64x64 ? NT_64x64 : (tile == NT_P128x32 ? NT_128x32 : (tile == NT_P128x64 ? NT_128x64 : NT_128x128));
 }
 
 static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st, int pinned) {
-    NtTile tile = choose_nt(p.g.M, p.Ng, vec4, pinned);
+    NtTile tile = choose_nt(p.g.M, p.Ng, vec4, pinned, halo_ok(p.g, vec4));
+    if (tile >= NT_H64x64) {
+        bool done = false;
+        switch (tile) {
+            case NT_H64x64: done = launch_halo<64, 64, 32, 32>(p, groups, st); tile = NT_64x64; break;
+            case NT_H128x32: done = launch_halo<128, 32, 32, 32>(p, groups, st); tile = NT_128x32; break;
+            case NT_H128x64: done = launch_halo<128, 64, 32, 32>(p, groups, st); tile = NT_128x64; break;
+            default: done = launch_halo<128, 128, 64, 32>(p, groups, st); tile = NT_128x128; break;
+        }
+        if (done) return;                                   // otherwise: the igemm tile of the same size (same row-tile height)
+    }
     if (tile >= NT_P64x64) {
         const bool plain = nt_mode(p.g) == 1 && p.g.M < (1LL << 31);
         if (plain) {
@@ -1088,6 +1112,14 @@ static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st
         case NT_256x32: launch_nt<256, 32, 64, 32, 4>(p, groups, st); break;
         default: break;
     }
+}
+
+// halo-kernel capability of a (descriptor, pass): pass 0 = forward, 1 = input gradient
+static bool halo_ok_desc(const suhpe_conv_t* d, int pass) {
+    if (!d || d->groups <= 0 || pass > 1 || d->stride != 1) return false;
+    const int cg = d->cin / d->groups, ng = d->cout / d->groups;
+    if (pass == 0) return halo_ok(make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0), cg % 4 == 0 && d->cin % 4 == 0);
+    return halo_ok(make_geom(d->n, d->ho, d->wo, d->h, d->w, d->cout, ng, d->r, d->s, d->stride, d->pad, 1), ng % 4 == 0 && d->cout % 4 == 0);
 }
 
 // wgrad (rows = cout, columns = k'): both extents pad; cost = padded area / measured relative efficiency
@@ -1147,13 +1179,13 @@ int suhpe_conv2d_fwd_stats_tiles(const suhpe_conv_t* d) {
     if (!d || d->groups <= 0) return 0;
     const int cg = d->cin / d->groups, ng = d->cout / d->groups;
     const int64_t M = (int64_t)d->n * d->ho * d->wo;
-    return (int)ceil_div(M, nt_tile_bm(choose_nt(M, ng, cg % 4 == 0 && d->cin % 4 == 0, pinned_tile(d, 0))));
+    return (int)ceil_div(M, nt_tile_bm(choose_nt(M, ng, cg % 4 == 0 && d->cin % 4 == 0, pinned_tile(d, 0), halo_ok_desc(d, 0))));
 }
 
 int suhpe_conv2d_fwd_stats_tile_rows(const suhpe_conv_t* d) {
     if (!d || d->groups <= 0) return 0;
     const int cg = d->cin / d->groups, ng = d->cout / d->groups;
-    return nt_tile_bm(choose_nt((int64_t)d->n * d->ho * d->wo, ng, cg % 4 == 0 && d->cin % 4 == 0, pinned_tile(d, 0)));
+    return nt_tile_bm(choose_nt((int64_t)d->n * d->ho * d->wo, ng, cg % 4 == 0 && d->cin % 4 == 0, pinned_tile(d, 0), halo_ok_desc(d, 0)));
 }
 
 static int conv2d_fwd_stats_impl(const suhpe_conv_t* d, const float* x, const float* w, float* y, float* stats, float* stats_extra,
@@ -1278,6 +1310,7 @@ int suhpe_conv2d_set_tile(const suhpe_conv_t* d, int pass, int tile) {
     const int ng = d->cout / d->groups, cg = d->cin / d->groups;
     const bool v4 = ng % 4 == 0 && d->cout % 4 == 0 && cg % 4 == 0 && d->cin % 4 == 0;
     SUHPE_REQUIRE(tile < 0 || (v4 && !(pass != 2 && tile == (int)NT_64x64_S)), "suhpe_conv2d_set_tile: the vector tiles need channel counts that are multiples of 4");
+    SUHPE_REQUIRE(pass == 2 || tile < (int)NT_H64x64 || halo_ok_desc(d, pass), "suhpe_conv2d_set_tile: the halo tiles need a 3x3 / stride 1 / pad 1 conv with evenly chunked channels");
     std::lock_guard<std::mutex> lock(tile_mutex());
     if (tile < 0) tile_table().erase(tile_key(d, pass));
     else tile_table()[tile_key(d, pass)] = tile;
@@ -1288,10 +1321,10 @@ const char* suhpe_conv2d_kernel_name(const suhpe_conv_t* d, int pass) {
     if (!d || d->groups <= 0) return "";
     const int ng = d->cout / d->groups, cg = d->cin / d->groups;
     const bool plain = d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0;
-    if (pass == 0) return kNtNames[effective_nt(choose_nt((int64_t)d->n * d->ho * d->wo, ng, cg % 4 == 0 && d->cin % 4 == 0, pinned_tile(d, 0)), plain)];
+    if (pass == 0) return kNtNames[effective_nt(choose_nt((int64_t)d->n * d->ho * d->wo, ng, cg % 4 == 0 && d->cin % 4 == 0, pinned_tile(d, 0), halo_ok_desc(d, 0)), plain, halo_ok_desc(d, 0))];
     if (pass == 1) {
         const int st = d->stride;
-        return kNtNames[effective_nt(choose_nt((int64_t)d->n * ((d->h + st - 1) / st) * ((d->w + st - 1) / st), cg, ng % 4 == 0 && d->cout % 4 == 0, pinned_tile(d, 1)), plain)];
+        return kNtNames[effective_nt(choose_nt((int64_t)d->n * ((d->h + st - 1) / st) * ((d->w + st - 1) / st), cg, ng % 4 == 0 && d->cout % 4 == 0, pinned_tile(d, 1), halo_ok_desc(d, 1)), plain, halo_ok_desc(d, 1))];
     }
     const bool va = ng % 4 == 0 && d->cout % 4 == 0, vb = cg % 4 == 0 && d->cin % 4 == 0;
     if (!(va && vb)) return va ? "igemm_tn_kernel<64,64,32,32,4,1>" : (vb ? "igemm_tn_kernel<64,64,32,32,1,4>" : "igemm_tn_kernel<64,64,32,32,1,1>");
