@@ -378,7 +378,7 @@ static bool halo_geom(const GatherGeom& g, int BM, int CC, HaloGeom* hg) {
         if (CC != 32) return false;
         h.P = g.OW + 2;
         const int pix_rows = (BM - 1) / g.OW + 2;                            // image rows a run of BM pixels can touch
-        const int zero_rows = (BM - 1) / (g.OW * g.OH) + 2;                  // zero rows between the images it spans
+        const int zero_rows = (BM - 1) / (g.OW * g.OH) + 1;                  // zero rows between the images it spans
         h.rows_cov = pix_rows + zero_rows + 2;
         h.nslots = h.rows_cov * h.P;
         if (h.nslots > 288) return false;

@@ -603,7 +603,7 @@ def test_dwconv_statistics_epilogue(n, h, c, stride, seg):
 
 
 HALO_SHAPES = [(3, 48, 192, 1, 56, 56), (2, 24, 24, 1, 112, 112), (5, 64, 256, 1, 28, 28), (9, 128, 128, 2, 14, 14), (70, 64, 64, 1, 7, 7),
-               (3, 96, 40, 1, 16, 24), (2, 192, 48, 1, 56, 56), (33, 256, 256, 2, 14, 14)]
+               (3, 96, 160, 1, 16, 24), (2, 192, 48, 1, 56, 56), (33, 256, 256, 2, 14, 14)]
 
 
 @pytest.mark.parametrize("cfg", HALO_SHAPES, ids=str)
