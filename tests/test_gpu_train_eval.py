@@ -168,3 +168,63 @@ def test_bucketed_exchange_bit_identical(tmp_path):
     for k in ("params", "grads", "ema", "bn"):
         assert torch.equal(res["4"][0][k], res["1"][0][k]), k       # bucketing does not change a bit
     assert float(res["4"][0]["grads"].abs().max()) > 0
+
+
+@pytest.mark.parametrize("network", ["effinetv2", "repvgg"])
+def test_foreign_checkpoint_loads_and_evaluates(tmp_path, network):
+    """A checkpoint written the way the REFERENCE writes it (src/agent.py:302-331: plain torch modules -- torchvision / RepVGG key
+    order, NCHW-contiguous filters, torch.optim.Adam's state) loads through SSLAgent.load_ckpt and evaluates to the oracle's
+    rotation matrices (the released *.pth files are not available offline; this is their format, produced by the oracle modules)."""
+    from types import SimpleNamespace
+
+    from oracle import fisher as OF
+    from oracle import networks as ON
+    from parity_utils import seeded_state_dict
+    from semiuhpe_amd.src.agent import SSLAgent
+    torch.manual_seed(5)
+    make = {"effinetv2": ON.EfficientNetV2S, "repvgg": ON.RepVggNet}[network]
+    net, ema = make(), make()
+    if network == "repvgg":
+        net.load_state_dict(seeded_state_dict(net.state_dict(), 31))
+    else:
+        for m in net.classifier:
+            if isinstance(m, torch.nn.Linear):
+                m.weight.data.mul_(20.0)
+    ema.load_state_dict(net.state_dict())
+    with torch.no_grad():
+        for p in ema.parameters():
+            p.mul_(0.99)
+    opt = torch.optim.Adam(net.parameters(), 1e-4)
+    x = torch.randn(4, 3, 96, 96)
+    net.train()
+    net(x).square().mean().backward()
+    opt.step()                                                   # Adam state with step = 1 and real moments
+    assert all(v.is_contiguous() for v in net.state_dict().values())
+    path = str(tmp_path / "foreign-best.pth")
+    torch.save({"clock": {"epoch": 3, "minibatch": 7, "iteration": 1234}, "model_state_dict": net.state_dict(),
+                "model_state_dict_ema": ema.state_dict(), "optimizer_state_dict": opt.state_dict()}, path)
+    cfg = SimpleNamespace(lr=1e-4, log_dir=str(tmp_path), model_dir=str(tmp_path), distribution="matrixFisher", is_full_range=network == "repvgg",
+                          rotate_aug=False, train_labeled="DAD3DHeads" if network == "repvgg" else "300WLP", train_unlabeled="300WLP",
+                          cutout_aug=False, cutmix_aug=False, conf_thres=1e9, type_unsuper="ce", SSL_lambda=1.0, is_ema=True, ema_decay=0.999,
+                          eman=False, stage1_iteration=0, network=network, num_classes=9, exp_name="t", date="t", left_ratio=0.95,
+                          save_feat=False, autotune=False)
+    agent = SSLAgent(cfg)
+    agent.load_ckpt(path)
+    assert agent.clock.iteration == 1234 and agent.clock.epoch == 3
+    fb = agent.optimizer.flat_buffers[0]
+    assert fb.step == 1
+    st = opt.state_dict()["state"]
+    for i, p in enumerate(fb.params):
+        assert torch.equal(fb.view_like(fb.exp_avg, i).cpu(), st[i]["exp_avg"]), i
+    net.eval(); ema.eval()
+    xe = torch.randn(6, 3, 96, 96, generator=torch.Generator().manual_seed(8))
+    with torch.no_grad():
+        for ref, hip in ((net, agent.net), (ema, agent.ema_net)):
+            hip.eval()
+            a_ref, a = ref(xe), hip(xe.cuda())
+            assert float((a.cpu() - a_ref).abs().max()) < 2e-4 * max(1.0, float(a_ref.abs().max()))
+            R_ref = OF.batch_torch_A_to_R(a_ref)
+            from semiuhpe_amd import kernels as K
+            assert float((K.fisher_svd_project(a).cpu() - R_ref).abs().max()) < 1e-4
+    # and the state dict written back has the reference's keys in the reference's order
+    assert list(agent.net.state_dict().keys()) == list(net.state_dict().keys())
