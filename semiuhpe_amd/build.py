@@ -25,7 +25,7 @@ def _hipcc():
 
 
 def _newest_header():
-    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inl"))]
     hs.append(os.path.join(HERE, "..", "include", "suhpe.h"))
     return max(os.path.getmtime(h) for h in hs)
 
@@ -54,7 +54,7 @@ def build(force=False, verbose=True):
         with ThreadPoolExecutor(max_workers=4) as ex:
             list(ex.map(compile_one, jobs))
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in srcs]
-    if jobs or not os.path.exists(LIB):
+    if jobs or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
