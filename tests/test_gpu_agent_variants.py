@@ -64,6 +64,12 @@ def _pair(seed=23, **kw):
         sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
     else:
         sd0 = seeded_state_dict(make().state_dict(), seed)
+        if cfg_o.network == "tinyvit":
+            # well-conditioned outputs: A = diag(4, 2.5, 1.5) + O(0.7) noise.  With the seeded head alone some samples come out with a
+            # singular value ~ 0.05 (det A ~ 0): the proper SVD and its backward are then so sensitive that the 4e-4 forward difference
+            # between two fp32 implementations shows up as percents in every gradient (tools/debug/tinyvit_agent_bisect.py)
+            sd0["head.7.weight"] = sd0["head.7.weight"] * 0.35
+            sd0["head.7.bias"] = torch.tensor([4.0, 0, 0, 0, 2.5, 0, 0, 0, 1.5])
 
     def factory():
         m = make()
