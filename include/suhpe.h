@@ -118,6 +118,21 @@ int suhpe_conv2d_fwd_stats_seg(const suhpe_conv_t* d, const float* x, const floa
 int suhpe_conv2d_tile_count(int pass);
 const char* suhpe_conv2d_tile_name(int pass, int tile);
 int suhpe_conv2d_set_tile(const suhpe_conv_t* d, int pass, int tile);
+/* Pointwise conv whose INPUT is act(BN(x)) [* per-sample scale] of a tensor x that was never normalised in memory: the loader of
+ * the GEMM applies  a <- act(a * a_scale[s][k] + a_shift[s][k]) * a_rowscale[row / a_hw][k]  while it stages the operand
+ * (s = batch segment of the row: rows < seg_row -> 0; a_rowscale (n, cin) may be NULL).  Used for torchvision's
+ * FusedMBConv (3x3 expand -> BatchNorm -> SiLU -> [1x1 project]) and MBConv (depthwise -> BatchNorm -> SiLU -> SqueezeExcitation
+ * scale -> [1x1 project]) blocks (reference src/networks.py:303): the activated / excited tensor is neither written nor read.
+ * a_scale / a_shift [segments][cin] come from suhpe_bn_affine_from_stats.  The forward also emits the BatchNorm statistics records
+ * of its OUTPUT like suhpe_conv2d_fwd_stats(_seg) (stats may be NULL); the filter gradient recomputes the same input from x. */
+int suhpe_bn_affine_from_stats(const float* mean, const float* rstd, const float* gamma, const float* beta, int segments, int c,
+                               float* scale, float* shift, suhpe_stream_t stream);
+int suhpe_conv2d_fwd_stats_xf(const suhpe_conv_t* d, const float* x, const float* w, float* y, float* stats, float* stats_extra,
+                              int64_t seg_row, const float* a_scale, const float* a_shift, const float* a_rowscale, int a_act, int a_hw,
+                              suhpe_stream_t stream);
+int suhpe_conv2d_wgrad_partial_xf(const suhpe_conv_t* d, const float* x, const float* dy, void* workspace, int64_t workspace_bytes,
+                                  const float* a_scale, const float* a_shift, const float* a_rowscale, int a_act, int a_hw,
+                                  int64_t seg_row, suhpe_stream_t stream);
 /* input gradient; wt is the transposed+flipped filter made by suhpe_conv2d_transpose_filter */
 int suhpe_conv2d_dgrad(const suhpe_conv_t* d, const float* dy, const float* wt, float* dx, suhpe_stream_t stream);
 int suhpe_conv2d_transpose_filter(const suhpe_conv_t* d, const float* w, float* wt, suhpe_stream_t stream);

@@ -95,6 +95,16 @@ struct NtParams {
                          // that contains the boundary emits its first-segment rows to `stats` and the rest to `stats_extra`
     int stat_cout;       // channels of the whole output (record pitch)
     int stat_gx;         // row tiles = ceil(M / BM)
+    // optional transform of the GATHERED operand while it is staged (pointwise GEMMs only, XF instantiations):
+    //   a[m][k] <- act(a[m][k] * a_scale[s][k] + a_shift[s][k]) * a_rowscale[m / a_hw][k]      (s = segment of row m, a_rowscale may be NULL)
+    // i.e. the producer's BatchNorm + activation (+ SqueezeExcitation scale) applied by the consumer's loader: the activated
+    // tensor is never written to or read from HBM (a_scale / a_shift are [segments][K] as suhpe_bn_affine_from_stats writes them)
+    const float* a_scale = nullptr;
+    const float* a_shift = nullptr;
+    const float* a_rowscale = nullptr;
+    int a_act = 0, a_hw = 1;
+    int64_t a_seg_row = 0;
+    unsigned a_div_mul = 0, a_div_shr = 0;
 };
 
 // ---------------------------------------------------------------------------------------------- igemm_nt
@@ -103,7 +113,7 @@ struct NtParams {
 // MODE 2: affine taps, coordinate = o*gm + sgn*tap + off (forward with any stride, dgrad with stride 1)
 // In every mode the tap of a thread's k advances incrementally (no division in the k loop), addresses are 32-bit
 // element offsets from a uniform base, and out-of-range taps are predicated (offset 0, value zeroed): no branches.
-template <int BM, int BN, int WM, int WN, int VEC, int MODE, bool AFF = false>
+template <int BM, int BN, int WM, int WN, int VEC, int MODE, bool AFF = false, bool XF = false>
 // The second launch bound (minimum waves per SIMD) caps the register budget: left alone the compiler spends 88-148 VGPRs on
 // prefetch depth, which leaves 2 workgroups (or 1, for the wgrad kernel) per CU; at <= 80 VGPRs three 8-wave workgroups are
 // resident and the MFMA pipe sees 6 waves per SIMD.
@@ -175,6 +185,26 @@ void igemm_nt_kernel(const NtParams p) {
             a_pix[i] = -1;
         }
     }
+    // ---- input transform (XF): which statistics segment the tile's rows use, and each row's sample for the per-sample scale
+    int xf_tile_seg = 0;                                     // 0 / 1: every row of the tile in that segment, 2: the tile straddles the boundary
+    bool xf_row_seg[XF ? A_ROWS : 1];
+    int xf_row_n[XF ? A_ROWS : 1];
+    BufRsrc xf_sr = xr, xf_hr = xr, xf_rr = xr;
+    if (XF) {
+        if (p.a_seg_row > 0) xf_tile_seg = m0 + BM <= p.a_seg_row ? 0 : (m0 >= p.a_seg_row ? 1 : 2);
+        const int64_t seg_bytes = (int64_t)(p.a_seg_row > 0 ? 2 : 1) * g.K * 4;
+        xf_sr = make_rsrc(p.a_scale, seg_bytes);
+        xf_hr = make_rsrc(p.a_shift, seg_bytes);
+        if (p.a_rowscale) xf_rr = make_rsrc(p.a_rowscale, (int64_t)((g.M + p.a_hw - 1) / p.a_hw) * g.K * 4);
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+            const int64_t m = m0 + lrow + i * ROW_STEP;
+            xf_row_seg[i] = p.a_seg_row > 0 && m >= p.a_seg_row;
+            xf_row_n[i] = (int)fast_div((unsigned)(m < g.M ? m : g.M - 1), p.a_div_mul, p.a_div_shr);
+        }
+    }
+    float xf_sc[2][2][VEC], xf_sh[2][2][VEC], xf_rs[2][XF ? A_ROWS : 1][VEC];
+
     // this thread's position in the reduction: k = tap*Cg + ci, tap = (r, s); advanced by BK per tile
     int kk = lcol, ci = lcol, tr = 0, ts = 0;
     if (MODE != 1 && g.R * g.S > 1) { const int tap = kk / g.Cg; ci = kk - tap * g.Cg; tr = tap / g.S; ts = tap - tr * g.S; }
@@ -218,6 +248,21 @@ void igemm_nt_kernel(const NtParams p) {
             const bool ok = kvalid & (b_off[i] >= 0);
             buf_load<VEC>(fr, ok ? ((unsigned)b_off[i] + (unsigned)fk) * 4u : kOob, b_reg[i]);
         }
+        if (XF) {                                            // scale / shift of this slab's k columns (both segments in a straddling tile)
+            constexpr int st = decltype(stage)::value;
+            const unsigned k4 = kvalid ? (unsigned)kk * 4u : kOob;
+            const unsigned seg0 = xf_tile_seg == 1 ? (unsigned)g.K * 4u : 0u;
+            buf_load<VEC>(xf_sr, kvalid ? seg0 + k4 : kOob, xf_sc[st][0]);
+            buf_load<VEC>(xf_hr, kvalid ? seg0 + k4 : kOob, xf_sh[st][0]);
+            if (xf_tile_seg == 2) {
+                buf_load<VEC>(xf_sr, kvalid ? (unsigned)g.K * 4u + k4 : kOob, xf_sc[st][1]);
+                buf_load<VEC>(xf_hr, kvalid ? (unsigned)g.K * 4u + k4 : kOob, xf_sh[st][1]);
+            }
+            if (p.a_rowscale) {
+#pragma unroll
+                for (int i = 0; i < A_ROWS; ++i) buf_load<VEC>(xf_rr, kvalid ? ((unsigned)xf_row_n[i] * (unsigned)g.K + (unsigned)kk) * 4u : kOob, xf_rs[st][i]);
+            }
+        }
         // advance to the next tile
         kk += BK;
         ci += BK;
@@ -228,6 +273,21 @@ void igemm_nt_kernel(const NtParams p) {
     auto store_tiles = [&](auto stage) {
         auto& a_reg = a_stage[decltype(stage)::value];
         auto& b_reg = b_stage[decltype(stage)::value];
+        if (XF) {
+            // rows beyond M / columns beyond K carry act(shift) instead of 0: harmless, those rows are never stored and the
+            // filter's columns beyond K are zero
+            constexpr int st = decltype(stage)::value;
+#pragma unroll
+            for (int i = 0; i < A_ROWS; ++i) {
+                const bool q = xf_tile_seg == 2 && xf_row_seg[i];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    float u = act_apply(a_reg[i][v] * (q ? xf_sc[st][1][v] : xf_sc[st][0][v]) + (q ? xf_sh[st][1][v] : xf_sh[st][0][v]), p.a_act);
+                    if (p.a_rowscale) u *= xf_rs[st][i][v];
+                    a_reg[i][v] = u;
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
             if (BM % ROW_STEP != 0 && lrow + i * ROW_STEP >= BM) continue;
@@ -668,9 +728,17 @@ struct TnParams {
     int64_t dy_bytes, x_bytes;  // tensor extents (buffer descriptors)
     int64_t m_per_split; // multiple of BK
     int tiles_m, tiles_n; // output tiles along cout and along k'
+    // optional transform of x while it is staged (pointwise convs, XF instantiations), see NtParams: the filter gradient of a
+    // conv whose input act(BN(x)) * rowscale was never materialised
+    const float* x_scale = nullptr;
+    const float* x_shift = nullptr;
+    const float* x_rowscale = nullptr;
+    int x_act = 0, x_hw = 1;
+    int64_t x_seg_row = 0;
+    unsigned x_div_mul = 0, x_div_shr = 0;
 };
 
-template <int BM, int BN, int WM, int WN, int VECA, int VECB>
+template <int BM, int BN, int WM, int WN, int VECA, int VECB, bool XF = false>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (VECA == 1 || VECB == 1) ? 1 : ((BM == 128 && BN == 128) ? 6 : 5))
 void igemm_tn_kernel(const TnParams p) {
     constexpr int WAVES_N = BN / WN;
@@ -718,6 +786,23 @@ void igemm_tn_kernel(const TnParams p) {
     const bool a_valid_col = i0 + a_col < p.Ng;
     const int dr = r - g.pad, ds = s - g.pad;          // wgrad always gathers x in forward form: g = o*stride - pad + tap
 
+    // input transform (XF, pointwise convs: k' = channel): this thread's channels are fixed, so scale / shift of both segments are
+    // loaded once; the per-sample scale is fetched per staged row
+    float xs[2][VECB], xh[2][VECB], xrs[XF ? B_IT : 1][VECB];
+    bool xseg[XF ? B_IT : 1];
+    BufRsrc xrr = xr;
+    if (XF) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int v = 0; v < VECB; ++v) {
+                const bool ok = kq + v < g.K && (q == 0 || p.x_seg_row > 0);
+                xs[q][v] = ok ? p.x_scale[q * g.K + kq + v] : 0.f;
+                xh[q][v] = ok ? p.x_shift[q * g.K + kq + v] : 0.f;
+            }
+        if (p.x_rowscale) xrr = make_rsrc(p.x_rowscale, (int64_t)((g.M + p.x_hw - 1) / p.x_hw) * g.K * 4);
+    }
+
     float a_reg[A_IT][VECA], b_reg[B_IT][VECB];
     auto load_tiles = [&](int64_t mb) {
 #pragma unroll
@@ -739,6 +824,13 @@ void igemm_tn_kernel(const TnParams p) {
             ok = ok & ((unsigned)gh < (unsigned)g.GH) & ((unsigned)gw < (unsigned)g.GW);
             buf_load<VECB>(xr, ok ? (((unsigned)n * (unsigned)(g.GH * g.GW) + (unsigned)(gh * g.GW + gw)) * (unsigned)g.ldg + (unsigned)ci) * 4u : kOob,
                            b_reg[i]);
+            if (XF) {
+                xseg[i] = p.x_seg_row > 0 && m >= p.x_seg_row;
+                if (p.x_rowscale) {
+                    const unsigned smp = fast_div(mu, p.x_div_mul, p.x_div_shr);
+                    buf_load<VECB>(xrr, ok ? (smp * (unsigned)g.K + (unsigned)kq) * 4u : kOob, xrs[i]);
+                }
+            }
         }
     };
     auto store_tiles = [&]() {
@@ -748,6 +840,16 @@ void igemm_tn_kernel(const TnParams p) {
             float* dst = &As[(a_row + i * RA) * BM + a_col];
             if constexpr (VECA == 4) *reinterpret_cast<float4*>(dst) = make_float4(a_reg[i][0], a_reg[i][1], a_reg[i][2], a_reg[i][3]);
             else dst[0] = a_reg[i][0];
+        }
+        if (XF) {                       // rows beyond the split read x = 0 -> act(shift): harmless, their dy rows are zero
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i)
+#pragma unroll
+                for (int v = 0; v < VECB; ++v) {
+                    float u = act_apply(b_reg[i][v] * (xseg[i] ? xs[1][v] : xs[0][v]) + (xseg[i] ? xh[1][v] : xh[0][v]), p.x_act);
+                    if (p.x_rowscale) u *= xrs[i][v];
+                    b_reg[i][v] = u;
+                }
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
@@ -972,7 +1074,9 @@ static void launch_nt(const NtParams& p_in, int groups, hipStream_t st) {
     const dim3 block((BM / WM) * (BN / WN) * 64);
     switch (nt_mode(p.g)) {
         case 1:
-            if (p.scale) hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1, true>), grid, block, 0, st, p);
+            if (p.a_scale) {
+                if constexpr (VEC == 4) hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1, false, true>), grid, block, 0, st, p);
+            } else if (p.scale) hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1, true>), grid, block, 0, st, p);
             else hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1>), grid, block, 0, st, p);
             break;
         case 2:
@@ -1092,7 +1196,7 @@ static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st
         if (done) return;                                   // otherwise: the igemm tile of the same size (same row-tile height)
     }
     if (tile >= NT_P64x64) {
-        const bool plain = nt_mode(p.g) == 1 && p.g.M < (1LL << 31);
+        const bool plain = nt_mode(p.g) == 1 && p.g.M < (1LL << 31) && !p.a_scale;         // (the input transform lives in igemm_nt_kernel)
         if (plain) {
             switch (tile) {
                 case NT_P64x64: launch_persistent<64, 64, 32, 32>(p, groups, st); return;
@@ -1213,6 +1317,31 @@ int suhpe_conv2d_fwd_stats_seg(const suhpe_conv_t* d, const float* x, const floa
                                int64_t seg_row, suhpe_stream_t stream) {
     SUHPE_REQUIRE(stats_extra && seg_row > 0, "suhpe_conv2d_fwd_stats_seg: stats_extra and a positive seg_row are required");
     return conv2d_fwd_stats_impl(d, x, w, y, stats, stats_extra, seg_row, stream);
+}
+
+static bool xf_desc_ok(const suhpe_conv_t* d) {
+    return d && d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0 && d->groups == 1 && d->cin % 4 == 0 && d->cout % 4 == 0;
+}
+
+int suhpe_conv2d_fwd_stats_xf(const suhpe_conv_t* d, const float* x, const float* w, float* y, float* stats, float* stats_extra, int64_t seg_row,
+                              const float* a_scale, const float* a_shift, const float* a_rowscale, int a_act, int a_hw, suhpe_stream_t stream) {
+    int rc = check_desc(d, "suhpe_conv2d_fwd_stats_xf");
+    if (rc) return rc;
+    SUHPE_REQUIRE(xf_desc_ok(d), "suhpe_conv2d_fwd_stats_xf: pointwise convs only (1x1, stride 1, pad 0, groups 1, channels %% 4 == 0)");
+    SUHPE_REQUIRE(x && w && y && a_scale && a_shift && aligned16(x) && aligned16(w) && aligned16(a_scale) && aligned16(a_shift) && aligned16(a_rowscale),
+                  "suhpe_conv2d_fwd_stats_xf: null or unaligned pointer");
+    SUHPE_REQUIRE(a_act >= SUHPE_ACT_NONE && a_act <= SUHPE_ACT_SIGMOID && a_hw > 0 && seg_row >= 0 && (!stats_extra || seg_row > 0) && (!seg_row || stats_extra || !stats),
+                  "suhpe_conv2d_fwd_stats_xf: bad activation / hw / segment arguments");
+    NtParams p;
+    p.g = make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, d->cin, 1, 1, 1, 0, 0);
+    p.x = x; p.f = w; p.bias = nullptr; p.y = y; p.Ng = d->cout; p.ldy = d->cout; p.ldf = p.g.K;
+    p.x_bytes = (int64_t)d->n * d->h * d->w * d->cin * 4; p.f_bytes = (int64_t)d->cout * p.g.K * 4;
+    p.stats = stats; p.stats_extra = stats_extra; p.seg_row = seg_row; p.stat_gx = stats ? suhpe_conv2d_fwd_stats_tiles(d) : 0; p.stat_cout = d->cout;
+    p.scale = p.shift = p.residual = nullptr; p.act = 0; p.res_mode = 0;
+    p.a_scale = a_scale; p.a_shift = a_shift; p.a_rowscale = a_rowscale; p.a_act = a_act; p.a_hw = a_hw; p.a_seg_row = seg_row;
+    magic_div((unsigned)a_hw, &p.a_div_mul, &p.a_div_shr);
+    dispatch_nt(p, 1, true, as_stream(stream), pinned_tile(d, 0));
+    return check_launch("suhpe_conv2d_fwd_stats_xf");
 }
 
 int suhpe_conv2d_transpose_filter(const suhpe_conv_t* d, const float* w, float* wt, suhpe_stream_t stream) {
@@ -1339,8 +1468,10 @@ int64_t suhpe_conv2d_wgrad_workspace_bytes(const suhpe_conv_t* d) {
     return (int64_t)wgrad_splits(d, bm, bn) * d->cout * K * 4;
 }
 
-int suhpe_conv2d_wgrad_partial(const suhpe_conv_t* d, const float* x, const float* dy, void* workspace, int64_t workspace_bytes,
-                               suhpe_stream_t stream) {
+struct XInput { const float* scale; const float* shift; const float* rowscale; int act, hw; int64_t seg_row; };
+
+static int wgrad_partial_impl(const suhpe_conv_t* d, const float* x, const float* dy, void* workspace, int64_t workspace_bytes, const XInput* xf,
+                              suhpe_stream_t stream) {
     int rc = check_desc(d, "suhpe_conv2d_wgrad");
     if (rc) return rc;
     SUHPE_REQUIRE(x && dy && workspace, "suhpe_conv2d_wgrad: null pointer");
@@ -1361,11 +1492,24 @@ int suhpe_conv2d_wgrad_partial(const suhpe_conv_t* d, const float* x, const floa
     p.tiles_m = (int)ceil_div(ng, bm);
     const bool va = (ng % 4 == 0) && (d->cout % 4 == 0) && aligned16(dy);
     const bool vb = (cg % 4 == 0) && (d->cin % 4 == 0) && aligned16(x);
+    if (xf) {
+        SUHPE_REQUIRE(va && vb, "suhpe_conv2d_wgrad_partial_xf: 16-byte aligned operands required");
+        p.x_scale = xf->scale; p.x_shift = xf->shift; p.x_rowscale = xf->rowscale; p.x_act = xf->act; p.x_hw = xf->hw; p.x_seg_row = xf->seg_row;
+        magic_div((unsigned)xf->hw, &p.x_div_mul, &p.x_div_shr);
+    }
     dim3 grid(p.tiles_m * p.tiles_n * splits, 1, d->groups);
     hipStream_t st = as_stream(stream);
 #define TN_LAUNCH(BM_, BN_, WM_, WN_, VA_, VB_) \
     hipLaunchKernelGGL((igemm_tn_kernel<BM_, BN_, WM_, WN_, VA_, VB_>), grid, dim3(((BM_) / (WM_)) * ((BN_) / (WN_)) * 64), 0, st, p)
-    if (va && vb) {
+#define TN_LAUNCH_XF(BM_, BN_, WM_, WN_) \
+    hipLaunchKernelGGL((igemm_tn_kernel<BM_, BN_, WM_, WN_, 4, 4, true>), grid, dim3(((BM_) / (WM_)) * ((BN_) / (WN_)) * 64), 0, st, p)
+    if (xf) {
+        if (bm == 128 && bn == 128) TN_LAUNCH_XF(128, 128, 64, 32);
+        else if (bm == 128 && bn == 64) TN_LAUNCH_XF(128, 64, 64, 32);
+        else if (bm == 64 && bn == 128) TN_LAUNCH_XF(64, 128, 32, 64);
+        else if (bm == 32 && bn == 128) TN_LAUNCH_XF(32, 128, 32, 32);
+        else TN_LAUNCH_XF(64, 64, 32, 32);
+    } else if (va && vb) {
         if (bm == 128 && bn == 128) TN_LAUNCH(128, 128, 64, 32, 4, 4);       // 8 wavefronts of 64x32
         else if (bm == 128 && bn == 64) TN_LAUNCH(128, 64, 64, 32, 4, 4);
         else if (bm == 64 && bn == 128) TN_LAUNCH(64, 128, 32, 64, 4, 4);
@@ -1378,7 +1522,23 @@ int suhpe_conv2d_wgrad_partial(const suhpe_conv_t* d, const float* x, const floa
         else TN_LAUNCH(64, 64, 32, 32, 1, 1);
     }
 #undef TN_LAUNCH
+#undef TN_LAUNCH_XF
     return check_launch("suhpe_conv2d_wgrad_partial");
+}
+
+int suhpe_conv2d_wgrad_partial(const suhpe_conv_t* d, const float* x, const float* dy, void* workspace, int64_t workspace_bytes,
+                               suhpe_stream_t stream) {
+    return wgrad_partial_impl(d, x, dy, workspace, workspace_bytes, nullptr, stream);
+}
+
+int suhpe_conv2d_wgrad_partial_xf(const suhpe_conv_t* d, const float* x, const float* dy, void* workspace, int64_t workspace_bytes,
+                                  const float* a_scale, const float* a_shift, const float* a_rowscale, int a_act, int a_hw, int64_t seg_row,
+                                  suhpe_stream_t stream) {
+    SUHPE_REQUIRE(xf_desc_ok(d), "suhpe_conv2d_wgrad_partial_xf: pointwise convs only (1x1, stride 1, pad 0, groups 1, channels %% 4 == 0)");
+    SUHPE_REQUIRE(a_scale && a_shift && a_act >= SUHPE_ACT_NONE && a_act <= SUHPE_ACT_SIGMOID && a_hw > 0 && seg_row >= 0 && aligned16(a_rowscale),
+                  "suhpe_conv2d_wgrad_partial_xf: bad transform arguments");
+    const XInput xf{a_scale, a_shift, a_rowscale, a_act, a_hw, seg_row};
+    return wgrad_partial_impl(d, x, dy, workspace, workspace_bytes, &xf, stream);
 }
 
 int suhpe_conv2d_wgrad_reduce(const suhpe_conv_t* d, const void* workspace, float* dw, int accumulate, suhpe_stream_t stream) {

@@ -287,6 +287,18 @@ __global__ void bn_eval_affine_kernel(const float* __restrict__ rm, const float*
     shift[ch] = (beta ? beta[ch] : 0.f) - rm[ch] * sc;
 }
 
+// train-mode BatchNorm as a per-channel affine map for a consumer that applies it while loading (suhpe_conv2d_fwd_stats_xf):
+// scale[s][c] = gamma[c] rstd[s][c], shift[s][c] = beta[c] - mean[s][c] scale[s][c] for each of `segs` statistics sets
+__global__ void bn_affine_from_stats_kernel(const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                            const float* __restrict__ beta, int segs, int c, float* __restrict__ scale, float* __restrict__ shift) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= segs * c) return;
+    const int ch = i % c;
+    const float sc = (gamma ? gamma[ch] : 1.f) * rstd[i];
+    scale[i] = sc;
+    shift[i] = (beta ? beta[ch] : 0.f) - mean[i] * sc;
+}
+
 // RepVGG structural re-parameterisation for eval (src/repvgg.py:104-142, get_equivalent_kernel_bias): the 3x3 branch, the
 // 1x1 branch and the identity BatchNorm collapse into one 3x3 filter and a bias,
 //   W[co][r][s][ci] = W3[co][r][s][ci] t3[co] + [r = s = 1] (W1[co][ci] t1[co] + [ci = co mod Cg] tid[co]),   t = gamma / sqrt(var + eps)
@@ -1598,6 +1610,13 @@ int suhpe_repvgg_fuse(const float* w3, const float* w1, const float* const* bn3,
     LAUNCH(repvgg_fuse_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), stream, w3, w1, b3, b1, bi, bnid ? 1 : 0, cout, cin_per_group, w_eq,
            ones, b_eq);
     return check_launch("suhpe_repvgg_fuse");
+}
+
+int suhpe_bn_affine_from_stats(const float* mean, const float* rstd, const float* gamma, const float* beta, int segments, int c, float* scale,
+                               float* shift, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(mean && rstd && scale && shift && c > 0 && (segments == 1 || segments == 2), "suhpe_bn_affine_from_stats: bad arguments");
+    LAUNCH(bn_affine_from_stats_kernel, dim3((segments * c + 255) / 256), dim3(256), stream, mean, rstd, gamma, beta, segments, c, scale, shift);
+    return check_launch("suhpe_bn_affine_from_stats");
 }
 
 int suhpe_bn_eval_affine(const float* rm, const float* rv, const float* gamma, const float* beta, int c, float eps, float* scale,

@@ -298,14 +298,28 @@ def bn_eval_affine(running_mean, running_var, gamma, beta, eps):
     return out[0], out[1]
 
 
-def conv2d_fwd_stats(x, w, stride=1, pad=0, groups=1, seg=None):
+def bn_affine_from_stats(mean, rstd, gamma, beta):
+    """train-mode BatchNorm statistics ([c] or [2, c]) -> (scale, shift) of the same shape: the per-channel affine map a consumer
+    applies while it loads (conv2d_fwd_stats / conv2d_wgrad with xf=...)"""
+    c = mean.shape[-1]
+    segs = mean.numel() // c
+    out = torch.empty((2,) + tuple(mean.shape), dtype=torch.float32, device=mean.device)
+    call("suhpe_bn_affine_from_stats", ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), segs, c, ptr(out[0]), ptr(out[1]))
+    return out[0], out[1]
+
+
+def conv2d_fwd_stats(x, w, stride=1, pad=0, groups=1, seg=None, xf=None):
     """Dense conv forward that also returns BatchNorm partial sums from its epilogue: (y, partials, tiles).
     seg = samples in the first batch segment: the statistics are kept per segment and the result is
-    (y, partials, tiles, (first-segment records, boundary record or None))."""
+    (y, partials, tiles, (first-segment records, boundary record or None)).
+    xf = (scale, shift, rowscale or None, act, hw, rows of the first segment): pointwise convs only -- the conv's input is
+    act(x * scale + shift) * rowscale[sample], applied by the GEMM's loader (x itself is the producer's raw output)."""
     _chk(x, "x")
     assert filter_is_physical(w)
     d = conv_desc(x.shape, w.shape, stride, pad, groups)
     y = torch.empty((d.n, d.ho, d.wo, d.cout), dtype=torch.float32, device=x.device)
+    if xf is not None:
+        return _conv2d_fwd_stats_xf(d, x, w, y, seg, xf)
     if AUTOTUNE:
         _autotune(d, 0, lambda: call("suhpe_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(w), None, ptr(y)))
     tiles = _lib.load().suhpe_conv2d_fwd_stats_tiles(ctypes.byref(d))
@@ -348,6 +362,27 @@ def dwconv_fwd_stats(x, w, stride=1, pad=1, seg=None):
     if two:
         return y, part, 2 * blocks, (blocks, None)
     return y, part, blocks
+
+
+def _conv2d_fwd_stats_xf(d, x, w, y, seg, xf):
+    scale, shift, rowscale, act, hw, rows_a = xf
+    lib = _lib.load()
+    if AUTOTUNE:
+        _autotune(d, 0, lambda: call("suhpe_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(w), None, ptr(y)))
+    tiles = lib.suhpe_conv2d_fwd_stats_tiles(ctypes.byref(d))
+    two = seg is not None and 0 < seg < d.n
+    seg_row = seg * d.ho * d.wo if two else 0
+    assert seg_row == int(rows_a), "the input transform and the statistics epilogue share one segment boundary"
+    part = torch.empty(d.cout * (tiles + (1 if two else 0)) * 4, dtype=torch.float32, device=x.device)
+    extra = part[d.cout * tiles * 4:] if two else None
+    with _Prof(d, 0):
+        call("suhpe_conv2d_fwd_stats_xf", ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(part), ptr(extra), int(seg_row), ptr(scale), ptr(shift),
+             ptr(rowscale), ACT[act], int(hw))
+    if two:
+        tile_rows = lib.suhpe_conv2d_fwd_stats_tile_rows(ctypes.byref(d))
+        straddle = seg_row % tile_rows != 0
+        return y, part, tiles, (seg_row // tile_rows + int(straddle), extra if straddle else None)
+    return y, part, tiles
 
 
 @_memop
@@ -577,8 +612,9 @@ def flush_wgrads(jobs):
     jobs.clear()                                     # the slabs go back to the caching allocator (same stream: safe to reuse)
 
 
-def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, groups=1, out=None, accumulate=False):
-    """Filter gradient in the filter's physical layout.  out: tensor with the filter's shape/strides."""
+def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, groups=1, out=None, accumulate=False, xf=None):
+    """Filter gradient in the filter's physical layout.  out: tensor with the filter's shape/strides.
+    xf: the forward's input transform (conv2d_fwd_stats): the conv's input is recomputed from x by the loader."""
     _chk(x, "x"); _chk(dy, "dy")
     d = conv_desc(x.shape, w_shape, stride, pad, groups)
     if out is None:
@@ -589,11 +625,20 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, groups=1, out=None, accumulate
     lib = _lib.load()
     side = _DEFER is not None and accumulate and WGRAD_OVERLAP
     with (_on_side_stream(x.device, x, dy) if side else _same_stream()):
-        _conv2d_wgrad(lib, d, x, dy, out, accumulate)
+        _conv2d_wgrad(lib, d, x, dy, out, accumulate, xf)
     return out
 
 
-def _conv2d_wgrad(lib, d, x, dy, out, accumulate):
+def _wgrad_partial(d, x, dy, ws, nbytes, xf):
+    if xf is None:
+        call("suhpe_conv2d_wgrad_partial", ctypes.byref(d), ptr(x), ptr(dy), ptr(ws), nbytes)
+    else:
+        scale, shift, rowscale, act, hw, rows_a = xf
+        call("suhpe_conv2d_wgrad_partial_xf", ctypes.byref(d), ptr(x), ptr(dy), ptr(ws), nbytes, ptr(scale), ptr(shift), ptr(rowscale), ACT[act],
+             int(hw), int(rows_a))
+
+
+def _conv2d_wgrad(lib, d, x, dy, out, accumulate, xf=None):
     if _is_depthwise(d) and d.cin % 4 == 0:
         nbytes = lib.suhpe_dwconv_wgrad_workspace_bytes(ctypes.byref(d))
         ws = workspace("wgrad", nbytes, x.device)
@@ -609,7 +654,7 @@ def _conv2d_wgrad(lib, d, x, dy, out, accumulate):
         defer = _DEFER is not None and accumulate
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if defer else workspace("wgrad", nbytes, x.device)
         with _Prof(d, 2):           # the profile brackets the split-K GEMM launch alone
-            call("suhpe_conv2d_wgrad_partial", ctypes.byref(d), ptr(x), ptr(dy), ptr(ws), nbytes)
+            _wgrad_partial(d, x, dy, ws, nbytes, xf)
         if defer:
             _DEFER.append((ws, out, out.numel(), lib.suhpe_conv2d_wgrad_splits(ctypes.byref(d))))
         else:

@@ -100,18 +100,25 @@ class Conv2d(Layer):
             tape.append(x)
         return y
 
-    def fwd_stats(self, x, tape):
+    def fwd_stats(self, x, tape, xf=None):
         """forward + BatchNorm partial statistics from the GEMM epilogue (dense, bias-free convs only) -> (y, (part, tiles))
-        (with batch segments: (y, (part, tiles, records of the first segment, boundary record)))"""
+        (with batch segments: (y, (part, tiles, records of the first segment, boundary record))).
+        xf (pointwise convs): the conv's input is act(x * scale + shift) * rowscale, applied by the GEMM's loader -- x is the raw
+        output of the producer whose BatchNorm + activation were never materialised (kernels.conv2d_fwd_stats)."""
         if not K.filter_is_physical(self.weight):
             self.weight.data = K.to_filter_layout(self.weight.data)
         if self._depthwise():
             out = K.dwconv_fwd_stats(x, self.weight, self.stride, self.padding, seg=_segment_of(x))
         else:
-            out = K.conv2d_fwd_stats(x, self.weight, self.stride, self.padding, self.groups, seg=_segment_of(x))
+            out = K.conv2d_fwd_stats(x, self.weight, self.stride, self.padding, self.groups, seg=_segment_of(x), xf=xf)
         if tape is not None:
-            tape.append(x)
+            tape.append(x if xf is None else (x, xf))
         return out[0], out[1:]
+
+    def takes_input_xform(self):
+        """can this conv apply its producer's BatchNorm + activation while loading?  (pointwise, 16-byte channel vectors)"""
+        return (XF_FUSION and self.kernel_size == 1 and self.stride == 1 and self.padding == 0 and self.groups == 1 and self.bias is None
+                and self.in_channels % 4 == 0 and self.out_channels % 4 == 0)
 
     def _depthwise(self):
         return self.groups > 1 and self.groups == self.in_channels == self.out_channels
@@ -129,8 +136,10 @@ class Conv2d(Layer):
         return self.bias is None and not self._depthwise()
 
     def bwd(self, dy, tape):
-        x = tape.pop()
-        K.conv2d_wgrad(x, dy, self.weight.shape, self.stride, self.padding, self.groups, out=grad_of(self.weight), accumulate=True)
+        x, xf = tape.pop(), None
+        if isinstance(x, tuple):                             # forward applied an input transform: the filter gradient recomputes it
+            x, xf = x
+        K.conv2d_wgrad(x, dy, self.weight.shape, self.stride, self.padding, self.groups, out=grad_of(self.weight), accumulate=True, xf=xf)
         if self.bias is not None:
             K.bias_grad(dy, self.out_channels, out=grad_of(self.bias), accumulate=True)
         if not self.need_input_grad:
@@ -184,6 +193,7 @@ class Linear(Layer):
 # single-process global-batch BatchNorm exactly; the default is per-rank statistics (standard data-parallel semantics).
 # Set by SSLAgent from config.sync_bn; it implies two separate student passes (no batch segments).
 SYNC_BN = False
+XF_FUSION = os.environ.get("SUHPE_XF_FUSION", "1") != "0"   # BatchNorm + activation (+ SE scale) of a producer applied by the consuming 1x1 conv's loader
 DW_STATS = os.environ.get("SUHPE_DW_STATS", "1") != "0"      # depthwise convs emit their BatchNorm's statistics records themselves
 
 _SEGMENT = None

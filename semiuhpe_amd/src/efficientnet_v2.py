@@ -57,14 +57,22 @@ class _ResidualBlock(Layer):
         return dy
 
     def fwd(self, x, tape):
-        if not self.use_res_connect:
-            return self.block[-1].fwd(self._front_fwd(x, tape), tape)
         y = self._front_fwd(x, tape)
         last = self.block[-1]
-        sd = self.stochastic_depth
+        xf = None
+        if isinstance(y, tuple):            # (raw tensor, input transform): the last conv applies the front's BatchNorm + activation itself
+            y, xf = y
         rowscale = None
-        if sd.training and sd.p > 0.0:
-            rowscale = draw_mask("stochastic_depth", (x.shape[0],), 1.0 - sd.p, x.device)
+        if self.use_res_connect:
+            sd = self.stochastic_depth
+            if sd.training and sd.p > 0.0:
+                rowscale = draw_mask("stochastic_depth", (x.shape[0],), 1.0 - sd.p, x.device)
+        res = x if self.use_res_connect else None
+        if xf is not None:
+            y1, partials = last[0].fwd_stats(y, tape, xf=xf)
+            return last[1].fwd(y1, tape, residual=res, partials=partials, post=self.use_res_connect, rowscale=rowscale)
+        if not self.use_res_connect:
+            return last.fwd(y, tape)
         return conv_bn_fwd(last[0], last[1], y, tape, residual=x, residual_after_act=True, rowscale=rowscale)
 
     def bwd(self, dy, tape):
@@ -84,6 +92,24 @@ class FusedMBConv(_ResidualBlock):
             layers = [ConvNormActivation(cin, cout, kernel, stride, act="silu", bn_eps=BN_EPS)]
         self.block = Sequential(*layers)
         self.stochastic_depth = StochasticDepth(sd_prob, "row")
+
+    # 3x3 expand -> BatchNorm -> SiLU -> 1x1 project: in training the project conv's loader applies the BatchNorm + SiLU of the
+    # expand conv's raw output (suhpe_conv2d_fwd_stats_xf), so the activated 4x-expanded tensor -- the largest activation of the
+    # network -- is neither written nor read; the tape holds the standard BatchNorm entry, so the default backward applies
+    def _front_fwd(self, x, tape):
+        if len(self.block) != 2:
+            return super()._front_fwd(x, tape)
+        (c0, b0), c1 = self.block[0], self.block[1][0]
+        from .. import layers as L
+        if not (b0.training and self.block[1][1].training and c1.takes_input_xform() and c0.fuses_stats() and not L.SYNC_BN):
+            return super()._front_fwd(x, tape)
+        y0, partials = c0.fwd_stats(x, tape)
+        mean, rstd, rows_a = b0.train_stats(y0, partials)
+        hw = y0.shape[1] * y0.shape[2]
+        if tape is not None:                # what _BatchNorm.bwd expects (segments: statistics pair + samples of the first segment)
+            tape.append((y0, (mean, rstd), rows_a // hw, True, None, None, hw) if rows_a else (y0, mean, rstd, True, None, None, hw))
+        sc, sh = K.bn_affine_from_stats(mean, rstd, b0.weight, b0.bias)
+        return y0, (sc, sh, None, b0.act, hw, rows_a)
 
 
 class MBConv(_ResidualBlock):
@@ -132,10 +158,14 @@ class MBConv(_ResidualBlock):
             (mean, rstd), rows_a = K.bn_eval_stats(bn_d.running_mean, bn_d.running_var, bn_d.eps), 0
         p = K.bn_act_pool(y, rows_a, c, mean, rstd, bn_d.weight, bn_d.bias, bn_d.act, hw)
         a1, s = K.se_mlp_fwd(p, se.fc1.weight, se.fc1.bias, se.fc2.weight, se.fc2.bias)
-        out = K.bn_act_scale_fwd(y, rows_a, c, mean, rstd, bn_d.weight, bn_d.bias, bn_d.act, s, hw)
         if tape is not None:
             tape.append((y, mean, rstd, rows_a, bn_d.training, p, a1, s, hw))
-        return out
+        proj = self.block[-1]
+        if bn_d.training and proj[1].training and proj[0].takes_input_xform():
+            # the project conv's loader applies silu(BN(y)) * s itself: nothing of the expanded width is written here
+            sc, sh = K.bn_affine_from_stats(mean, rstd, bn_d.weight, bn_d.bias)
+            return y, (sc, sh, s, bn_d.act, hw, rows_a)
+        return K.bn_act_scale_fwd(y, rows_a, c, mean, rstd, bn_d.weight, bn_d.bias, bn_d.act, s, hw)
 
     def _dw_se_bwd(self, dout, tape):
         (conv_d, bn_d), se = self.block[-3], self.block[-2]
