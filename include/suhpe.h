@@ -399,10 +399,20 @@ int suhpe_window_attn_fwd(const float* qkv, const float* bias_table, const int32
                           int ws, int heads, int dh, int noff, float scale, float* out, float* probs, void* workspace,
                           suhpe_stream_t stream);
 int64_t suhpe_window_attn_probs_elems(int B, int H, int W, int ws, int heads);
-/* dqkv gets every element written; dbias_table (+)= gradient (atomic accumulate); workspace: probs_elems floats */
+/* dqkv gets every element written; workspace: probs_elems floats, left holding dS (the score gradient, (windows, heads, N, N)).
+ * dbias_table: NULL, or (+)= the bias-table gradient by atomic accumulation (order-dependent rounding); the reproducible form is
+ * dbias_table = NULL here followed by suhpe_window_attn_dbias on the same workspace. */
 int suhpe_window_attn_bwd(const float* qkv, const float* probs, const float* dout, const int32_t* bias_idx, int B,
                           int H, int W, int ws, int heads, int dh, int noff, float scale, float* dqkv,
                           float* dbias_table, void* workspace, suhpe_stream_t stream);
+
+/* Bias-table gradient of tiny_vit.Attention (attention_biases[:, attention_bias_idxs], src/tiny_vit.py:237-260) without atomics:
+ * dbias_table[h][o] += sum over windows and over the (i, j) with bias_idx[i][j] == o of dS, in a fixed order.  inv_ptr (noff + 1) /
+ * inv_list (N*N) is the inverse of bias_idx in CSR form (pairs i*N + j grouped by offset, ascending).  dS: suhpe_window_attn_bwd's
+ * workspace.  workspace here: suhpe_window_attn_dbias_workspace_bytes(ws, heads). */
+int64_t suhpe_window_attn_dbias_workspace_bytes(int ws, int heads);
+int suhpe_window_attn_dbias(const float* dS, const int32_t* inv_ptr, const int32_t* inv_list, int B, int H, int W, int ws, int heads,
+                            int noff, float* dbias_table, void* workspace, suhpe_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -514,6 +514,34 @@ __global__ __launch_bounds__(256) void window_attn_dbias_kernel(const float* __r
     if (w1 > w0) atomicAdd(&dbias[h * noff + bias_idx[ij]], s);
 }
 
+// ---- the same gradient without atomics (bit-reproducible): stage 1 sums dS over chunks of windows in a fixed order,
+//   part[chunk][h][ij] = sum_{w in chunk} dS[w][h][ij];
+// stage 2 gives a thread one table entry (h, offset) and adds, in a fixed order, the (i, j) pairs that use that offset (their
+// list comes from the inverse of bias_idx, built once per attention module on the host) over all chunks.
+__global__ __launch_bounds__(256) void window_attn_dbias_part_kernel(const float* __restrict__ dS, int nwin, int heads, int N, float* __restrict__ part) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, per_head = (int64_t)N * N, total = heads * per_head;
+    if (e >= total) return;
+    const int per = (nwin + gridDim.y - 1) / gridDim.y, w0 = blockIdx.y * per, w1 = min(nwin, w0 + per);
+    float s = 0.f;
+#pragma unroll 8
+    for (int w = w0; w < w1; ++w) s += dS[(int64_t)w * total + e];
+    part[(int64_t)blockIdx.y * total + e] = s;
+}
+__global__ __launch_bounds__(256) void window_attn_dbias_gather_kernel(const float* __restrict__ part, int chunks, int heads, int N, int noff,
+                                                                      const int32_t* __restrict__ inv_ptr, const int32_t* __restrict__ inv_list,
+                                                                      float* __restrict__ dbias) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= heads * noff) return;
+    const int h = e / noff, off = e - h * noff;
+    const int64_t per_head = (int64_t)N * N, total = heads * per_head;
+    float s = 0.f;
+    for (int q = inv_ptr[off]; q < inv_ptr[off + 1]; ++q) {
+        const int64_t at = h * per_head + inv_list[q];
+        for (int c = 0; c < chunks; ++c) s += part[c * total + at];
+    }
+    dbias[e] += s;
+}
+
 static int attn_geom(AttnGeom* g, int B, int H, int W, int ws, int heads, int dh, int noff, float scale, const char* who) {
     if (dh != DH || ws <= 0 || H % ws || W % ws || ws * ws > MAXN || B <= 0 || heads <= 0) {
         set_error("%s: needs head_dim 32, window dividing the feature map and window area <= %d (got dh=%d ws=%d H=%d W=%d)", who, MAXN, dh, ws, H, W);
@@ -609,6 +637,22 @@ int suhpe_window_attn_bwd(const float* qkv, const float* probs, const float* dou
                            heads, g.N, noff, dbias_table);
     }
     return check_launch("suhpe_window_attn_bwd");
+}
+
+int64_t suhpe_window_attn_dbias_workspace_bytes(int ws, int heads) { return (int64_t)8 * heads * ws * ws * ws * ws * (int64_t)sizeof(float); }
+
+int suhpe_window_attn_dbias(const float* dS, const int32_t* inv_ptr, const int32_t* inv_list, int B, int H, int W, int ws, int heads, int noff,
+                            float* dbias_table, void* workspace, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(dS && inv_ptr && inv_list && dbias_table && workspace && ws > 0 && B > 0 && heads > 0 && noff > 0 && H % ws == 0 && W % ws == 0,
+                  "suhpe_window_attn_dbias: bad arguments");
+    const int N = ws * ws, nwin = B * (H / ws) * (W / ws);
+    const int chunks = nwin >= 64 ? 8 : (nwin >= 8 ? 2 : 1);
+    const int64_t total = (int64_t)heads * N * N;
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(window_attn_dbias_part_kernel, dim3((unsigned)ceil_div(total, 256), chunks), dim3(256), 0, as_stream(stream), dS, nwin, heads, N, part);
+    hipLaunchKernelGGL(window_attn_dbias_gather_kernel, dim3((heads * noff + 255) / 256), dim3(256), 0, as_stream(stream), part, chunks, heads, N, noff,
+                       inv_ptr, inv_list, dbias_table);
+    return check_launch("suhpe_window_attn_dbias");
 }
 
 }  // extern "C"

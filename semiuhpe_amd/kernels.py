@@ -1215,13 +1215,18 @@ def window_attn_fwd(qkv, bias_table, bias_idx, B, H, W, ws, heads, scale, save_p
 
 
 @_memop
-def window_attn_bwd(qkv, probs, dout, bias_idx, B, H, W, ws, heads, noff, scale, dbias):
+def window_attn_bwd(qkv, probs, dout, bias_idx, B, H, W, ws, heads, noff, scale, dbias, inverse=None):
+    """inverse = (inv_ptr, inv_list) int32 device tensors (CSR inverse of bias_idx): the bias-table gradient is then reduced in a
+    fixed order (bit-reproducible); without it the backward kernel's atomic accumulation is used"""
     _chk(qkv, "qkv"); _chk(dout, "dout")
     dh = qkv.shape[-1] // (3 * heads)
     dqkv = torch.empty_like(qkv)
     ws_buf = workspace("attn", probs.numel() * 4, qkv.device)
     call("suhpe_window_attn_bwd", ptr(qkv), ptr(probs), ptr(dout), ptr(bias_idx), B, H, W, ws, heads, dh, noff, float(scale), ptr(dqkv),
-         ptr(dbias), ptr(ws_buf))
+         None if inverse is not None else ptr(dbias), ptr(ws_buf))
+    if inverse is not None:
+        ws2 = workspace("attn_dbias", _lib.load().suhpe_window_attn_dbias_workspace_bytes(ws, heads), qkv.device)
+        call("suhpe_window_attn_dbias", ptr(ws_buf), ptr(inverse[0]), ptr(inverse[1]), B, H, W, ws, heads, noff, ptr(dbias), ptr(ws2))
     return dqkv
 
 

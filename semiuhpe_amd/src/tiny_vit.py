@@ -7,6 +7,8 @@ Linear and the windowed attention kernel all address the same tensor.
 """
 import itertools
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -120,6 +122,9 @@ def attention_bias_index(ws):
     return torch.tensor(idx, dtype=torch.long).view(len(pts), len(pts)), len(seen)
 
 
+DETERMINISTIC_DBIAS = os.environ.get("SUHPE_ATOMIC_DBIAS", "0") != "1"     # fixed-order bias-table gradient (no atomics)
+
+
 class Attention(Layer):
     """src/tiny_vit.py:216-286 (attn_ratio = 1): LayerNorm -> qkv -> windowed softmax(q k^T s + bias) v -> proj"""
 
@@ -134,6 +139,18 @@ class Attention(Layer):
         self.attention_biases = nn.Parameter(torch.zeros(num_heads, n))
         self.register_buffer("attention_bias_idxs", idx, persistent=False)
         self._idx32 = None
+        self._inverse = None
+
+    def _inverse_index(self, device):
+        """CSR inverse of attention_bias_idxs (pairs i*N + j grouped by table offset): the fixed-order bias-gradient reduction"""
+        if self._inverse is None or self._inverse[0].device != device:
+            flat = self.attention_bias_idxs.reshape(-1).cpu()
+            order = torch.argsort(flat, stable=True)
+            counts = torch.bincount(flat, minlength=self.attention_biases.shape[1])
+            ptrs = torch.zeros(counts.numel() + 1, dtype=torch.long)
+            ptrs[1:] = torch.cumsum(counts, 0)
+            self._inverse = (ptrs.to(device=device, dtype=torch.int32).contiguous(), order.to(device=device, dtype=torch.int32).contiguous())
+        return self._inverse
 
     def _index(self, device):
         if self._idx32 is None or self._idx32.device != device:
@@ -155,7 +172,8 @@ class Attention(Layer):
         d_out = self.proj.bwd(dy.view(-1, C), tape)
         qkv, probs, _ = tape.pop()
         dqkv = K.window_attn_bwd(qkv, probs, d_out, self._index(dy.device), B, H, W, self.window, self.num_heads,
-                                 self.attention_biases.shape[1], self.scale, grad_of(self.attention_biases))
+                                 self.attention_biases.shape[1], self.scale, grad_of(self.attention_biases),
+                                 inverse=self._inverse_index(dy.device) if DETERMINISTIC_DBIAS else None)
         d_xn = self.qkv.bwd(dqkv, tape)
         return self.norm.bwd(d_xn.view(B, H, W, C), tape)
 

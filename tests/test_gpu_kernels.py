@@ -711,3 +711,41 @@ def test_producer_batchnorm_applied_by_consumer_loader(kind, stride, cin, cout, 
     for k in r0:
         assert rel(r1[k], r0[k]) < 1e-6, k
     assert saved1 < saved0                                   # the activated tensor is not on the tape any more
+
+
+@pytest.mark.parametrize("ws,heads,B,H", [(7, 6, 6, 28), (14, 12, 5, 14), (7, 18, 9, 7)])
+def test_attention_bias_gradient_fixed_order(ws, heads, B, H):
+    """suhpe_window_attn_dbias: the bias-table gradient reduced without atomics -- equal to the atomic accumulation within summation
+    noise, to a float64 scatter-add of dS exactly to rounding, and bit-identical from run to run"""
+    from semiuhpe_amd import kernels as K
+    from semiuhpe_amd.src import tiny_vit as T
+    torch.manual_seed(ws * heads)
+    att = T.Attention(heads * 32, 32, heads, ws).cuda()
+    att.attention_biases.data.normal_(0, 0.5)
+    g = torch.Generator().manual_seed(B)
+    qkv = torch.randn(B * H * H, heads * 96, generator=g).cuda()
+    dout = torch.randn(B * H * H, heads * 32, generator=g).cuda()
+    idx = att._index(qkv.device)
+    noff = att.attention_biases.shape[1]
+    out, probs = K.window_attn_fwd(qkv, att.attention_biases, idx, B, H, H, ws, heads, att.scale)
+
+    def run(inverse):
+        db = torch.zeros(heads, noff, device="cuda")
+        dq = K.window_attn_bwd(qkv, probs, dout, idx, B, H, H, ws, heads, noff, att.scale, db, inverse=inverse)
+        return dq, db
+
+    dq_a, db_atomic = run(None)
+    inv = att._inverse_index(qkv.device)
+    dq1, db1 = run(inv)
+    dS = K.workspace("attn", probs.numel() * 4, qkv.device)[:probs.numel() * 4].view(torch.float32).view(-1, heads, ws * ws * ws * ws).clone()
+    dq2, db2 = run(inv)
+    assert torch.equal(dq1, dq_a) and torch.equal(db1, db2)                 # reproducible bit for bit
+    ref = torch.zeros(heads, noff, dtype=torch.float64)
+    ref.index_add_(1, att.attention_bias_idxs.reshape(-1).cpu(), dS.double().sum(0).cpu())
+    scale = float(ref.abs().max())
+    assert float((db1.double().cpu() - ref).abs().max()) < 2e-6 * scale
+    assert float((db_atomic.double().cpu() - ref).abs().max()) < 2e-5 * scale
+    # accumulation semantics: a second call adds on top
+    db = db1.clone()
+    K.window_attn_bwd(qkv, probs, dout, idx, B, H, H, ws, heads, noff, att.scale, db, inverse=inv)
+    assert float((db - 2 * db1).abs().max()) < 1e-6 * scale
