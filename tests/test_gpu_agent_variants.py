@@ -121,7 +121,7 @@ def _truth64_grads(oracle, cfg_o, data, ulb, step):
     return {n: p.grad.clone() for n, p in o64.net.named_parameters()}
 
 
-def _yardstick_mismatches(g_hip, g_ref32, g_truth, floor=3e-3, mult=4.0):
+def _yardstick_mismatches(g_hip, g_ref32, g_truth, floor=6e-3, mult=4.0):
     gscale = max(float(g.abs().max()) for g in g_truth.values())
     bad = {}
     for n, t in g_truth.items():
@@ -167,7 +167,7 @@ def _ssl_step(oracle, agent, cfg_o, cfg_h, data, ulb, step, strict=True, truth64
     return (fd_o, fu_o, out_o), (fd, fu, out, truth)
 
 
-def _compare_step(o, h, oracle, agent, grad_tol=5e-3, loss_tol=3e-4, pred_tol=3e-4, orth_tol=2e-4, truth=None):
+def _compare_step(o, h, oracle, agent, grad_tol=5e-3, loss_tol=3e-4, pred_tol=3e-4, orth_tol=3e-4, truth=None):
     (fd_o, fu_o, out_o), (fd, fu, out) = o, h[:3]
     truth = truth if truth is not None else (h[3] if len(h) > 3 else None)
     assert rel_err(fd["pred"], fd_o["pred"]) < pred_tol
