@@ -33,6 +33,14 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 32;          // reduction chunk staged per LDS tile
 constexpr int LDK = BK + 4;     // padded LDS row (floats): 144 B keeps 16-B alignment and spreads banks
 
+// activation of the input transforms (XF loaders): SiLU on the hardware exponential (v_exp_f32, ~1 ulp of exp2) -- the accurate
+// expf / erff paths of act_apply cost the GEMM loaders dozens of VGPRs and scratch; none / ReLU / SiLU are what the producers of
+// a pointwise conv's input use (torchvision MBConv / FusedMBConv)
+__device__ __forceinline__ float xf_act(float u, int act) {
+    const float s = u / (1.f + __expf(-u));
+    return act == SUHPE_ACT_SILU ? s : (act == SUHPE_ACT_RELU ? fmaxf(u, 0.f) : u);
+}
+
 struct GatherGeom {
     int N, GH, GW;       // gathered tensor spatial dims
     int OH, OW;          // GEMM-row enumeration: m = (n, oh, ow)
@@ -107,18 +115,23 @@ struct NtParams {
     unsigned a_div_mul = 0, a_div_shr = 0;
 };
 
+template <int VEC> __device__ __forceinline__ void vload_lds(const float* p, float* o) {
+    if constexpr (VEC == 4) { const float4 v = *reinterpret_cast<const float4*>(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+    else o[0] = p[0];
+}
+
 // ---------------------------------------------------------------------------------------------- igemm_nt
 // MODE 0: generic gather (any stride, dgrad with stride > 1: per-tap divisibility test)
 // MODE 1: pointwise (1x1, stride 1, no padding): the gathered row IS row m
 // MODE 2: affine taps, coordinate = o*gm + sgn*tap + off (forward with any stride, dgrad with stride 1)
 // In every mode the tap of a thread's k advances incrementally (no division in the k loop), addresses are 32-bit
 // element offsets from a uniform base, and out-of-range taps are predicated (offset 0, value zeroed): no branches.
-template <int BM, int BN, int WM, int WN, int VEC, int MODE, bool AFF = false, bool XF = false>
+template <int BM, int BN, int WM, int WN, int VEC, int MODE, bool AFF = false, int XF = 0>
 // The second launch bound (minimum waves per SIMD) caps the register budget: left alone the compiler spends 88-148 VGPRs on
 // prefetch depth, which leaves 2 workgroups (or 1, for the wgrad kernel) per CU; at <= 80 VGPRs three 8-wave workgroups are
 // resident and the MFMA pipe sees 6 waves per SIMD.
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64,
-                             (VEC == 1 || BM == 256) ? 1 : ((WM == 64 && WN == 64) ? 3 : (((BM / WM) * (BN / WN) > 8 || BN == 32 || BN == 128 || MODE == 0) ? 5 : 6)))
+                             (VEC == 1 || BM == 256) ? 1 : (XF ? 4 : ((WM == 64 && WN == 64) ? 3 : (((BM / WM) * (BN / WN) > 8 || BN == 32 || BN == 128 || MODE == 0) ? 5 : 6))))
 void igemm_nt_kernel(const NtParams p) {
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -185,25 +198,32 @@ void igemm_nt_kernel(const NtParams p) {
             a_pix[i] = -1;
         }
     }
-    // ---- input transform (XF): which statistics segment the tile's rows use, and each row's sample for the per-sample scale
+    // ---- input transform (XF): scale / shift of every k column (both segments) are staged once in dynamic LDS; the per-sample
+    // scale (XF == 2) is fetched with the tile's rows and carried through the register stages
+    extern __shared__ __attribute__((aligned(16))) float xf_lds[];          // [segments][2][Kpad]: scale then shift
     int xf_tile_seg = 0;                                     // 0 / 1: every row of the tile in that segment, 2: the tile straddles the boundary
     bool xf_row_seg[XF ? A_ROWS : 1];
-    int xf_row_n[XF ? A_ROWS : 1];
-    BufRsrc xf_sr = xr, xf_hr = xr, xf_rr = xr;
+    int xf_row_n[XF == 2 ? A_ROWS : 1];
+    BufRsrc xf_rr = xr;
+    const int xf_kpad = (g.K + 3) & ~3;
     if (XF) {
         if (p.a_seg_row > 0) xf_tile_seg = m0 + BM <= p.a_seg_row ? 0 : (m0 >= p.a_seg_row ? 1 : 2);
-        const int64_t seg_bytes = (int64_t)(p.a_seg_row > 0 ? 2 : 1) * g.K * 4;
-        xf_sr = make_rsrc(p.a_scale, seg_bytes);
-        xf_hr = make_rsrc(p.a_shift, seg_bytes);
-        if (p.a_rowscale) xf_rr = make_rsrc(p.a_rowscale, (int64_t)((g.M + p.a_hw - 1) / p.a_hw) * g.K * 4);
+        const int segs = p.a_seg_row > 0 ? 2 : 1;
+        for (int i = t; i < segs * g.K; i += NT) {
+            const int sg = i / g.K, k = i - sg * g.K;
+            xf_lds[(sg * 2 + 0) * xf_kpad + k] = p.a_scale[i];
+            xf_lds[(sg * 2 + 1) * xf_kpad + k] = p.a_shift[i];
+        }
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
             const int64_t m = m0 + lrow + i * ROW_STEP;
             xf_row_seg[i] = p.a_seg_row > 0 && m >= p.a_seg_row;
-            xf_row_n[i] = (int)fast_div((unsigned)(m < g.M ? m : g.M - 1), p.a_div_mul, p.a_div_shr);
+            if (XF == 2) xf_row_n[i] = (int)fast_div((unsigned)(m < g.M ? m : g.M - 1), p.a_div_mul, p.a_div_shr);
         }
+        if (XF == 2) xf_rr = make_rsrc(p.a_rowscale, (int64_t)((g.M + p.a_hw - 1) / p.a_hw) * g.K * 4);
+        // (the first store_tiles comes after the first global loads have returned; a barrier orders the staging before it)
     }
-    float xf_sc[2][2][VEC], xf_sh[2][2][VEC], xf_rs[2][XF ? A_ROWS : 1][VEC];
+    float xf_rs[2][XF == 2 ? A_ROWS : 1][VEC];
 
     // this thread's position in the reduction: k = tap*Cg + ci, tap = (r, s); advanced by BK per tile
     int kk = lcol, ci = lcol, tr = 0, ts = 0;
@@ -248,20 +268,10 @@ void igemm_nt_kernel(const NtParams p) {
             const bool ok = kvalid & (b_off[i] >= 0);
             buf_load<VEC>(fr, ok ? ((unsigned)b_off[i] + (unsigned)fk) * 4u : kOob, b_reg[i]);
         }
-        if (XF) {                                            // scale / shift of this slab's k columns (both segments in a straddling tile)
+        if (XF == 2) {                                       // per-sample scale of this slab's k columns, one vector per row
             constexpr int st = decltype(stage)::value;
-            const unsigned k4 = kvalid ? (unsigned)kk * 4u : kOob;
-            const unsigned seg0 = xf_tile_seg == 1 ? (unsigned)g.K * 4u : 0u;
-            buf_load<VEC>(xf_sr, kvalid ? seg0 + k4 : kOob, xf_sc[st][0]);
-            buf_load<VEC>(xf_hr, kvalid ? seg0 + k4 : kOob, xf_sh[st][0]);
-            if (xf_tile_seg == 2) {
-                buf_load<VEC>(xf_sr, kvalid ? (unsigned)g.K * 4u + k4 : kOob, xf_sc[st][1]);
-                buf_load<VEC>(xf_hr, kvalid ? (unsigned)g.K * 4u + k4 : kOob, xf_sh[st][1]);
-            }
-            if (p.a_rowscale) {
 #pragma unroll
-                for (int i = 0; i < A_ROWS; ++i) buf_load<VEC>(xf_rr, kvalid ? ((unsigned)xf_row_n[i] * (unsigned)g.K + (unsigned)kk) * 4u : kOob, xf_rs[st][i]);
-            }
+            for (int i = 0; i < A_ROWS; ++i) buf_load<VEC>(xf_rr, kvalid ? ((unsigned)xf_row_n[i] * (unsigned)g.K + (unsigned)kk) * 4u : kOob, xf_rs[st][i]);
         }
         // advance to the next tile
         kk += BK;
@@ -270,20 +280,30 @@ void igemm_nt_kernel(const NtParams p) {
             while (ci >= g.Cg && g.R * g.S > 1) { ci -= g.Cg; if (++ts == g.S) { ts = 0; ++tr; } }
         }
     };
-    auto store_tiles = [&](auto stage) {
+    auto store_tiles = [&](auto stage, int kt_store = 0) {
         auto& a_reg = a_stage[decltype(stage)::value];
         auto& b_reg = b_stage[decltype(stage)::value];
         if (XF) {
             // rows beyond M / columns beyond K carry act(shift) instead of 0: harmless, those rows are never stored and the
             // filter's columns beyond K are zero
             constexpr int st = decltype(stage)::value;
+            const int k = kt_store * BK + lcol;
+            const int kc = k < xf_kpad ? k : 0;
+            const int s0 = xf_tile_seg == 1 ? 1 : 0;
+            float sc0[VEC], sh0[VEC], sc1[VEC], sh1[VEC];
+            vload_lds<VEC>(&xf_lds[(s0 * 2 + 0) * xf_kpad + kc], sc0);
+            vload_lds<VEC>(&xf_lds[(s0 * 2 + 1) * xf_kpad + kc], sh0);
+            if (xf_tile_seg == 2) {
+                vload_lds<VEC>(&xf_lds[2 * xf_kpad + kc], sc1);
+                vload_lds<VEC>(&xf_lds[3 * xf_kpad + kc], sh1);
+            }
 #pragma unroll
             for (int i = 0; i < A_ROWS; ++i) {
                 const bool q = xf_tile_seg == 2 && xf_row_seg[i];
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
-                    float u = act_apply(a_reg[i][v] * (q ? xf_sc[st][1][v] : xf_sc[st][0][v]) + (q ? xf_sh[st][1][v] : xf_sh[st][0][v]), p.a_act);
-                    if (p.a_rowscale) u *= xf_rs[st][i][v];
+                    float u = xf_act(a_reg[i][v] * (q ? sc1[v] : sc0[v]) + (q ? sh1[v] : sh0[v]), p.a_act);
+                    if (XF == 2) u *= xf_rs[st][i][v];
                     a_reg[i][v] = u;
                 }
             }
@@ -347,12 +367,13 @@ void igemm_nt_kernel(const NtParams p) {
         mma_tile();
         __syncthreads();
         if (kt + 1 < nk) {
-            store_tiles(nxt);                         // tile kt+1, loaded one iteration ago
+            store_tiles(nxt, kt + 1);                 // tile kt+1, loaded one iteration ago
             __syncthreads();
         }
     };
     load_tiles(S0{});
-    store_tiles(S0{});
+    if (XF) __syncthreads();                          // the staged scale / shift vectors are visible to every thread
+    store_tiles(S0{}, 0);
     __syncthreads();
     if (nk > 1) load_tiles(S1{});
     for (int kt = 0; kt < nk; kt += 2) {
@@ -739,7 +760,7 @@ struct TnParams {
 };
 
 template <int BM, int BN, int WM, int WN, int VECA, int VECB, bool XF = false>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (VECA == 1 || VECB == 1) ? 1 : ((BM == 128 && BN == 128) ? 6 : 5))
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (VECA == 1 || VECB == 1) ? 1 : (XF ? 4 : ((BM == 128 && BN == 128) ? 6 : 5)))
 void igemm_tn_kernel(const TnParams p) {
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -788,18 +809,19 @@ void igemm_tn_kernel(const TnParams p) {
 
     // input transform (XF, pointwise convs: k' = channel): this thread's channels are fixed, so scale / shift of both segments are
     // loaded once; the per-sample scale is fetched per staged row
-    float xs[2][VECB], xh[2][VECB], xrs[XF ? B_IT : 1][VECB];
+    float xs0[VECB], xh0[VECB], xs1[VECB], xh1[VECB], xrs[XF ? B_IT : 1][VECB];
     bool xseg[XF ? B_IT : 1];
     BufRsrc xrr = xr;
     if (XF) {
+        const bool two = p.x_seg_row > 0;
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int v = 0; v < VECB; ++v) {
-                const bool ok = kq + v < g.K && (q == 0 || p.x_seg_row > 0);
-                xs[q][v] = ok ? p.x_scale[q * g.K + kq + v] : 0.f;
-                xh[q][v] = ok ? p.x_shift[q * g.K + kq + v] : 0.f;
-            }
+        for (int v = 0; v < VECB; ++v) {
+            const bool ok = kq + v < g.K;
+            xs0[v] = ok ? p.x_scale[kq + v] : 0.f;
+            xh0[v] = ok ? p.x_shift[kq + v] : 0.f;
+            xs1[v] = (ok && two) ? p.x_scale[g.K + kq + v] : 0.f;
+            xh1[v] = (ok && two) ? p.x_shift[g.K + kq + v] : 0.f;
+        }
         if (p.x_rowscale) xrr = make_rsrc(p.x_rowscale, (int64_t)((g.M + p.x_hw - 1) / p.x_hw) * g.K * 4);
     }
 
@@ -846,7 +868,7 @@ void igemm_tn_kernel(const TnParams p) {
             for (int i = 0; i < B_IT; ++i)
 #pragma unroll
                 for (int v = 0; v < VECB; ++v) {
-                    float u = act_apply(b_reg[i][v] * (xseg[i] ? xs[1][v] : xs[0][v]) + (xseg[i] ? xh[1][v] : xh[0][v]), p.x_act);
+                    float u = xf_act(b_reg[i][v] * (xseg[i] ? xs1[v] : xs0[v]) + (xseg[i] ? xh1[v] : xh0[v]), p.x_act);
                     if (p.x_rowscale) u *= xrs[i][v];
                     b_reg[i][v] = u;
                 }
@@ -1075,7 +1097,11 @@ static void launch_nt(const NtParams& p_in, int groups, hipStream_t st) {
     switch (nt_mode(p.g)) {
         case 1:
             if (p.a_scale) {
-                if constexpr (VEC == 4) hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1, false, true>), grid, block, 0, st, p);
+                if constexpr (VEC == 4) {
+                    const size_t lds = (size_t)(p.a_seg_row > 0 ? 2 : 1) * 2 * ((p.g.K + 3) & ~3) * sizeof(float);
+                    if (p.a_rowscale) hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1, false, 2>), grid, block, lds, st, p);
+                    else hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1, false, 1>), grid, block, lds, st, p);
+                }
             } else if (p.scale) hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1, true>), grid, block, 0, st, p);
             else hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1>), grid, block, 0, st, p);
             break;
@@ -1330,8 +1356,9 @@ int suhpe_conv2d_fwd_stats_xf(const suhpe_conv_t* d, const float* x, const float
     SUHPE_REQUIRE(xf_desc_ok(d), "suhpe_conv2d_fwd_stats_xf: pointwise convs only (1x1, stride 1, pad 0, groups 1, channels %% 4 == 0)");
     SUHPE_REQUIRE(x && w && y && a_scale && a_shift && aligned16(x) && aligned16(w) && aligned16(a_scale) && aligned16(a_shift) && aligned16(a_rowscale),
                   "suhpe_conv2d_fwd_stats_xf: null or unaligned pointer");
-    SUHPE_REQUIRE(a_act >= SUHPE_ACT_NONE && a_act <= SUHPE_ACT_SIGMOID && a_hw > 0 && seg_row >= 0 && (!stats_extra || seg_row > 0) && (!seg_row || stats_extra || !stats),
-                  "suhpe_conv2d_fwd_stats_xf: bad activation / hw / segment arguments");
+    SUHPE_REQUIRE((a_act == SUHPE_ACT_NONE || a_act == SUHPE_ACT_RELU || a_act == SUHPE_ACT_SILU) && a_hw > 0 && seg_row >= 0 && (!stats_extra || seg_row > 0) &&
+                      (!seg_row || stats_extra || !stats) && d->cin <= 4096,
+                  "suhpe_conv2d_fwd_stats_xf: activation must be none / relu / silu; bad hw / segment arguments; cin <= 4096");
     NtParams p;
     p.g = make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, d->cin, 1, 1, 1, 0, 0);
     p.x = x; p.f = w; p.bias = nullptr; p.y = y; p.Ng = d->cout; p.ldy = d->cout; p.ldf = p.g.K;
@@ -1535,8 +1562,9 @@ int suhpe_conv2d_wgrad_partial_xf(const suhpe_conv_t* d, const float* x, const f
                                   const float* a_scale, const float* a_shift, const float* a_rowscale, int a_act, int a_hw, int64_t seg_row,
                                   suhpe_stream_t stream) {
     SUHPE_REQUIRE(xf_desc_ok(d), "suhpe_conv2d_wgrad_partial_xf: pointwise convs only (1x1, stride 1, pad 0, groups 1, channels %% 4 == 0)");
-    SUHPE_REQUIRE(a_scale && a_shift && a_act >= SUHPE_ACT_NONE && a_act <= SUHPE_ACT_SIGMOID && a_hw > 0 && seg_row >= 0 && aligned16(a_rowscale),
-                  "suhpe_conv2d_wgrad_partial_xf: bad transform arguments");
+    SUHPE_REQUIRE(a_scale && a_shift && (a_act == SUHPE_ACT_NONE || a_act == SUHPE_ACT_RELU || a_act == SUHPE_ACT_SILU) && a_hw > 0 && seg_row >= 0 &&
+                      aligned16(a_rowscale),
+                  "suhpe_conv2d_wgrad_partial_xf: bad transform arguments (activation: none / relu / silu)");
     const XInput xf{a_scale, a_shift, a_rowscale, a_act, a_hw, seg_row};
     return wgrad_partial_impl(d, x, dy, workspace, workspace_bytes, &xf, stream);
 }

@@ -694,7 +694,17 @@ def test_producer_batchnorm_applied_by_consumer_loader(kind, stride, cin, cout, 
         tape = []
         with L.batch_segments(seg):
             y = blk.fwd(x, tape)
-            n_saved = sum(t.numel() for e in tape for t in (e if isinstance(e, tuple) else (e,)) if torch.is_tensor(t) and t.dim() == 4)
+            seen = {}
+
+            def walk(e):
+                if torch.is_tensor(e):
+                    if e.dim() == 4:
+                        seen[e.data_ptr()] = e.numel()
+                elif isinstance(e, (tuple, list)):
+                    for q in e:
+                        walk(q)
+            walk(tape)
+            n_saved = sum(seen.values())                    # distinct activation-sized tensors held for the backward
             dx = blk.bwd(dy, tape)
         assert not tape
         return y, dx, {n: p.grad.clone() for n, p in blk.named_parameters()}, {k: v.clone() for k, v in blk.state_dict().items() if "running" in k}, n_saved
