@@ -37,7 +37,7 @@ constexpr int LDK = BK + 4;     // padded LDS row (floats): 144 B keeps 16-B ali
 // expf / erff paths of act_apply cost the GEMM loaders dozens of VGPRs and scratch; none / ReLU / SiLU are what the producers of
 // a pointwise conv's input use (torchvision MBConv / FusedMBConv)
 __device__ __forceinline__ float xf_act(float u, int act) {
-    const float s = u / (1.f + __expf(-u));
+    const float s = u * __builtin_amdgcn_rcpf(1.f + __expf(-u));       // v_exp_f32 + v_rcp_f32: ~1 ulp each
     return act == SUHPE_ACT_SILU ? s : (act == SUHPE_ACT_RELU ? fmaxf(u, 0.f) : u);
 }
 
@@ -131,7 +131,7 @@ template <int BM, int BN, int WM, int WN, int VEC, int MODE, bool AFF = false, i
 // prefetch depth, which leaves 2 workgroups (or 1, for the wgrad kernel) per CU; at <= 80 VGPRs three 8-wave workgroups are
 // resident and the MFMA pipe sees 6 waves per SIMD.
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64,
-                             (VEC == 1 || BM == 256) ? 1 : (XF ? 4 : ((WM == 64 && WN == 64) ? 3 : (((BM / WM) * (BN / WN) > 8 || BN == 32 || BN == 128 || MODE == 0) ? 5 : 6))))
+                             (VEC == 1 || BM == 256) ? 1 : (XF ? (XF == 2 ? 3 : 4) : ((WM == 64 && WN == 64) ? 3 : (((BM / WM) * (BN / WN) > 8 || BN == 32 || BN == 128 || MODE == 0) ? 5 : 6))))
 void igemm_nt_kernel(const NtParams p) {
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -198,22 +198,18 @@ void igemm_nt_kernel(const NtParams p) {
             a_pix[i] = -1;
         }
     }
-    // ---- input transform (XF): scale / shift of every k column (both segments) are staged once in dynamic LDS; the per-sample
-    // scale (XF == 2) is fetched with the tile's rows and carried through the register stages
-    extern __shared__ __attribute__((aligned(16))) float xf_lds[];          // [segments][2][Kpad]: scale then shift
+    // ---- input transform (XF): the scale / shift vectors of a slab's k columns ride with the slab's loads through the register
+    // stages (tiny, cache-resident arrays); a tile that straddles the segment boundary loads both statistics sets; the per-sample
+    // scale (XF == 2) is one more vector per row
     int xf_tile_seg = 0;                                     // 0 / 1: every row of the tile in that segment, 2: the tile straddles the boundary
     bool xf_row_seg[XF ? A_ROWS : 1];
     int xf_row_n[XF == 2 ? A_ROWS : 1];
-    BufRsrc xf_rr = xr;
-    const int xf_kpad = (g.K + 3) & ~3;
+    BufRsrc xf_sr = xr, xf_hr = xr, xf_rr = xr;
     if (XF) {
         if (p.a_seg_row > 0) xf_tile_seg = m0 + BM <= p.a_seg_row ? 0 : (m0 >= p.a_seg_row ? 1 : 2);
-        const int segs = p.a_seg_row > 0 ? 2 : 1;
-        for (int i = t; i < segs * g.K; i += NT) {
-            const int sg = i / g.K, k = i - sg * g.K;
-            xf_lds[(sg * 2 + 0) * xf_kpad + k] = p.a_scale[i];
-            xf_lds[(sg * 2 + 1) * xf_kpad + k] = p.a_shift[i];
-        }
+        const int64_t seg_bytes = (int64_t)(p.a_seg_row > 0 ? 2 : 1) * g.K * 4;
+        xf_sr = make_rsrc(p.a_scale, seg_bytes);
+        xf_hr = make_rsrc(p.a_shift, seg_bytes);
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
             const int64_t m = m0 + lrow + i * ROW_STEP;
@@ -221,8 +217,8 @@ void igemm_nt_kernel(const NtParams p) {
             if (XF == 2) xf_row_n[i] = (int)fast_div((unsigned)(m < g.M ? m : g.M - 1), p.a_div_mul, p.a_div_shr);
         }
         if (XF == 2) xf_rr = make_rsrc(p.a_rowscale, (int64_t)((g.M + p.a_hw - 1) / p.a_hw) * g.K * 4);
-        // (the first store_tiles comes after the first global loads have returned; a barrier orders the staging before it)
     }
+    float xf_sc0[2][VEC], xf_sh0[2][VEC], xf_sc1[2][VEC], xf_sh1[2][VEC];
     float xf_rs[2][XF == 2 ? A_ROWS : 1][VEC];
 
     // this thread's position in the reduction: k = tap*Cg + ci, tap = (r, s); advanced by BK per tile
@@ -268,10 +264,19 @@ void igemm_nt_kernel(const NtParams p) {
             const bool ok = kvalid & (b_off[i] >= 0);
             buf_load<VEC>(fr, ok ? ((unsigned)b_off[i] + (unsigned)fk) * 4u : kOob, b_reg[i]);
         }
-        if (XF == 2) {                                       // per-sample scale of this slab's k columns, one vector per row
+        if (XF) {
             constexpr int st = decltype(stage)::value;
+            const unsigned k4 = (unsigned)kk * 4u, seg0 = xf_tile_seg == 1 ? (unsigned)g.K * 4u : 0u;
+            buf_load<VEC>(xf_sr, kvalid ? seg0 + k4 : kOob, xf_sc0[st]);
+            buf_load<VEC>(xf_hr, kvalid ? seg0 + k4 : kOob, xf_sh0[st]);
+            if (xf_tile_seg == 2) {                          // (workgroup-uniform: one tile per launch at most)
+                buf_load<VEC>(xf_sr, kvalid ? (unsigned)g.K * 4u + k4 : kOob, xf_sc1[st]);
+                buf_load<VEC>(xf_hr, kvalid ? (unsigned)g.K * 4u + k4 : kOob, xf_sh1[st]);
+            }
+            if (XF == 2) {                                   // per-sample scale of this slab's k columns, one vector per row
 #pragma unroll
-            for (int i = 0; i < A_ROWS; ++i) buf_load<VEC>(xf_rr, kvalid ? ((unsigned)xf_row_n[i] * (unsigned)g.K + (unsigned)kk) * 4u : kOob, xf_rs[st][i]);
+                for (int i = 0; i < A_ROWS; ++i) buf_load<VEC>(xf_rr, kvalid ? ((unsigned)xf_row_n[i] * (unsigned)g.K + (unsigned)kk) * 4u : kOob, xf_rs[st][i]);
+            }
         }
         // advance to the next tile
         kk += BK;
@@ -287,22 +292,13 @@ void igemm_nt_kernel(const NtParams p) {
             // rows beyond M / columns beyond K carry act(shift) instead of 0: harmless, those rows are never stored and the
             // filter's columns beyond K are zero
             constexpr int st = decltype(stage)::value;
-            const int k = kt_store * BK + lcol;
-            const int kc = k < xf_kpad ? k : 0;
-            const int s0 = xf_tile_seg == 1 ? 1 : 0;
-            float sc0[VEC], sh0[VEC], sc1[VEC], sh1[VEC];
-            vload_lds<VEC>(&xf_lds[(s0 * 2 + 0) * xf_kpad + kc], sc0);
-            vload_lds<VEC>(&xf_lds[(s0 * 2 + 1) * xf_kpad + kc], sh0);
-            if (xf_tile_seg == 2) {
-                vload_lds<VEC>(&xf_lds[2 * xf_kpad + kc], sc1);
-                vload_lds<VEC>(&xf_lds[3 * xf_kpad + kc], sh1);
-            }
+            (void)kt_store;
 #pragma unroll
             for (int i = 0; i < A_ROWS; ++i) {
                 const bool q = xf_tile_seg == 2 && xf_row_seg[i];
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
-                    float u = xf_act(a_reg[i][v] * (q ? sc1[v] : sc0[v]) + (q ? sh1[v] : sh0[v]), p.a_act);
+                    float u = xf_act(a_reg[i][v] * (q ? xf_sc1[st][v] : xf_sc0[st][v]) + (q ? xf_sh1[st][v] : xf_sh0[st][v]), p.a_act);
                     if (XF == 2) u *= xf_rs[st][i][v];
                     a_reg[i][v] = u;
                 }
@@ -372,7 +368,6 @@ void igemm_nt_kernel(const NtParams p) {
         }
     };
     load_tiles(S0{});
-    if (XF) __syncthreads();                          // the staged scale / shift vectors are visible to every thread
     store_tiles(S0{}, 0);
     __syncthreads();
     if (nk > 1) load_tiles(S1{});
@@ -1098,7 +1093,7 @@ static void launch_nt(const NtParams& p_in, int groups, hipStream_t st) {
         case 1:
             if (p.a_scale) {
                 if constexpr (VEC == 4) {
-                    const size_t lds = (size_t)(p.a_seg_row > 0 ? 2 : 1) * 2 * ((p.g.K + 3) & ~3) * sizeof(float);
+                    const size_t lds = 0;
                     if (p.a_rowscale) hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1, false, 2>), grid, block, lds, st, p);
                     else hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1, false, 1>), grid, block, lds, st, p);
                 }
