@@ -720,7 +720,8 @@ def test_producer_batchnorm_applied_by_consumer_loader(kind, stride, cin, cout, 
         assert rel(g1[n], g0[n]) < 2e-4, n
     for k in r0:
         assert rel(r1[k], r0[k]) < 1e-6, k
-    assert saved1 < saved0                                   # the activated tensor is not on the tape any more
+    if kind == "fused" or blk._dw_se_fused():                # (an SE block whose squeeze width is not a multiple of 4 keeps the layer-by-layer form)
+        assert saved1 < saved0                               # the activated tensor is not on the tape any more
 
 
 @pytest.mark.parametrize("ws,heads,B,H", [(7, 6, 6, 28), (14, 12, 5, 14), (7, 18, 9, 7)])
