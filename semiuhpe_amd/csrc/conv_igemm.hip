@@ -285,25 +285,30 @@ void igemm_nt_kernel(const NtParams p) {
             while (ci >= g.Cg && g.R * g.S > 1) { ci -= g.Cg; if (++ts == g.S) { ts = 0; ++tr; } }
         }
     };
+    // the input transform of a staged tile, in registers.  It is issued BEFORE the MFMAs of the previous tile (the tile's loads
+    // are one slab old by then), so its VALU work fills the issue slots between that wave's dependent MFMAs instead of
+    // lengthening the store phase between the two barriers
+    auto xform_tiles = [&](auto stage) __attribute__((always_inline)) {
+        if (!XF) return;
+        auto& a_reg = a_stage[decltype(stage)::value];
+        constexpr int st = decltype(stage)::value;
+        // rows beyond M / columns beyond K carry act(shift) instead of 0: harmless, those rows are never stored and the
+        // filter's columns beyond K are zero
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+            const bool q = xf_tile_seg == 2 && xf_row_seg[i];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                float u = xf_act(a_reg[i][v] * (q ? xf_sc1[st][v] : xf_sc0[st][v]) + (q ? xf_sh1[st][v] : xf_sh0[st][v]), p.a_act);
+                if (XF == 2) u *= xf_rs[st][i][v];
+                a_reg[i][v] = u;
+            }
+        }
+    };
     auto store_tiles = [&](auto stage, int kt_store = 0) {
         auto& a_reg = a_stage[decltype(stage)::value];
         auto& b_reg = b_stage[decltype(stage)::value];
-        if (XF) {
-            // rows beyond M / columns beyond K carry act(shift) instead of 0: harmless, those rows are never stored and the
-            // filter's columns beyond K are zero
-            constexpr int st = decltype(stage)::value;
-            (void)kt_store;
-#pragma unroll
-            for (int i = 0; i < A_ROWS; ++i) {
-                const bool q = xf_tile_seg == 2 && xf_row_seg[i];
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) {
-                    float u = xf_act(a_reg[i][v] * (q ? xf_sc1[st][v] : xf_sc0[st][v]) + (q ? xf_sh1[st][v] : xf_sh0[st][v]), p.a_act);
-                    if (XF == 2) u *= xf_rs[st][i][v];
-                    a_reg[i][v] = u;
-                }
-            }
-        }
+        (void)kt_store;
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
             if (BM % ROW_STEP != 0 && lrow + i * ROW_STEP >= BM) continue;
@@ -360,6 +365,7 @@ void igemm_nt_kernel(const NtParams p) {
     // tile j lives in register stage j & 1
     auto step = [&](int kt, auto cur, auto nxt) {
         if (kt + 2 < nk) load_tiles(cur);             // stage `cur` held tile kt, already in LDS: refill it with tile kt+2
+        if (kt + 1 < nk) xform_tiles(nxt);            // (XF) tile kt+1 in registers, under this tile's MFMAs
         mma_tile();
         __syncthreads();
         if (kt + 1 < nk) {
@@ -368,6 +374,7 @@ void igemm_nt_kernel(const NtParams p) {
         }
     };
     load_tiles(S0{});
+    xform_tiles(S0{});
     store_tiles(S0{}, 0);
     __syncthreads();
     if (nk > 1) load_tiles(S1{});
