@@ -115,9 +115,9 @@ class Conv2d(Layer):
             tape.append(x if xf is None else (x, xf))
         return out[0], out[1:]
 
-    def takes_input_xform(self):
+    def takes_input_xform(self, level=1):
         """can this conv apply its producer's BatchNorm + activation while loading?  (pointwise, 16-byte channel vectors)"""
-        return (XF_FUSION and self.kernel_size == 1 and self.stride == 1 and self.padding == 0 and self.groups == 1 and self.bias is None
+        return (XF_FUSION >= level and self.kernel_size == 1 and self.stride == 1 and self.padding == 0 and self.groups == 1 and self.bias is None
                 and self.in_channels % 4 == 0 and self.out_channels % 4 == 0)
 
     def _depthwise(self):
@@ -193,7 +193,11 @@ class Linear(Layer):
 # single-process global-batch BatchNorm exactly; the default is per-rank statistics (standard data-parallel semantics).
 # Set by SSLAgent from config.sync_bn; it implies two separate student passes (no batch segments).
 SYNC_BN = False
-XF_FUSION = os.environ.get("SUHPE_XF_FUSION", "1") != "0"   # BatchNorm + activation (+ SE scale) of a producer applied by the consuming 1x1 conv's loader
+# A producer's train-mode BatchNorm + activation (+ SqueezeExcitation scale) applied by the consuming 1x1 conv's loader instead of a
+# kernel of its own: 0 = never, 1 = FusedMBConv blocks (BatchNorm + SiLU, the network's largest tensors: a measured win),
+# 2 = MBConv blocks too (their per-sample excitation needs one more vector load per row and slab in the GEMM loader, which costs
+# the GEMMs more than the removed pass saves on MI355X -- it remains as the memory-saving mode: the excited tensor is never stored)
+XF_FUSION = int(os.environ.get("SUHPE_XF_FUSION", "1"))
 DW_STATS = os.environ.get("SUHPE_DW_STATS", "1") != "0"      # depthwise convs emit their BatchNorm's statistics records themselves
 
 _SEGMENT = None

@@ -161,7 +161,7 @@ class MBConv(_ResidualBlock):
         if tape is not None:
             tape.append((y, mean, rstd, rows_a, bn_d.training, p, a1, s, hw))
         proj = self.block[-1]
-        if bn_d.training and proj[1].training and proj[0].takes_input_xform():
+        if bn_d.training and proj[1].training and proj[0].takes_input_xform(level=2):
             # the project conv's loader applies silu(BN(y)) * s itself: nothing of the expanded width is written here
             sc, sh = K.bn_affine_from_stats(mean, rstd, bn_d.weight, bn_d.bias)
             return y, (sc, sh, s, bn_d.act, hw, rows_a)

@@ -54,11 +54,15 @@ def test_state_dict_keys_and_eval_forward(models):
     assert float((R.cpu() - R_ref).abs().max()) < 1e-4
 
 
-def test_train_forward_backward(models):
+@pytest.mark.parametrize("xf", [1, 0, 2])
+def test_train_forward_backward(models, xf):
+    """xf: layers.XF_FUSION -- 0: every BatchNorm + activation is a kernel of its own, 1 (default): the FusedMBConv project convs apply
+    their producer's BatchNorm + SiLU while loading, 2: the MBConv project convs as well (with the SqueezeExcitation scale)"""
     from oracle import networks as ON
     from semiuhpe_amd import layers as L
     ref, hip = models
     ref.train(); hip.train()
+    xf_default, L.XF_FUSION = L.XF_FUSION, xf
     tape = MaskTape(7)
     x = torch.randn(6, 3, 96, 96, generator=torch.Generator().manual_seed(3))
     dy = torch.randn(6, 9, generator=torch.Generator().manual_seed(4))
@@ -74,8 +78,11 @@ def test_train_forward_backward(models):
     L.set_mask_hook(tape.replay)
     for p in hip.parameters():
         p.grad = None
-    y = hip(x.cuda())
-    y.backward(dy.cuda())
+    try:
+        y = hip(x.cuda())
+        y.backward(dy.cuda())
+    finally:
+        L.XF_FUSION = xf_default
     L.set_mask_hook(None)
     assert tape.done()
     assert rel_err(y, y_ref) < 2e-4

@@ -684,8 +684,10 @@ def test_producer_batchnorm_applied_by_consumer_loader(kind, stride, cin, cout, 
     ho = 14 // stride
     dy = torch.randn(8, ho, ho, cout, generator=g).cuda()
 
+    xf_default = L.XF_FUSION
+
     def run(fused):
-        L.XF_FUSION = fused
+        L.XF_FUSION = 2 if fused else 0
         blk.load_state_dict(state0)
         blk.train()
         for p in blk.parameters():
@@ -713,7 +715,7 @@ def test_producer_batchnorm_applied_by_consumer_loader(kind, stride, cin, cout, 
         y0, dx0, g0, r0, saved0 = run(False)
         y1, dx1, g1, r1, saved1 = run(True)
     finally:
-        L.XF_FUSION = True
+        L.XF_FUSION = xf_default
     rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
     assert rel(y1, y0) < 2e-5 and rel(dx1, dx0) < 1e-4
     for n in g0:
