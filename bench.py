@@ -166,8 +166,8 @@ def cpu_leg():
     C1 (the reference's own CPU-runnable config: supervised train_func_s1 steps, B=32) 2 warm-up + 5 timed, and the C2 step
     shape (B=32 + muB=128 SSL step, the workload of `value`) 1 small warm-up + 2 timed -- a bounded sample (about a minute of
     CPU work on 32 threads).  `value` is the C2 rate (same workload as the GPU line).  The same leg holds the Euler-MAE parity
-    check of the HIP path against this CPU path on a 256-image sample of the 8d evaluation set (tools/mae_parity.py; the full
-    1 964 images run in tests/test_gpu_mae_parity.py)."""
+    check of the HIP path against this CPU path on the 1 964 images of the 8d evaluation set (tools/mae_parity.py, about 15 s of CPU
+    evaluation; also asserted in tests/test_gpu_mae_parity.py)."""
     from oracle import networks as ON
     from oracle.agent import OracleAgent, synthetic_batches
     ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -206,7 +206,7 @@ def cpu_leg():
     try:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import mae_parity
-        mae = mae_parity.run(n_images=256, warm_steps=3, train_batch=(8, 16), size=224, network="effinetv2")
+        mae = mae_parity.run(n_images=mae_parity.EVAL_IMAGES, warm_steps=3, train_batch=(8, 16), size=224, network="effinetv2")
     except Exception as e:                                     # the throughput line must not die with the checker
         mae = {"error": repr(e)}
     return {"value": round((B_LABELED + B_LABELED * MU) / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(),
