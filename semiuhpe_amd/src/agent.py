@@ -108,6 +108,13 @@ class SSLAgent:
             if self._bn_flat_all is not None:
                 D.broadcast_(self._bn_flat_all.data, 0)
         self._grad_seed = D.grad_seed(self.device)
+        # The host enqueues a step in a third of the time the GPU needs for it and nothing in the step synchronises, so it would run
+        # many steps ahead; every tensor that crosses to the side stream (record_stream) stays unavailable to the caching allocator
+        # until the GPU has passed it, so the RESERVED pool grew to ~5 steps' worth of activations (74 GiB for a 14 GiB step).  The
+        # host now waits for the end of step i - depth before it enqueues step i: the launch queue stays 1-2 steps deep (the GPU never
+        # idles) and the pool holds what `depth` steps need.
+        self._flight_depth = max(1, int(getattr(config, "steps_in_flight", os.environ.get("SUHPE_STEPS_IN_FLIGHT", "2"))))
+        self._flight_events = []
         # gradient exchange in reverse-layer buckets, overlapped with the backward (one stream for RCCL beside the compute
         # streams); SUHPE_GRAD_BUCKETS=1 (or config.grad_buckets) = one collective after the backward
         self._buckets = None
@@ -281,8 +288,19 @@ class SSLAgent:
             if self._bn_flat_all is not None:
                 D.allreduce_avg_(self._bn_flat_all.data)
 
+    def _throttle(self):
+        """keep at most `steps_in_flight` training steps enqueued ahead of the GPU (bounds the caching allocator's pool)"""
+        if len(self._flight_events) >= self._flight_depth:
+            self._flight_events.pop(0).synchronize()
+
+    def _step_done(self):
+        ev = torch.cuda.Event()
+        ev.record()
+        self._flight_events.append(ev)
+
     def train_func(self, data, ulb_data):
         """one SSL step (reference :194-218)"""
+        self._throttle()
         _mode(self.net, True)
         _mode(self.ema_net, True)
         stage2_iter = self.clock.iteration - self.config.stage1_iteration
@@ -297,10 +315,12 @@ class SSLAgent:
             loss_all.backward(self._grad_seed)
         self._exchange()
         self.optimizer.step()
+        self._step_done()
         return fisher_dict, fisher_dict_unsuper, dict(SSL_lambda=SSL_lambda, loss_all=loss_all.detach())
 
     def train_func_s1(self, data):
         """supervised step (reference :254-266); the EMA teacher is not touched in stage 1"""
+        self._throttle()
         _mode(self.net, True)
         self.optimizer.zero_grad()
         fisher_dict, _ = self.forward(data, None)
@@ -308,6 +328,7 @@ class SSLAgent:
         fisher_dict["loss"].backward(self._grad_seed)
         self._exchange()
         self.optimizer.step()
+        self._step_done()
         return fisher_dict
 
     def val_func(self, data, eval_ema=False):
