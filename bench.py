@@ -275,7 +275,9 @@ def main():
     if world > 1:
         from semiuhpe_amd.src.distributed import init_from_env
         init_from_env(os.environ.get("SUHPE_DIST_BACKEND", "nccl"))
-    dt, info, roof = gpu_leg(args, rank, world, device)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):            # library / evaluation prints go to stderr: stdout carries the ONE JSON line
+        dt, info, roof = gpu_leg(args, rank, world, device)
     if rank == 0:
         ms = dt / args.steps * 1e3
         out = {
@@ -292,7 +294,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             torch.cuda.empty_cache()
-            out["cpu_baseline"] = cpu_leg()
+            with contextlib.redirect_stdout(sys.stderr):
+                out["cpu_baseline"] = cpu_leg()
             out["mae_parity"] = out["cpu_baseline"].pop("mae_parity", None)
         print(json.dumps(out), flush=True)
     if world > 1:

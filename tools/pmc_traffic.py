@@ -16,7 +16,7 @@ import csv, glob, json, re, sys
 def normalize(name):
     """rocprofv3 kernel name -> the name bench.py / suhpe_conv2d_kernel_name uses"""
     name = re.sub(r"\(.*$", "", name.replace("void ", "").replace("suhpe::", "")).replace(" ", "")
-    m = re.match(r"(igemm_nt_kernel<\d+,\d+,\d+,\d+,\d+),\d+(,(true|false))*>", name)     # drop MODE and the epilogue / input-transform flags
+    m = re.match(r"(igemm_nt_kernel<\d+,\d+,\d+,\d+,\d+),\d+(,(true|false|\d+))*>", name)     # drop MODE and the epilogue / input-transform flags
     if m:
         return m.group(1) + ">"
     m = re.match(r"(igemm_nt3x3_kernel<\d+,\d+,\d+,\d+),\d+(,(true|false))*>", name)          # drop the channel chunk, tile kind, epilogue flag
