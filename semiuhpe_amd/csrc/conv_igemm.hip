@@ -131,7 +131,7 @@ template <int BM, int BN, int WM, int WN, int VEC, int MODE, bool AFF = false, i
 // prefetch depth, which leaves 2 workgroups (or 1, for the wgrad kernel) per CU; at <= 80 VGPRs three 8-wave workgroups are
 // resident and the MFMA pipe sees 6 waves per SIMD.
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64,
-                             (VEC == 1 || BM == 256) ? 1 : (XF ? (XF == 2 ? 3 : 4) : ((WM == 64 && WN == 64) ? 3 : (((BM / WM) * (BN / WN) > 8 || BN == 32 || BN == 128 || MODE == 0) ? 5 : 6))))
+                             (VEC == 1 || BM == 256) ? 1 : (XF ? (XF == 2 ? 3 : 4) : ((WM == 64 && WN == 64) ? 2 : ((WM == 64 && (BM / WM) * (BN / WN) == 4) ? 3 : (((BM / WM) * (BN / WN) > 8 || BN == 32 || BN == 128 || MODE == 0) ? 5 : 6)))))
 void igemm_nt_kernel(const NtParams p) {
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -1099,7 +1099,7 @@ static void launch_nt(const NtParams& p_in, int groups, hipStream_t st) {
     switch (nt_mode(p.g)) {
         case 1:
             if (p.a_scale) {
-                if constexpr (VEC == 4) {
+                if constexpr (VEC == 4 && !(WM == 64 && (BM / WM) * (BN / WN) == 4)) {
                     const size_t lds = 0;
                     if (p.a_rowscale) hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1, false, 2>), grid, block, lds, st, p);
                     else hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1, false, 1>), grid, block, lds, st, p);
@@ -1124,13 +1124,16 @@ static void launch_nt(const NtParams& p_in, int groups, hipStream_t st) {
 // NT_P* tile falls back to the igemm tile of the same size
 // NT_H*: the 3x3 / stride 1 halo-tile kernel (conv_halo.inl); on any other geometry a pinned NT_H* tile runs the igemm tile of the same size
 enum NtTile { NT_64x64_S = 0, NT_64x64, NT_128x32, NT_128x128, NT_128x64, NT_256x32, NT_P64x64, NT_P128x32, NT_P128x64, NT_P128x128,
-              NT_H64x64, NT_H128x32, NT_H128x64, NT_H128x128, NT_TILES };
+              NT_H64x64, NT_H128x32, NT_H128x64, NT_H128x128,
+              NT_W128x128, NT_W128x64,       // four wavefronts with 64x64 / 64x32 accumulators each: half the LDS fragment reads per MFMA
+              NT_TILES };
 static const char* kNtNames[] = {"igemm_nt_kernel<64,64,32,32,1>", "igemm_nt_kernel<64,64,32,32,4>", "igemm_nt_kernel<128,32,32,32,4>",
                                  "igemm_nt_kernel<128,128,64,32,4>", "igemm_nt_kernel<128,64,32,32,4>", "igemm_nt_kernel<256,32,64,32,4>",
                                  "gemm_nt_persistent<64,64,32,32>", "gemm_nt_persistent<128,32,32,32>", "gemm_nt_persistent<128,64,32,32>",
                                  "gemm_nt_persistent<128,128,64,32>",
                                  "igemm_nt3x3_kernel<64,64,32,32>", "igemm_nt3x3_kernel<128,32,32,32>", "igemm_nt3x3_kernel<128,64,32,32>",
-                                 "igemm_nt3x3_kernel<128,128,64,32>"};
+                                 "igemm_nt3x3_kernel<128,128,64,32>",
+                                 "igemm_nt_kernel<128,128,64,64,4>", "igemm_nt_kernel<128,64,64,32,4>"};
 
 struct TnTile { int bm, bn; const char* name; };
 static const TnTile kTnTiles[] = {
@@ -1203,6 +1206,7 @@ static void launch_persistent(const NtParams& p_in, int groups, hipStream_t st) 
 
 // a pinned persistent tile on a shape that is not a plain GEMM runs the igemm tile of the same size
 static NtTile effective_nt(NtTile tile, bool plain, bool halo = false) {
+    if (tile >= NT_W128x128) return tile;
     if (tile >= NT_H64x64) {
         if (halo) return tile;
         return tile == NT_H64x64 ? NT_64x64 : (tile == NT_H128x32 ? NT_128x32 : (tile == NT_H128x64 ? NT_128x64 : NT_128x128));
@@ -1213,6 +1217,9 @@ static NtTile effective_nt(NtTile tile, bool plain, bool halo = false) {
 
 static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st, int pinned) {
     NtTile tile = choose_nt(p.g.M, p.Ng, vec4, pinned, halo_ok(p.g, vec4));
+    if (tile >= NT_W128x128 && p.a_scale) tile = tile == NT_W128x128 ? NT_128x128 : NT_128x64;     // (no input-transform form of the wide-accumulator tiles)
+    if (tile == NT_W128x128) { launch_nt<128, 128, 64, 64, 4>(p, groups, st); return; }
+    if (tile == NT_W128x64) { launch_nt<128, 64, 64, 32, 4>(p, groups, st); return; }
     if (tile >= NT_H64x64) {
         bool done = false;
         switch (tile) {
@@ -1468,7 +1475,7 @@ int suhpe_conv2d_set_tile(const suhpe_conv_t* d, int pass, int tile) {
     const int ng = d->cout / d->groups, cg = d->cin / d->groups;
     const bool v4 = ng % 4 == 0 && d->cout % 4 == 0 && cg % 4 == 0 && d->cin % 4 == 0;
     SUHPE_REQUIRE(tile < 0 || (v4 && !(pass != 2 && tile == (int)NT_64x64_S)), "suhpe_conv2d_set_tile: the vector tiles need channel counts that are multiples of 4");
-    SUHPE_REQUIRE(pass == 2 || tile < (int)NT_H64x64 || halo_ok_desc(d, pass), "suhpe_conv2d_set_tile: the halo tiles need a 3x3 / stride 1 / pad 1 conv with evenly chunked channels");
+    SUHPE_REQUIRE(pass == 2 || tile < (int)NT_H64x64 || tile >= (int)NT_W128x128 || halo_ok_desc(d, pass), "suhpe_conv2d_set_tile: the halo tiles need a 3x3 / stride 1 / pad 1 conv with evenly chunked channels");
     std::lock_guard<std::mutex> lock(tile_mutex());
     if (tile < 0) tile_table().erase(tile_key(d, pass));
     else tile_table()[tile_key(d, pass)] = tile;

@@ -1,0 +1,36 @@
+#!/bin/bash
+# Clock, MFMA-pipe and LDS activity of the NT GEMM tiles on pointwise shapes of the C2 step (run from the repo root through gpurun):
+#   bash tools/gemm_clock_study.sh > gpurun_out/gemm_clock_study.txt
+# One rocprofv3 --pmc pass per (shape, tile): GRBM_GUI_ACTIVE (summed over the 8 XCDs: / 8 / duration = the clock the chip held),
+# SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES / 4 (share of the time a SIMD's matrix pipe was busy; 1.000 on tools/micro/mfma_peak),
+# SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES, SQ_LDS_BANK_CONFLICT.
+R=$(pwd); cd /tmp && export TMPDIR=/tmp PYTHONPATH=$R
+for shape in "31360 960 160" "31360 160 960" "7840 1536 256" "31360 960 2048"; do
+  for tile in 1 3 4 6 8 14 15; do
+    rm -rf /tmp/pm; rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d /tmp/pm -- python3 $R/tools/gemm_pmc.py $shape 0 $tile > /dev/null 2>&1
+    python3 - "$shape" $tile <<'PY'
+import csv,glob,sys
+f=glob.glob('/tmp/pm/**/*counter_collection.csv',recursive=True)[0]
+rows=[r for r in csv.DictReader(open(f)) if 'gemm' in r['Kernel_Name']]
+last=max(int(r['Dispatch_Id']) for r in rows)
+d={r['Counter_Name']:float(r['Counter_Value']) for r in rows if int(r['Dispatch_Id'])==last}
+rr=[r for r in rows if int(r['Dispatch_Id'])==last][0]
+dur=int(rr['End_Timestamp'])-int(rr['Start_Timestamp'])
+m,n,k=[int(v) for v in sys.argv[1].split()]
+name=rr['Kernel_Name'].replace('void suhpe::','')[:44]
+print(f"M N K {sys.argv[1]:16s} tile {sys.argv[2]:>2s} {name:44s} {dur/1e3:7.1f} us {2*m*n*k/dur/1e3:6.1f} TF/s  clock {d['GRBM_GUI_ACTIVE']/8/(dur/1e3):5.0f} MHz  mfma_busy {d['SQ_VALU_MFMA_BUSY_CYCLES']/d['SQ_BUSY_CU_CYCLES']/4:.3f}  lds_active {d['SQ_LDS_IDX_ACTIVE']/d['SQ_BUSY_CU_CYCLES']:.3f}  bank_conflicts {d['SQ_LDS_BANK_CONFLICT']/max(1,d['SQ_LDS_IDX_ACTIVE']):.3f}")
+PY
+  done
+done
+rm -rf /tmp/pm; rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d /tmp/pm -- python3 $R/tools/micro/run_mfma_peak.py > /tmp/mp.log 2>&1
+python3 - <<'PY'
+import csv,glob
+f=glob.glob('/tmp/pm/**/*counter_collection.csv',recursive=True)
+rows=list(csv.DictReader(open(f[0])))
+last=max(int(r['Dispatch_Id']) for r in rows)
+d={r['Counter_Name']:float(r['Counter_Value']) for r in rows if int(r['Dispatch_Id'])==last}
+rr=[r for r in rows if int(r['Dispatch_Id'])==last][0]
+dur=int(rr['End_Timestamp'])-int(rr['Start_Timestamp'])
+print(f"register-only MFMA loop ({rr['Kernel_Name'][:30]}): clock {d['GRBM_GUI_ACTIVE']/8/(dur/1e3):5.0f} MHz  mfma_busy {d['SQ_VALU_MFMA_BUSY_CYCLES']/d['SQ_BUSY_CU_CYCLES']/4:.3f}")
+PY
+grep -i "TF" /tmp/mp.log | tail -2
