@@ -40,11 +40,18 @@ __device__ __forceinline__ DwXf4 dw_xf_load(const DwXform& xf, int ch) {
     }
     return r;
 }
+// activation of the input transform: SiLU on the hardware exponential / reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each) -- the
+// depthwise kernels evaluate it 1.5x (forward) to 3x (filter gradient) per element, which the accurate expf path (dozens of VALU
+// instructions) turned into the kernels' bound; other activations keep act_apply
+__device__ __forceinline__ float dw_act(float u, int act) {
+    if (act == SUHPE_ACT_SILU) return u * __builtin_amdgcn_rcpf(1.f + __expf(-u));
+    return act_apply(u, act);
+}
 template <bool XF>
 __device__ __forceinline__ float4 dw_xf(const DwXf4& t, float4 v) {
     if (!XF) return v;
-    return make_float4(act_apply(v.x * t.sc[0] + t.sh[0], t.act), act_apply(v.y * t.sc[1] + t.sh[1], t.act),
-                       act_apply(v.z * t.sc[2] + t.sh[2], t.act), act_apply(v.w * t.sc[3] + t.sh[3], t.act));
+    return make_float4(dw_act(v.x * t.sc[0] + t.sh[0], t.act), dw_act(v.y * t.sc[1] + t.sh[1], t.act),
+                       dw_act(v.z * t.sc[2] + t.sh[2], t.act), dw_act(v.w * t.sc[3] + t.sh[3], t.act));
 }
 
 __device__ __forceinline__ bool dw_coord(const DwGeom& g, int o, int tap, int extent, int* out) {

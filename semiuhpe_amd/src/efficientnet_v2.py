@@ -29,7 +29,7 @@ BN_EPS = 1e-3           # torchvision: partial(nn.BatchNorm2d, eps=1e-03) for th
 # Folding the expand conv's BatchNorm + SiLU into the depthwise loaders removes two passes over the largest activation but
 # makes the depthwise kernels recompute the SiLU 1.5x (forward) to 3x (filter gradient) per element: measured 84.1 vs 79.7
 # ms/step on C2, so it is off; the kernels and their tests stay (memory-saving mode: the expanded tensor is never stored).
-FUSE_EXPAND_BN_INTO_DW = False
+FUSE_EXPAND_BN_INTO_DW = os.environ.get("SUHPE_FUSE_EXPAND_DW", "0") == "1"
 FUSE_DW_BN_SE = os.environ.get("SUHPE_FUSE_DW_BN_SE", "1") != "0"     # depthwise BatchNorm + SiLU + SqueezeExcitation as one section (MBConv._dw_se_*)
 STOCHASTIC_DEPTH_PROB = 0.2
 

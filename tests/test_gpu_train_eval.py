@@ -228,3 +228,18 @@ def test_foreign_checkpoint_loads_and_evaluates(tmp_path, network):
             assert float((K.fisher_svd_project(a).cpu() - R_ref).abs().max()) < 1e-4
     # and the state dict written back has the reference's keys in the reference's order
     assert list(agent.net.state_dict().keys()) == list(net.state_dict().keys())
+
+
+def test_rccl_api_on_one_rank():
+    """the data-parallel plumbing on the nccl (= RCCL) backend with one rank: real RCCL calls, handles and stream hand-offs
+    (tests/nccl_single_worker.py); the boxes of this pool have a single GPU, so N > 1 over RCCL stays for the driver's SCALE run"""
+    import socket, subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SUHPE_AUTOTUNE="0", PYTHONPATH=ROOT)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_single_worker.py"), str(port)], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and "NCCL_SINGLE_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
