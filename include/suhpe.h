@@ -174,11 +174,13 @@ int suhpe_dwconv_fwd_stats(const suhpe_conv_t* d, const float* x, const float* w
 /* The same depthwise forward / filter gradient with the producer's BatchNorm + activation applied while loading the input:
  * x is the raw output of the preceding conv, the kernels use act(gamma*(x-mean)*rstd + beta) (zero at padding taps), so the
  * normalised tensor of an MBConv's expand conv never exists in memory (torchvision MBConv: Conv2dNormActivation 1x1 ->
- * Conv2dNormActivation depthwise).  gamma / beta may be NULL. */
+ * Conv2dNormActivation depthwise).  gamma / beta may be NULL.  seg_n > 0: batch segments -- mean / rstd hold two planes
+ * [2][C], the first for the samples [0, seg_n), the second for the rest (seg_n = 0: one plane [C]).  stats (forward, may be
+ * NULL): the output's BatchNorm statistics records exactly as suhpe_dwconv_fwd_stats writes them, same seg_n. */
 int suhpe_dwconv_bnact_fwd(const suhpe_conv_t* d, const float* x, const float* mean, const float* rstd, const float* gamma,
-                           const float* beta, int act, const float* w, float* y, suhpe_stream_t stream);
+                           const float* beta, int act, int seg_n, const float* w, float* y, float* stats, suhpe_stream_t stream);
 int suhpe_dwconv_bnact_wgrad(const suhpe_conv_t* d, const float* x, const float* mean, const float* rstd, const float* gamma,
-                             const float* beta, int act, const float* dy, float* dw, int accumulate, void* workspace,
+                             const float* beta, int act, int seg_n, const float* dy, float* dw, int accumulate, void* workspace,
                              int64_t workspace_bytes, suhpe_stream_t stream);
 /* db[c] (+)= sum over rows of dy (rows, c) */
 int suhpe_bias_grad(const float* dy, int64_t rows, int c, float* db, int accumulate, void* workspace,

@@ -25,20 +25,27 @@ struct DwGeom {
 // Optional input transform of the forward / filter-gradient kernels: the depthwise conv of an MBConv reads the expand
 // conv's raw output x and applies that conv's BatchNorm + activation while loading, v -> act(v*sc[c] + sh[c]) with
 // sc = gamma*rstd, sh = beta - mean*sc, so the normalised tensor is never written to or read from HBM.  Padding taps stay 0
-// (the padding is applied to the activated tensor).  mean == NULL: no transform.
-struct DwXform { const float* mean; const float* rstd; const float* gamma; const float* beta; int act; };
+// (the padding is applied to the activated tensor).  mean == NULL: no transform.  Batch segments (seg_n > 0): the samples
+// [0, seg_n) were normalised with mean[0..C) / rstd[0..C), the others with mean[C..2C) / rstd[C..2C) (gamma / beta are the
+// layer's); every thread walks its samples in increasing order, so it reloads its scale / shift once, when it crosses seg_n.
+struct DwXform { const float* mean; const float* rstd; const float* gamma; const float* beta; int act; int seg_n; int C; };
 struct DwXf4 { float sc[4], sh[4]; int act; bool on; };
-__device__ __forceinline__ DwXf4 dw_xf_load(const DwXform& xf, int ch) {
+__device__ __forceinline__ DwXf4 dw_xf_load(const DwXform& xf, int ch, int seg = 0) {
     DwXf4 r;
     r.on = xf.mean != nullptr;
     r.act = xf.act;
+    const int sch = seg * xf.C + ch;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         const float g = (r.on && xf.gamma) ? xf.gamma[ch + v] : 1.f, b = (r.on && xf.beta) ? xf.beta[ch + v] : 0.f;
-        r.sc[v] = r.on ? xf.rstd[ch + v] * g : 1.f;
-        r.sh[v] = r.on ? b - xf.mean[ch + v] * r.sc[v] : 0.f;
+        r.sc[v] = r.on ? xf.rstd[sch + v] * g : 1.f;
+        r.sh[v] = r.on ? b - xf.mean[sch + v] * r.sc[v] : 0.f;
     }
     return r;
+}
+template <bool XF>
+__device__ __forceinline__ void dw_xf_cross(DwXf4& xf, bool& second, const DwXform& xform, int ch, int n) {
+    if (XF && xform.seg_n > 0 && !second && n >= xform.seg_n) { xf = dw_xf_load(xform, ch, 1); second = true; }
 }
 // activation of the input transform: SiLU on the hardware exponential / reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each) -- the
 // depthwise kernels evaluate it 1.5x (forward) to 3x (filter gradient) per element, which the accurate expf path (dozens of VALU
@@ -84,12 +91,14 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const DwGeom g, const floa
     }
     __syncthreads();
     if (rsub >= g.rp || col0 + col >= cv) return;
-    const DwXf4 xf = dw_xf_load(xform, (col0 + col) * 4);
+    DwXf4 xf = dw_xf_load(xform, (col0 + col) * 4);
+    bool xsecond = false;
     const int64_t p0 = (int64_t)blockIdx.x * g.pix_per_block;
     int64_t p1 = p0 + g.pix_per_block;
     if (p1 > g.P) p1 = g.P;
     for (int64_t p = p0 + rsub; p < p1; p += g.rp) {
         const int n = (int)(p / ((int64_t)g.OH * g.OW));
+        dw_xf_cross<XF>(xf, xsecond, xform, (col0 + col) * 4, n);
         const int rem = (int)(p - (int64_t)n * g.OH * g.OW);
         const int oh = rem / g.OW, ow = rem - oh * g.OW;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -205,12 +214,13 @@ __global__ __launch_bounds__(256) void dw3x3_row_kernel(const float* __restrict_
 #pragma unroll
     for (int k = 0; k < 9; ++k) wv[k] = *reinterpret_cast<const float4*>(&wl[(k * cw + (active ? col : 0)) * 4]);
     const int coff = (col0 + col) * 4;
-    const DwXf4 xf = dw_xf_load(xform, active ? coff : 0);
+    DwXf4 xf = dw_xf_load(xform, active ? coff : 0);
     DwStat st_a, st;
-    bool crossed = false;
+    bool crossed = false, xsecond = false;
     if (STATS) { dw_stat_zero(st_a); dw_stat_zero(st); }
     for (int row = blockIdx.x * rp + rsub; active && row < N * OH; row += gridDim.x * rp) {
         const int n = row / OH, oh = row - n * OH;
+        dw_xf_cross<XF>(xf, xsecond, xform, coff, n);
         if (STATS && seg_n > 0 && !crossed && n >= seg_n) { st_a = st; dw_stat_zero(st); crossed = true; }
         const int ih0 = oh * stride - 1;
         bool rok[3];
@@ -289,13 +299,14 @@ __global__ __launch_bounds__(256) void dw3x3_s1_kernel(const float* __restrict__
     for (int k = 0; k < 9; ++k) wv[k] = *reinterpret_cast<const float4*>(&wl[(k * cw + (active ? col : 0)) * 4]);
     const BufRsrc sr = make_rsrc(src, src_bytes);
     const unsigned coff = (unsigned)(col0 + col) * 16u, pix = (unsigned)C * 4u;       // byte offsets
-    const DwXf4 xf = dw_xf_load(xform, active ? (col0 + col) * 4 : 0);
+    DwXf4 xf = dw_xf_load(xform, active ? (col0 + col) * 4 : 0);
     const int groups_h = (H + kDwRows - 1) / kDwRows;                                  // row groups per image
     DwStat st_a, st;
-    bool crossed = false;
+    bool crossed = false, xsecond = false;
     if (STATS) { dw_stat_zero(st_a); dw_stat_zero(st); }
     for (int rg = blockIdx.x * rp + rsub; active && rg < N * groups_h; rg += gridDim.x * rp) {
         const int n = rg / groups_h, oh0 = (rg - n * groups_h) * kDwRows;
+        dw_xf_cross<XF>(xf, xsecond, xform, (col0 + col) * 4, n);
         if (STATS && seg_n > 0 && !crossed && n >= seg_n) { st_a = st; dw_stat_zero(st); crossed = true; }
         unsigned rbase[kDwRows + 2];
         bool rok[kDwRows + 2];
@@ -376,9 +387,11 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_row_kernel(const float* __res
     for (int k = 0; k < 9; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (rsub < rp && col0 + col < cv) {
         const int coff = (col0 + col) * 4;
-        const DwXf4 xf = dw_xf_load(xform, coff);
+        DwXf4 xf = dw_xf_load(xform, coff);
+        bool xsecond = false;
         for (int row = blockIdx.x * rp + rsub; row < N * OH; row += gridDim.x * rp) {
             const int n = row / OH, oh = row - n * OH;
+            dw_xf_cross<XF>(xf, xsecond, xform, coff, n);
             const int ih0 = oh * stride - 1;
             bool rok[3];
             int64_t rbase[3];
@@ -439,12 +452,14 @@ __global__ __launch_bounds__(256) void dw_wgrad_partial(const DwGeom g, const fl
 #pragma unroll
     for (int i = 0; i < kMaxTaps; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (rsub < g.rp && col0 + col < cv) {
-        const DwXf4 xf = dw_xf_load(xform, (col0 + col) * 4);
+        DwXf4 xf = dw_xf_load(xform, (col0 + col) * 4);
+        bool xsecond = false;
         const int64_t p0 = (int64_t)blockIdx.x * g.pix_per_block;
         int64_t p1 = p0 + g.pix_per_block;
         if (p1 > g.P) p1 = g.P;
         for (int64_t p = p0 + rsub; p < p1; p += g.rp) {
             const int n = (int)(p / ((int64_t)g.OH * g.OW));
+            dw_xf_cross<XF>(xf, xsecond, xform, (col0 + col) * 4, n);
             const int rem = (int)(p - (int64_t)n * g.OH * g.OW);
             const int oh = rem / g.OW, ow = rem - oh * g.OW;
             const float4 dv = *reinterpret_cast<const float4*>(dy + p * g.C + (col0 + col) * 4);
@@ -567,13 +582,16 @@ static int dwconv_fwd_impl(const suhpe_conv_t* d, const float* x, const float* w
     int cw, rp, gx, ny;
     if (dw_fwd_fast_grid(d, &s1, &cw, &rp, &gx, &ny)) {
         if (stats) {
-            SUHPE_REQUIRE(!DW_XF_ON, "suhpe_dwconv_fwd_stats: not combined with the input transform");
+#define DW_LAUNCH_STATS(kern, ...)                                                                                          \
+    do {                                                                                                                    \
+        if (DW_XF_ON) hipLaunchKernelGGL((kern<true, true>), dim3(gx, ny), dim3(256), 0, as_stream(stream), __VA_ARGS__);  \
+        else hipLaunchKernelGGL((kern<false, true>), dim3(gx, ny), dim3(256), 0, as_stream(stream), __VA_ARGS__);          \
+    } while (0)
             if (s1)
-                hipLaunchKernelGGL((dw3x3_s1_kernel<false, true>), dim3(gx, ny), dim3(256), 0, as_stream(stream), x, (int64_t)d->n * d->h * d->w * d->cin * 4, w, y,
-                                   d->n, d->h, d->w, d->cin, 0, cw, rp, xf, stats, seg_n);
+                DW_LAUNCH_STATS(dw3x3_s1_kernel, x, (int64_t)d->n * d->h * d->w * d->cin * 4, w, y, d->n, d->h, d->w, d->cin, 0, cw, rp, xf, stats, seg_n);
             else
-                hipLaunchKernelGGL((dw3x3_row_kernel<false, true>), dim3(gx, ny), dim3(256), 0, as_stream(stream), x, w, y, d->n, d->h, d->w, d->ho, d->wo, d->cin,
-                                   d->stride, 0, cw, rp, xf, stats, seg_n);
+                DW_LAUNCH_STATS(dw3x3_row_kernel, x, w, y, d->n, d->h, d->w, d->ho, d->wo, d->cin, d->stride, 0, cw, rp, xf, stats, seg_n);
+#undef DW_LAUNCH_STATS
             return check_launch("suhpe_dwconv_fwd_stats");
         }
         if (s1)
@@ -591,7 +609,7 @@ static int dwconv_fwd_impl(const suhpe_conv_t* d, const float* x, const float* w
     return check_launch("suhpe_dwconv_fwd");
 }
 
-static const DwXform kNoXform{nullptr, nullptr, nullptr, nullptr, 0};
+static const DwXform kNoXform{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
 
 int suhpe_dwconv_fwd(const suhpe_conv_t* d, const float* x, const float* w, float* y, suhpe_stream_t stream) {
     return dwconv_fwd_impl(d, x, w, y, kNoXform, stream);
@@ -610,9 +628,11 @@ int suhpe_dwconv_fwd_stats(const suhpe_conv_t* d, const float* x, const float* w
 }
 
 int suhpe_dwconv_bnact_fwd(const suhpe_conv_t* d, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                           int act, const float* w, float* y, suhpe_stream_t stream) {
-    SUHPE_REQUIRE(mean && rstd, "suhpe_dwconv_bnact_fwd: mean / rstd required");
-    return dwconv_fwd_impl(d, x, w, y, DwXform{mean, rstd, gamma, beta, act}, stream);
+                           int act, int seg_n, const float* w, float* y, float* stats, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(d && mean && rstd, "suhpe_dwconv_bnact_fwd: mean / rstd required");
+    SUHPE_REQUIRE(seg_n >= 0 && seg_n < d->n, "suhpe_dwconv_bnact_fwd: 0 <= seg_n < n");
+    SUHPE_REQUIRE(!stats || suhpe_dwconv_fwd_stats_blocks(d) > 0, "suhpe_dwconv_bnact_fwd: this shape has no statistics epilogue (suhpe_dwconv_fwd_stats_blocks)");
+    return dwconv_fwd_impl(d, x, w, y, DwXform{mean, rstd, gamma, beta, act, seg_n, d->cin}, stream, stats, seg_n);
 }
 
 int suhpe_dwconv_dgrad(const suhpe_conv_t* d, const float* dy, const float* w, float* dx, suhpe_stream_t stream) {
@@ -674,10 +694,11 @@ int suhpe_dwconv_wgrad(const suhpe_conv_t* d, const float* x, const float* dy, f
 }
 
 int suhpe_dwconv_bnact_wgrad(const suhpe_conv_t* d, const float* x, const float* mean, const float* rstd, const float* gamma,
-                             const float* beta, int act, const float* dy, float* dw, int accumulate, void* workspace,
+                             const float* beta, int act, int seg_n, const float* dy, float* dw, int accumulate, void* workspace,
                              int64_t workspace_bytes, suhpe_stream_t stream) {
-    SUHPE_REQUIRE(mean && rstd, "suhpe_dwconv_bnact_wgrad: mean / rstd required");
-    return dwconv_wgrad_impl(d, x, dy, dw, accumulate, workspace, workspace_bytes, DwXform{mean, rstd, gamma, beta, act}, stream);
+    SUHPE_REQUIRE(d && mean && rstd, "suhpe_dwconv_bnact_wgrad: mean / rstd required");
+    SUHPE_REQUIRE(seg_n >= 0 && seg_n < d->n, "suhpe_dwconv_bnact_wgrad: 0 <= seg_n < n");
+    return dwconv_wgrad_impl(d, x, dy, dw, accumulate, workspace, workspace_bytes, DwXform{mean, rstd, gamma, beta, act, seg_n, d->cin}, stream);
 }
 
 }  // extern "C"

@@ -225,32 +225,45 @@ def _dw_fwd(d, x, w, y):
 
 
 @_memop
-def dwconv_bnact_fwd(x, mean, rstd, gamma, beta, act, w, stride=1, pad=1):
-    """depthwise conv of act(BN(x)) without materialising it: x is the producer conv's raw output (N,H,W,C)"""
+def dwconv_bnact_fwd(x, mean, rstd, gamma, beta, act, w, stride=1, pad=1, seg=None, stats=False):
+    """depthwise conv of act(BN(x)) without materialising it: x is the producer conv's raw output (N,H,W,C); seg = samples of the
+    first batch segment (mean / rstd are then [2, C]); stats: also the output's BatchNorm records, result as dwconv_fwd_stats"""
     _chk(x, "x")
     c = x.shape[-1]
     d = conv_desc(x.shape, w.shape, stride, pad, c)
     assert _is_depthwise(d) and c % 4 == 0
+    two = seg is not None and 0 < seg < d.n
+    assert mean.numel() == rstd.numel() == (2 if two else 1) * c and mean.is_contiguous() and rstd.is_contiguous()
     y = torch.empty((d.n, d.ho, d.wo, d.cout), dtype=torch.float32, device=x.device)
-    call("suhpe_dwconv_bnact_fwd", ctypes.byref(d), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ACT[act], ptr(w), ptr(y))
-    return y
+    part = None
+    if stats:
+        blocks = _lib.load().suhpe_dwconv_fwd_stats_blocks(ctypes.byref(d))
+        assert blocks > 0
+        part = torch.empty((2 if two else 1) * blocks * c * 4, dtype=torch.float32, device=x.device)
+    call("suhpe_dwconv_bnact_fwd", ctypes.byref(d), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ACT[act], int(seg) if two else 0, ptr(w),
+         ptr(y), ptr(part))
+    if not stats:
+        return y
+    return (y, part, 2 * blocks, (blocks, None)) if two else (y, part, blocks)
 
 
 @_memop
-def dwconv_bnact_wgrad(x, mean, rstd, gamma, beta, act, dy, w_shape, stride=1, pad=1, out=None, accumulate=False):
+def dwconv_bnact_wgrad(x, mean, rstd, gamma, beta, act, dy, w_shape, stride=1, pad=1, out=None, accumulate=False, seg=None):
     """filter gradient of the depthwise conv whose input is act(BN(x)), recomputed from x while loading"""
     _chk(x, "x"); _chk(dy, "dy")
     c = x.shape[-1]
     d = conv_desc(x.shape, w_shape, stride, pad, c)
     assert _is_depthwise(d) and c % 4 == 0
+    two = seg is not None and 0 < seg < d.n
+    assert mean.numel() == rstd.numel() == (2 if two else 1) * c
     if out is None:
         out = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
         accumulate = False
     lib = _lib.load()
     nbytes = lib.suhpe_dwconv_wgrad_workspace_bytes(ctypes.byref(d))
     ws = workspace("wgrad", nbytes, x.device)
-    call("suhpe_dwconv_bnact_wgrad", ctypes.byref(d), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ACT[act], ptr(dy), ptr(out),
-         int(accumulate), ptr(ws), nbytes)
+    call("suhpe_dwconv_bnact_wgrad", ctypes.byref(d), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ACT[act], int(seg) if two else 0, ptr(dy),
+         ptr(out), int(accumulate), ptr(ws), nbytes)
     return out
 
 
@@ -347,10 +360,15 @@ def dwconv_stats_blocks(x_shape, w_shape, stride, pad):
 
 
 @_memop
-def dwconv_fwd_stats(x, w, stride=1, pad=1, seg=None):
+def dwconv_fwd_stats(x, w, stride=1, pad=1, seg=None, xf=None):
     """depthwise forward + BatchNorm statistics records of its output, in conv2d_fwd_stats's result format:
-    (y, part, tiles) or, with seg = samples of the first batch segment, (y, part, tiles, (first-segment records, None))"""
+    (y, part, tiles) or, with seg = samples of the first batch segment, (y, part, tiles, (first-segment records, None)).
+    xf = ("bn", mean, rstd, gamma, beta, act, seg): the input is act(BN(x)) of the producer, applied while loading."""
     _chk(x, "x")
+    if xf is not None:
+        _, mean, rstd, gamma, beta, act, xseg = xf
+        assert (xseg or None) == (seg or None)
+        return dwconv_bnact_fwd(x, mean, rstd, gamma, beta, act, w, stride, pad, seg=seg, stats=True)
     c = x.shape[-1]
     d = conv_desc(x.shape, w.shape, stride, pad, c)
     blocks = _lib.load().suhpe_dwconv_fwd_stats_blocks(ctypes.byref(d))
@@ -624,7 +642,8 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, groups=1, out=None, accumulate
     assert filter_is_physical(out)
     lib = _lib.load()
     side = _DEFER is not None and accumulate and WGRAD_OVERLAP
-    with (_on_side_stream(x.device, x, dy) if side else _same_stream()):
+    held = [t for t in (xf or ()) if torch.is_tensor(t)]        # the transform's vectors are read on the side stream too
+    with (_on_side_stream(x.device, x, dy, *held) if side else _same_stream()):
         _conv2d_wgrad(lib, d, x, dy, out, accumulate, xf)
     return out
 
@@ -642,7 +661,11 @@ def _conv2d_wgrad(lib, d, x, dy, out, accumulate, xf=None):
     if _is_depthwise(d) and d.cin % 4 == 0:
         nbytes = lib.suhpe_dwconv_wgrad_workspace_bytes(ctypes.byref(d))
         ws = workspace("wgrad", nbytes, x.device)
-        _dw_wgrad(d, x, dy, out, accumulate, ws, nbytes)
+        if xf is None:
+            _dw_wgrad(d, x, dy, out, accumulate, ws, nbytes)
+        else:                                           # ("bn", mean, rstd, gamma, beta, act, samples of the first segment)
+            _, mean, rstd, gamma, beta, act, seg = xf
+            dwconv_bnact_wgrad(x, mean, rstd, gamma, beta, act, dy, tuple(out.shape), d.stride, d.pad, out=out, accumulate=accumulate, seg=seg)
     else:
         if AUTOTUNE:
             def trial():                                # whole wgrad (split-K GEMM + slab reduction) into a scratch filter

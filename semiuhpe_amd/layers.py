@@ -108,7 +108,7 @@ class Conv2d(Layer):
         if not K.filter_is_physical(self.weight):
             self.weight.data = K.to_filter_layout(self.weight.data)
         if self._depthwise():
-            out = K.dwconv_fwd_stats(x, self.weight, self.stride, self.padding, seg=_segment_of(x))
+            out = K.dwconv_fwd_stats(x, self.weight, self.stride, self.padding, seg=_segment_of(x), xf=xf)
         else:
             out = K.conv2d_fwd_stats(x, self.weight, self.stride, self.padding, self.groups, seg=_segment_of(x), xf=xf)
         if tape is not None:

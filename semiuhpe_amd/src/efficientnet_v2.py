@@ -128,11 +128,15 @@ class MBConv(_ResidualBlock):
         self.has_expand = exp != cin
 
     # The expand conv's BatchNorm + SiLU is applied by the depthwise kernels while they load (suhpe_dwconv_bnact_fwd /
-    # _wgrad): the normalised, 4-6x expanded tensor — the largest activation of the block — is never written or re-read.
-    # Its BatchNorm still gets exact statistics (from the expand conv's epilogue) and an exact backward (from x and dy).
-    def _fusable(self, tape):
-        exp_bn = self.block[0][1]
-        return FUSE_EXPAND_BN_INTO_DW and self.has_expand and self.block[1][0].in_channels % 4 == 0 and self.block[1][0].kernel_size == 3 and (exp_bn.training or tape is not None)
+    # _wgrad): the normalised, 4-6x expanded tensor -- the largest activation of the block -- is never written or re-read.
+    # Its BatchNorm still gets exact statistics (from the expand conv's epilogue) and the standard backward (from the raw
+    # output and the gradient the depthwise dgrad returns).  Train mode, inside the fused depthwise-SE section only.
+    def _expand_folded(self):
+        from .. import layers as L
+        if not (FUSE_EXPAND_BN_INTO_DW and self.has_expand and self._dw_se_fused() and not L.SYNC_BN):
+            return False
+        (conv_e, bn_e), (conv_d, bn_d) = self.block[0], self.block[1]
+        return bn_e.training and bn_d.training and conv_e.fuses_stats() and conv_d.fuses_stats()
 
     # depthwise conv -> BatchNorm -> SiLU -> SqueezeExcitation as ONE section around the BatchNorm (kernels.bn_act_pool /
     # bn_act_scale_fwd / se_bn_bwd_*): the activated tensor z = silu(BN(y)) is never stored; forward = squeeze pass (read y) +
@@ -143,12 +147,12 @@ class MBConv(_ResidualBlock):
         conv_d, se = self.block[-3][0], self.block[-2]
         return FUSE_DW_BN_SE and not L.SYNC_BN and se._fused() and conv_d.in_channels % 4 == 0
 
-    def _dw_se_fwd(self, x, tape):
+    def _dw_se_fwd(self, x, tape, xf=None):
         (conv_d, bn_d), se = self.block[-3], self.block[-2]
         c = bn_d.num_features
         partials = None
         if bn_d.training and conv_d.fuses_stats():
-            y, partials = conv_d.fwd_stats(x, tape)
+            y, partials = conv_d.fwd_stats(x, tape, xf=xf)
         else:
             y = conv_d.fwd(x, tape)
         hw = y.shape[1] * y.shape[2]
@@ -179,47 +183,34 @@ class MBConv(_ResidualBlock):
         return conv_d.bwd(dy, tape)
 
     def _front_fwd(self, x, tape):
-        if not self._fusable(tape):
-            # expand -> depthwise conv -> BatchNorm + SiLU + squeeze -> excitation
-            layers = list(self.block)[:-1]
-            if self.has_expand:
-                x = layers[0].fwd(x, tape)
-            if self._dw_se_fused():
-                return self._dw_se_fwd(x, tape)
-            dw, se = layers[-2], layers[-1]
-            z, pooled = conv_bn_fwd(dw[0], dw[1], x, tape, pool=True)
-            return se.fwd(z, tape, pooled=pooled)
-        (conv_e, bn_e), (conv_d, bn_d), se = self.block[0], self.block[1], self.block[2]
-        c = bn_e.num_features
-        if bn_e.training:
+        # expand -> depthwise conv -> BatchNorm + SiLU + squeeze -> excitation
+        layers = list(self.block)[:-1]
+        if self._expand_folded():
+            conv_e, bn_e = layers[0]
             y0, partials = conv_e.fwd_stats(x, tape)
-            mean, rstd = K.bn_stats_from_partials(partials[0], partials[1], y0.numel() // c, c, bn_e.eps, bn_e.momentum, bn_e.running_mean,
-                                                  bn_e.running_var, bn_e.num_batches_tracked)
-        else:
-            y0 = conv_e.fwd(x, tape)
-            mean, rstd = K.bn_eval_stats(bn_e.running_mean, bn_e.running_var, bn_e.eps)
-        if not K.filter_is_physical(conv_d.weight):
-            conv_d.weight.data = K.to_filter_layout(conv_d.weight.data)
-        z = K.dwconv_bnact_fwd(y0, mean, rstd, bn_e.weight, bn_e.bias, bn_e.act, conv_d.weight, conv_d.stride, conv_d.padding)
-        if tape is not None:
-            tape.append((y0, mean, rstd, bn_e.training))
-        return se.fwd(bn_d.fwd(z, tape), tape)
+            mean, rstd, rows_a = bn_e.train_stats(y0, partials)
+            hw = y0.shape[1] * y0.shape[2]
+            if tape is not None:            # what _BatchNorm.bwd expects
+                tape.append((y0, (mean, rstd), rows_a // hw, True, None, None, hw) if rows_a else (y0, mean, rstd, True, None, None, hw))
+            return self._dw_se_fwd(y0, tape, xf=("bn", mean, rstd, bn_e.weight, bn_e.bias, bn_e.act, rows_a // hw))
+        if self.has_expand:
+            x = layers[0].fwd(x, tape)
+        if self._dw_se_fused():
+            return self._dw_se_fwd(x, tape)
+        dw, se = layers[-2], layers[-1]
+        z, pooled = conv_bn_fwd(dw[0], dw[1], x, tape, pool=True)
+        return se.fwd(z, tape, pooled=pooled)
 
     def _front_bwd(self, dy, tape):
-        if not self._fusable(tape):
-            if self._dw_se_fused():
-                d = self._dw_se_bwd(dy, tape)
-                return self.block[0].bwd(d, tape) if self.has_expand else d
-            return super()._front_bwd(dy, tape)
-        (conv_e, bn_e), (conv_d, bn_d), se = self.block[0], self.block[1], self.block[2]
-        dz = bn_d.bwd(se.bwd(dy, tape), tape)
-        y0, mean, rstd, train_stats = tape.pop()
-        K.dwconv_bnact_wgrad(y0, mean, rstd, bn_e.weight, bn_e.bias, bn_e.act, dz, conv_d.weight.shape, conv_d.stride, conv_d.padding,
-                             out=grad_of(conv_d.weight), accumulate=True)
-        d_act = K.conv2d_dgrad(dz, conv_d.weight, y0.shape, conv_d.stride, conv_d.padding, conv_d.groups)
-        dy0 = K.bn_act_bwd(y0, d_act, bn_e.num_features, mean, rstd, bn_e.weight, bn_e.bias, bn_e.act, train_stats, grad_of(bn_e.weight),
-                           grad_of(bn_e.bias), True)
-        return conv_e.bwd(dy0, tape)
+        if self._dw_se_fused():
+            d = self._dw_se_bwd(dy, tape)
+            if not self.has_expand:
+                return d
+            if self._expand_folded():       # d is the gradient of the activated tensor the depthwise conv recomputed
+                conv_e, bn_e = self.block[0]
+                return conv_e.bwd(bn_e.bwd(d, tape), tape)
+            return self.block[0].bwd(d, tape)
+        return super()._front_bwd(dy, tape)
 
 
 def regression_head(in_dim, hidden1, hidden2, num_classes):

@@ -54,14 +54,18 @@ def test_state_dict_keys_and_eval_forward(models):
     assert float((R.cpu() - R_ref).abs().max()) < 1e-4
 
 
-@pytest.mark.parametrize("xf", [1, 0, 2])
+@pytest.mark.parametrize("xf", [1, 0, 2, "fold"])
 def test_train_forward_backward(models, xf):
     """xf: layers.XF_FUSION -- 0: every BatchNorm + activation is a kernel of its own, 1 (default): the FusedMBConv project convs apply
-    their producer's BatchNorm + SiLU while loading, 2: the MBConv project convs as well (with the SqueezeExcitation scale)"""
+    their producer's BatchNorm + SiLU while loading, 2: the MBConv project convs as well (with the SqueezeExcitation scale);
+    "fold": the opt-in SUHPE_FUSE_EXPAND_DW path (MBConv expand BatchNorm + SiLU applied by the depthwise kernels' loaders)"""
     from oracle import networks as ON
     from semiuhpe_amd import layers as L
+    from semiuhpe_amd.src import efficientnet_v2 as EV
     ref, hip = models
     ref.train(); hip.train()
+    fold_default, EV.FUSE_EXPAND_BN_INTO_DW = EV.FUSE_EXPAND_BN_INTO_DW, xf == "fold"
+    xf = 1 if xf == "fold" else xf
     xf_default, L.XF_FUSION = L.XF_FUSION, xf
     tape = MaskTape(7)
     x = torch.randn(6, 3, 96, 96, generator=torch.Generator().manual_seed(3))
@@ -83,6 +87,7 @@ def test_train_forward_backward(models, xf):
         y.backward(dy.cuda())
     finally:
         L.XF_FUSION = xf_default
+        EV.FUSE_EXPAND_BN_INTO_DW = fold_default
     L.set_mask_hook(None)
     assert tape.done()
     assert rel_err(y, y_ref) < 2e-4
@@ -105,10 +110,19 @@ def _config(**kw):
     return SimpleNamespace(**base)
 
 
-@pytest.mark.parametrize("merge", [True, False])
-def test_agent_ssl_step_matches_oracle(models, merge):
+@pytest.fixture
+def fold_expand(request):
+    from semiuhpe_amd.src import efficientnet_v2 as EV
+    keep, EV.FUSE_EXPAND_BN_INTO_DW = EV.FUSE_EXPAND_BN_INTO_DW, request.param
+    yield request.param
+    EV.FUSE_EXPAND_BN_INTO_DW = keep
+
+
+@pytest.mark.parametrize("merge,fold_expand", [(True, False), (False, False), (True, True)], indirect=["fold_expand"])
+def test_agent_ssl_step_matches_oracle(models, merge, fold_expand):
     """Two SSL steps (EMA copy at step 0, alpha=1/2 at step 1) of SSLAgent vs oracle.agent.OracleAgent; with the student's
-    labeled and strong passes run as one segmented batch (the default) and as the reference's two passes."""
+    labeled and strong passes run as one segmented batch (the default) and as the reference's two passes; fold_expand: the
+    opt-in depthwise-loader fold of the expand BatchNorm, under batch segments."""
     from oracle import networks as ON
     from oracle.agent import OracleAgent, synthetic_batches
     from semiuhpe_amd import layers as L

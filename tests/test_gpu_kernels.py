@@ -130,23 +130,44 @@ def test_tile_menu_every_pinned_tile_matches(K, cfg):
             lib.suhpe_conv2d_set_tile(ctypes.byref(d), pid, -1)
 
 
-@pytest.mark.parametrize("n,c,hw,stride,act", [(8, 96, 14, 1, "silu"), (40, 64, 14, 1, "silu"), (3, 32, 15, 2, "silu"), (2, 24, 9, 1, "gelu"), (64, 128, 7, 1, "silu")])
-def test_depthwise_with_folded_batchnorm_input(K, n, c, hw, stride, act):
+@pytest.mark.parametrize("n,c,hw,stride,act,seg", [(8, 96, 14, 1, "silu", None), (40, 64, 14, 1, "silu", 8), (3, 32, 15, 2, "silu", 1), (2, 24, 9, 1, "gelu", None),
+                                                   (64, 128, 7, 1, "silu", 13), (160, 256, 14, 1, "silu", 32), (6, 20, 6, 1, "silu", 4)])
+def test_depthwise_with_folded_batchnorm_input(K, n, c, hw, stride, act, seg):
     """suhpe_dwconv_bnact_fwd / _wgrad: depthwise conv (and its filter gradient) of act(BN(x)) computed from x while loading
-    == the unfused bn_act_fwd -> depthwise chain (zero padding applied after the activation)"""
+    == the unfused bn_act_fwd -> depthwise chain (zero padding applied after the activation); with batch segments each
+    segment is normalised with its own statistics; the statistics epilogue of the output rides along unchanged"""
     g = torch.Generator().manual_seed(n + c)
     x = (torch.randn(n, hw, hw, c, generator=g) * 1.3 + 0.2).cuda()
-    mean, rstd = K.bn_stats(x, c, 1e-3, 0.1)
+    if seg:
+        x[seg:] = x[seg:] * 0.6 - 0.4                       # the two segments have visibly different statistics
+        mean, rstd = K.bn_stats_seg(x, seg * hw * hw, c, 1e-3, 0.1)
+    else:
+        mean, rstd = K.bn_stats(x, c, 1e-3, 0.1)
     gamma, beta = (torch.rand(c, generator=g) + 0.5).cuda(), (torch.randn(c, generator=g) * 0.3).cuda()
     w = K.to_filter_layout((torch.randn(c, 1, 3, 3, generator=g) / 3).cuda())
-    y_act = K.bn_act_fwd(x, c, mean, rstd, gamma, beta, act)
+    if seg:
+        y_act = K.bn_act_fwd_seg(x, seg * hw * hw, c, mean, rstd, gamma, beta, act)
+    else:
+        y_act = K.bn_act_fwd(x, c, mean, rstd, gamma, beta, act)
     ref = K.conv2d_fwd(y_act, w, None, stride, 1, c)
-    out = K.dwconv_bnact_fwd(x, mean, rstd, gamma, beta, act, w, stride, 1)
-    assert rel(out, ref.cpu()) < 2e-6
+    out = K.dwconv_bnact_fwd(x, mean, rstd, gamma, beta, act, w, stride, 1, seg=seg)
+    assert rel(out, ref.cpu()) < 4e-6                       # SiLU on v_exp / v_rcp: ~1 ulp each
     dy = torch.randn(ref.shape, generator=g).cuda()
     dw_ref = K.conv2d_wgrad(y_act, dy, w.shape, stride, 1, c)
-    dw = K.dwconv_bnact_wgrad(x, mean, rstd, gamma, beta, act, dy, w.shape, stride, 1)
+    dw = K.dwconv_bnact_wgrad(x, mean, rstd, gamma, beta, act, dy, w.shape, stride, 1, seg=seg)
     assert rel(dw, dw_ref.cpu()) < 2e-5
+    if K.dwconv_stats_blocks(x.shape, w.shape, stride, 1):
+        res = K.dwconv_bnact_fwd(x, mean, rstd, gamma, beta, act, w, stride, 1, seg=seg, stats=True)
+        assert rel(res[0], out.cpu()) < 1e-6                # the STATS instantiation contracts one multiply-add differently
+        rows = out.numel() // c
+        if seg:
+            rows_a = seg * out.shape[1] * out.shape[2]
+            m2, r2 = K.bn_stats_from_partials_seg(res[1], res[2], res[3][0], res[3][1], rows, rows_a, c, 1e-3, 0.1)
+            m0, r0 = K.bn_stats_seg(out, rows_a, c, 1e-3, 0.1)
+        else:
+            m2, r2 = K.bn_stats_from_partials(res[1], res[2], rows, c, 1e-3, 0.1)
+            m0, r0 = K.bn_stats(out, c, 1e-3, 0.1)
+        assert (m2 - m0).abs().max().item() < 2e-6 and rel(r2, r0.cpu()) < 2e-6
 
 
 def test_deferred_wgrad_reduction_is_bit_identical(K):
