@@ -12,9 +12,14 @@ lib = _lib.load()
 lib.suhpe_conv2d_tile_name.restype = ctypes.c_char_p
 
 
+def short(name):
+    kind = "P" if "persistent" in name else ("H" if "3x3" in name else ("S" if "split" in name else ""))
+    a = name.split("<")[1].rstrip(">").split(",")
+    return kind + "x".join(a[:2]) + ("w" + "x".join(a[2:4]) if len(a) > 3 else "") + ("v1" if len(a) > 4 and a[4] == "1" else "")
+
+
 def menu(pass_id):
-    return {i: ("P" if "persistent" in lib.suhpe_conv2d_tile_name(pass_id, i).decode() else "") + "x".join(lib.suhpe_conv2d_tile_name(pass_id, i).decode().split("<")[1].split(",")[:2])
-            for i in range(lib.suhpe_conv2d_tile_count(pass_id))}
+    return {i: short(lib.suhpe_conv2d_tile_name(pass_id, i).decode()) for i in range(lib.suhpe_conv2d_tile_count(pass_id))}
 flush = torch.empty(1 << 26, dtype=torch.float32, device="cuda")
 
 
