@@ -79,3 +79,13 @@ def test_euler_geodesic(lib):
     out = np.zeros(n, np.float32)
     lib.host_geodesic_deg(fp(R), fp(D["R2"]), n, fp(out))
     assert np.abs(out - D["geodesic_deg"]).max() < 1e-3
+
+
+def test_head_math_under_sanitizers(tmp_path):
+    """AddressSanitizer + UndefinedBehaviorSanitizer over the head math the gfx950 kernels share with this host build
+    (random, degenerate and extreme-scale inputs through every entry point; GPU sanitizers are not available on the pool)"""
+    exe = str(tmp_path / "head_sanitize")
+    subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           os.path.join(HERE, "host_build", "head_sanitize_main.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "HEAD_SANITIZE_OK non-finite 0" in r.stdout, r.stdout + r.stderr[-2000:]
