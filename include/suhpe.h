@@ -416,6 +416,27 @@ int64_t suhpe_window_attn_dbias_workspace_bytes(int ws, int heads);
 int suhpe_window_attn_dbias(const float* dS, const int32_t* inv_ptr, const int32_t* inv_list, int B, int H, int W, int ws, int heads,
                             int noff, float* dbias_table, void* workspace, suhpe_stream_t stream);
 
+/* ---- data-parallel exchange (new capability: the reference trains on one GPU, train.py:24-25).
+ * One communicator per rank (= per process, = per GPU) over RCCL / xGMI; float32 payloads; every call is enqueued on `stream`
+ * and returns without synchronising.  Bring-up: rank 0 calls suhpe_comm_unique_id, hands the 128 bytes to the other ranks by
+ * any host channel (the Python host uses torch.distributed's store), every rank calls suhpe_comm_init with its device current.
+ * RCCL is loaded at run time (librccl.so.1): suhpe_comm_available() == 0 on a box without it, and only this family fails.
+ *   allreduce : buf <- sum (average = 0) or mean (average = 1) over ranks, in place  -- gradient buckets, BatchNorm buffers,
+ *               loss scalars (replaces nothing in the reference; DistributedDataParallel semantics)
+ *   allgather : recv[r * count_per_rank ...] <- rank r's send                          -- per-rank entropy vectors of
+ *               compute_dynamic_entropy_threshold (src/agent.py:357-417)
+ *   broadcast : buf <- root's buf                                                      -- initial weights / teacher copy */
+typedef struct suhpe_comm_s* suhpe_comm_t;
+int suhpe_comm_available(void);
+int suhpe_comm_unique_id(void* id128);
+int suhpe_comm_init(suhpe_comm_t* comm, const void* id128, int rank, int world);
+int suhpe_comm_rank(suhpe_comm_t comm);
+int suhpe_comm_world(suhpe_comm_t comm);
+int suhpe_comm_allreduce(suhpe_comm_t comm, float* buf, int64_t count, int average, suhpe_stream_t stream);
+int suhpe_comm_allgather(suhpe_comm_t comm, const float* send, float* recv, int64_t count_per_rank, suhpe_stream_t stream);
+int suhpe_comm_broadcast(suhpe_comm_t comm, float* buf, int64_t count, int root, suhpe_stream_t stream);
+int suhpe_comm_destroy(suhpe_comm_t comm);
+
 #ifdef __cplusplus
 }
 #endif

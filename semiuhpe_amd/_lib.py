@@ -25,7 +25,7 @@ class ConvDesc(ctypes.Structure):
 
 _CTYPES = {
     "int": ctypes.c_int, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64, "float": ctypes.c_float,
-    "suhpe_stream_t": ctypes.c_void_p, "void": None,
+    "suhpe_stream_t": ctypes.c_void_p, "suhpe_comm_t": ctypes.c_void_p, "void": None,
 }
 
 

@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsuhpe.so")
-SOURCES = ["common.hip", "head.hip", "nn_elem.hip", "layout_aug.hip", "conv_igemm.hip", "dwconv.hip", "attention.hip", "se_fused.hip", "augment.hip"]
+SOURCES = ["common.hip", "head.hip", "nn_elem.hip", "layout_aug.hip", "conv_igemm.hip", "dwconv.hip", "attention.hip", "se_fused.hip", "augment.hip", "comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
@@ -55,7 +55,7 @@ def build(force=False, verbose=True):
             list(ex.map(compile_one, jobs))
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in srcs]
     if jobs or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -35,8 +35,90 @@ def init_from_env(backend="nccl"):
     return world()
 
 
+# ------------------------------------------------------------------------------------------------ the C-ABI communicator
+class NativeComm:
+    """suhpe_comm_* (include/suhpe.h): this rank's RCCL communicator behind the C ABI -- float32 device tensors, enqueued on the
+    current stream of the tensor's device.  The 128-byte unique id travels from rank 0 over the torch.distributed process group
+    (any backend), or is passed in.  Opt-in (SUHPE_COMM=native, see native()): torch.distributed's own RCCL binding is the default
+    transport of the training step, this is the path a non-PyTorch host would take."""
+
+    def __init__(self, rank=None, world_size=None, unique_id=None):
+        import ctypes
+        from .. import _lib
+        self._ct, self._libmod = ctypes, _lib
+        self.lib = _lib.load()
+        if not self.lib.suhpe_comm_available():
+            raise RuntimeError("semiuhpe_amd: librccl.so.1 not found: suhpe_comm_* unavailable")
+        r, w = world()
+        self.rank = r if rank is None else rank
+        self.world = w if world_size is None else world_size
+        if unique_id is None:
+            box = [None]
+            if self.rank == 0:
+                buf = ctypes.create_string_buffer(128)
+                self._check(self.lib.suhpe_comm_unique_id(buf))
+                box[0] = buf.raw
+            if self.world > 1:
+                dist.broadcast_object_list(box, src=0)
+            unique_id = box[0]
+        self.unique_id = bytes(unique_id)
+        self.handle = ctypes.c_void_p()
+        self._check(self.lib.suhpe_comm_init(ctypes.byref(self.handle), self.unique_id, self.rank, self.world))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(self._libmod.last_error())
+
+    @staticmethod
+    def _chk(t):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), "suhpe_comm_*: contiguous float32 device tensors"
+
+    def _stream(self, t):
+        return self._ct.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+    def allreduce_(self, t, average=False):
+        self._chk(t)
+        self._check(self.lib.suhpe_comm_allreduce(self.handle, self._ct.c_void_p(t.data_ptr()), t.numel(), int(bool(average)), self._stream(t)))
+        return t
+
+    def allgather(self, t):
+        """-> (world, *t.shape): rank r's tensor in row r (equal shapes on every rank)"""
+        self._chk(t)
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=torch.float32, device=t.device)
+        self._check(self.lib.suhpe_comm_allgather(self.handle, self._ct.c_void_p(t.data_ptr()), self._ct.c_void_p(out.data_ptr()), t.numel(), self._stream(t)))
+        return out
+
+    def broadcast_(self, t, src=0):
+        self._chk(t)
+        self._check(self.lib.suhpe_comm_broadcast(self.handle, self._ct.c_void_p(t.data_ptr()), t.numel(), int(src), self._stream(t)))
+        return t
+
+    def close(self):
+        if self.handle:
+            self._check(self.lib.suhpe_comm_destroy(self.handle))
+            self.handle = self._ct.c_void_p()
+
+
+_NATIVE = None
+
+
+def native():
+    """the process-wide NativeComm when SUHPE_COMM=native and more than one rank runs (created on first use), else None"""
+    global _NATIVE
+    if _NATIVE is None and os.environ.get("SUHPE_COMM", "") == "native" and world()[1] > 1 and torch.cuda.is_available():
+        _NATIVE = NativeComm()
+    return _NATIVE
+
+
+def _native_for(t):
+    return native() if (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()) else None
+
+
 def allreduce_sum_(t):
     if world()[1] > 1:
+        nc = _native_for(t)
+        if nc is not None:
+            return nc.allreduce_(t)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
@@ -44,6 +126,9 @@ def allreduce_sum_(t):
 def allreduce_avg_(t):
     """Average across ranks inside the collective (RCCL implements AVG); only used on device tensors."""
     if world()[1] > 1:
+        nc = _native_for(t)
+        if nc is not None:
+            return nc.allreduce_(t, average=True)
         if dist.get_backend() == "gloo":          # gloo has no AVG (CPU tests, and the single-box rehearsal of bench.py --gpus 2)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             t.div_(world()[1])
@@ -54,6 +139,9 @@ def allreduce_avg_(t):
 
 def broadcast_(t, src=0):
     if world()[1] > 1:
+        nc = _native_for(t)
+        if nc is not None:
+            return nc.broadcast_(t, src)
         dist.broadcast(t, src)
     return t
 
@@ -163,7 +251,11 @@ class BucketedAllReduce:
             for st in (self.streams() if self.streams else [torch.cuda.current_stream(self.flat.device)]):
                 self.comm.wait_stream(st)
             with torch.cuda.stream(self.comm):
-                self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+                nc = native()
+                if nc is not None:
+                    nc.allreduce_(view)          # enqueued on the communication stream: stream order is the only handle needed
+                else:
+                    self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
         else:
             self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
 

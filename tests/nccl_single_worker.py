@@ -60,6 +60,21 @@ if __name__ == "__main__":
     g1, g2 = fb.grad, ref.optimizer.flat_buffers[0].grad
     assert torch.equal(g1, g2) and float(g1.abs().max()) > 0      # identity collectives: same gradient as the plain step
     assert torch.equal(fb.data, ref.optimizer.flat_buffers[0].data)
+    # the C-ABI communicator (suhpe_comm_*) on the same single rank: its own RCCL communicator next to torch's
+    nc = D.NativeComm(rank=0, world_size=1)
+    v = torch.arange(1000, dtype=torch.float32, device="cuda")
+    nc.allreduce_(v); nc.allreduce_(v, average=True); nc.broadcast_(v, 0)
+    got = nc.allgather(v)
+    torch.cuda.synchronize()
+    assert got.shape == (1, 1000) and torch.equal(got[0], v) and torch.equal(v.cpu(), torch.arange(1000, dtype=torch.float32))
+    fb2 = fb.grad.clone()
+    D._NATIVE = nc                                                # the bucketed exchange through suhpe_comm_allreduce
+    bk = D.BucketedAllReduce(fb2, bounds)
+    bk.finish()
+    torch.cuda.synchronize()
+    assert torch.equal(fb2, fb.grad)
+    D._NATIVE = None
+    nc.close()
     ent = D.gather_varlen(torch.randn(5, device="cuda"))
     assert ent.numel() == 5
     dist.barrier()
