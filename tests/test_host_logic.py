@@ -126,3 +126,64 @@ def test_shard_loader_splits_batch_and_samples():
     import pytest
     with pytest.raises(ValueError):
         shard_loader(DataLoader(ds, batch_size=9), 0, 2)
+
+
+def test_build_loaders_uses_importable_reference_style_loaders(tmp_path, monkeypatch):
+    """the reference's `src.datasets.dataset_<NAME>.get_dataloader_<NAME>(phase, config)` functions are used
+    unchanged when importable.  A stand-in package with that interface (map-style datasets emitting the batch-dict keys of
+    SURVEY 8b; NOT the reference's code) is put on sys.path: build_loaders selects the loaders train.py:47-76 selects for the
+    experiment name, shards the two training loaders per rank and leaves the test loader whole."""
+    import importlib, sys, textwrap
+    from types import SimpleNamespace
+    pkg = tmp_path / "src" / "datasets"
+    pkg.mkdir(parents=True)
+    (tmp_path / "src" / "__init__.py").write_text("")
+    (pkg / "__init__.py").write_text("")
+    for name in ("300WLP", "AFLW2000", "DAD3DHeads", "COCOHead", "WildHead"):
+        (pkg / f"dataset_{name}.py").write_text(textwrap.dedent(f"""
+            import torch
+            from torch.utils.data import Dataset, DataLoader
+            CALLS = []
+            class _Heads(Dataset):
+                def __init__(self, n, phase): self.n, self.phase = n, phase
+                def __len__(self): return self.n
+                def __getitem__(self, i):
+                    return {{"idx": i, "img": torch.full((3, 8, 8), float(i)), "img_strong": torch.zeros(3, 8, 8), "rot_mat": torch.eye(3),
+                            "euler_angles": torch.zeros(3), "aug_rot_mat": torch.eye(3), "src": "{name}:" + self.phase}}
+            def get_dataloader_{name}(phase, config):
+                CALLS.append(phase)
+                train = "train" in phase
+                bs = config.batch_size if phase in ("train", "train_all") else (round(config.batch_size * config.ulb_batch_ratio) if train else 4)
+                return DataLoader(_Heads(96, phase), batch_size=bs, shuffle=train, drop_last=train)
+            """))
+    for m in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
+        monkeypatch.delitem(sys.modules, m)
+    monkeypatch.syspath_prepend(str(tmp_path))
+    from semiuhpe_amd.src.datasets import build_loaders
+    cfg = SimpleNamespace(exp_name="300WLP_WildHead", is_full_range=False, synthetic=False, batch_size=8, ulb_batch_ratio=2, stage1_iteration=0,
+                          max_iteration=10, rotate_aug=True)
+    train, ulb, test = build_loaders(cfg, rank=1, world=2)
+    assert importlib.import_module("src.datasets.dataset_300WLP").CALLS == ["train_all"]
+    assert importlib.import_module("src.datasets.dataset_WildHead").CALLS == ["ulb_train"]
+    assert importlib.import_module("src.datasets.dataset_AFLW2000").CALLS == ["test"]
+    b, u, t = next(iter(train)), next(iter(ulb)), next(iter(test))
+    assert b["img"].shape == (4, 3, 8, 8) and u["img"].shape == (8, 3, 8, 8) and t["img"].shape[0] == 4      # per-rank shares of 8 and 16; test whole
+    assert b["src"][0] == "300WLP:train_all" and u["src"][0] == "WildHead:ulb_train" and t["src"][0] == "AFLW2000:test"
+    other = next(iter(build_loaders(cfg, rank=0, world=2)[0]))
+    train.sampler.set_epoch(0)
+    seen = {int(i) for bb in train for i in bb["idx"]}
+    assert len(seen) == 48                                            # this rank's half of the 96 samples, no duplicates
+    assert set(b.keys()) == set(other.keys())
+    # without the package the error says what to do
+    for m in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
+        monkeypatch.delitem(sys.modules, m)
+    monkeypatch.setattr(sys, "path", [p for p in sys.path if p != str(tmp_path)])
+    import pytest as _pt
+    try:
+        importlib.import_module("src.datasets.dataset_300WLP")
+        importable = True
+    except ImportError:
+        importable = False
+    if not importable:
+        with _pt.raises(ImportError, match="--synthetic"):
+            build_loaders(cfg)
