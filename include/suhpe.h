@@ -135,6 +135,9 @@ int suhpe_conv2d_wgrad_partial_xf(const suhpe_conv_t* d, const float* x, const f
                                   int64_t seg_row, suhpe_stream_t stream);
 /* input gradient; wt is the transposed+flipped filter made by suhpe_conv2d_transpose_filter */
 int suhpe_conv2d_dgrad(const suhpe_conv_t* d, const float* dy, const float* wt, float* dx, suhpe_stream_t stream);
+/* the same input gradient with a skip connection's gradient added in the epilogue: dx = dgrad(dy) + skip (skip: the shape of dx,
+ * may be NULL) -- the backward of `x + block(x)` (torchvision MBConv / FusedMBConv use_res_connect) without a separate add pass */
+int suhpe_conv2d_dgrad_add(const suhpe_conv_t* d, const float* dy, const float* wt, const float* skip, float* dx, suhpe_stream_t stream);
 int suhpe_conv2d_transpose_filter(const suhpe_conv_t* d, const float* w, float* wt, suhpe_stream_t stream);
 /* The same for many filters in one launch: jobs_dev = device array of njobs records of six int64 (w, wt, groups, cout/groups,
  * cin/groups, r*s), chunk_start_dev[j] = first 1024-element chunk of job j, chunk_start_dev[njobs] = total_chunks. */

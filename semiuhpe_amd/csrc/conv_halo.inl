@@ -287,7 +287,8 @@ void igemm_nt3x3_kernel(const NtParams p, const HaloGeom hg) {
                     const int col = n0 + wn * WN + j * 32 + r32;
                     if (col >= p.Ng) continue;
                     if constexpr (!AFF_) {
-                        y[orow * p.ldy + col] = acc[i][j][e] + (p.bias ? p.bias[grp * p.Ng + col] : 0.f);
+                        y[orow * p.ldy + col] = acc[i][j][e] + (p.bias ? p.bias[grp * p.Ng + col] : 0.f) +
+                                                (p.res_mode == 3 ? p.residual[orow * p.ldy + grp * p.Ng + col] : 0.f);
                     } else {
                         float v = acc[i][j][e] * p.scale[grp * p.Ng + col] + p.shift[grp * p.Ng + col];
                         const float rv = p.res_mode ? p.residual[orow * p.ldy + grp * p.Ng + col] : 0.f;

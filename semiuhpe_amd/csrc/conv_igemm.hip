@@ -493,7 +493,8 @@ void igemm_nt_kernel(const NtParams p) {
                         orow = ((int64_t)n * g.YH + a * g.om + g.ph) * g.YW + bb * g.om + g.pw;
                     }
                     if constexpr (!AFF_) {
-                        y[orow * p.ldy + col] = acc[i][j][e] + bv;
+                        // res_mode 3: plain skip-connection add (input gradient + the gradient that bypassed the block)
+                        y[orow * p.ldy + col] = acc[i][j][e] + bv + (p.res_mode == 3 ? p.residual[orow * p.ldy + grp * p.Ng + col] : 0.f);
                     } else {
                         float v = acc[i][j][e] * sc + sh;
                         const float rv = p.res_mode ? p.residual[orow * p.ldy + grp * p.Ng + col] : 0.f;
@@ -715,7 +716,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM * BN >= 128 * 128) 
 #if SUHPE_PROBE == 4
                             if (acc[i][j][e] == 12345.678f)
 #endif
-                            y[(int64_t)row * p.ldy + col] = acc[i][j][e] + bv;
+                            y[(int64_t)row * p.ldy + col] = acc[i][j][e] + bv + (p.res_mode == 3 ? p.residual[(int64_t)row * p.ldy + grp * p.Ng + col] : 0.f);
                         } else {
                             float v = acc[i][j][e] * sc + sh;
                             const float rv = p.res_mode ? p.residual[(int64_t)row * p.ldy + grp * p.Ng + col] : 0.f;
@@ -1512,6 +1513,10 @@ int suhpe_transpose_filters_batched(const void* jobs_dev, const int64_t* chunk_s
 }
 
 int suhpe_conv2d_dgrad(const suhpe_conv_t* d, const float* dy, const float* wt, float* dx, suhpe_stream_t stream) {
+    return suhpe_conv2d_dgrad_add(d, dy, wt, nullptr, dx, stream);
+}
+
+int suhpe_conv2d_dgrad_add(const suhpe_conv_t* d, const float* dy, const float* wt, const float* skip, float* dx, suhpe_stream_t stream) {
     int rc = check_desc(d, "suhpe_conv2d_dgrad");
     if (rc) return rc;
     SUHPE_REQUIRE(dy && wt && dx, "suhpe_conv2d_dgrad: null pointer");
@@ -1523,7 +1528,7 @@ int suhpe_conv2d_dgrad(const suhpe_conv_t* d, const float* dy, const float* wt, 
         p.g = make_geom(d->n, d->ho, d->wo, d->h, d->w, d->cout, ng, d->r, d->s, d->stride, d->pad, 1);
         p.x = dy; p.f = wt; p.bias = nullptr; p.y = dx; p.Ng = cg; p.ldy = d->cin; p.ldf = p.g.K;
         p.x_bytes = (int64_t)d->n * d->ho * d->wo * d->cout * 4; p.f_bytes = (int64_t)d->cout * cg * d->r * d->s * 4;
-        p.stats = nullptr; p.stats_extra = nullptr; p.seg_row = 0; p.stat_gx = 0; p.stat_cout = 0; p.scale = p.shift = p.residual = nullptr; p.act = 0; p.res_mode = 0;
+        p.stats = nullptr; p.stats_extra = nullptr; p.seg_row = 0; p.stat_gx = 0; p.stat_cout = 0; p.scale = p.shift = nullptr; p.residual = skip; p.act = 0; p.res_mode = skip ? 3 : 0;
         dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 1));
     } else {
         // one launch per parity class of the input pixel: only the taps r = (ph+pad) mod stride (+ k*stride) reach it,
@@ -1542,7 +1547,7 @@ int suhpe_conv2d_dgrad(const suhpe_conv_t* d, const float* dy, const float* wt, 
                 p.g = g;
                 p.x = dy; p.f = wt; p.bias = nullptr; p.y = dx; p.Ng = cg; p.ldy = d->cin; p.ldf = d->r * d->s * ng;
                 p.x_bytes = (int64_t)d->n * d->ho * d->wo * d->cout * 4; p.f_bytes = (int64_t)d->cout * cg * d->r * d->s * 4;
-                p.stats = nullptr; p.stats_extra = nullptr; p.seg_row = 0; p.stat_gx = 0; p.stat_cout = 0; p.scale = p.shift = p.residual = nullptr; p.act = 0; p.res_mode = 0;
+                p.stats = nullptr; p.stats_extra = nullptr; p.seg_row = 0; p.stat_gx = 0; p.stat_cout = 0; p.scale = p.shift = nullptr; p.residual = skip; p.act = 0; p.res_mode = skip ? 3 : 0;
                 dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 1));
             }
     }

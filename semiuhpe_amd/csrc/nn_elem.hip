@@ -8,6 +8,7 @@
 // torchvision SqueezeExcitation / StochasticDepth("row"), nn.Dropout, nn.LayerNorm, optim.Adam (src/agent.py:37),
 // the EMA loop (src/agent.py:298-299).
 #include "common.h"
+#include <cstdlib>
 
 namespace suhpe {
 
@@ -71,10 +72,10 @@ static EwGeom ew_geom(int64_t rows, int c, int vec) {
 // Two batch segments in one launch.  Row blocks [0, nb_a) cover rows [0, rows_a) with the first statistics set, the blocks
 // after them the remaining rows with the second set: every per-channel array of statistics (mean, rstd, backward sums) is
 // then [2][c], and the reduction records of the two segments never mix.  nb_a == 0: ordinary single-segment launch.
-struct SegArgs { int64_t rows_a; int nb_a; };
+struct SegArgs { int64_t rows_a; int nb_a; int rev; };     // rev: walk the row blocks from the last to the first (see kRevSecondPass)
 // -> the block's index inside its segment; `rows` becomes the segment's row count, row_off its first row, set its index
 __device__ __forceinline__ int seg_select(const SegArgs& sg, int64_t* rows, int64_t* row_off, int* set) {
-    int bx = blockIdx.x;
+    int bx = sg.rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
     *row_off = 0;
     *set = 0;
     if (sg.nb_a > 0) {
@@ -83,6 +84,11 @@ __device__ __forceinline__ int seg_select(const SegArgs& sg, int64_t* rows, int6
     }
     return bx;
 }
+
+// The second pass of a two-pass op (BatchNorm backward: sums, then apply) re-reads what the first pass just streamed.  Walking its row
+// blocks from the last to the first meets the most recently touched lines first, i.e. whatever part of the tensors is still in
+// L2 / Infinity Cache; in the same order as the first pass the cached tail is evicted before it is reached.  SUHPE_REV_PASS=0: off.
+static const int kRevSecondPass = !(getenv("SUHPE_REV_PASS") && atoi(getenv("SUHPE_REV_PASS")) == 0);
 
 template <int VEC> struct VecT;
 template <> struct VecT<4> { using type = float4; };
@@ -167,7 +173,7 @@ __device__ __forceinline__ void block_combine(const float* s0, const float* s1, 
 // shifted by k = the block's first-row value, so the variance is never the difference of two large sums.
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ x, int64_t rows, int c, int cw, int rp,
-                                                        int64_t rows_per_block, float* __restrict__ part, const SegArgs sg = SegArgs{0, 0}) {
+                                                        int64_t rows_per_block, float* __restrict__ part, const SegArgs sg = SegArgs{0, 0, 0}) {
     __shared__ float lds[256 * 2 * VEC];
     int64_t row_off;
     int set;
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          int act, const float* __restrict__ residual, int post,
                                                          const float* __restrict__ rowscale, int hw,
-                                                         float* __restrict__ y, const SegArgs sg = SegArgs{0, 0}) {
+                                                         float* __restrict__ y, const SegArgs sg = SegArgs{0, 0, 0}) {
     int64_t rows_s = rows, row_off;
     int set;
     const int bx = seg_select(sg, &rows_s, &row_off, &set);
@@ -459,7 +465,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
                                                       int64_t rows_per_block, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, int act, const float* __restrict__ rowscale,
-                                                      int hw, float* __restrict__ part, const SegArgs sg = SegArgs{0, 0}) {
+                                                      int hw, float* __restrict__ part, const SegArgs sg = SegArgs{0, 0, 0}) {
     __shared__ float lds[256 * 2 * VEC];
     int64_t row_off;
     int set;
@@ -554,7 +560,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ x,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta, int act,
                                                     const float* __restrict__ sums, float inv_rows, int train_stats,
                                                     const float* __restrict__ rowscale, int hw, float* __restrict__ dx,
-                                                    const SegArgs sg = SegArgs{0, 0}, float inv_rows_b = 0.f) {
+                                                    const SegArgs sg = SegArgs{0, 0, 0}, float inv_rows_b = 0.f) {
     int64_t rows_s = rows, row_off;
     int set;
     const int bx = seg_select(sg, &rows_s, &row_off, &set);
@@ -1685,7 +1691,7 @@ static int bn_act_bwd_impl(const float* x, const float* dy, const float* y_out, 
         LAUNCH(bn_bwd_finalize, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
         const EwGeom e = ew_geom(rows, c, 4);
         LAUNCH(bn_bwd_apply<4>, dim3(e.gx, e.ny), dim3(256), stream, x, dy, y_out, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd,
-               gamma, beta, act, sums, inv_rows, train_stats, rowscale, hw, dx);
+               gamma, beta, act, sums, inv_rows, train_stats, rowscale, hw, dx, SegArgs{0, 0, kRevSecondPass}, 0.f);
     } else {
         const ColGeom g = col_geom(rows, c, 1);
         LAUNCH(bn_bwd_partial<1>, dim3(g.gx, g.ny), dim3(256), stream, x, dy, y_out, rows, c, g.cw, g.rp, g.rows_per_block, mean,
@@ -1693,7 +1699,7 @@ static int bn_act_bwd_impl(const float* x, const float* dy, const float* y_out, 
         LAUNCH(bn_bwd_finalize, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
         const EwGeom e = ew_geom(rows, c, 1);
         LAUNCH(bn_bwd_apply<1>, dim3(e.gx, e.ny), dim3(256), stream, x, dy, y_out, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd,
-               gamma, beta, act, sums, inv_rows, train_stats, rowscale, hw, dx);
+               gamma, beta, act, sums, inv_rows, train_stats, rowscale, hw, dx, SegArgs{0, 0, kRevSecondPass}, 0.f);
     }
     return check_launch(who);
 }
@@ -1723,7 +1729,7 @@ int suhpe_bn_stats_seg(const float* x, int64_t rows, int64_t rows_a, int c, floa
     const int vec = vec4_ok(c, x) ? 4 : 1;
     const ColGeom g = col_geom(rows, c, vec);
     const int gx_a = (int)ceil_div(rows_a, g.rows_per_block), gx_b = (int)ceil_div(rows - rows_a, g.rows_per_block);
-    const SegArgs sg{rows_a, gx_a};
+    const SegArgs sg{rows_a, gx_a, 0};
     if (vec == 4) LAUNCH(bn_stats_partial<4>, dim3(gx_a + gx_b, g.ny), dim3(256), stream, x, rows, c, g.cw, g.rp, g.rows_per_block, part, sg);
     else LAUNCH(bn_stats_partial<1>, dim3(gx_a + gx_b, g.ny), dim3(256), stream, x, rows, c, g.cw, g.rp, g.rows_per_block, part, sg);
     LAUNCH(bn_stats_finalize2, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, gx_a, gx_b, c, rows_a, rows - rows_a, eps, momentum,
@@ -1750,7 +1756,7 @@ int suhpe_bn_act_fwd_seg(const float* x, int64_t rows, int64_t rows_a, int c, co
     const int vec = vec4_ok(c, x, y, residual) ? 4 : 1;
     const EwGeom g = ew_geom(rows, c, vec);
     const int gx_a = (int)ceil_div(rows_a, (int64_t)g.rows_per_block), gx_b = (int)ceil_div(rows - rows_a, (int64_t)g.rows_per_block);
-    const SegArgs sg{rows_a, gx_a};
+    const SegArgs sg{rows_a, gx_a, 0};
     if (vec == 4)
         LAUNCH(bn_act_fwd_kernel<4>, dim3(gx_a + gx_b, g.ny), dim3(256), stream, x, (int)rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta, act,
                residual, post, rowscale, hw, y, sg);
@@ -1790,10 +1796,10 @@ int suhpe_bn_act_bwd_apply(const float* x, const float* dy, const float* y_out, 
     const float inv = 1.0f / (float)total_rows;
     if (vec == 4)
         LAUNCH(bn_bwd_apply<4>, dim3(e.gx, e.ny), dim3(256), stream, x, dy, y_out, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd, gamma, beta, act, sums,
-               inv, 1, rowscale, hw, dx);
+               inv, 1, rowscale, hw, dx, SegArgs{0, 0, kRevSecondPass}, 0.f);
     else
         LAUNCH(bn_bwd_apply<1>, dim3(e.gx, e.ny), dim3(256), stream, x, dy, y_out, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd, gamma, beta, act, sums,
-               inv, 1, rowscale, hw, dx);
+               inv, 1, rowscale, hw, dx, SegArgs{0, 0, kRevSecondPass}, 0.f);
     return check_launch("suhpe_bn_act_bwd_apply");
 }
 
@@ -1804,7 +1810,7 @@ int suhpe_bn_act_pool_fwd(const float* x, int64_t rows, int64_t rows_a, int c, i
                   "suhpe_bn_act_pool_fwd: bad arguments (whole samples per segment: rows %% hw == 0, rows_a %% hw == 0)");
     const int vec = (vec4_ok(c, x, y) && vec4_ok(c, pool)) ? 4 : 1;
     const int cv = c / vec, cw = cv < 64 ? cv : 64, ny = (cv + cw - 1) / cw, rp = 256 / cw;
-    const SegArgs sg{rows_a, (int)(rows_a / hw)};
+    const SegArgs sg{rows_a, (int)(rows_a / hw), 0};
     const dim3 grid((unsigned)(rows / hw), ny);
     if (vec == 4) LAUNCH(bn_act_pool_fwd_kernel<4>, grid, dim3(256), stream, x, (int)rows, c, cw, rp, hw, mean, rstd, gamma, beta, act, y, pool, sg);
     else LAUNCH(bn_act_pool_fwd_kernel<1>, grid, dim3(256), stream, x, (int)rows, c, cw, rp, hw, mean, rstd, gamma, beta, act, y, pool, sg);
@@ -1871,10 +1877,10 @@ int suhpe_bn_act_bwd_seg(const float* x, const float* dy, const float* y_out, in
     const int vec = (vec4_ok(c, x, dy, dx) && vec4_ok(c, y_out)) ? 4 : 1;
     const ColGeom g = col_geom(rows, c, vec);
     const int gx_a = (int)ceil_div(rows_a, g.rows_per_block), gx_b = (int)ceil_div(rows - rows_a, g.rows_per_block);
-    const SegArgs sg{rows_a, gx_a};
+    const SegArgs sg{rows_a, gx_a, 0};
     const EwGeom e = ew_geom(rows, c, vec);
     const int ex_a = (int)ceil_div(rows_a, (int64_t)e.rows_per_block), ex_b = (int)ceil_div(rows - rows_a, (int64_t)e.rows_per_block);
-    const SegArgs se{rows_a, ex_a};
+    const SegArgs se{rows_a, ex_a, kRevSecondPass};
     const float inv_a = 1.0f / (float)rows_a, inv_b = 1.0f / (float)(rows - rows_a);
     if (vec == 4) {
         LAUNCH(bn_bwd_partial<4>, dim3(gx_a + gx_b, g.ny), dim3(256), stream, x, dy, y_out, rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta,
@@ -1915,11 +1921,11 @@ int suhpe_repvgg_bn_fwd(const float* const* x, const float* const* mean, const f
     const int vec = (vec4_ok(c, b.x[0], b.x[1], y) && vec4_ok(c, b.x[2])) ? 4 : 1;
     const EwGeom g = ew_geom(rows, c, vec);
     int gx = g.gx;
-    SegArgs sg{0, 0};
+    SegArgs sg{0, 0, 0};
     if (rows_a > 0) {
         const int gx_a = (int)ceil_div(rows_a, (int64_t)g.rows_per_block);
         gx = gx_a + (int)ceil_div(rows - rows_a, (int64_t)g.rows_per_block);
-        sg = SegArgs{rows_a, gx_a};
+        sg = SegArgs{rows_a, gx_a, 0};
     }
     if (vec == 4) LAUNCH(bn3_act_fwd_kernel<4>, dim3(gx, g.ny), dim3(256), stream, b, (int)rows, c, g.cw, g.rp, g.rows_per_block, y, sg);
     else LAUNCH(bn3_act_fwd_kernel<1>, dim3(gx, g.ny), dim3(256), stream, b, (int)rows, c, g.cw, g.rp, g.rows_per_block, y, sg);
@@ -1946,15 +1952,15 @@ int suhpe_repvgg_bn_bwd(const float* const* x, const float* const* mean, const f
     const ColGeom g = col_geom(rows, c, vec);
     const EwGeom e = ew_geom(rows, c, vec);
     int gx_a = g.gx, gx = g.gx, ex = e.gx;
-    SegArgs sg{0, 0}, se{0, 0};
+    SegArgs sg{0, 0, 0}, se{0, 0, 0};
     float inv_a = 1.0f / (float)rows, inv_b = 0.f;
     if (rows_a > 0) {
         gx_a = (int)ceil_div(rows_a, g.rows_per_block);
         gx = gx_a + (int)ceil_div(rows - rows_a, g.rows_per_block);
         const int ex_a = (int)ceil_div(rows_a, (int64_t)e.rows_per_block);
         ex = ex_a + (int)ceil_div(rows - rows_a, (int64_t)e.rows_per_block);
-        sg = SegArgs{rows_a, gx_a};
-        se = SegArgs{rows_a, ex_a};
+        sg = SegArgs{rows_a, gx_a, 0};
+        se = SegArgs{rows_a, ex_a, 0};
         inv_a = 1.0f / (float)rows_a;
         inv_b = 1.0f / (float)(rows - rows_a);
     }

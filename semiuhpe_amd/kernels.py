@@ -482,11 +482,15 @@ def _transpose_registered(reg):
     call("suhpe_transpose_filters_batched", ptr(table), ptr(starts), n, total)
 
 
-def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, groups=1):
-    _chk(dy, "dy")
+def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, groups=1, skip=None):
+    """input gradient; skip (dense convs): a tensor of the input's shape added in the GEMM epilogue -- the gradient that bypassed
+    the block through its skip connection (dx = dgrad(dy) + skip, no separate add pass)"""
+    _chk(dy, "dy"); _chk(skip, "skip")
     d = conv_desc(x_shape, w.shape, stride, pad, groups)
     dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
+    assert skip is None or tuple(skip.shape) == tuple(x_shape)
     if _is_depthwise(d) and d.cin % 4 == 0:
+        assert skip is None
         _dw_dgrad(d, dy, w, dx)
     else:
         key = (w.data_ptr(), d.cin, d.cout, d.r, d.s, d.groups)
@@ -501,7 +505,7 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, groups=1):
         if AUTOTUNE:
             _autotune(d, 1, lambda: call("suhpe_conv2d_dgrad", ctypes.byref(d), ptr(dy), ptr(wt), ptr(dx)))
         with _Prof(d, 1):
-            call("suhpe_conv2d_dgrad", ctypes.byref(d), ptr(dy), ptr(wt), ptr(dx))
+            call("suhpe_conv2d_dgrad_add", ctypes.byref(d), ptr(dy), ptr(wt), ptr(skip), ptr(dx))
     return dx
 
 

@@ -75,6 +75,31 @@ def _filter_param(cout, cg, r, s):
     return nn.Parameter(w)
 
 
+# The backward of `x + block(x)`: the gradient that bypasses the block is added by the input-gradient GEMM of the block's FIRST conv
+# (kernels.conv2d_dgrad(skip=...)) instead of a pass of its own.  The residual block parks the tensor here right before it runs
+# its layers' backward; the conv it names picks it up.  SUHPE_SKIP_ADD_FUSION=0: separate add kernel.
+SKIP_ADD_FUSION = os.environ.get("SUHPE_SKIP_ADD_FUSION", "1") != "0"
+_PENDING_SKIP = None
+
+
+def park_skip(conv, dy):
+    """-> True when `conv` (the first layer of a residual block) will add dy in its input-gradient epilogue"""
+    global _PENDING_SKIP
+    if not (SKIP_ADD_FUSION and isinstance(conv, Conv2d) and not conv._depthwise() and conv.need_input_grad):
+        return False
+    assert _PENDING_SKIP is None
+    _PENDING_SKIP = (conv, dy)
+    return True
+
+
+def take_pending_skip(conv):
+    global _PENDING_SKIP
+    if _PENDING_SKIP is not None and _PENDING_SKIP[0] is conv:
+        skip, _PENDING_SKIP = _PENDING_SKIP[1], None
+        return skip
+    return None
+
+
 class Conv2d(Layer):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, groups=1, bias=False):
         super().__init__()
@@ -135,16 +160,18 @@ class Conv2d(Layer):
         """eval mode without a tape: BatchNorm + activation (+ skip) folded into the GEMM epilogue (dense convs only)"""
         return self.bias is None and not self._depthwise()
 
-    def bwd(self, dy, tape):
+    def bwd(self, dy, tape, skip=None):
         x, xf = tape.pop(), None
         if isinstance(x, tuple):                             # forward applied an input transform: the filter gradient recomputes it
             x, xf = x
         K.conv2d_wgrad(x, dy, self.weight.shape, self.stride, self.padding, self.groups, out=grad_of(self.weight), accumulate=True, xf=xf)
         if self.bias is not None:
             K.bias_grad(dy, self.out_channels, out=grad_of(self.bias), accumulate=True)
+        if skip is None:
+            skip = take_pending_skip(self)
         if not self.need_input_grad:
             return None
-        return K.conv2d_dgrad(dy, self.weight, x.shape, self.stride, self.padding, self.groups)
+        return K.conv2d_dgrad(dy, self.weight, x.shape, self.stride, self.padding, self.groups, skip=skip)
 
     def extra_repr(self):
         return f"{self.in_channels}, {self.out_channels}, k={self.kernel_size}, s={self.stride}, p={self.padding}, g={self.groups}"

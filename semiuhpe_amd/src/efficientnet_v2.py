@@ -76,8 +76,15 @@ class _ResidualBlock(Layer):
         return conv_bn_fwd(last[0], last[1], y, tape, residual=x, residual_after_act=True, rowscale=rowscale)
 
     def bwd(self, dy, tape):
-        d = self._front_bwd(self.block[-1].bwd(dy, tape), tape)
-        return K.add(d, dy) if self.use_res_connect else d  # (the last BatchNorm's backward applies the keep scale)
+        from ..layers import park_skip
+        first = self.block[0]
+        fused = self.use_res_connect and park_skip(first[0] if isinstance(first, ConvNormActivation) else None, dy)
+        d = self._front_bwd(self.block[-1].bwd(dy, tape), tape)     # (the last BatchNorm's backward applies the keep scale)
+        if fused:                           # the first conv's input-gradient epilogue added dy
+            from .. import layers as L
+            assert L._PENDING_SKIP is None, "the parked skip gradient was not consumed"
+            return d
+        return K.add(d, dy) if self.use_res_connect else d
 
 
 class FusedMBConv(_ResidualBlock):

@@ -76,11 +76,20 @@ class RepVGGBlock(Layer):
         dxs = K.repvgg_bn_bwd(xs, means, rstds, [b.weight for b in bns], dout.contiguous(), y, rows_a, bns[0].num_features,
                               [grad_of(b.weight) for b in bns], [grad_of(b.bias) for b in bns])
         self.rbr_1x1.conv.need_input_grad = self.rbr_dense.conv.need_input_grad = self.need_input_grad
-        dx1 = self.rbr_1x1.conv.bwd(dxs[1], tape)
-        dx3 = self.rbr_dense.conv.bwd(dxs[0], tape)
+        return self._branch_dgrads(dxs[0], dxs[1], dxs[2] if len(dxs) == 3 else None, tape)
+
+    def _branch_dgrads(self, d_t3, d_t1, d_xid, tape):
+        """input gradients of the 1x1 and the 3x3 branch (+ the identity branch's), summed: each GEMM adds the sum so far in its
+        epilogue (kernels.conv2d_dgrad(skip=...)) unless layers.SKIP_ADD_FUSION is off"""
+        from .. import layers as L
+        fuse = L.SKIP_ADD_FUSION and self.need_input_grad
+        dx1 = self.rbr_1x1.conv.bwd(d_t1, tape, skip=d_xid if fuse else None)
+        dx3 = self.rbr_dense.conv.bwd(d_t3, tape, skip=dx1 if fuse else None)
         if not self.need_input_grad:
             return None
-        return K.add3(dx3, dx1, dxs[2]) if len(dxs) == 3 else K.add(dx3, dx1)
+        if fuse:
+            return dx3
+        return K.add3(dx3, dx1, d_xid) if d_xid is not None else K.add(dx3, dx1)
 
     def bwd(self, dout, tape):
         if isinstance(tape[-1], tuple) and len(tape[-1]) == 6 and tape[-1][0] == "fused_tail":
@@ -91,11 +100,7 @@ class RepVGGBlock(Layer):
         d_xid = self.rbr_identity.bwd(g, tape) if self.rbr_identity is not None else None
         d_t1 = self.rbr_1x1.bn.bwd(g, tape)
         self.rbr_1x1.conv.need_input_grad = self.rbr_dense.conv.need_input_grad = self.need_input_grad
-        dx1 = self.rbr_1x1.conv.bwd(d_t1, tape)
-        dx3 = self.rbr_dense.conv.bwd(d_t3, tape)
-        if not self.need_input_grad:
-            return None
-        return K.add3(dx3, dx1, d_xid) if d_xid is not None else K.add(dx3, dx1)
+        return self._branch_dgrads(d_t3, d_t1, d_xid, tape)
 
 
 def b1g2_stage_configs():

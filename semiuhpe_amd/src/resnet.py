@@ -34,8 +34,10 @@ class Bottleneck(Layer):
             d_id = self.downsample[0].bwd(self.downsample[1].bwd(g, tape), tape)
         else:
             d_id = g
-        d = self.conv1.bwd(self.bn1.bwd(self.conv2.bwd(self.bn2.bwd(d, tape), tape), tape), tape)
-        return K.add(d, d_id)
+        from .. import layers as L
+        fuse = L.SKIP_ADD_FUSION and self.conv1.need_input_grad       # the identity path's gradient rides in conv1's input-gradient epilogue
+        d = self.conv1.bwd(self.bn1.bwd(self.conv2.bwd(self.bn2.bwd(d, tape), tape), tape), tape, skip=d_id if fuse else None)
+        return d if fuse else K.add(d, d_id)
 
 
 class ResNet50(Network):

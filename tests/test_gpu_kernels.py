@@ -857,3 +857,29 @@ def test_split_bf16_tiles():
     env = dict(os.environ, SUHPE_SPLIT_BF16="1", PYTHONPATH=root)
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "split_tiles_worker.py")], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "SPLIT_TILES_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("cfg", [(6, 48, 192, 3, 1, 1, 1, 28, 28), (40, 160, 960, 1, 1, 0, 1, 14, 14), (4, 64, 128, 3, 2, 1, 1, 30, 30), (2, 128, 128, 3, 1, 1, 2, 14, 14),
+                                 (160, 960, 160, 1, 1, 0, 1, 14, 14)])
+def test_dgrad_with_skip_add(K, cfg):
+    """suhpe_conv2d_dgrad_add: dx = dgrad(dy) + skip from the GEMM epilogue == the input gradient followed by a separate add, bit
+    for bit, on every tile of the menu (igemm, persistent, halo; stride 2 = the parity-class launches; groups)"""
+    import ctypes
+    from semiuhpe_amd import _lib
+    lib = _lib.load()
+    n, cin, cout, k, stride, pad, groups, h, w = cfg
+    g = torch.Generator().manual_seed(21)
+    wg = K.to_filter_layout((torch.randn(cout, cin // groups, k, k, generator=g) / (k * (cin // groups) ** 0.5)).cuda())
+    ho = (h + 2 * pad - k) // stride + 1
+    dy = torch.randn(n, ho, ho, cout, generator=g).cuda()
+    skip = torch.randn(n, h, w, cin, generator=g).cuda()
+    d = K.conv_desc((n, h, w, cin), wg.shape, stride, pad, groups)
+    try:
+        for tile in range(-1, lib.suhpe_conv2d_tile_count(1)):
+            if lib.suhpe_conv2d_set_tile(ctypes.byref(d), 1, tile) != 0:
+                continue
+            plain = K.conv2d_dgrad(dy, wg, (n, h, w, cin), stride, pad, groups)
+            fused = K.conv2d_dgrad(dy, wg, (n, h, w, cin), stride, pad, groups, skip=skip)
+            assert torch.equal(fused, plain + skip), tile
+    finally:
+        lib.suhpe_conv2d_set_tile(ctypes.byref(d), 1, -1)
