@@ -151,6 +151,12 @@ def run(n_images=EVAL_IMAGES, warm_steps=3, train_batch=(8, 16), size=224, netwo
            "same_weights": cmp(R_same, mae_same), "own_trajectory": cmp(R_own, mae_own),
            "ema_same_weights_max_abs_dR": float(np.abs(R_ema - R_ema_cpu).max()),
            "tolerance": {"max_abs_dR": 1e-4, "d_mae_deg": 0.05},
+           "within_tolerance": {"same_weights": bool(np.abs(R_same - R_cpu).max() <= 1e-4 and max(abs(mae_same[k] - mae_cpu[k]) for k in mae_cpu) <= 0.05),
+                                "ema_same_weights": bool(np.abs(R_ema - R_ema_cpu).max() <= 1e-4)},
+           "note": "the bars apply to same_weights (the eval path on identical weights).  own_trajectory adds the divergence of the two training "
+                   "trajectories: Adam turns fp32 summation-order noise in near-zero gradient entries into +-lr parameter differences, and with "
+                   "random-init weights eval-mode BatchNorm (running statistics three steps old) feeds the SVD head near-zero matrices whose Euler "
+                   "angles sit at the +-180 degree wrap -- one image crossing it moves a MAE by 0.18 degrees; reported, not held to the bars",
            "cpu_eval_s": round(t_cpu - t_train, 1), "train_s": round(t_train - t_start, 1)}
     if verbose:
         print(out)
