@@ -83,7 +83,7 @@ def _hip_eval(agent, cfg, batches, eval_ema=False):
     return np.concatenate(Rs), mae
 
 
-def run(n_images=EVAL_IMAGES, warm_steps=3, train_batch=(8, 16), size=224, network="effinetv2", threads=None, verbose=False):
+def run(n_images=EVAL_IMAGES, warm_steps=3, train_batch=(8, 16), size=224, network="effinetv2", threads=None, verbose=False, conditioned=True):
     from oracle import networks as ON
     from oracle.agent import OracleAgent, synthetic_batches
     from parity_utils import MaskTape
@@ -96,9 +96,26 @@ def run(n_images=EVAL_IMAGES, warm_steps=3, train_batch=(8, 16), size=224, netwo
     make = {"effinetv2": ON.EfficientNetV2S, "repvgg": ON.RepVggNet, "tinyvit": ON.TinyViT21M}[network]
     ref = make()
     head = getattr(ref, "classifier", None) or getattr(ref, "linear_reg", None) or getattr(ref, "head", None)
-    for m in head:
-        if isinstance(m, torch.nn.Linear):
-            m.weight.data.mul_(20.0)      # random-init heads emit A ~ 0 (N(0, 0.01) weights): lift it so the SVD is well conditioned
+    linears = [m for m in head if isinstance(m, torch.nn.Linear)]
+    for m in linears:
+        m.weight.data.mul_(20.0)          # random-init heads emit A ~ 0 (N(0, 0.01) weights): lift it so the SVD is well conditioned
+    if conditioned:
+        # A freshly initialised network is a degenerate evaluation subject: eval-mode BatchNorm with running statistics (0, 1) lets the
+        # activations collapse, the head then feeds the SVD near-zero matrices and the Euler angles land on the +-180 degree wrap.  The
+        # shared INITIAL state is therefore completed the way a pretrained checkpoint would be: running statistics = the batch statistics
+        # of one seeded batch (one train-mode pass of the oracle with momentum 1), and the last layer biased towards the identity
+        # rotation so that the predictions scatter around a frontal pose (A = 4 I + O(1)).  Everything after that is the 8d protocol.
+        linears[-1].bias.data.copy_(4.0 * torch.eye(3).reshape(-1)[:linears[-1].bias.numel()])
+        bns = [m for m in ref.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+        keep = [m.momentum for m in bns]
+        for m in bns:
+            m.momentum = 1.0
+        ref.train()
+        with torch.no_grad():
+            ref(synthetic_batches(16, 0, size=size, seed=7777)[0]["img"])
+        for m, mom in zip(bns, keep):
+            m.momentum = mom
+            m.num_batches_tracked.zero_()
     sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
 
     def factory():
@@ -152,11 +169,14 @@ def run(n_images=EVAL_IMAGES, warm_steps=3, train_batch=(8, 16), size=224, netwo
            "ema_same_weights_max_abs_dR": float(np.abs(R_ema - R_ema_cpu).max()),
            "tolerance": {"max_abs_dR": 1e-4, "d_mae_deg": 0.05},
            "within_tolerance": {"same_weights": bool(np.abs(R_same - R_cpu).max() <= 1e-4 and max(abs(mae_same[k] - mae_cpu[k]) for k in mae_cpu) <= 0.05),
-                                "ema_same_weights": bool(np.abs(R_ema - R_ema_cpu).max() <= 1e-4)},
-           "note": "the bars apply to same_weights (the eval path on identical weights).  own_trajectory adds the divergence of the two training "
-                   "trajectories: Adam turns fp32 summation-order noise in near-zero gradient entries into +-lr parameter differences, and with "
-                   "random-init weights eval-mode BatchNorm (running statistics three steps old) feeds the SVD head near-zero matrices whose Euler "
-                   "angles sit at the +-180 degree wrap -- one image crossing it moves a MAE by 0.18 degrees; reported, not held to the bars",
+                                "ema_same_weights": bool(np.abs(R_ema - R_ema_cpu).max() <= 1e-4),
+                                "own_trajectory_mae": bool(max(abs(mae_own[k] - mae_cpu[k]) for k in mae_cpu) <= 0.05)},
+           "initial_state": ("seeded weights, head x20, last-layer bias 4*vec(I), BatchNorm running statistics of one seeded batch (see run())"
+                             if conditioned else "seeded weights, head x20"),
+           "note": "same_weights = the eval path on identical weights: both bars.  own_trajectory = each path evaluates the weights it trained "
+                   "itself for the K steps: the MAE bar holds; its rotation matrices carry the divergence of two fp32 training trajectories "
+                   "(Adam turns summation-order noise in near-zero gradient entries into +-lr parameter differences), so max_abs_dR there is "
+                   "reported, not held to 1e-4",
            "cpu_eval_s": round(t_cpu - t_train, 1), "train_s": round(t_train - t_start, 1)}
     if verbose:
         print(out)
