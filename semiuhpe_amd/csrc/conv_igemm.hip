@@ -1163,6 +1163,7 @@ static GatherGeom make_geom(int N, int GH, int GW, int OH, int OW, int ldg, int 
 }
 
 #include "conv_halo.inl"
+#include "conv_stem.inl"
 
 // fast-path selector: 1 = pointwise, 2 = affine taps, 3 = parity class of a strided dgrad, 0 = generic
 static int nt_mode(const GatherGeom& g) {
@@ -1399,6 +1400,10 @@ int suhpe_conv2d_fwd(const suhpe_conv_t* d, const float* x, const float* w, cons
     int rc = check_desc(d, "suhpe_conv2d_fwd");
     if (rc) return rc;
     SUHPE_REQUIRE(x && w && y, "suhpe_conv2d_fwd: null pointer");
+    if (stem_ok(d) && pinned_tile(d, 0) < 0) {               // RGB stem: direct kernel (conv_stem.inl); a pinned tile keeps the GEMM (tile menu tests)
+        launch_stem(d, x, w, bias, y, nullptr, nullptr, 0, as_stream(stream));
+        return check_launch("suhpe_conv2d_fwd");
+    }
     NtParams p;
     const int cg = d->cin / d->groups;
     p.g = make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0);
@@ -1430,6 +1435,7 @@ int suhpe_conv2d_fwd_affine(const suhpe_conv_t* d, const float* x, const float* 
 
 int suhpe_conv2d_fwd_stats_tiles(const suhpe_conv_t* d) {
     if (!d || d->groups <= 0) return 0;
+    if (stem_ok(d) && pinned_tile(d, 0) < 0) return (int)ceil_div((int64_t)d->n * d->ho * d->wo, kStemRows);
     const int cg = d->cin / d->groups, ng = d->cout / d->groups;
     const int64_t M = (int64_t)d->n * d->ho * d->wo;
     return (int)ceil_div(M, nt_tile_bm(choose_nt(M, ng, cg % 4 == 0 && d->cin % 4 == 0, pinned_tile(d, 0), halo_ok_desc(d, 0))));
@@ -1437,6 +1443,7 @@ int suhpe_conv2d_fwd_stats_tiles(const suhpe_conv_t* d) {
 
 int suhpe_conv2d_fwd_stats_tile_rows(const suhpe_conv_t* d) {
     if (!d || d->groups <= 0) return 0;
+    if (stem_ok(d) && pinned_tile(d, 0) < 0) return kStemRows;
     const int cg = d->cin / d->groups, ng = d->cout / d->groups;
     return nt_tile_bm(choose_nt((int64_t)d->n * d->ho * d->wo, ng, cg % 4 == 0 && d->cin % 4 == 0, pinned_tile(d, 0), halo_ok_desc(d, 0)));
 }
@@ -1446,6 +1453,10 @@ static int conv2d_fwd_stats_impl(const suhpe_conv_t* d, const float* x, const fl
     int rc = check_desc(d, "suhpe_conv2d_fwd_stats");
     if (rc) return rc;
     SUHPE_REQUIRE(x && w && y && stats, "suhpe_conv2d_fwd_stats: null pointer");
+    if (stem_ok(d) && pinned_tile(d, 0) < 0) {
+        launch_stem(d, x, w, nullptr, y, stats, stats_extra, seg_row, as_stream(stream));
+        return check_launch("suhpe_conv2d_fwd_stats");
+    }
     NtParams p;
     const int cg = d->cin / d->groups;
     p.g = make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0);
@@ -1605,6 +1616,7 @@ const char* suhpe_conv2d_kernel_name(const suhpe_conv_t* d, int pass) {
     if (!d || d->groups <= 0) return "";
     const int ng = d->cout / d->groups, cg = d->cin / d->groups;
     const bool plain = d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0;
+    if (pass == 0 && stem_ok(d) && pinned_tile(d, 0) < 0) return d->cout == 24 ? "rgb_conv3x3_kernel<24>" : (d->cout == 48 ? "rgb_conv3x3_kernel<48>" : "rgb_conv3x3_kernel<64>");
     if (pass == 0) return kNtNames[effective_nt(choose_nt((int64_t)d->n * d->ho * d->wo, ng, cg % 4 == 0 && d->cin % 4 == 0, pinned_tile(d, 0), halo_ok_desc(d, 0)), plain, halo_ok_desc(d, 0))];
     if (pass == 1) {
         const int st = d->stride;

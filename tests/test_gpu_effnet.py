@@ -173,7 +173,9 @@ def test_agent_ssl_step_matches_oracle(models, merge, fold_expand):
         assert rel_err(fu["entropy"], fu_o["entropy"]) < 2e-4
         assert abs(float(fu["mask_ratio"]) - float(fu_o["mask_ratio"])) < 1e-6
         assert rel_err(fu["unsuper_loss"], fu_o["unsuper_loss"]) < 5e-4
-        assert rel_err(out["loss_all"], out_o["loss_all"]) < 5e-4
+        # loss_all = loss + lambda * unsuper_loss can nearly cancel (-0.08 from terms of order 1): its tolerance is set by its terms
+        scale = float(abs(fd_o["loss"])) + float(abs(fu_o["unsuper_loss"]))
+        assert abs(float(out["loss_all"]) - float(out_o["loss_all"])) < 5e-4 * max(scale, abs(float(out_o["loss_all"])))
         assert rel_err(fu["err_weakAll_gt"], fu_o["err_weakAll_gt"]) < 1e-3
         bad = grad_mismatches(g_ref, {n: p.grad for n, p in agent.net.named_parameters()}, 5e-3)
         assert not bad, f"step {step}: {len(bad)} gradients off: {list(bad.items())[:8]}"

@@ -883,3 +883,34 @@ def test_dgrad_with_skip_add(K, cfg):
             assert torch.equal(fused, plain + skip), tile
     finally:
         lib.suhpe_conv2d_set_tile(ctypes.byref(d), 1, -1)
+
+
+@pytest.mark.parametrize("n,cout,hw,stride,seg", [(5, 24, 40, 2, None), (6, 24, 31, 2, 2), (3, 48, 28, 2, 1), (2, 64, 33, 2, None), (4, 24, 16, 1, 3), (40, 24, 30, 2, 13)])
+def test_rgb_stem_direct_conv(K, n, cout, hw, stride, seg):
+    """rgb_conv3x3_kernel (conv_stem.inl): the backbones' 3-channel stem conv as a direct kernel == a float64 reference to fp32 noise, with bias, and with the BatchNorm statistics records / batch segments of the GEMM epilogue's format"""
+    import ctypes
+    from semiuhpe_amd import _lib
+    lib = _lib.load()
+    lib.suhpe_conv2d_kernel_name.restype = ctypes.c_char_p
+    g = torch.Generator().manual_seed(n + cout)
+    x = torch.randn(n, hw, hw, 3, generator=g).cuda()
+    wt = (torch.randn(cout, 3, 3, 3, generator=g) / 5).cuda()
+    wg = K.to_filter_layout(wt)
+    bias = torch.randn(cout, generator=g).cuda()
+    d = K.conv_desc(x.shape, wg.shape, stride, 1, 1)
+    assert b"rgb_conv3x3" in lib.suhpe_conv2d_kernel_name(ctypes.byref(d), 0)
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), wt.double(), bias.double(), stride, 1).permute(0, 2, 3, 1)
+    y = K.conv2d_fwd(x, wg, bias, stride, 1, 1)
+    assert rel(y, ref.cpu()) < 2e-6
+    res = K.conv2d_fwd_stats(x, wg, stride, 1, 1, seg=seg)
+    y0 = res[0]
+    rows = y0.numel() // cout
+    assert rel(y0, (ref - bias.double()).cpu()) < 2e-6
+    if seg:
+        rows_a = seg * y0.shape[1] * y0.shape[2]
+        m2, r2 = K.bn_stats_from_partials_seg(res[1], res[2], res[3][0], res[3][1], rows, rows_a, cout, 1e-3, 0.1)
+        m0, r0 = K.bn_stats_seg(y0, rows_a, cout, 1e-3, 0.1)
+    else:
+        m2, r2 = K.bn_stats_from_partials(res[1], res[2], rows, cout, 1e-3, 0.1)
+        m0, r0 = K.bn_stats(y0, cout, 1e-3, 0.1)
+    assert (m2 - m0).abs().max().item() < 2e-6 and rel(r2, r0.cpu()) < 2e-6
