@@ -88,8 +88,13 @@ __global__ __launch_bounds__(256) void rgb_conv3x3_kernel(const float* __restric
 
 constexpr int kStemRows = 256;
 static const bool kStemDirect = !(getenv("SUHPE_STEM_DIRECT") && atoi(getenv("SUHPE_STEM_DIRECT")) == 0);     // SUHPE_STEM_DIRECT=0: the implicit-GEMM path
+// 3 -> 24 (EfficientNetV2-S) and 3 -> 48 (TinyViT).  RepVGG's 3 -> 64 stem stays on the GEMM: the kernel handles it (tests/test_gpu_kernels.py
+// runs COUT = 64 through launch_stem's instantiation), but RepVGG's reference-golden gradient check (4 images of 64x64, BatchNorm over 64
+// samples in layer3) sits on ReLU-mask flips: with a different -- equally accurate -- rounding of the stem one sampled gradient moves by
+// 5 % (tools/debug/stem_ab2.py: forward activations agree to 1e-7 .. 3e-5), past that test's bar.
 static bool stem_ok(const suhpe_conv_t* d) {
-    return kStemDirect && d && d->groups == 1 && d->cin == 3 && d->r == 3 && d->s == 3 && (d->cout == 24 || d->cout == 48 || d->cout == 64) &&
+    static const bool all = getenv("SUHPE_STEM_DIRECT") && atoi(getenv("SUHPE_STEM_DIRECT")) == 2;       // 2: the 64-channel stem too
+    return kStemDirect && d && d->groups == 1 && d->cin == 3 && d->r == 3 && d->s == 3 && (d->cout == 24 || d->cout == 48 || (all && d->cout == 64)) &&
            (int64_t)d->n * d->h * d->w * 3 < ((int64_t)1 << 31);
 }
 static void launch_stem(const suhpe_conv_t* d, const float* x, const float* w, const float* bias, float* y, float* stats, float* stats_extra,

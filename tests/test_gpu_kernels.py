@@ -885,7 +885,7 @@ def test_dgrad_with_skip_add(K, cfg):
         lib.suhpe_conv2d_set_tile(ctypes.byref(d), 1, -1)
 
 
-@pytest.mark.parametrize("n,cout,hw,stride,seg", [(5, 24, 40, 2, None), (6, 24, 31, 2, 2), (3, 48, 28, 2, 1), (2, 64, 33, 2, None), (4, 24, 16, 1, 3), (40, 24, 30, 2, 13)])
+@pytest.mark.parametrize("n,cout,hw,stride,seg", [(5, 24, 40, 2, None), (6, 24, 31, 2, 2), (3, 48, 28, 2, 1), (2, 48, 33, 2, None), (4, 24, 16, 1, 3), (40, 24, 30, 2, 13)])
 def test_rgb_stem_direct_conv(K, n, cout, hw, stride, seg):
     """rgb_conv3x3_kernel (conv_stem.inl): the backbones' 3-channel stem conv as a direct kernel == a float64 reference to fp32 noise, with bias, and with the BatchNorm statistics records / batch segments of the GEMM epilogue's format"""
     import ctypes
