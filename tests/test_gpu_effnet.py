@@ -172,7 +172,9 @@ def test_agent_ssl_step_matches_oracle(models, merge, fold_expand):
         assert rel_err(fd["err_deg"], fd_o["err_deg"]) < 1e-3
         assert rel_err(fu["entropy"], fu_o["entropy"]) < 2e-4
         assert abs(float(fu["mask_ratio"]) - float(fu_o["mask_ratio"])) < 1e-6
-        assert rel_err(fu["unsuper_loss"], fu_o["unsuper_loss"]) < 5e-4
+        # (the opt-in fold path recomputes SiLU on v_exp / v_rcp in the depthwise loaders, ~1 ulp each: a little more noise on this small
+        # difference of order-1 terms)
+        assert rel_err(fu["unsuper_loss"], fu_o["unsuper_loss"]) < (1e-3 if fold_expand else 5e-4)
         # loss_all = loss + lambda * unsuper_loss can nearly cancel (-0.08 from terms of order 1): its tolerance is set by its terms
         scale = float(abs(fd_o["loss"])) + float(abs(fu_o["unsuper_loss"]))
         assert abs(float(out["loss_all"]) - float(out_o["loss_all"])) < 5e-4 * max(scale, abs(float(out_o["loss_all"])))
