@@ -55,3 +55,64 @@ for (n, cin, cout, k, stride, pad, groups, h, w) in [(20, 160, 320, 1, 1, 0, 1, 
             assert float((ya.double() - F.silu(y_ref * sc.double() + sh.double())).abs().max()) < 2e-5, names[tile]
             lib.suhpe_conv2d_set_tile(ctypes.byref(d), 0, -1)
 print("SPLIT_TILES_OK worst error ratio vs the fp32 tile %.2f" % worst)
+
+# ---- network level: EfficientNetV2-S with EVERY forward / input-gradient GEMM pinned to a split tile, against the CPU oracle at the
+# tolerances of tests/test_gpu_effnet.py (rotation matrices 1e-4, outputs 2e-4, gradients 2e-3 of each tensor's max)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from parity_utils import MaskTape, grad_mismatches, rel_err
+from oracle import networks as ON, fisher as OF
+from semiuhpe_amd import layers as L
+from semiuhpe_amd.src.efficientnet_v2 import EfficientNetV2S
+
+pinned = set()
+
+
+def pin_split(d, pass_id, run):
+    if pass_id < 2 and not (d.cin % 4 or d.cout % 4 or (d.cin // d.groups) % 4 or (d.cout // d.groups) % 4):
+        key = (pass_id, d.n, d.h, d.w, d.cin, d.cout, d.r, d.s, d.stride, d.pad, d.groups)
+        if key not in pinned:
+            assert lib.suhpe_conv2d_set_tile(ctypes.byref(d), pass_id, split[0]) == 0          # 64x64 split tile
+            pinned.add(key)
+
+
+K._autotune, K.AUTOTUNE = pin_split, True
+torch.manual_seed(0)
+ref = ON.EfficientNetV2S()
+gg = torch.Generator().manual_seed(1)
+for mod in ref.modules():
+    if isinstance(mod, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d)):
+        mod.running_mean.copy_(torch.randn(mod.num_features, generator=gg) * 0.1)
+        mod.running_var.copy_(torch.rand(mod.num_features, generator=gg) * 0.5 + 0.75)
+        mod.weight.data.copy_(torch.rand(mod.num_features, generator=gg) * 0.5 + 0.75)
+        mod.bias.data.copy_(torch.randn(mod.num_features, generator=gg) * 0.1)
+for mod in ref.classifier:
+    if isinstance(mod, torch.nn.Linear):
+        mod.weight.data.mul_(20.0)
+hip = EfficientNetV2S()
+hip.load_state_dict(ref.state_dict())
+hip.cuda()
+ref.eval(); hip.eval()
+xe = torch.randn(3, 3, 224, 224, generator=torch.Generator().manual_seed(2))
+with torch.no_grad():
+    ye_ref, ye = ref(xe), hip(xe.cuda())
+assert rel_err(ye, ye_ref) < 2e-4
+assert float((K.fisher_svd_project(ye).cpu() - OF.batch_torch_A_to_R(ye_ref)).abs().max()) < 1e-4
+ref.train(); hip.train()
+tape = MaskTape(7)
+xt = torch.randn(6, 3, 96, 96, generator=torch.Generator().manual_seed(3))
+dyt = torch.randn(6, 9, generator=torch.Generator().manual_seed(4))
+bn_before = {k: v.clone() for k, v in ref.state_dict().items() if "running" in k}
+ON.set_mask_hook(tape.record)
+yt_ref = ref(xt)
+yt_ref.backward(dyt)
+ON.set_mask_hook(None)
+hip.load_state_dict({**hip.state_dict(), **bn_before})
+L.set_mask_hook(tape.replay)
+yt = hip(xt.cuda())
+yt.backward(dyt.cuda())
+L.set_mask_hook(None)
+assert tape.done() and rel_err(yt, yt_ref) < 2e-4
+bad = grad_mismatches({n: p.grad for n, p in ref.named_parameters()}, {n: p.grad for n, p in hip.named_parameters()}, 2e-3)
+assert not bad, f"{len(bad)} gradients off: {list(bad.items())[:6]}"
+assert len(pinned) > 50, len(pinned)
+print("SPLIT_NETWORK_OK %d (shape, pass) pairs on split tiles" % len(pinned))

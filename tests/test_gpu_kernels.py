@@ -850,13 +850,14 @@ def test_tile_database_is_the_tested_tile_set(K):
 
 def test_split_bf16_tiles():
     """the opt-in split-bf16 NT tiles (SUHPE_SPLIT_BF16=1: an fp32 product as six exact bf16 MFMA planes) are as close to a
-    float64 reference as the fp32-MFMA tile, in every loader mode and with the fused epilogues (tests/split_tiles_worker.py);
+    float64 reference as the fp32-MFMA tile, in every loader mode and with the fused epilogues, and EfficientNetV2-S with every forward /
+    input-gradient GEMM pinned to a split tile meets the oracle at the network tolerances (tests/split_tiles_worker.py);
     without the switch suhpe_conv2d_set_tile refuses them (test_tile_menu_every_pinned_tile_matches)"""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SUHPE_SPLIT_BF16="1", PYTHONPATH=root)
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "split_tiles_worker.py")], cwd=root, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "SPLIT_TILES_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    assert r.returncode == 0 and "SPLIT_TILES_OK" in r.stdout and "SPLIT_NETWORK_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
 
 @pytest.mark.parametrize("cfg", [(6, 48, 192, 3, 1, 1, 1, 28, 28), (40, 160, 960, 1, 1, 0, 1, 14, 14), (4, 64, 128, 3, 2, 1, 1, 30, 30), (2, 128, 128, 3, 1, 1, 2, 14, 14),
