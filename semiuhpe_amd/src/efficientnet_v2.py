@@ -30,6 +30,7 @@ BN_EPS = 1e-3           # torchvision: partial(nn.BatchNorm2d, eps=1e-03) for th
 # makes the depthwise kernels recompute the SiLU 1.5x (forward) to 3x (filter gradient) per element: measured 84.1 vs 79.7
 # ms/step on C2, so it is off; the kernels and their tests stay (memory-saving mode: the expanded tensor is never stored).
 FUSE_EXPAND_BN_INTO_DW = os.environ.get("SUHPE_FUSE_EXPAND_DW", "0") == "1"
+FUSE_EXPAND_NO_TAPE = os.environ.get("SUHPE_FUSE_EXPAND_NO_TAPE", "1") != "0"      # the same fold in train-mode forwards that keep no tape (teacher pass)
 FUSE_DW_BN_SE = os.environ.get("SUHPE_FUSE_DW_BN_SE", "1") != "0"     # depthwise BatchNorm + SiLU + SqueezeExcitation as one section (MBConv._dw_se_*)
 STOCHASTIC_DEPTH_PROB = 0.2
 
@@ -138,9 +139,12 @@ class MBConv(_ResidualBlock):
     # _wgrad): the normalised, 4-6x expanded tensor -- the largest activation of the block -- is never written or re-read.
     # Its BatchNorm still gets exact statistics (from the expand conv's epilogue) and the standard backward (from the raw
     # output and the gradient the depthwise dgrad returns).  Train mode, inside the fused depthwise-SE section only.
-    def _expand_folded(self):
+    def _expand_folded(self, no_tape=False):
+        """no_tape: a forward without a backward (the teacher pass): there the fold costs one SiLU recompute in the depthwise forward
+        loader and saves the whole BatchNorm pass over the expanded tensor (FUSE_EXPAND_NO_TAPE); with a tape the filter gradient
+        would recompute the activation three times per element, which costs more than the pass (FUSE_EXPAND_BN_INTO_DW, off)."""
         from .. import layers as L
-        if not (FUSE_EXPAND_BN_INTO_DW and self.has_expand and self._dw_se_fused() and not L.SYNC_BN):
+        if not ((FUSE_EXPAND_BN_INTO_DW or (no_tape and FUSE_EXPAND_NO_TAPE)) and self.has_expand and self._dw_se_fused() and not L.SYNC_BN):
             return False
         (conv_e, bn_e), (conv_d, bn_d) = self.block[0], self.block[1]
         return bn_e.training and bn_d.training and conv_e.fuses_stats() and conv_d.fuses_stats()
@@ -192,7 +196,7 @@ class MBConv(_ResidualBlock):
     def _front_fwd(self, x, tape):
         # expand -> depthwise conv -> BatchNorm + SiLU + squeeze -> excitation
         layers = list(self.block)[:-1]
-        if self._expand_folded():
+        if self._expand_folded(no_tape=tape is None):
             conv_e, bn_e = layers[0]
             y0, partials = conv_e.fwd_stats(x, tape)
             mean, rstd, rows_a = bn_e.train_stats(y0, partials)
