@@ -116,6 +116,8 @@ int suhpe_conv2d_fwd_stats_seg(const suhpe_conv_t* d, const float* x, const floa
  * pin is process-wide and keyed by the whole descriptor.  Results of pass 0 / 1 do not depend on the tile; pass 2
  * changes the split-K partition (summation order) with it. */
 int suhpe_conv2d_tile_count(int pass);
+/* start-up stagger of the GEMM workgroups (0 = off): see stagger_wait in csrc/conv_igemm.hip */
+int suhpe_conv2d_set_stagger(int quanta, int first_gen);
 const char* suhpe_conv2d_tile_name(int pass, int tile);
 int suhpe_conv2d_set_tile(const suhpe_conv_t* d, int pass, int tile);
 /* Pointwise conv whose INPUT is act(BN(x)) [* per-sample scale] of a tensor x that was never normalised in memory: the loader of

@@ -135,7 +135,21 @@ struct NtParams {
     int a_act = 0, a_hw = 1;
     int64_t a_seg_row = 0;
     unsigned a_div_mul = 0, a_div_shr = 0;
+    // start-up stagger (see stagger_wait): workgroups of the first resident generation delay their first barrier by
+    // (hardware wave slot) * stagger quanta so that co-resident workgroups run out of phase
+    int stagger = 0, stagger_first = 0;
 };
+
+// Workgroups that start together on a CU finish together: their epilogues (no MFMA work) and the prologues of the workgroups
+// that replace them coincide, and the matrix pipes idle for that whole interval every generation.  The first generation is
+// therefore spread out once: wave 0 of a workgroup sleeps (its wave slot on the SIMD) * quanta * 4096 cycles before the first
+// barrier (its first loads are already in flight); later generations inherit the offsets, because a workgroup starts when one ends.
+__device__ __forceinline__ void stagger_wait(int quanta, int first_gen) {
+    if (quanta > 0 && (int)blockIdx.x < first_gen && threadIdx.x < 64) {
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 7u;      // HW_REG_HW_ID.WAVE_ID
+        for (unsigned i = 0; i < slot * (unsigned)quanta; ++i) __builtin_amdgcn_s_sleep(64);
+    }
+}
 
 template <int VEC> __device__ __forceinline__ void vload_lds(const float* p, float* o) {
     if constexpr (VEC == 4) { const float4 v = *reinterpret_cast<const float4*>(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
@@ -456,6 +470,7 @@ void igemm_nt_kernel(const NtParams p) {
         }
     };
     load_tiles(S0{});
+    stagger_wait(p.stagger, p.stagger_first);
     xform_tiles(S0{});
     store_tiles(S0{}, 0);
     __syncthreads();
@@ -1173,9 +1188,15 @@ static int nt_mode(const GatherGeom& g) {
     return 0;
 }
 
+#include "conv_resident.inl"
+
+static int g_stagger = 0, g_stagger_first = 0;     // experiment knob (suhpe_conv2d_set_stagger)
+static thread_local bool g_nt_unsupported = false;  // set when a dispatch reached a (tile, form) that has no instantiation
+
 template <int BM, int BN, int WM, int WN, int VEC, bool SPLIT = false>
 static void launch_nt(const NtParams& p_in, int groups, hipStream_t st) {
     NtParams p = p_in;
+    p.stagger = g_stagger; p.stagger_first = g_stagger_first;
     if constexpr (SPLIT) {       // (the input-transform forms stay on the fp32 tiles: dispatch_nt maps them before it gets here)
         p.col_tiles = (int)ceil_div(p.Ng, BN);
         const dim3 grid_s((unsigned)(ceil_div(ceil_div(p.g.M, BM), 8) * 8 * p.col_tiles), 1, groups), block_s((BM / WM) * (BN / WN) * 64);
@@ -1200,10 +1221,13 @@ static void launch_nt(const NtParams& p_in, int groups, hipStream_t st) {
     switch (nt_mode(p.g)) {
         case 1:
             if (p.a_scale) {
-                if constexpr (VEC == 4 && !(WM == 64 && (BM / WM) * (BN / WN) == 4)) {
+                // (the wide-accumulator W tiles have no input-transform form: dispatch_nt maps them to the 8-wave tiles first)
+                if constexpr (VEC == 4 && !(WM == 64 && BN >= 64 && (BM / WM) * (BN / WN) == 4)) {
                     const size_t lds = 0;
                     if (p.a_rowscale) hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1, false, 2>), grid, block, lds, st, p);
                     else hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1, false, 1>), grid, block, lds, st, p);
+                } else {
+                    g_nt_unsupported = true;                 // never a silent no-op: the caller turns this into an error code
                 }
             } else if (p.scale) hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1, true>), grid, block, 0, st, p);
             else hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1>), grid, block, 0, st, p);
@@ -1228,6 +1252,7 @@ enum NtTile { NT_64x64_S = 0, NT_64x64, NT_128x32, NT_128x128, NT_128x64, NT_256
               NT_H64x64, NT_H128x32, NT_H128x64, NT_H128x128,
               NT_W128x128, NT_W128x64,       // four wavefronts with 64x64 / 64x32 accumulators each: half the LDS fragment reads per MFMA
               NT_S64x64, NT_S128x32, NT_S128x64, NT_S128x128,   // split-bf16 instantiations (six bf16 MFMA planes per fp32 product), four wavefronts
+              NT_R128x16, NT_R64x8,          // operand-resident pointwise kernel (conv_resident.inl): 128 / 64 resident rows, 16 / 8 wavefronts
               NT_TILES };
 static const char* kNtNames[] = {"igemm_nt_kernel<64,64,32,32,1>", "igemm_nt_kernel<64,64,32,32,4>", "igemm_nt_kernel<128,32,32,32,4>",
                                  "igemm_nt_kernel<128,128,64,32,4>", "igemm_nt_kernel<128,64,32,32,4>", "igemm_nt_kernel<256,32,64,32,4>",
@@ -1237,7 +1262,8 @@ static const char* kNtNames[] = {"igemm_nt_kernel<64,64,32,32,1>", "igemm_nt_ker
                                  "igemm_nt3x3_kernel<128,128,64,32>",
                                  "igemm_nt_kernel<128,128,64,64,4>", "igemm_nt_kernel<128,64,64,32,4>",
                                  "igemm_nt_kernel<64,64,32,32,4,split>", "igemm_nt_kernel<128,32,32,32,4,split>", "igemm_nt_kernel<128,64,64,32,4,split>",
-                                 "igemm_nt_kernel<128,128,64,64,4,split>"};
+                                 "igemm_nt_kernel<128,128,64,64,4,split>",
+                                 "gemm_nt_resident<128,2,16>", "gemm_nt_resident<64,2,8>"};
 
 struct TnTile { int bm, bn; const char* name; };
 static const TnTile kTnTiles[] = {
@@ -1281,7 +1307,8 @@ static NtTile choose_nt(int64_t M, int ng, bool vec4, int pinned, bool halo = fa
     return ceil_div(M, 128) * ceil_div(ng, 64) >= 512 ? NT_128x64 : NT_64x64;
 }
 
-static int nt_tile_bm(NtTile t) { return (t == NT_64x64_S || t == NT_64x64 || t == NT_P64x64 || t == NT_H64x64 || t == NT_S64x64) ? 64 : (t == NT_256x32 ? 256 : 128); }
+// (row-tile height = rows per BatchNorm statistics record; the resident tiles emit one record per 64-row unit)
+static int nt_tile_bm(NtTile t) { return (t == NT_64x64_S || t == NT_64x64 || t == NT_P64x64 || t == NT_H64x64 || t == NT_S64x64 || t >= NT_R128x16) ? 64 : (t == NT_256x32 ? 256 : 128); }
 // The split tiles are opt-in (SUHPE_SPLIT_BF16=1): the default path computes every product on the fp32 matrix-core instruction.
 // Disabled, suhpe_conv2d_set_tile refuses them (the autotuner skips refused tiles) and a tile pinned earlier runs the fp32
 // tile of the same row-tile height.
@@ -1314,7 +1341,8 @@ static void launch_persistent(const NtParams& p_in, int groups, hipStream_t st) 
 }
 
 // a pinned persistent tile on a shape that is not a plain GEMM runs the igemm tile of the same size
-static NtTile effective_nt(NtTile tile, bool plain, bool halo = false) {
+static NtTile effective_nt(NtTile tile, bool plain, bool halo = false, bool resident128 = false, bool resident64 = false) {
+    if (tile >= NT_R128x16) return ((tile == NT_R128x16 && resident128) || (tile == NT_R64x8 && resident64)) ? tile : NT_64x64;   // (same record height)
     if (tile >= NT_S64x64) return kSplitEnabled ? tile : unsplit_nt(tile);
     if (tile >= NT_W128x128) return tile;
     if (tile >= NT_H64x64) {
@@ -1327,6 +1355,11 @@ static NtTile effective_nt(NtTile tile, bool plain, bool halo = false) {
 
 static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st, int pinned) {
     NtTile tile = choose_nt(p.g.M, p.Ng, vec4, pinned, halo_ok(p.g, vec4));
+    if (tile >= NT_R128x16) {
+        if (tile == NT_R128x16 && resident_ok(p, vec4, 128)) { launch_resident<128, 2, 16>(p, groups, st); return; }
+        if (tile == NT_R64x8 && resident_ok(p, vec4, 64)) { launch_resident<64, 2, 8>(p, groups, st); return; }
+        tile = NT_64x64;                                    // (same statistics-record height as the resident tiles)
+    }
     if (tile >= NT_S64x64 && (p.a_scale || !kSplitEnabled)) tile = unsplit_nt(tile);                // (the input transform lives in the fp32 tiles)
     if (tile == NT_S64x64) { launch_nt<64, 64, 32, 32, 4, true>(p, groups, st); return; }
     if (tile == NT_S128x32) { launch_nt<128, 32, 32, 32, 4, true>(p, groups, st); return; }
@@ -1374,6 +1407,15 @@ static bool halo_ok_desc(const suhpe_conv_t* d, int pass) {
     const int cg = d->cin / d->groups, ng = d->cout / d->groups;
     if (pass == 0) return halo_ok(make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0), cg % 4 == 0 && d->cin % 4 == 0);
     return halo_ok(make_geom(d->n, d->ho, d->wo, d->h, d->w, d->cout, ng, d->r, d->s, d->stride, d->pad, 1), ng % 4 == 0 && d->cout % 4 == 0);
+}
+
+// resident-kernel capability of a (descriptor, pass): pass 0 = forward, 1 = input gradient (plain pointwise GEMMs only)
+static bool resident_ok_desc(const suhpe_conv_t* d, int pass, int BM) {
+    if (!d || d->groups <= 0 || pass > 1 || d->r != 1 || d->s != 1 || d->stride != 1 || d->pad != 0) return false;
+    const int cg = d->cin / d->groups, ng = d->cout / d->groups;
+    if (cg % 4 || ng % 4 || d->cin % 4 || d->cout % 4) return false;
+    const int K = pass == 0 ? cg : ng;
+    return resident_lds_bytes(K, BM) <= kResidentLdsMax && (int64_t)d->n * d->h * d->w < (1LL << 31);
 }
 
 // wgrad (rows = cout, columns = k'): both extents pad; cost = padded area / measured relative efficiency
@@ -1501,7 +1543,9 @@ int suhpe_conv2d_fwd_stats_xf(const suhpe_conv_t* d, const float* x, const float
     p.scale = p.shift = p.residual = nullptr; p.act = 0; p.res_mode = 0;
     p.a_scale = a_scale; p.a_shift = a_shift; p.a_rowscale = a_rowscale; p.a_act = a_act; p.a_hw = a_hw; p.a_seg_row = seg_row;
     magic_div((unsigned)a_hw, &p.a_div_mul, &p.a_div_shr);
+    g_nt_unsupported = false;
     dispatch_nt(p, 1, true, as_stream(stream), pinned_tile(d, 0));
+    if (g_nt_unsupported) { set_error("suhpe_conv2d_fwd_stats_xf: the selected tile has no input-transform instantiation"); return SUHPE_EINVAL; }
     return check_launch("suhpe_conv2d_fwd_stats_xf");
 }
 
@@ -1589,6 +1633,8 @@ static void wgrad_tile(const suhpe_conv_t* d, int* bm, int* bn) {
     *bn = t.bn;
 }
 
+int suhpe_conv2d_set_stagger(int quanta, int first_gen) { g_stagger = quanta; g_stagger_first = first_gen; return SUHPE_OK; }
+
 int suhpe_conv2d_tile_count(int pass) { return pass == 2 ? TN_TILES : (int)NT_TILES; }
 
 const char* suhpe_conv2d_tile_name(int pass, int tile) {
@@ -1605,7 +1651,9 @@ int suhpe_conv2d_set_tile(const suhpe_conv_t* d, int pass, int tile) {
     const bool v4 = ng % 4 == 0 && d->cout % 4 == 0 && cg % 4 == 0 && d->cin % 4 == 0;
     SUHPE_REQUIRE(tile < 0 || (v4 && !(pass != 2 && tile == (int)NT_64x64_S)), "suhpe_conv2d_set_tile: the vector tiles need channel counts that are multiples of 4");
     SUHPE_REQUIRE(pass == 2 || tile < (int)NT_H64x64 || tile >= (int)NT_W128x128 || halo_ok_desc(d, pass), "suhpe_conv2d_set_tile: the halo tiles need a 3x3 / stride 1 / pad 1 conv with evenly chunked channels");
-    SUHPE_REQUIRE(pass == 2 || tile < (int)NT_S64x64 || kSplitEnabled, "suhpe_conv2d_set_tile: the split-bf16 tiles are opt-in (SUHPE_SPLIT_BF16=1)");
+    SUHPE_REQUIRE(pass == 2 || tile < (int)NT_S64x64 || tile >= (int)NT_R128x16 || kSplitEnabled, "suhpe_conv2d_set_tile: the split-bf16 tiles are opt-in (SUHPE_SPLIT_BF16=1)");
+    SUHPE_REQUIRE(pass == 2 || tile < (int)NT_R128x16 || resident_ok_desc(d, pass, tile == (int)NT_R128x16 ? 128 : 64),
+                  "suhpe_conv2d_set_tile: the resident tiles need a 1x1 / stride 1 conv whose BM x K block fits the LDS");
     std::lock_guard<std::mutex> lock(tile_mutex());
     if (tile < 0) tile_table().erase(tile_key(d, pass));
     else tile_table()[tile_key(d, pass)] = tile;
@@ -1617,10 +1665,10 @@ const char* suhpe_conv2d_kernel_name(const suhpe_conv_t* d, int pass) {
     const int ng = d->cout / d->groups, cg = d->cin / d->groups;
     const bool plain = d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0;
     if (pass == 0 && stem_ok(d) && pinned_tile(d, 0) < 0) return d->cout == 24 ? "rgb_conv3x3_kernel<24>" : (d->cout == 48 ? "rgb_conv3x3_kernel<48>" : "rgb_conv3x3_kernel<64>");
-    if (pass == 0) return kNtNames[effective_nt(choose_nt((int64_t)d->n * d->ho * d->wo, ng, cg % 4 == 0 && d->cin % 4 == 0, pinned_tile(d, 0), halo_ok_desc(d, 0)), plain, halo_ok_desc(d, 0))];
+    if (pass == 0) return kNtNames[effective_nt(choose_nt((int64_t)d->n * d->ho * d->wo, ng, cg % 4 == 0 && d->cin % 4 == 0, pinned_tile(d, 0), halo_ok_desc(d, 0)), plain, halo_ok_desc(d, 0), resident_ok_desc(d, 0, 128), resident_ok_desc(d, 0, 64))];
     if (pass == 1) {
         const int st = d->stride;
-        return kNtNames[effective_nt(choose_nt((int64_t)d->n * ((d->h + st - 1) / st) * ((d->w + st - 1) / st), cg, ng % 4 == 0 && d->cout % 4 == 0, pinned_tile(d, 1), halo_ok_desc(d, 1)), plain, halo_ok_desc(d, 1))];
+        return kNtNames[effective_nt(choose_nt((int64_t)d->n * ((d->h + st - 1) / st) * ((d->w + st - 1) / st), cg, ng % 4 == 0 && d->cout % 4 == 0, pinned_tile(d, 1), halo_ok_desc(d, 1)), plain, halo_ok_desc(d, 1), resident_ok_desc(d, 1, 128), resident_ok_desc(d, 1, 64))];
     }
     const bool va = ng % 4 == 0 && d->cout % 4 == 0, vb = cg % 4 == 0 && d->cin % 4 == 0;
     if (!(va && vb)) return va ? "igemm_tn_kernel<64,64,32,32,4,1>" : (vb ? "igemm_tn_kernel<64,64,32,32,1,4>" : "igemm_tn_kernel<64,64,32,32,1,1>");

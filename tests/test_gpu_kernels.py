@@ -102,10 +102,13 @@ def test_tile_menu_every_pinned_tile_matches(K, cfg):
             for tile in range(lib.suhpe_conv2d_tile_count(pid)):
                 halo = b"nt3x3" in lib.suhpe_conv2d_tile_name(pid, tile)
                 split = b"split" in lib.suhpe_conv2d_tile_name(pid, tile)
+                resident = b"resident" in lib.suhpe_conv2d_tile_name(pid, tile)
                 if lib.suhpe_conv2d_set_tile(ctypes.byref(d), pid, tile) != 0:
-                    # the scalar-loader tile is refused for vector shapes, the halo tiles for anything but 3x3 / stride 1 / pad 1
-                    assert pid < 2 and (tile == 0 or halo or split)     # (split: opt-in, SUHPE_SPLIT_BF16=1)
+                    # the scalar-loader tile is refused for vector shapes, the halo tiles for anything but 3x3 / stride 1 / pad 1,
+                    # the resident tiles for anything but 1x1 / stride 1
+                    assert pid < 2 and (tile == 0 or halo or split or resident)     # (split: opt-in, SUHPE_SPLIT_BF16=1)
                     continue
+                assert not resident or k == 1
                 if halo or split:   # halo: channel-chunk-major reduction order; split: six bf16 planes per product -- same sums, different rounding
                     out = K.conv2d_fwd(x, wg, None, stride, pad, groups) if pid == 0 else K.conv2d_dgrad(dy, wg, x.shape, stride, pad, groups)
                     assert rel(out, (y0 if pid == 0 else dx0).cpu()) < 3e-6, tile
@@ -784,6 +787,88 @@ def test_attention_bias_gradient_fixed_order(ws, heads, B, H):
     db = db1.clone()
     K.window_attn_bwd(qkv, probs, dout, idx, B, H, H, ws, heads, noff, att.scale, db, inverse=inv)
     assert float((db - 2 * db1).abs().max()) < 1e-6 * scale
+
+
+RESIDENT_SHAPES = [
+    # (n, cin, cout, groups, h, w, seg): 1x1 / stride 1 convs as the resident kernel sees them
+    (40, 160, 960, 1, 14, 14, 8),      # the C2 expand shape (M = 7840: a last partial row tile at both tile heights)
+    (8, 40, 72, 1, 14, 14, 3),         # K = 40 (one padded slab), N = 72 (a ragged stripe), boundary inside a 64-row unit (3 * 196 = 588)
+    (5, 256, 96, 2, 7, 7, None),       # grouped, M = 245 < one 128-row tile
+    (160, 64, 256, 1, 7, 7, 32),       # boundary at a unit edge (32 * 49 = 1568 = 24.5 units: straddles)
+    (3, 608, 64, 1, 9, 9, None),       # the largest K of the 64-row tile (the 128-row tile is refused)
+]
+
+
+@pytest.mark.parametrize("cfg", RESIDENT_SHAPES, ids=str)
+def test_resident_pointwise_kernel(K, cfg):
+    """gemm_nt_resident (conv_resident.inl): both resident tiles, forward and input gradient, are bit-equal to the igemm tile (same k
+    order per output element) -- plain, with bias, with the skip add, with the folded eval BatchNorm epilogue -- and their per-unit
+    BatchNorm statistics records (one or two batch segments, a unit that straddles the boundary) finish to the statistics of the
+    stand-alone pass; refused where the BM x K block does not fit the LDS."""
+    import ctypes
+    from semiuhpe_amd import _lib
+    lib = _lib.load()
+    lib.suhpe_conv2d_tile_name.restype = ctypes.c_char_p
+    n, cin, cout, groups, h, w, seg = cfg
+    g = torch.Generator().manual_seed(31)
+    x = (torch.randn(n, h, w, cin, generator=g) + 0.2).cuda()
+    wg = K.to_filter_layout((torch.randn(cout, cin // groups, 1, 1, generator=g) / (cin // groups) ** 0.5).cuda())
+    bias = torch.randn(cout, generator=g).cuda()
+    dy = torch.randn(n, h, w, cout, generator=g).cuda()
+    skip = torch.randn(n, h, w, cin, generator=g).cuda()
+    scale, shift = (torch.rand(cout, generator=g) + 0.5).cuda(), torch.randn(cout, generator=g).cuda()
+    res = torch.randn(n, h, w, cout, generator=g).cuda()
+    d = K.conv_desc(x.shape, wg.shape, 1, 0, groups)
+    tiles = [t for t in range(lib.suhpe_conv2d_tile_count(0)) if b"resident" in lib.suhpe_conv2d_tile_name(0, t)]
+    assert len(tiles) == 2
+    igemm = [t for t in range(lib.suhpe_conv2d_tile_count(0)) if lib.suhpe_conv2d_tile_name(0, t) == b"igemm_nt_kernel<64,64,32,32,4>"][0]
+    rows = n * h * w
+
+    def run_all():
+        out = [K.conv2d_fwd(x, wg, None, 1, 0, groups), K.conv2d_fwd(x, wg, bias, 1, 0, groups),
+               K.conv2d_dgrad(dy, wg, x.shape, 1, 0, groups), K.conv2d_dgrad(dy, wg, x.shape, 1, 0, groups, skip=skip),
+               K.conv2d_fwd_affine(x, wg, scale, shift, "silu", res, True, 1, 0, groups),
+               K.conv2d_fwd_affine(x, wg, scale, shift, "relu", res, False, 1, 0, groups)]
+        if seg is None:
+            y, part, nt = K.conv2d_fwd_stats(x, wg, 1, 0, groups)
+            st = K.bn_stats_from_partials(part, nt, rows, cout, 1e-3, 0.1)
+        else:
+            y, part, nt, (first, extra) = K.conv2d_fwd_stats(x, wg, 1, 0, groups, seg=seg)
+            st = K.bn_stats_from_partials_seg(part, nt, first, extra, rows, seg * h * w, cout, 1e-3, 0.1)
+        return out + [y], st
+
+    try:
+        for pid in (0, 1):
+            assert lib.suhpe_conv2d_set_tile(ctypes.byref(d), pid, igemm) == 0
+        ref, st_ref = run_all()
+        ran = 0
+        for tile in tiles:
+            ok = [lib.suhpe_conv2d_set_tile(ctypes.byref(d), pid, tile) == 0 for pid in (0, 1)]
+            bm = 128 if b"<128" in lib.suhpe_conv2d_tile_name(0, tile) else 64
+            fits = lambda kk: bm * ((kk + 31) // 32 * 32 + 4) * 4 <= 160 * 1024      # the BM x K block (rows padded by 4 floats) in 160 KB of LDS
+            assert ok[0] == fits(cin // groups) and ok[1] == fits(cout // groups), (tile, ok)
+            for pid in (0, 1):
+                if not ok[pid]:
+                    lib.suhpe_conv2d_set_tile(ctypes.byref(d), pid, igemm)
+            lib.suhpe_conv2d_kernel_name.restype = ctypes.c_char_p
+            assert (b"resident" in lib.suhpe_conv2d_kernel_name(ctypes.byref(d), 0)) == ok[0]
+            out, st = run_all()
+            for i, (a, b) in enumerate(zip(out, ref)):
+                assert torch.equal(a, b), (tile, i)
+            for a, b in zip(st, st_ref):
+                assert rel(a, b.cpu()) < 2e-6, tile
+            ran += ok[0]
+        assert ran >= 1
+        yd = ref[0].double().cpu().reshape(rows, cout)
+        if seg is None:
+            assert rel(st_ref[0], yd.mean(0)) < 2e-5 and rel(st_ref[1], (yd.var(0, unbiased=False) + 1e-3).rsqrt()) < 2e-5
+        else:
+            ra = seg * h * w
+            for i, part_rows in enumerate((yd[:ra], yd[ra:])):
+                assert rel(st_ref[0][i], part_rows.mean(0)) < 2e-5 and rel(st_ref[1][i], (part_rows.var(0, unbiased=False) + 1e-3).rsqrt()) < 2e-5
+    finally:
+        for pid in (0, 1):
+            lib.suhpe_conv2d_set_tile(ctypes.byref(d), pid, -1)
 
 
 def _db_entries(max_elems=160 * 112 * 112 * 96):
