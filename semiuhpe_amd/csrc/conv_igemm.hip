@@ -1270,6 +1270,7 @@ static const TnTile kTnTiles[] = {
     {128, 128, "igemm_tn_kernel<128,128,64,32,4,4>"}, {128, 64, "igemm_tn_kernel<128,64,64,32,4,4>"},
     {64, 128, "igemm_tn_kernel<64,128,32,64,4,4>"},   {64, 64, "igemm_tn_kernel<64,64,32,32,4,4>"},
     {32, 128, "igemm_tn_kernel<32,128,32,32,4,4>"},
+    {128, 32, "igemm_tn_kernel<128,32,32,32,4,4>"},   // narrow k' (Cin = 160: five exact column tiles instead of 2.5 of 64)
 };
 constexpr int TN_TILES = (int)(sizeof(kTnTiles) / sizeof(kTnTiles[0]));
 
@@ -1421,7 +1422,7 @@ static bool resident_ok_desc(const suhpe_conv_t* d, int pass, int BM) {
 // wgrad (rows = cout, columns = k'): both extents pad; cost = padded area / measured relative efficiency
 static int choose_tn(int ng, int K, int pinned) {
     if (pinned >= 0 && pinned < TN_TILES) return pinned;
-    static const double eff[TN_TILES] = {0.85, 0.95, 0.95, 1.0, 0.9};
+    static const double eff[TN_TILES] = {0.85, 0.95, 0.95, 1.0, 0.9, 0.9};
     int best = 3;
     double best_cost = 1e30;
     for (int i = 0; i < TN_TILES; ++i) {
@@ -1723,12 +1724,14 @@ static int wgrad_partial_impl(const suhpe_conv_t* d, const float* x, const float
         else if (bm == 128 && bn == 64) TN_LAUNCH_XF(128, 64, 64, 32);
         else if (bm == 64 && bn == 128) TN_LAUNCH_XF(64, 128, 32, 64);
         else if (bm == 32 && bn == 128) TN_LAUNCH_XF(32, 128, 32, 32);
+        else if (bm == 128 && bn == 32) TN_LAUNCH_XF(128, 32, 32, 32);
         else TN_LAUNCH_XF(64, 64, 32, 32);
     } else if (va && vb) {
         if (bm == 128 && bn == 128) TN_LAUNCH(128, 128, 64, 32, 4, 4);       // 8 wavefronts of 64x32
         else if (bm == 128 && bn == 64) TN_LAUNCH(128, 64, 64, 32, 4, 4);
         else if (bm == 64 && bn == 128) TN_LAUNCH(64, 128, 32, 64, 4, 4);
         else if (bm == 32 && bn == 128) TN_LAUNCH(32, 128, 32, 32, 4, 4);
+        else if (bm == 128 && bn == 32) TN_LAUNCH(128, 32, 32, 32, 4, 4);
         else TN_LAUNCH(64, 64, 32, 32, 4, 4);
     } else {
         // odd channel counts (RGB stem, 9-D head): scalar loaders, generic 64x64 tile (wgrad_tile returned 64x64)

@@ -105,20 +105,22 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_nt_resident(const NtPara
         if constexpr (!AFF) {
             const float bv = (p.bias && okc) ? p.bias[grp * p.Ng + col] : 0.f;
             if (p.res_mode == 3) {                               // skip-connection gradient added to the input gradient
-                float rv[TMU][16];
+                // eight loads in flight, then their eight stores (a full set of 32 skip values would cost the kernel a wave per SIMD)
 #pragma unroll
                 for (int i = 0; i < TMU; ++i)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int ro = i * 32 + (e & 3) + 8 * (e >> 2);
-                        rv[i][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, ro < lim ? voff : kOob, (unsigned)ro * ldy4, 0));
-                    }
+                    for (int e0 = 0; e0 < 16; e0 += 8) {
+                        float rv[8];
 #pragma unroll
-                for (int i = 0; i < TMU; ++i)
+                        for (int e = 0; e < 8; ++e) {
+                            const int ro = i * 32 + ((e0 + e) & 3) + 8 * ((e0 + e) >> 2);
+                            rv[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, ro < lim ? voff : kOob, (unsigned)ro * ldy4, 0));
+                        }
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int ro = i * 32 + (e & 3) + 8 * (e >> 2);
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][e] + bv + rv[i][e]), yr, ro < lim ? voff : kOob, (unsigned)ro * ldy4, 0);
+                        for (int e = 0; e < 8; ++e) {
+                            const int ro = i * 32 + ((e0 + e) & 3) + 8 * ((e0 + e) >> 2);
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][e0 + e] + bv + rv[e]), yr, ro < lim ? voff : kOob, (unsigned)ro * ldy4, 0);
+                        }
                     }
             } else {
 #pragma unroll
@@ -153,24 +155,25 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_nt_resident(const NtPara
             const int64_t cut64 = p.seg_row - rowb;
             const bool two = p.stats_extra && cut64 > 0 && cut64 < nrows;
             const int cut = two ? (int)cut64 : nrows;           // rows [0, cut) -> record 1, [cut, nrows) -> record 2
-            float a0 = 0.f, q0 = 0.f, a1 = 0.f, q1 = 0.f;
+            float4* rec = reinterpret_cast<float4*>(p.stats) + (int64_t)(row_tile * RU + part) * p.stat_cout + grp * p.Ng + col;
+            // sums over the unit's rows [lo, hi)
+            auto emit = [&](int lo, int hi, float4* dst) __attribute__((always_inline)) {
+                float a = 0.f, q = 0.f;
 #pragma unroll
-            for (int i = 0; i < TMU; ++i)
+                for (int i = 0; i < TMU; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int lr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    const float v = acc[i][e] - k;
-                    const float v0 = lr < cut ? v : 0.f, v1 = (lr >= cut && lr < nrows) ? v : 0.f;
-                    a0 += v0; q0 += v0 * v0;
-                    a1 += v1; q1 += v1 * v1;
-                }
-            a0 += __shfl_xor(a0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
-            a1 += __shfl_xor(a1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
-            if (h == 0 && okc) {
-                float4* rec = reinterpret_cast<float4*>(p.stats) + (int64_t)(row_tile * RU + part) * p.stat_cout + grp * p.Ng + col;
-                *rec = make_float4(a0, q0, k, (float)cut);
-                if (two) reinterpret_cast<float4*>(p.stats_extra)[grp * p.Ng + col] = make_float4(a1, q1, k, (float)(nrows - cut));
-            }
+                    for (int e = 0; e < 16; ++e) {
+                        const int lr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        const float v = (lr >= lo && lr < hi) ? acc[i][e] - k : 0.f;
+                        a += v;
+                        q += v * v;
+                    }
+                a += __shfl_xor(a, 32, 64);
+                q += __shfl_xor(q, 32, 64);
+                if (h == 0 && okc) *dst = make_float4(a, q, k, (float)(hi - lo));
+            };
+            emit(0, cut, rec);
+            if (two) emit(cut, nrows, reinterpret_cast<float4*>(p.stats_extra) + grp * p.Ng + col);
         }
     };
 
