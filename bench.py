@@ -139,15 +139,77 @@ def gpu_leg(args, rank, world, device):
     return dt, info, roof
 
 
+def csrc_digest():
+    """sha256 over the kernel sources (semiuhpe_amd/csrc/*.hip|*.inl|*.h + include/suhpe.h), in name order: what a counter pass was
+    taken on.  tools/pmc_traffic.py stores it in profiles/pmc_traffic.json."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "semiuhpe_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".inl", ".h")))
+    for f in files + [os.path.join(ROOT, "include", "suhpe.h")]:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see
-    tools/pmc_traffic.py and profiles/README.md); None when that kernel was not in the profiled run."""
+    tools/pmc_traffic.py and profiles/README.md).  Self-checking: the passes record the digest of the kernel sources they ran on;
+    when the sources have changed since, the figure is withheld (None) instead of going stale silently.  None also when that kernel
+    was not in the profiled run."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
         return None
     with open(path) as fh:
-        rec = json.load(fh).get("kernels", {}).get(kernel)
+        doc = json.load(fh)
+    if doc.get("csrc_digest") != csrc_digest():
+        print(f"bench.py: profiles/pmc_traffic.json was taken on other kernel sources (digest {doc.get('csrc_digest')} != {csrc_digest()}): "
+              "roofline.traffic withheld; re-run tools/profile_round.sh", file=sys.stderr)
+        return None
+    rec = doc.get("kernels", {}).get(kernel)
     return rec["hbm_bytes_per_launch"] if rec else None
+
+
+def other_config_leg(network, B, muB, warm=3, steps=8):
+    """The other single-GPU BASELINE configs, timed by the same process after the C2 region (never `value`): C3 = RepVGG-B1g2 64 + 256
+    (DAD3DHeads, full range), C5 per GPU = TinyViT-21M 32 + 128 (300WLP, rotation augmentation); `warm` untimed + `steps` timed SSL
+    steps on resident synthetic batches, with the config's own SURVEY 8d step roofline."""
+    from semiuhpe_amd.src.agent import SSLAgent
+    from semiuhpe_amd.synthetic import synthetic_batches
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from count_work import step_work
+    cfg = make_config(os.path.join("/tmp", f"suhpe_bench_{os.getpid()}_{network}"))
+    cfg.network = network
+    full = network == "repvgg"
+    cfg.is_full_range, cfg.rotate_aug = full, True
+    cfg.train_labeled = "DAD3DHeads" if full else "300WLP"
+    torch.manual_seed(1234)
+    agent = SSLAgent(cfg)
+    data, ulb = synthetic_batches(B, muB, size=224, seed=0, full_range=full, rotate_aug=True)
+    data = {k: v.cuda() for k, v in data.items()}
+    ulb = {k: v.cuda() for k, v in ulb.items()}
+    cfg.conf_thres = float(agent.compute_dynamic_entropy_threshold([ulb]))
+    for _ in range(warm):
+        agent.train_func(data, ulb)
+        agent.clock.tick()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fd, fu, out = agent.train_func(data, ulb)
+        agent.clock.tick()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    agent.check_finite()
+    s = step_work(network, B, muB)
+    res = {"network": network, "per_gpu_batch": f"{B}+{muB}", "warmup": warm, "steps": steps, "ms_per_step": round(ms, 2),
+           "images_per_s": round((B + muB) / (ms * 1e-3), 1), "mask_ratio": float(fu["mask_ratio"]), "loss_all": float(out["loss_all"]),
+           "step_roofline": {"t_roof_ms": round(s["t_roof"] * 1e3, 2), "frac": round(s["t_roof"] * 1e3 / ms, 4), "flop_per_step": s["flop"],
+                             "achieved_tflops": round(s["flop"] / (ms * 1e-3) / 1e12, 2)}}
+    agent.logs_writer.close()
+    del agent, data, ulb
+    torch.cuda.empty_cache()
+    return res
 
 
 def step_roofline(ms_per_step):
@@ -277,6 +339,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the C3 / C5 step timings that follow the C2 region")
     ap.add_argument("--serial", action="store_true", help="one stream: no teacher / filter-gradient overlap (per-kernel profiling)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -311,6 +374,17 @@ def main():
             "roofline": roof,
             "step_roofline": step_roofline(ms),
         }
+        if world == 1 and not args.no_other_configs and not args.serial:
+            # the other single-GPU configs of BASELINE.json, after (outside) the C2 timed region: informational, never `value`
+            torch.cuda.empty_cache()
+            others = {}
+            with contextlib.redirect_stdout(sys.stderr):
+                for tag, (net, b, mu) in (("C3", ("repvgg", 64, 256)), ("C5_per_gpu", ("tinyvit", 32, 128))):
+                    try:
+                        others[tag] = other_config_leg(net, b, mu)
+                    except Exception as e:                  # the C2 line must not die with the extra configs
+                        others[tag] = {"error": repr(e)}
+            out["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline:
             torch.cuda.empty_cache()
             with contextlib.redirect_stdout(sys.stderr):

@@ -586,11 +586,8 @@ int suhpe_window_attn_fwd(const float* qkv, const float* bias_table, const int32
         hipLaunchKernelGGL(window_attn_fwd_mfma<64>, grid, dim3(128), lds, as_stream(stream), g, qkv, dense, out, probs);
     } else if (g.N <= 224) {
         const size_t lds = (size_t)(224 * KP + DH * (224 + 4) + 4 * 32 * PP) * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_fwd_mfma<224>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
+        // (per-device attribute: set before every launch, no process-wide flag)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_fwd_mfma<224>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(window_attn_fwd_mfma<224>, grid, dim3(256), lds, as_stream(stream), g, qkv, dense, out, probs);
     } else {
         const size_t lds = (size_t)(2 * g.N * PITCH + 4 * DH + 4 * MAXN) * sizeof(float);
@@ -612,11 +609,7 @@ int suhpe_window_attn_bwd(const float* qkv, const float* probs, const float* dou
     SUHPE_REQUIRE(qkv && probs && dout && bias_idx && dqkv && workspace, "suhpe_window_attn_bwd: null pointer");
     SUHPE_REQUIRE((int64_t)B * H * W * heads * 3 * DH * 4 < 0x7fffffffLL, "suhpe_window_attn_bwd: qkv must be smaller than 2 GiB");
     const size_t lds = (size_t)(4 * g.N * PITCH + 8 * MAXN) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // per device
     float* dS = static_cast<float*>(workspace);
     const int nwin = B * g.nwy * g.nwx;
     if (g.N <= 64) {

@@ -402,8 +402,8 @@ static bool launch_halo_cc(const NtParams& p_in, int groups, hipStream_t st) {
 #define HALO_LAUNCH(PATCH_, AFF_)                                                                                               \
     do {                                                                                                                        \
         auto kern = igemm_nt3x3_kernel<BM, BN, WM, WN, CC, PATCH_, AFF_>;                                                       \
-        static bool attr_set = false;                                                                                           \
-        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
+        /* the attribute is per device: set before every launch (no process-wide flag to go stale on a second GPU) */            \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
         hipLaunchKernelGGL(kern, grid, block, lds, st, p, hg);                                                                  \
     } while (0)
     if (hg.patch) { if (p.scale) HALO_LAUNCH(true, true); else HALO_LAUNCH(true, false); }

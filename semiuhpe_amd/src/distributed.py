@@ -261,6 +261,12 @@ class BucketedAllReduce:
 
     def touched(self, offset):
         """a layer is about to write gradients at flat offset `offset`"""
+        if self.active and self.next + 1 < len(self.bounds) - 1 and offset >= self.bounds[self.next + 1]:
+            # the slice lies in a bucket whose collective is already enqueued: this gradient would never be exchanged and the
+            # ranks would step apart silently (a module registered out of forward order, a shared parameter, a second backward)
+            raise RuntimeError(f"BucketedAllReduce: gradient write at flat offset {offset} after its bucket "
+                               f"[{self.bounds[self.next + 1]}, ...) was sent; the backward does not visit the parameters in reverse "
+                               "registration order -- run with SUHPE_GRAD_BUCKETS=1 (one exchange after the backward)")
         while self.active and self.next > 0 and offset < self.bounds[self.next]:
             self._send(self.next)
             self.next -= 1

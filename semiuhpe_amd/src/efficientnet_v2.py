@@ -79,12 +79,15 @@ class _ResidualBlock(Layer):
     def bwd(self, dy, tape):
         from ..layers import park_skip
         first = self.block[0]
+        from .. import layers as L
         fused = self.use_res_connect and park_skip(first[0] if isinstance(first, ConvNormActivation) else None, dy)
-        d = self._front_bwd(self.block[-1].bwd(dy, tape), tape)     # (the last BatchNorm's backward applies the keep scale)
-        if fused:                           # the first conv's input-gradient epilogue added dy
-            from .. import layers as L
-            assert L._PENDING_SKIP is None, "the parked skip gradient was not consumed"
-            return d
+        try:
+            d = self._front_bwd(self.block[-1].bwd(dy, tape), tape)     # (the last BatchNorm's backward applies the keep scale)
+            if fused:                       # the first conv's input-gradient epilogue added dy
+                assert L._PENDING_SKIP is None, "the parked skip gradient was not consumed"
+                return d
+        finally:
+            L._PENDING_SKIP = None          # an exception between park and take must not poison every later backward of the process
         return K.add(d, dy) if self.use_res_connect else d
 
 

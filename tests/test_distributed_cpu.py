@@ -87,8 +87,13 @@ def _bucket_worker(rank, world, port, out):
     for off in reversed(offsets):                               # the backward touches the units back to front
         br.touched(off)
     in_flight = list(sent)
+    try:                                                        # a write into a bucket that is already on the wire must not pass silently
+        br.touched(offsets[-1])
+        late = False
+    except RuntimeError:
+        late = True
     br.finish()
-    out[rank] = dict(whole=whole.numpy(), bucketed=flat.numpy(), bounds=bounds, in_flight=in_flight, sent=sent)
+    out[rank] = dict(whole=whole.numpy(), bucketed=flat.numpy(), bounds=bounds, in_flight=in_flight, sent=sent, late_raises=late)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -106,6 +111,7 @@ def test_bucketed_allreduce_is_bit_identical_and_early():
     assert all(x % 500 == 0 for x in b[1:-1])                   # cut at unit (parameter-block) starts only
     assert r0["sent"] == list(range(len(b) - 2, -1, -1))        # back to front, every bucket once
     assert len(r0["in_flight"]) == len(b) - 2                   # all but the first bucket were sent before finish()
+    assert r0["late_raises"] and r1["late_raises"]              # out-of-order gradient writes are an error, not a silent divergence
 
 
 def test_bucket_boundaries_follow_network_units():

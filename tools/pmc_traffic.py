@@ -26,6 +26,9 @@ def normalize(name):
     if m:
         return m.group(1) + ">"
     m = re.match(r"(gemm_nt_persistent<\d+,\d+,\d+,\d+),(true|false)>", name)
+    if m:
+        return m.group(1) + ">"
+    m = re.match(r"(gemm_nt_resident<\d+,\d+,\d+),(true|false)>", name)
     return m.group(1) + ">" if m else name
 
 
@@ -50,8 +53,11 @@ if __name__ == "__main__":
         wb, wn = write.get(k, [0.0, 0])
         res[k] = {"launches": max(fn, wn), "fetch_bytes_per_launch": round(2.0 * fb / max(fn, 1)), "write_bytes_per_launch": round(wb / max(wn, 1))}
         res[k]["hbm_bytes_per_launch"] = res[k]["fetch_bytes_per_launch"] + res[k]["write_bytes_per_launch"]
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench                      # csrc_digest(): the kernel sources these passes ran on (bench.py withholds the figure once they change)
     json.dump({"note": "FETCH_SIZE x2 (gfx950 16-B/lane loads) + WRITE_SIZE, KiB -> bytes, averaged per launch over the profiled run",
-               "kernels": res}, open(out, "w"), indent=1)
+               "csrc_digest": bench.csrc_digest(), "kernels": res}, open(out, "w"), indent=1)
     top = sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]
     for k, v in top:
         print(f"{k[:60]:60s} x{v['launches']:6d} fetch {v['fetch_bytes_per_launch']/1e6:9.2f} MB write {v['write_bytes_per_launch']/1e6:9.2f} MB")
