@@ -60,7 +60,7 @@ def gpu_leg(args, rank, world, device):
     agent = SSLAgent(cfg)
     if args.serial:
         agent.overlap_teacher, K.WGRAD_OVERLAP = False, False
-    data, ulb = synthetic(rank, device, B_LABELED, B_LABELED * MU)
+    data, ulb = synthetic(rank, device, B_LABELED, B_LABELED * MU, size=args.size)
     # dynamic threshold at warm-up: the batch's left_ratio quantile of teacher entropies, so ~95% pass the filter
     cfg.conf_thres = float(agent.compute_dynamic_entropy_threshold([ulb]))
     torch.manual_seed(100 + rank)
@@ -88,6 +88,16 @@ def gpu_leg(args, rank, world, device):
     gib = 1.0 / (1 << 30)
     info = dict(mask_ratio=float(fu["mask_ratio"]), loss_all=float(out["loss_all"]), conf_thres=float(cfg.conf_thres),
                 hbm_gib={"peak_allocated": round(torch.cuda.max_memory_allocated() * gib, 2), "reserved": round(torch.cuda.memory_reserved() * gib, 2)})
+    if world > 1:
+        # data-parallel replicas must hold the same bits after the timed steps: every rank's student / teacher parameters and
+        # BatchNorm buffers as (sum, sum of squares) in float64, gathered and compared (outside the timed region)
+        fbs = [fb.data for fb in agent.optimizer.flat_buffers] + [agent._ema_flat.data] + ([agent._bn_flat_all.data] if agent._bn_flat_all is not None else [])
+        sig = torch.stack([torch.stack([t.double().sum(), (t.double() ** 2).sum()]) for t in fbs]).flatten()
+        if dist.get_backend() != "nccl":
+            sig = sig.cpu()                                 # (gloo gathers host tensors)
+        sigs = [torch.empty_like(sig) for _ in range(world)]
+        dist.all_gather(sigs, sig)
+        info["replicas_identical"] = bool(all(torch.equal(sigs[0], s_) for s_ in sigs))
 
     # ---- roofline of the dominant kernel: same step, every dense-conv launch bracketed by HIP events on the
     # launch stream (torch's current stream is the stream the C ABI launches on)
@@ -341,6 +351,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the C3 / C5 step timings that follow the C2 region")
     ap.add_argument("--serial", action="store_true", help="one stream: no teacher / filter-gradient overlap (per-kernel profiling)")
+    ap.add_argument("--size", type=int, default=224, help="image size; anything but 224 is a rehearsal (tests), not the BASELINE workload")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)                                   # does not return
@@ -356,6 +367,10 @@ def main():
     device = torch.device("cuda", local)
     if world > 1:
         from semiuhpe_amd.src.distributed import init_from_env
+        # the ranks share the host: cap each rank's torch CPU threads at its share of the cores (the hot path has no CPU arithmetic, but
+        # 8 ranks x the default thread pool oversubscribe the host on the few torch-CPU ops of the setup)
+        ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), ncores // world)))
         init_from_env(os.environ.get("SUHPE_DIST_BACKEND", "nccl"))
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):            # library / evaluation prints go to stderr: stdout carries the ONE JSON line
@@ -369,12 +384,13 @@ def main():
             "config": {"workload": "C2 SemiUHPE 300WLP_AFLW2000: EfficientNetV2-S, per-GPU bs=32 labeled + 128 unlabeled (ulb_ratio 4), "
                                    "224x224 synthetic heads, dynamic_thres(left_ratio 0.95)+CutOut+CutMix, CE unsup loss, Adam lr 1e-4",
                        "per_gpu_batch": "32+128", "parallelism": f"dp{world}", "global_batch": (B_LABELED + B_LABELED * MU) * world,
+                       **({} if args.size == 224 else {"rehearsal_image_size": args.size}),
                        "streams": "1 (--serial)" if args.serial else "2 (teacher pass and filter-gradient GEMMs beside the main stream)",
                        **info},
             "roofline": roof,
             "step_roofline": step_roofline(ms),
         }
-        if world == 1 and not args.no_other_configs and not args.serial:
+        if world == 1 and not args.no_other_configs and not args.serial and args.size == 224:
             # the other single-GPU configs of BASELINE.json, after (outside) the C2 timed region: informational, never `value`
             torch.cuda.empty_cache()
             others = {}

@@ -200,8 +200,16 @@ def _autotune(d, pass_id, run):
             ms = min(ms, e0.elapsed_time(e1))
         if ms < best[0]:
             best = (ms, tile)
-    lib.suhpe_conv2d_set_tile(ctypes.byref(d), pass_id, best[1])
-    _tile_db()[skey] = names[best[1]]
+    winner = best[1]
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # every rank timed the menu (they reach a new shape at the same point of the step), rank 0's winner is the one all pin: the
+        # replicas then run the same kernels (same speed, and the same split-K partition of the filter gradients)
+        t = torch.tensor([winner], dtype=torch.int32, device="cuda")
+        dist.broadcast(t, 0)
+        winner = int(t.item())
+    lib.suhpe_conv2d_set_tile(ctypes.byref(d), pass_id, winner)
+    _tile_db()[skey] = names[winner]
 
 
 def conv2d_fwd(x, w, bias=None, stride=1, pad=0, groups=1):

@@ -135,6 +135,20 @@ def test_bench_spawns_its_own_ranks():
     assert out["value"] > 0 and "cpu_baseline" not in out
 
 
+def test_bench_eight_rank_rehearsal():
+    """`python bench.py --gpus 8` exactly as the driver's SCALE command starts it (no launcher: the parent spawns the 8 ranks), on ONE GPU
+    with the gloo backend and 96-pixel images: eight children, one JSON line, n_gpus 8, global batch 1280, the bucketed gradient exchange
+    under the backward, and replicas that hold the same bits after the steps."""
+    env = dict(os.environ, SUHPE_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", SUHPE_STEPS_IN_FLIGHT="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = _bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--size", "96"], env, timeout=1200)
+    assert out["n_gpus"] == 8 and out["config"]["global_batch"] == 1280 and out["config"]["parallelism"] == "dp8"
+    assert out["config"]["rehearsal_image_size"] == 96 and out["scaling"] == "weak"
+    assert out["config"]["replicas_identical"] is True
+    assert out["value"] > 0 and "cpu_baseline" not in out and "other_configs" not in out
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
 def test_bench_two_ranks_over_rccl():
     """the same command on the backend it is written for (nccl = RCCL over xGMI)"""
