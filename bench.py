@@ -324,25 +324,6 @@ def spawn_ranks(args):
     raise SystemExit(rc)
 
 
-def optional_split_leg(args):
-    """Informational, NOT `value`: the same step with the opt-in split-bf16 GEMM tiles (SUHPE_SPLIT_BF16=1: forward / input-gradient GEMMs
-    compute an fp32 product as six exact bf16 MFMA planes), timed by a child process with the same steps / warm-up."""
-    import subprocess
-    if os.environ.get("SUHPE_SPLIT_BF16", "0") not in ("", "0") or os.environ.get("SUHPE_BENCH_OPTIONAL", "1") == "0":
-        return None
-    env = dict(os.environ, SUHPE_SPLIT_BF16="1")
-    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline"]
-    try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-        line = json.loads(r.stdout.strip().splitlines()[-1])
-        return {"value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"],
-                "note": "opt-in, not the bench path: SUHPE_SPLIT_BF16=1 + tiles_mi355x_split.json; storage, accumulation and parity bars unchanged "
-                        "(tests/split_tiles_worker.py); every other number in this line is the fp32-MFMA path"}
-    except Exception as e:                                  # the optional leg never fails the bench
-        print(f"bench.py: optional split-bf16 leg skipped ({type(e).__name__}: {e})", file=sys.stderr)
-        return None
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -406,9 +387,6 @@ def main():
             with contextlib.redirect_stdout(sys.stderr):
                 out["cpu_baseline"] = cpu_leg()
             out["mae_parity"] = out["cpu_baseline"].pop("mae_parity", None)
-            opt = optional_split_leg(args)
-            if opt is not None:
-                out["optional_modes"] = {"split_bf16": opt}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -442,6 +442,21 @@ int suhpe_comm_allgather(suhpe_comm_t comm, const float* send, float* recv, int6
 int suhpe_comm_broadcast(suhpe_comm_t comm, float* buf, int64_t count, int root, suhpe_stream_t stream);
 int suhpe_comm_destroy(suhpe_comm_t comm);
 
+/* ---- demo renderer: the reference's native Sim3DR functions, bit-identical at any alpha (csrc/raster.hip).
+ * suhpe_mesh_normals  <- _get_normal (Sim3DR/lib/rasterize_kernel.cpp:163-221, called by Sim3DR/Sim3DR.py:8-11): per-vertex normals =
+ *   un-normalised triangle normals summed over each vertex's triangles in triangle order, normalised.  vt_start[nver + 1] / vt_tris[3 ntri]:
+ *   the vertex -> triangle adjacency in CSR form, each vertex's triangles in increasing index (host-built, fixed per mesh).
+ * suhpe_rasterize     <- _rasterize (rasterize_kernel.cpp:225-297, Sim3DR/Sim3DR.py:14-29): z-buffer rasterisation of per-vertex colours
+ *   into an interleaved uint8 image (h, w, c), triangles in index order, strict depth test against depth_buffer (h, w) (initialise to
+ *   -1e8 as Sim3DR.py:24), blend (1 - alpha) * image + alpha * 255 * colour on every accepted triangle, reverse != 0 flips the image
+ *   rows.  vertices (nver, 3) = (x, y, depth) in pixels, triangles (ntri, 3) int32, colors (nver, c) in [0, 1].  workspace: device scratch
+ *   of suhpe_rasterize_workspace_bytes(ntri). */
+int suhpe_mesh_normals(const float* vertices, const int* triangles, const int* vt_start, const int* vt_tris, int nver, int ntri,
+                       float* normals, suhpe_stream_t stream);
+int64_t suhpe_rasterize_workspace_bytes(int ntri);
+int suhpe_rasterize(unsigned char* image, const float* vertices, const int* triangles, const float* colors, float* depth_buffer, int ntri,
+                    int h, int w, int c, float alpha, int reverse, void* workspace, int64_t workspace_bytes, suhpe_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

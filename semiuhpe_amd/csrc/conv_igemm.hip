@@ -41,28 +41,6 @@ __device__ __forceinline__ float xf_act(float u, int act) {
     return act == SUHPE_ACT_SILU ? s : (act == SUHPE_ACT_RELU ? fmaxf(u, 0.f) : u);
 }
 
-// ---- fp32 GEMM on the bf16 matrix cores by operand splitting (the SPLIT instantiations).
-// An fp32 operand is staged into LDS as three bf16 planes x = h + m + l (round-to-nearest at each step: |m| <= 2^-8 |x|,
-// |l| <= 2^-16 |x|, the three-way sum restores x to <= 2^-24 |x|), and a product a*b is accumulated as the six largest of the
-// nine cross terms (l*h, h*l, m*m, m*h, h*m, h*h), each EXACT in the fp32 accumulator of v_mfma_f32_32x32x16_bf16; the dropped
-// terms (m*l, l*m, l*l) are <= 2^-24 |a||b| each.  Measured against a double reference the result is as close as the fp32
-// instruction's (tools/proto/split_gemm.hip: max 1.4e-7 / mean 1.4e-8 of sum|a||b| vs 1.8e-7 / 1.7e-8), at 1/16 of the fp32
-// instruction's cycles per product plane: six planes cost 3/8 of the fp32 MFMA time.
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-constexpr int SP_PITCH = 80;    // bytes per LDS row of one plane: 32 bf16 + 16 bytes of padding (conflict-free ds_read_b128)
-__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
-    const f32x2_t v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));       // v_cvt_pk_bf16_f32 (round to nearest even)
-}
-__device__ __forceinline__ void split2(float a, float b, uint32_t& h, uint32_t& m, uint32_t& l) {
-    h = pk_bf16(a, b);
-    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
-    m = pk_bf16(ra, rb);
-    l = pk_bf16(ra - __uint_as_float(m << 16), rb - __uint_as_float(m & 0xffff0000u));
-}
-
 struct GatherGeom {
     int N, GH, GW;       // gathered tensor spatial dims
     int OH, OW;          // GEMM-row enumeration: m = (n, oh, ow)
@@ -162,22 +140,19 @@ template <int VEC> __device__ __forceinline__ void vload_lds(const float* p, flo
 // MODE 2: affine taps, coordinate = o*gm + sgn*tap + off (forward with any stride, dgrad with stride 1)
 // In every mode the tap of a thread's k advances incrementally (no division in the k loop), addresses are 32-bit
 // element offsets from a uniform base, and out-of-range taps are predicated (offset 0, value zeroed): no branches.
-template <int BM, int BN, int WM, int WN, int VEC, int MODE, bool AFF = false, int XF = 0, bool SPLIT = false>
+template <int BM, int BN, int WM, int WN, int VEC, int MODE, bool AFF = false, int XF = 0>
 // The second launch bound (minimum waves per SIMD) caps the register budget: left alone the compiler spends 88-148 VGPRs on
 // prefetch depth, which leaves 2 workgroups (or 1, for the wgrad kernel) per CU; at <= 80 VGPRs three 8-wave workgroups are
 // resident and the MFMA pipe sees 6 waves per SIMD.
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64,
-                             SPLIT ? ((WM == 64 && WN == 64) ? 2 : ((WM == 64 || WN == 64) ? 3 : 5)) :
                              (VEC == 1 || BM == 256) ? 1 : (XF ? (XF == 2 ? 3 : 4) : ((WM == 64 && WN == 64) ? 2 : ((WM == 64 && (BM / WM) * (BN / WN) == 4) ? 3 : (((BM / WM) * (BN / WN) > 8 || BN == 32 || BN == 128 || MODE == 0) ? 5 : 6)))))
 void igemm_nt_kernel(const NtParams p) {
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NT = (BM / WM) * (BN / WN) * 64;          // threads: 4 to 10 wavefronts (tile widths are multiples of 32)
     static_assert(NT >= 256 && NT <= 1024 && NT % 32 == 0, "4 to 16 waves per workgroup");
-    static_assert(!SPLIT || VEC == 4, "the split instantiations stage 16-byte vectors");
-    // SPLIT: three bf16 planes of [rows][SP_PITCH bytes] per operand (= rows * 60 floats)
-    __shared__ __attribute__((aligned(16))) float As[SPLIT ? BM * (3 * SP_PITCH / 4) : BM * LDK];
-    __shared__ __attribute__((aligned(16))) float Bs[SPLIT ? BN * (3 * SP_PITCH / 4) : BN * LDK];
+    __shared__ __attribute__((aligned(16))) float As[BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
 
     const GatherGeom& g = p.g;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -348,33 +323,6 @@ void igemm_nt_kernel(const NtParams p) {
         auto& a_reg = a_stage[decltype(stage)::value];
         auto& b_reg = b_stage[decltype(stage)::value];
         (void)kt_store;
-        if constexpr (SPLIT) {
-            uint8_t* ab = reinterpret_cast<uint8_t*>(As);
-            uint8_t* bb = reinterpret_cast<uint8_t*>(Bs);
-#pragma unroll
-            for (int i = 0; i < A_ROWS; ++i) {
-                if (BM % ROW_STEP != 0 && lrow + i * ROW_STEP >= BM) continue;
-                uint32_t h0, m0_, l0, h1, m1, l1;
-                split2(a_reg[i][0], a_reg[i][1], h0, m0_, l0);
-                split2(a_reg[i][2], a_reg[i][3], h1, m1, l1);
-                uint8_t* dst = ab + (lrow + i * ROW_STEP) * SP_PITCH + lcol * 2;
-                *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-                *reinterpret_cast<uint2*>(dst + BM * SP_PITCH) = make_uint2(m0_, m1);
-                *reinterpret_cast<uint2*>(dst + 2 * BM * SP_PITCH) = make_uint2(l0, l1);
-            }
-#pragma unroll
-            for (int i = 0; i < B_ROWS; ++i) {
-                if (lrow + i * ROW_STEP >= BN) continue;
-                uint32_t h0, m0_, l0, h1, m1, l1;
-                split2(b_reg[i][0], b_reg[i][1], h0, m0_, l0);
-                split2(b_reg[i][2], b_reg[i][3], h1, m1, l1);
-                uint8_t* dst = bb + (lrow + i * ROW_STEP) * SP_PITCH + lcol * 2;
-                *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-                *reinterpret_cast<uint2*>(dst + BN * SP_PITCH) = make_uint2(m0_, m1);
-                *reinterpret_cast<uint2*>(dst + 2 * BN * SP_PITCH) = make_uint2(l0, l1);
-            }
-            return;
-        }
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
             if (BM % ROW_STEP != 0 && lrow + i * ROW_STEP >= BM) continue;
@@ -404,36 +352,6 @@ void igemm_nt_kernel(const NtParams p) {
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     auto mma_tile = [&]() {
-        if constexpr (SPLIT) {
-            // lane (r32, h) holds k = 8h .. 8h+7 of row r32 of each plane: one ds_read_b128 per plane and 32-row block
-            const uint8_t* ab = reinterpret_cast<const uint8_t*>(As);
-            const uint8_t* bb = reinterpret_cast<const uint8_t*>(Bs);
-#pragma unroll
-            for (int s = 0; s < BK / 16; ++s) {
-                bf16x8_t fa[TM][3], fb[TN][3];
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) fa[i][pl] = *reinterpret_cast<const bf16x8_t*>(ab + pl * BM * SP_PITCH + (wm * WM + i * 32 + r32) * SP_PITCH + s * 32 + h * 16);
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) fb[j][pl] = *reinterpret_cast<const bf16x8_t*>(bb + pl * BN * SP_PITCH + (wn * WN + j * 32 + r32) * SP_PITCH + s * 32 + h * 16);
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        floatx16 c = acc[i][j];                 // smallest terms first
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);
-                        acc[i][j] = c;
-                    }
-            }
-            return;
-        }
         // fragments of k-group kg+1 are read from LDS before the MFMAs of kg issue (two register sets)
         float4 af[2][TM], bf[2][TN];
         auto read_frags = [&](int kg, int set) __attribute__((always_inline)) {
@@ -1193,27 +1111,10 @@ static int nt_mode(const GatherGeom& g) {
 static int g_stagger = 0, g_stagger_first = 0;     // experiment knob (suhpe_conv2d_set_stagger)
 static thread_local bool g_nt_unsupported = false;  // set when a dispatch reached a (tile, form) that has no instantiation
 
-template <int BM, int BN, int WM, int WN, int VEC, bool SPLIT = false>
+template <int BM, int BN, int WM, int WN, int VEC>
 static void launch_nt(const NtParams& p_in, int groups, hipStream_t st) {
     NtParams p = p_in;
     p.stagger = g_stagger; p.stagger_first = g_stagger_first;
-    if constexpr (SPLIT) {       // (the input-transform forms stay on the fp32 tiles: dispatch_nt maps them before it gets here)
-        p.col_tiles = (int)ceil_div(p.Ng, BN);
-        const dim3 grid_s((unsigned)(ceil_div(ceil_div(p.g.M, BM), 8) * 8 * p.col_tiles), 1, groups), block_s((BM / WM) * (BN / WN) * 64);
-        switch (nt_mode(p.g)) {
-            case 1:
-                if (p.scale) hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, 4, 1, true, 0, true>), grid_s, block_s, 0, st, p);
-                else hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, 4, 1, false, 0, true>), grid_s, block_s, 0, st, p);
-                break;
-            case 2:
-                if (p.scale) hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, 4, 2, true, 0, true>), grid_s, block_s, 0, st, p);
-                else hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, 4, 2, false, 0, true>), grid_s, block_s, 0, st, p);
-                break;
-            case 3: hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, 4, 3, false, 0, true>), grid_s, block_s, 0, st, p); break;
-            default: hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, 4, 0, false, 0, true>), grid_s, block_s, 0, st, p); break;
-        }
-        return;
-    }
     p.col_tiles = (int)ceil_div(p.Ng, BN);
     const int64_t row_tiles8 = ceil_div(ceil_div(p.g.M, BM), 8) * 8;
     dim3 grid((unsigned)(row_tiles8 * p.col_tiles), 1, groups);
@@ -1251,7 +1152,6 @@ static void launch_nt(const NtParams& p_in, int groups, hipStream_t st) {
 enum NtTile { NT_64x64_S = 0, NT_64x64, NT_128x32, NT_128x128, NT_128x64, NT_256x32, NT_P64x64, NT_P128x32, NT_P128x64, NT_P128x128,
               NT_H64x64, NT_H128x32, NT_H128x64, NT_H128x128,
               NT_W128x128, NT_W128x64,       // four wavefronts with 64x64 / 64x32 accumulators each: half the LDS fragment reads per MFMA
-              NT_S64x64, NT_S128x32, NT_S128x64, NT_S128x128,   // split-bf16 instantiations (six bf16 MFMA planes per fp32 product), four wavefronts
               NT_R128x16, NT_R64x8,          // operand-resident pointwise kernel (conv_resident.inl): 128 / 64 resident rows, 16 / 8 wavefronts
               NT_TILES };
 static const char* kNtNames[] = {"igemm_nt_kernel<64,64,32,32,1>", "igemm_nt_kernel<64,64,32,32,4>", "igemm_nt_kernel<128,32,32,32,4>",
@@ -1261,8 +1161,6 @@ static const char* kNtNames[] = {"igemm_nt_kernel<64,64,32,32,1>", "igemm_nt_ker
                                  "igemm_nt3x3_kernel<64,64,32,32>", "igemm_nt3x3_kernel<128,32,32,32>", "igemm_nt3x3_kernel<128,64,32,32>",
                                  "igemm_nt3x3_kernel<128,128,64,32>",
                                  "igemm_nt_kernel<128,128,64,64,4>", "igemm_nt_kernel<128,64,64,32,4>",
-                                 "igemm_nt_kernel<64,64,32,32,4,split>", "igemm_nt_kernel<128,32,32,32,4,split>", "igemm_nt_kernel<128,64,64,32,4,split>",
-                                 "igemm_nt_kernel<128,128,64,64,4,split>",
                                  "gemm_nt_resident<128,2,16>", "gemm_nt_resident<64,2,8>"};
 
 struct TnTile { int bm, bn; const char* name; };
@@ -1309,12 +1207,7 @@ static NtTile choose_nt(int64_t M, int ng, bool vec4, int pinned, bool halo = fa
 }
 
 // (row-tile height = rows per BatchNorm statistics record; the resident tiles emit one record per 64-row unit)
-static int nt_tile_bm(NtTile t) { return (t == NT_64x64_S || t == NT_64x64 || t == NT_P64x64 || t == NT_H64x64 || t == NT_S64x64 || t >= NT_R128x16) ? 64 : (t == NT_256x32 ? 256 : 128); }
-// The split tiles are opt-in (SUHPE_SPLIT_BF16=1): the default path computes every product on the fp32 matrix-core instruction.
-// Disabled, suhpe_conv2d_set_tile refuses them (the autotuner skips refused tiles) and a tile pinned earlier runs the fp32
-// tile of the same row-tile height.
-static const bool kSplitEnabled = getenv("SUHPE_SPLIT_BF16") && atoi(getenv("SUHPE_SPLIT_BF16")) != 0;
-static NtTile unsplit_nt(NtTile t) { return t == NT_S64x64 ? NT_64x64 : (t == NT_S128x32 ? NT_128x32 : (t == NT_S128x64 ? NT_128x64 : (t == NT_S128x128 ? NT_128x128 : t))); }
+static int nt_tile_bm(NtTile t) { return (t == NT_64x64_S || t == NT_64x64 || t == NT_P64x64 || t == NT_H64x64 || t >= NT_R128x16) ? 64 : (t == NT_256x32 ? 256 : 128); }
 // the halo kernel runs 3x3 / stride 1 / pad 1 forward and input-gradient GEMMs whose channel counts chunk evenly
 static bool halo_ok(const GatherGeom& g, bool vec4) { return vec4 && halo_capable(g, 128) && halo_capable(g, 64); }
 
@@ -1344,7 +1237,6 @@ static void launch_persistent(const NtParams& p_in, int groups, hipStream_t st) 
 // a pinned persistent tile on a shape that is not a plain GEMM runs the igemm tile of the same size
 static NtTile effective_nt(NtTile tile, bool plain, bool halo = false, bool resident128 = false, bool resident64 = false) {
     if (tile >= NT_R128x16) return ((tile == NT_R128x16 && resident128) || (tile == NT_R64x8 && resident64)) ? tile : NT_64x64;   // (same record height)
-    if (tile >= NT_S64x64) return kSplitEnabled ? tile : unsplit_nt(tile);
     if (tile >= NT_W128x128) return tile;
     if (tile >= NT_H64x64) {
         if (halo) return tile;
@@ -1361,11 +1253,6 @@ static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st
         if (tile == NT_R64x8 && resident_ok(p, vec4, 64)) { launch_resident<64, 2, 8>(p, groups, st); return; }
         tile = NT_64x64;                                    // (same statistics-record height as the resident tiles)
     }
-    if (tile >= NT_S64x64 && (p.a_scale || !kSplitEnabled)) tile = unsplit_nt(tile);                // (the input transform lives in the fp32 tiles)
-    if (tile == NT_S64x64) { launch_nt<64, 64, 32, 32, 4, true>(p, groups, st); return; }
-    if (tile == NT_S128x32) { launch_nt<128, 32, 32, 32, 4, true>(p, groups, st); return; }
-    if (tile == NT_S128x64) { launch_nt<128, 64, 64, 32, 4, true>(p, groups, st); return; }
-    if (tile == NT_S128x128) { launch_nt<128, 128, 64, 64, 4, true>(p, groups, st); return; }
     if (tile >= NT_W128x128 && p.a_scale) tile = tile == NT_W128x128 ? NT_128x128 : NT_128x64;     // (no input-transform form of the wide-accumulator tiles)
     if (tile == NT_W128x128) { launch_nt<128, 128, 64, 64, 4>(p, groups, st); return; }
     if (tile == NT_W128x64) { launch_nt<128, 64, 64, 32, 4>(p, groups, st); return; }
@@ -1652,7 +1539,6 @@ int suhpe_conv2d_set_tile(const suhpe_conv_t* d, int pass, int tile) {
     const bool v4 = ng % 4 == 0 && d->cout % 4 == 0 && cg % 4 == 0 && d->cin % 4 == 0;
     SUHPE_REQUIRE(tile < 0 || (v4 && !(pass != 2 && tile == (int)NT_64x64_S)), "suhpe_conv2d_set_tile: the vector tiles need channel counts that are multiples of 4");
     SUHPE_REQUIRE(pass == 2 || tile < (int)NT_H64x64 || tile >= (int)NT_W128x128 || halo_ok_desc(d, pass), "suhpe_conv2d_set_tile: the halo tiles need a 3x3 / stride 1 / pad 1 conv with evenly chunked channels");
-    SUHPE_REQUIRE(pass == 2 || tile < (int)NT_S64x64 || tile >= (int)NT_R128x16 || kSplitEnabled, "suhpe_conv2d_set_tile: the split-bf16 tiles are opt-in (SUHPE_SPLIT_BF16=1)");
     SUHPE_REQUIRE(pass == 2 || tile < (int)NT_R128x16 || resident_ok_desc(d, pass, tile == (int)NT_R128x16 ? 128 : 64),
                   "suhpe_conv2d_set_tile: the resident tiles need a 1x1 / stride 1 conv whose BM x K block fits the LDS");
     std::lock_guard<std::mutex> lock(tile_mutex());

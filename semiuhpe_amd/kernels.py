@@ -140,8 +140,7 @@ def _tile_db():
     global _TILE_DB
     if _TILE_DB is None:
         _TILE_DB = {}
-        split = os.environ.get("SUHPE_SPLIT_BF16", "0") not in ("", "0")      # opt-in split-bf16 GEMM tiles: their own tuned table
-        path = os.environ.get("SUHPE_TILE_DB", _TILE_DB_PATH.replace(".json", "_split.json") if split else _TILE_DB_PATH)
+        path = os.environ.get("SUHPE_TILE_DB", _TILE_DB_PATH)
         if os.path.exists(path):
             with open(path) as fh:
                 _TILE_DB = dict(json.load(fh).get("tiles", {}))

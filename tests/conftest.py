@@ -17,6 +17,11 @@ os.environ.setdefault("SUHPE_AUTOTUNE", "0")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
+    # The CPU oracle is the slow half of most GPU tests.  torch's default thread pool = every hardware thread of the host (256 on the
+    # GPU box), where the oracle's small convolutions run 2-3x SLOWER than on 32 threads (measured for bench.py's cpu_baseline): cap it.
+    import torch
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(ncores, 32)))
 
 
 @pytest.fixture(scope="session")

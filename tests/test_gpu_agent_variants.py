@@ -207,8 +207,10 @@ def test_c5_tinyvit_rotate_aug_step():
     oracle, agent, cfg_o, cfg_h = _pair(network="tinyvit", rotate_aug=True, train_labeled="300WLP")
     for step in range(2):
         data, ulb = _batches(3, 6, 224, step)
-        o, h = _ssl_step(oracle, agent, cfg_o, cfg_h, data, ulb, step, truth64=True)
-        _compare_step(o, h, oracle, agent, pred_tol=1e-3, orth_tol=5e-4)
+        # the float64 yardstick (a second, double-precision oracle step) on the first step; the second step (EMA alpha = 1/2, Adam's
+        # second update, after the re-synchronisation) is held to the plain gradient tolerance
+        o, h = _ssl_step(oracle, agent, cfg_o, cfg_h, data, ulb, step, truth64=step == 0)
+        _compare_step(o, h, oracle, agent, pred_tol=1e-3, orth_tol=5e-4, grad_tol=2e-2)
         for (n, pe), (_, po) in zip(agent.ema_net.named_parameters(), oracle.ema_net.named_parameters()):
             assert rel_err(pe, po) < 1e-6, n
         _resync(oracle, agent)
@@ -311,7 +313,7 @@ def test_c1_train_func_s1_batch32():
         agent.optimizer.load_state_dict(oracle.optimizer.state_dict())
 
 
-@pytest.mark.parametrize("network", ["effinetv2", "repvgg"])
+@pytest.mark.parametrize("network", ["effinetv2", "repvgg", "tinyvit"])
 def test_val_funcs_match_oracle(network):
     """val_func(eval_ema=False/True) and val_func_s1 in eval mode: loss, rotation matrices, Euler / geodesic error, and the
     out_dict {mask_ratio, err_pseudo_gt} with a strict subset selected by the entropy filter"""
@@ -323,7 +325,7 @@ def test_val_funcs_match_oracle(network):
         for p in oracle.ema_net.parameters():
             p.mul_(1.01)
     agent.ema_net.load_state_dict(oracle.ema_net.state_dict())
-    data, _ = _batches(12, 0, 96, 5, full_range=full)
+    data, _ = _batches(12, 0, 224 if network == "tinyvit" else 96, 5, full_range=full)      # (TinyViT's window grid is fixed to 224 x 224 inputs)
     dev = {k: v.cuda() for k, v in data.items()}
     for eval_ema in (False, True):
         cfg_o.conf_thres = cfg_h.conf_thres = 1e9

@@ -101,15 +101,14 @@ def test_tile_menu_every_pinned_tile_matches(K, cfg):
             lib.suhpe_conv2d_tile_name.restype = ctypes.c_char_p
             for tile in range(lib.suhpe_conv2d_tile_count(pid)):
                 halo = b"nt3x3" in lib.suhpe_conv2d_tile_name(pid, tile)
-                split = b"split" in lib.suhpe_conv2d_tile_name(pid, tile)
                 resident = b"resident" in lib.suhpe_conv2d_tile_name(pid, tile)
                 if lib.suhpe_conv2d_set_tile(ctypes.byref(d), pid, tile) != 0:
                     # the scalar-loader tile is refused for vector shapes, the halo tiles for anything but 3x3 / stride 1 / pad 1,
                     # the resident tiles for anything but 1x1 / stride 1
-                    assert pid < 2 and (tile == 0 or halo or split or resident)     # (split: opt-in, SUHPE_SPLIT_BF16=1)
+                    assert pid < 2 and (tile == 0 or halo or resident)
                     continue
                 assert not resident or k == 1
-                if halo or split:   # halo: channel-chunk-major reduction order; split: six bf16 planes per product -- same sums, different rounding
+                if halo:            # channel-chunk-major reduction order: same sums, different rounding
                     out = K.conv2d_fwd(x, wg, None, stride, pad, groups) if pid == 0 else K.conv2d_dgrad(dy, wg, x.shape, stride, pad, groups)
                     assert rel(out, (y0 if pid == 0 else dx0).cpu()) < 3e-6, tile
                 elif pid == 0:
@@ -931,18 +930,6 @@ def test_tile_database_is_the_tested_tile_set(K):
             assert rel(out, ref.cpu()) < 3e-5, (key, name)
         checked[pid] += 1
     assert all(v > 30 for v in checked.values()), checked
-
-
-def test_split_bf16_tiles():
-    """the opt-in split-bf16 NT tiles (SUHPE_SPLIT_BF16=1: an fp32 product as six exact bf16 MFMA planes) are as close to a
-    float64 reference as the fp32-MFMA tile, in every loader mode and with the fused epilogues, and EfficientNetV2-S with every forward /
-    input-gradient GEMM pinned to a split tile meets the oracle at the network tolerances (tests/split_tiles_worker.py);
-    without the switch suhpe_conv2d_set_tile refuses them (test_tile_menu_every_pinned_tile_matches)"""
-    import subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SUHPE_SPLIT_BF16="1", PYTHONPATH=root)
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "split_tiles_worker.py")], cwd=root, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "SPLIT_TILES_OK" in r.stdout and "SPLIT_NETWORK_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
 
 @pytest.mark.parametrize("cfg", [(6, 48, 192, 3, 1, 1, 1, 28, 28), (40, 160, 960, 1, 1, 0, 1, 14, 14), (4, 64, 128, 3, 2, 1, 1, 30, 30), (2, 128, 128, 3, 1, 1, 2, 14, 14),

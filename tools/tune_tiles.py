@@ -13,7 +13,7 @@ lib.suhpe_conv2d_tile_name.restype = ctypes.c_char_p
 
 
 def short(name):
-    kind = "P" if "persistent" in name else ("H" if "3x3" in name else ("S" if "split" in name else ""))
+    kind = "P" if "persistent" in name else ("H" if "3x3" in name else ("R" if "resident" in name else ""))
     a = name.split("<")[1].rstrip(">").split(",")
     return kind + "x".join(a[:2]) + ("w" + "x".join(a[2:4]) if len(a) > 3 else "") + ("v1" if len(a) > 4 and a[4] == "1" else "")
 
