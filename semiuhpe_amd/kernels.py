@@ -619,13 +619,14 @@ def flush_wgrads(jobs):
     dev = jobs[0][0].device
     n = len(jobs)
     if len(_flush_ring) < 4:
-        _flush_ring.append([torch.empty((1024, 4), dtype=torch.int64).pin_memory(), torch.empty(1025, dtype=torch.int64).pin_memory(), None])
+        # job table (1024 x 4) and chunk starts (1025) in ONE pinned staging buffer: one upload per flush
+        _flush_ring.append([torch.empty(1024 * 4 + 1025, dtype=torch.int64).pin_memory(), None, None])
     slot = _flush_ring[_flush_turn % len(_flush_ring)]
     _flush_turn += 1
     if slot[2] is not None:
         slot[2].synchronize()                       # the upload that last used this staging buffer has run (normally long ago)
     assert n <= 1024
-    table, starts = slot[0], slot[1]
+    stage = slot[0]
     total = 0
     rows, st = [], []
     for slab, out, count, splits in jobs:
@@ -633,9 +634,10 @@ def flush_wgrads(jobs):
         st.append(total)
         total += (count + 1023) // 1024
     st.append(total)
-    table[:n] = torch.tensor(rows, dtype=torch.int64)
-    starts[:n + 1] = torch.tensor(st, dtype=torch.int64)
-    table_d, starts_d = table[:n].to(dev, non_blocking=True), starts[:n + 1].to(dev, non_blocking=True)
+    stage[:4 * n] = torch.tensor(rows, dtype=torch.int64).reshape(-1)
+    stage[4 * n:5 * n + 1] = torch.tensor(st, dtype=torch.int64)
+    both = stage[:5 * n + 1].to(dev, non_blocking=True)
+    table_d, starts_d = both[:4 * n], both[4 * n:]
     slot[2] = torch.cuda.Event()
     slot[2].record()
     call("suhpe_wgrad_reduce_batched", ptr(table_d), ptr(starts_d), n, total)

@@ -51,11 +51,24 @@ def random_cutmix_tensor(image, mask_holes_num=3, normal=False):
 
 def strong_view_nhwc(image, cutout, cutmix, mask_holes_num=3, normal=True, out=None):
     """Fused path used by the agent: CutOut then CutMix (same RNG order as calling the two functions above in
-    sequence) while converting the NCHW loader batch to the backbone's NHWC layout; one read, one write."""
+    sequence) while converting the NCHW loader batch to the backbone's NHWC layout; one read, one write.  The step's random tables
+    (CutOut boxes, CutMix boxes, permutation: host RNG, the reference's draw order) travel in ONE pinned upload."""
     N, _, width, height = image.shape
-    co = _to_dev(draw_boxes(N, width, height, mask_holes_num, normal), image.device) if cutout else None
+    co = draw_boxes(N, width, height, mask_holes_num, normal) if cutout else None
     cm = perm = None
     if cutmix:
-        cm = _to_dev(draw_boxes(N, width, height, mask_holes_num, normal), image.device)
-        perm = _to_dev(torch.randperm(N).int(), image.device)
+        cm = draw_boxes(N, width, height, mask_holes_num, normal)
+        perm = torch.randperm(N).int()
+    parts = [t for t in (co, cm, perm) if t is not None]
+    if parts:
+        sizes = [t.numel() for t in parts]
+        packed = _to_dev(torch.cat([t.reshape(-1) for t in parts]), image.device)
+        views, off = [], 0
+        for t, n in zip(parts, sizes):
+            views.append(packed[off:off + n].view(t.shape))
+            off += n
+        it = iter(views)
+        co = next(it) if co is not None else None
+        cm = next(it) if cm is not None else None
+        perm = next(it) if perm is not None else None
     return K.strong_aug(image.contiguous(), co, cm, perm, mask_holes_num, src_nhwc=False, dst_nhwc=True, out=out)

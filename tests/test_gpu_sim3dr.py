@@ -41,7 +41,7 @@ def test_renderer_reproduces_the_reference_images():
         over = R.render_app(np.ascontiguousarray(v, dtype=np.float32), R.triangles, over)
         assert np.array_equal(over, stage)
     res = R.render(G["frame"], tv, alpha=0.9)
-    assert np.array_equal(res, np.clip(np.rint(0.1 * G["frame"].astype(np.float64) + 0.9 * G["stage1"]), 0, 255).astype(np.uint8))
+    assert np.array_equal(res, np.clip(np.rint((1 - 0.9) * G["frame"].astype(np.float64) + 0.9 * G["stage1"]), 0, 255).astype(np.uint8))
     img = G["frame"].copy()
     Sim3DR.rasterize(np.ascontiguousarray(tv[0], dtype=np.float32), R.triangles, G["colors"], bg=img, alpha=0.6, reverse=True)
     assert np.array_equal(img, G["img_alpha06_reversed"])

@@ -39,6 +39,21 @@ class Mode(TorchDispatchMode):
         return out
 
 
+# custom autograd Functions run their backward on the autograd engine's thread, where this thread's mode is not active: wrap them
+import torch.autograd.function as AF
+from semiuhpe_amd import layers as L
+from semiuhpe_amd.src import agent as AG
+from semiuhpe_amd.src.fisher import fisher_utils as FU
+for mod in (L, AG, FU):
+    for name in dir(mod):
+        cls = getattr(mod, name)
+        if isinstance(cls, type) and issubclass(cls, torch.autograd.Function) and cls is not torch.autograd.Function:
+            orig = cls.backward
+
+            def wrapped(ctx, *g, _orig=orig):
+                with Mode():
+                    return _orig(ctx, *g)
+            cls.backward = staticmethod(wrapped)
 with Mode():
     agent.train_func(data, ulb)
 torch.cuda.synchronize()
