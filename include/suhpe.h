@@ -166,6 +166,21 @@ int suhpe_wgrad_reduce_batched(const void* jobs_dev, const int64_t* chunk_start_
 /* depthwise 3x3 (groups == cin == cout, cin % 4 == 0); w in torch layout [c][r*s] */
 int suhpe_dwconv_fwd(const suhpe_conv_t* d, const float* x, const float* w, float* y, suhpe_stream_t stream);
 int suhpe_dwconv_dgrad(const suhpe_conv_t* d, const float* dy, const float* w, float* dx, suhpe_stream_t stream);
+/* Input gradient of a depthwise conv whose INPUT was act(BN(bn_x)) with train-mode statistics (torchvision MBConv: expand conv ->
+ * BatchNorm -> SiLU -> depthwise, reference src/networks.py:303): besides dx = the gradient of the activated tensor, the kernel
+ * reduces that BatchNorm's backward sums over what it produces, g = dx * act'(gamma xhat + beta): sums[c][2] = (sum g, sum g xhat)
+ * (seg_n > 0: two batch segments of seg_n / n - seg_n samples, mean / rstd [2][c], sums [2][c][2]); dgamma / dbeta (+)= their totals.
+ * The BatchNorm backward then needs only its apply pass (suhpe_bn_act_bwd_apply / _apply_seg): no reduction pass over (bn_x, dx).
+ * Served shapes: suhpe_dwconv_dgrad_bnsums_ok(d) (3x3 / pad 1 / stride 1, the sliding-window kernel); workspace: device scratch.
+ * (Measured and dropped: an apply pass that recomputes dx from dy as well -- dx never stored -- made the step 3 ms SLOWER: the stencil +
+ * SiLU' twice costs more than the tensor pass it saves.) */
+int suhpe_dwconv_dgrad_bnsums_ok(const suhpe_conv_t* d);
+int64_t suhpe_dwconv_dgrad_bnsums_workspace_bytes(const suhpe_conv_t* d);
+int suhpe_dwconv_dgrad_bnsums(const suhpe_conv_t* d, const float* dy, const float* w, float* dx, const float* bn_x, const float* mean,
+                              const float* rstd, const float* gamma, const float* beta, int act, int seg_n, float* sums, float* dgamma,
+                              float* dbeta, int accumulate, void* workspace, int64_t workspace_bytes, suhpe_stream_t stream);
+int suhpe_bn_act_bwd_apply_seg(const float* x, const float* dy, int64_t rows, int64_t rows_a, int c, const float* mean, const float* rstd,
+                               const float* gamma, const float* beta, int act, const float* sums, float* dx, suhpe_stream_t stream);
 int64_t suhpe_dwconv_wgrad_workspace_bytes(const suhpe_conv_t* d);
 int suhpe_dwconv_wgrad(const suhpe_conv_t* d, const float* x, const float* dy, float* dw, int accumulate,
                        void* workspace, int64_t workspace_bytes, suhpe_stream_t stream);

@@ -41,6 +41,10 @@ inline int grid_for(int64_t work_items, int block) {
     return (int)g;
 }
 
+// nn_elem.hip: finish BatchNorm-backward partial records [row block][channel] float2 (sum g, sum g xhat) into sums / dgamma / dbeta;
+// gx_a > 0: two batch segments, records [0, gx_a) and [gx_a, gx)
+void launch_bn_bwd_finalize(const float* part, int gx_a, int gx, int c, float* sums, float* dgamma, float* dbeta, int accumulate, hipStream_t st);
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

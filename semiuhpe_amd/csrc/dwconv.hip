@@ -279,10 +279,17 @@ __global__ __launch_bounds__(256) void dw3x3_row_kernel(const float* __restrict_
 // FETCH_SIZE measured 2.7x the input).  Padding taps read zero through the buffer descriptor's bounds check, and the
 // column ahead is loaded one step early (the wait lands at its first use).
 constexpr int kDwRows = 4;
-template <bool XF, bool STATS = false>
+// BNB (input-gradient use): the outputs are the gradient d of act(BN(bn_x)) -- the depthwise conv's input was the activated output
+// of a train-mode BatchNorm over bn_x (torchvision MBConv: 1x1 expand -> BatchNorm -> SiLU -> depthwise).  The kernel then also
+// accumulates that BatchNorm's backward sums over the outputs it produces, g = d * act'(gamma xhat + beta): (sum g, sum g xhat) per
+// channel, in the [row block][channel] float2 records of bn_bwd_partial (nn_elem.hip), one record plane per batch segment -- so the
+// BatchNorm backward needs no reduction pass of its own over (bn_x, d): one read of bn_x here instead of a read of both there.
+struct DwBnb { const float* x; const float* mean; const float* rstd; const float* gamma; const float* beta; int act; int seg_n; float* part; };
+
+template <bool XF, bool STATS = false, bool BNB = false>
 __global__ __launch_bounds__(256) void dw3x3_s1_kernel(const float* __restrict__ src, int64_t src_bytes, const float* __restrict__ w,
                                                        float* __restrict__ dst, int N, int H, int W, int C, int flip, int cw, int rp, const DwXform xform,
-                                                       float* __restrict__ stats = nullptr, int seg_n = 0) {
+                                                       float* __restrict__ stats = nullptr, int seg_n = 0, const DwBnb bnb = DwBnb{}) {
     __shared__ __attribute__((aligned(16))) float wl[9 * 256 * 4];
     const int t = threadIdx.x, col = t % cw, rsub = t / cw;
     const int cv = C / 4, col0 = blockIdx.y * cw;
@@ -293,7 +300,7 @@ __global__ __launch_bounds__(256) void dw3x3_s1_kernel(const float* __restrict__
     }
     __syncthreads();
     const bool active = rsub < rp && col0 + col < cv;
-    if (!STATS && !active) return;
+    if (!STATS && !BNB && !active) return;
     float4 wv[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) wv[k] = *reinterpret_cast<const float4*>(&wl[(k * cw + (active ? col : 0)) * 4]);
@@ -304,10 +311,30 @@ __global__ __launch_bounds__(256) void dw3x3_s1_kernel(const float* __restrict__
     DwStat st_a, st;
     bool crossed = false, xsecond = false;
     if (STATS) { dw_stat_zero(st_a); dw_stat_zero(st); }
+    // BNB: this thread's four channels of the BatchNorm (statistics of the current segment) and its running sums
+    float b_mu[4], b_rs[4], b_ga[4], b_be[4], b_s0[4] = {0.f, 0.f, 0.f, 0.f}, b_s1[4] = {0.f, 0.f, 0.f, 0.f}, b_a0[4] = {0.f, 0.f, 0.f, 0.f},
+          b_a1[4] = {0.f, 0.f, 0.f, 0.f};
+    bool b_crossed = false;
+    if (BNB) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int ch = active ? (col0 + col) * 4 + v : 0;
+            b_mu[v] = bnb.mean[ch]; b_rs[v] = bnb.rstd[ch];
+            b_ga[v] = bnb.gamma ? bnb.gamma[ch] : 1.f; b_be[v] = bnb.beta ? bnb.beta[ch] : 0.f;
+        }
+    }
     for (int rg = blockIdx.x * rp + rsub; active && rg < N * groups_h; rg += gridDim.x * rp) {
         const int n = rg / groups_h, oh0 = (rg - n * groups_h) * kDwRows;
         dw_xf_cross<XF>(xf, xsecond, xform, (col0 + col) * 4, n);
         if (STATS && seg_n > 0 && !crossed && n >= seg_n) { st_a = st; dw_stat_zero(st); crossed = true; }
+        if (BNB && bnb.seg_n > 0 && !b_crossed && n >= bnb.seg_n) {           // second batch segment: its statistics, fresh sums
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                b_a0[v] = b_s0[v]; b_a1[v] = b_s1[v]; b_s0[v] = 0.f; b_s1[v] = 0.f;
+                b_mu[v] = bnb.mean[C + (col0 + col) * 4 + v]; b_rs[v] = bnb.rstd[C + (col0 + col) * 4 + v];
+            }
+            b_crossed = true;
+        }
         unsigned rbase[kDwRows + 2];
         bool rok[kDwRows + 2];
 #pragma unroll
@@ -345,6 +372,14 @@ __global__ __launch_bounds__(256) void dw3x3_s1_kernel(const float* __restrict__
                 enter(r, 2, ow + 1);
                 ld(r, 3, ow + 2);                            // needed at the next step
             }
+            float4 bx[kDwRows];
+            if (BNB) {                                       // the BatchNorm input at the output positions: loads issued ahead of the taps' arithmetic
+#pragma unroll
+                for (int j = 0; j < kDwRows; ++j) {
+                    const int oh = oh0 + j < H ? oh0 + j : H - 1;
+                    bx[j] = *reinterpret_cast<const float4*>(bnb.x + (((int64_t)n * H + oh) * W + ow) * C + (col0 + col) * 4);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < kDwRows; ++j) {
                 if (oh0 + j >= H) break;
@@ -359,6 +394,44 @@ __global__ __launch_bounds__(256) void dw3x3_s1_kernel(const float* __restrict__
                     }
                 *reinterpret_cast<float4*>(dst + (((int64_t)n * H + oh0 + j) * W + ow) * C + (col0 + col) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
                 if (STATS) dw_stat_add(st, acc);
+                if (BNB) {
+                    const float xv[4] = {bx[j].x, bx[j].y, bx[j].z, bx[j].w};
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const float xh = (xv[v] - b_mu[v]) * b_rs[v];
+                        const float g = acc[v] * act_grad(xh * b_ga[v] + b_be[v], bnb.act);
+                        b_s0[v] += g;
+                        b_s1[v] += g * xh;
+                    }
+                }
+            }
+        }
+    }
+    if (BNB) {
+        // threads of the workgroup that share a channel vector, added in a fixed order; records [plane][blockIdx.x][C] float2
+        const bool two = bnb.seg_n > 0;
+        if (two && !b_crossed) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { b_a0[v] = b_s0[v]; b_a1[v] = b_s1[v]; b_s0[v] = 0.f; b_s1[v] = 0.f; }
+        }
+        float* scratch = wl;
+        for (int plane = 0; plane < (two ? 2 : 1); ++plane) {
+            const float* q0 = (two && plane == 0) ? b_a0 : b_s0;
+            const float* q1 = (two && plane == 0) ? b_a1 : b_s1;
+            __syncthreads();
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { scratch[t * 8 + v] = active ? q0[v] : 0.f; scratch[t * 8 + 4 + v] = active ? q1[v] : 0.f; }
+            __syncthreads();
+            if (t < cw && (col0 + t) * 4 < C) {
+                float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int r = 0; r < rp; ++r) {
+                    const float* e = &scratch[(r * cw + t) * 8];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) { a0[v] += e[v]; a1[v] += e[4 + v]; }
+                }
+                float2* rec = reinterpret_cast<float2*>(bnb.part) + ((int64_t)plane * gridDim.x + blockIdx.x) * C + (col0 + t) * 4;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) rec[v] = make_float2(a0[v], a1[v]);
             }
         }
     }
@@ -657,6 +730,44 @@ int suhpe_dwconv_dgrad(const suhpe_conv_t* d, const float* dy, const float* w, f
     const int gx = (int)ceil_div(g.P, g.pix_per_block), ny = (int)ceil_div(g.C / 4, g.cw);
     DW_LAUNCH(dw_conv_kernel, dim3(gx, ny), dim3(256), 0, as_stream(stream), g, dy, w, dx, kNoXform);
     return check_launch("suhpe_dwconv_dgrad");
+}
+
+// which descriptors suhpe_dwconv_dgrad_bnsums serves: the sliding-window stride-1 kernel's (3x3 / pad 1 / stride 1, large tensors)
+static bool dw_bnsums_ok(const suhpe_conv_t* d) {
+    return d && dw_fast(d) && d->stride == 1 && d->cin % 4 == 0 && (int64_t)d->n * d->h * d->w * d->cin * 4 < ((int64_t)1 << 31) &&
+           (int64_t)d->n * ((d->h + kDwRows - 1) / kDwRows) * (d->cin / 4) >= 65536;
+}
+
+int suhpe_dwconv_dgrad_bnsums_ok(const suhpe_conv_t* d) { return dw_bnsums_ok(d) ? 1 : 0; }
+
+int64_t suhpe_dwconv_dgrad_bnsums_workspace_bytes(const suhpe_conv_t* d) {
+    if (!dw_bnsums_ok(d)) return 0;
+    int cw, rp, gx, ny;
+    dw_row_grid(d->cin, d->n * ((d->h + kDwRows - 1) / kDwRows), 4096, &cw, &rp, &gx, &ny);
+    return (int64_t)2 * gx * d->cin * 2 * sizeof(float);
+}
+
+int suhpe_dwconv_dgrad_bnsums(const suhpe_conv_t* d, const float* dy, const float* w, float* dx, const float* bn_x, const float* mean,
+                              const float* rstd, const float* gamma, const float* beta, int act, int seg_n, float* sums, float* dgamma,
+                              float* dbeta, int accumulate, void* workspace, int64_t workspace_bytes, suhpe_stream_t stream) {
+    int rc = dw_check(d, "suhpe_dwconv_dgrad_bnsums");
+    if (rc) return rc;
+    SUHPE_REQUIRE(dw_bnsums_ok(d), "suhpe_dwconv_dgrad_bnsums: 3x3 / pad 1 / stride 1 depthwise convs of the sliding-window kernel only (see _ok)");
+    SUHPE_REQUIRE(dy && w && dx && bn_x && mean && rstd && sums && workspace && seg_n >= 0 && seg_n < d->n, "suhpe_dwconv_dgrad_bnsums: bad arguments");
+    SUHPE_REQUIRE(act >= SUHPE_ACT_NONE && act <= SUHPE_ACT_SIGMOID, "suhpe_dwconv_dgrad_bnsums: unknown activation %d", act);
+    if (workspace_bytes < suhpe_dwconv_dgrad_bnsums_workspace_bytes(d)) {
+        set_error("suhpe_dwconv_dgrad_bnsums: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)suhpe_dwconv_dgrad_bnsums_workspace_bytes(d));
+        return SUHPE_EWORKSPACE;
+    }
+    int cw, rp, gx, ny;
+    dw_row_grid(d->cin, d->n * ((d->h + kDwRows - 1) / kDwRows), 4096, &cw, &rp, &gx, &ny);
+    float* part = static_cast<float*>(workspace);
+    const DwBnb bnb{bn_x, mean, rstd, gamma, beta, act, seg_n, part};
+    hipLaunchKernelGGL((dw3x3_s1_kernel<false, false, true>), dim3(gx, ny), dim3(256), 0, as_stream(stream), dy, (int64_t)d->n * d->h * d->w * d->cin * 4, w,
+                       dx, d->n, d->h, d->w, d->cin, 1, cw, rp, kNoXform, nullptr, 0, bnb);
+    // finish: (sum g, sum g xhat) per channel and segment -> sums [c][2] / [2][c][2], dgamma / dbeta (nn_elem.hip's finalisers)
+    launch_bn_bwd_finalize(part, seg_n > 0 ? gx : 0, seg_n > 0 ? 2 * gx : gx, d->cin, sums, dgamma, dbeta, accumulate, as_stream(stream));
+    return check_launch("suhpe_dwconv_dgrad_bnsums");
 }
 
 int64_t suhpe_dwconv_wgrad_workspace_bytes(const suhpe_conv_t* d) {

@@ -1574,6 +1574,15 @@ using namespace suhpe;
 
 #define LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL(kern, grid, block, 0, as_stream(stream), __VA_ARGS__)
 
+namespace suhpe {
+void launch_bn_bwd_finalize(const float* part, int gx_a, int gx, int c, float* sums, float* dgamma, float* dbeta, int accumulate, hipStream_t st) {
+    if (gx_a > 0)
+        hipLaunchKernelGGL(bn_bwd_finalize2, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, gx_a, gx, c, sums, dgamma, dbeta, accumulate);
+    else
+        hipLaunchKernelGGL(bn_bwd_finalize, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, gx, c, sums, dgamma, dbeta, accumulate);
+}
+}  // namespace suhpe
+
 extern "C" {
 
 // records (one spare row block for the two-segment launches) + per-channel backward sums of up to two segments
@@ -1801,6 +1810,24 @@ int suhpe_bn_act_bwd_apply(const float* x, const float* dy, const float* y_out, 
         LAUNCH(bn_bwd_apply<1>, dim3(e.gx, e.ny), dim3(256), stream, x, dy, y_out, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd, gamma, beta, act, sums,
                inv, 1, rowscale, hw, dx, SegArgs{0, 0, kRevSecondPass}, 0.f);
     return check_launch("suhpe_bn_act_bwd_apply");
+}
+
+/* the apply pass alone with two batch segments: sums [2][c][2] from a producer that reduced them (suhpe_dwconv_dgrad_bnsums) */
+int suhpe_bn_act_bwd_apply_seg(const float* x, const float* dy, int64_t rows, int64_t rows_a, int c, const float* mean, const float* rstd,
+                               const float* gamma, const float* beta, int act, const float* sums, float* dx, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(x && dy && dx && sums && mean && rstd && rows > 0 && rows < (1LL << 31) && c > 0 && seg_ok(rows, rows_a), "suhpe_bn_act_bwd_apply_seg: bad arguments");
+    const int vec = vec4_ok(c, x, dy, dx) ? 4 : 1;
+    const EwGeom e = ew_geom(rows, c, vec);
+    const int ex_a = (int)ceil_div(rows_a, (int64_t)e.rows_per_block), ex_b = (int)ceil_div(rows - rows_a, (int64_t)e.rows_per_block);
+    const SegArgs se{rows_a, ex_a, kRevSecondPass};
+    const float inv_a = 1.0f / (float)rows_a, inv_b = 1.0f / (float)(rows - rows_a);
+    if (vec == 4)
+        LAUNCH(bn_bwd_apply<4>, dim3(ex_a + ex_b, e.ny), dim3(256), stream, x, dy, (const float*)nullptr, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd,
+               gamma, beta, act, sums, inv_a, 1, (const float*)nullptr, 1, dx, se, inv_b);
+    else
+        LAUNCH(bn_bwd_apply<1>, dim3(ex_a + ex_b, e.ny), dim3(256), stream, x, dy, (const float*)nullptr, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd,
+               gamma, beta, act, sums, inv_a, 1, (const float*)nullptr, 1, dx, se, inv_b);
+    return check_launch("suhpe_bn_act_bwd_apply_seg");
 }
 
 int suhpe_bn_act_pool_fwd(const float* x, int64_t rows, int64_t rows_a, int c, int hw, const float* mean, const float* rstd, const float* gamma,

@@ -280,6 +280,39 @@ def _dw_dgrad(d, dy, w, dx):
     call("suhpe_dwconv_dgrad", ctypes.byref(d), ptr(dy), ptr(w), ptr(dx))
 
 
+def dwconv_dgrad_bnsums_ok(x_shape, w_shape, stride, pad):
+    """can the depthwise input-gradient kernel also reduce the producer BatchNorm's backward sums for this shape?"""
+    d = conv_desc(x_shape, w_shape, stride, pad, x_shape[-1])
+    return _is_depthwise(d) and bool(_lib.load().suhpe_dwconv_dgrad_bnsums_ok(ctypes.byref(d)))
+
+
+@_memop
+def dwconv_dgrad_bnsums(dy, w, x_shape, stride, pad, bn_x, mean, rstd, gamma, beta, act, seg_n, dgamma, dbeta):
+    """depthwise input gradient dx (= gradient of act(BN(bn_x))) + that BatchNorm's backward sums from the same kernel
+    (suhpe_dwconv_dgrad_bnsums): -> (dx, sums [2c] or [2, 2c]); dgamma / dbeta are accumulated into"""
+    _chk(dy, "dy"); _chk(bn_x, "bn_x")
+    d = conv_desc(x_shape, w.shape, stride, pad, x_shape[-1])
+    c = d.cin
+    two = seg_n > 0
+    assert mean.numel() == rstd.numel() == (2 if two else 1) * c and tuple(bn_x.shape) == tuple(x_shape)
+    dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
+    sums = torch.empty(((2, 2 * c) if two else (2 * c,)), dtype=torch.float32, device=dy.device)
+    nbytes = _lib.load().suhpe_dwconv_dgrad_bnsums_workspace_bytes(ctypes.byref(d))
+    ws = workspace("dw_bnsums", nbytes, dy.device)
+    call("suhpe_dwconv_dgrad_bnsums", ctypes.byref(d), ptr(dy), ptr(w), ptr(dx), ptr(bn_x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ACT[act],
+         int(seg_n) if two else 0, ptr(sums), ptr(dgamma), ptr(dbeta), 1, ptr(ws), nbytes)
+    return dx, sums
+
+
+@_memop
+def bn_act_bwd_apply_seg(x, dy, rows_a, c, mean, rstd, gamma, beta, act, sums):
+    """the BatchNorm backward's apply pass with two batch segments, from sums [2, 2c] a producer reduced"""
+    dx = torch.empty_like(x)
+    call("suhpe_bn_act_bwd_apply_seg", ptr(x), ptr(dy), x.numel() // c, int(rows_a), c, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ACT[act], ptr(sums),
+         ptr(dx))
+    return dx
+
+
 @_memop
 def _dw_wgrad(d, x, dy, out, accumulate, ws, nbytes):
     call("suhpe_dwconv_wgrad", ctypes.byref(d), ptr(x), ptr(dy), ptr(out), int(accumulate), ptr(ws), nbytes)

@@ -31,6 +31,8 @@ BN_EPS = 1e-3           # torchvision: partial(nn.BatchNorm2d, eps=1e-03) for th
 # ms/step on C2, so it is off; the kernels and their tests stay (memory-saving mode: the expanded tensor is never stored).
 FUSE_EXPAND_BN_INTO_DW = os.environ.get("SUHPE_FUSE_EXPAND_DW", "0") == "1"
 FUSE_EXPAND_NO_TAPE = os.environ.get("SUHPE_FUSE_EXPAND_NO_TAPE", "1") != "0"      # the same fold in train-mode forwards that keep no tape (teacher pass)
+# the expand BatchNorm's backward sums reduced by the depthwise input-gradient kernel (no reduction pass over the expanded tensor pair)
+BN_SUMS_FROM_DW = os.environ.get("SUHPE_BN_SUMS_FROM_DW", "1") != "0"
 FUSE_DW_BN_SE = os.environ.get("SUHPE_FUSE_DW_BN_SE", "1") != "0"     # depthwise BatchNorm + SiLU + SqueezeExcitation as one section (MBConv._dw_se_*)
 STOCHASTIC_DEPTH_PROB = 0.2
 
@@ -185,7 +187,9 @@ class MBConv(_ResidualBlock):
             return y, (sc, sh, s, bn_d.act, hw, rows_a)
         return K.bn_act_scale_fwd(y, rows_a, c, mean, rstd, bn_d.weight, bn_d.bias, bn_d.act, s, hw)
 
-    def _dw_se_bwd(self, dout, tape):
+    def _dw_se_bwd(self, dout, tape, expand=None):
+        """expand: the block's (expand conv, BatchNorm) pair when its backward follows (it is run here, so that the depthwise
+        input-gradient kernel can hand that BatchNorm its backward sums)"""
         (conv_d, bn_d), se = self.block[-3], self.block[-2]
         y, mean, rstd, rows_a, train_stats, p, a1, s, hw = tape.pop()
         c = bn_d.num_features
@@ -194,7 +198,41 @@ class MBConv(_ResidualBlock):
                           grad_of(se.fc2.weight), grad_of(se.fc2.bias))
         chan = K.se_bn_bwd_combine(sums, s, dp, rows_a // hw, hw, grad_of(bn_d.weight), grad_of(bn_d.bias), True)
         dy = K.se_bn_bwd_apply(y, dout, rows_a, c, mean, rstd, bn_d.weight, bn_d.bias, bn_d.act, s, dp, chan, train_stats, hw)
-        return conv_d.bwd(dy, tape)
+        if expand is not None and self._bn_sums_from_dw(conv_d, tape):
+            return self._dw_dgrad_expand_bwd(conv_d, expand, dy, tape)
+        d = conv_d.bwd(dy, tape)
+        return d if expand is None else expand.bwd(d, tape)
+
+    def _bn_sums_from_dw(self, conv_d, tape):
+        """the tape's next two entries are the depthwise conv's plain input and the expand BatchNorm's train-mode record in a form the
+        fused kernels take (one tensor of statistics, or the (mean[2, c], rstd[2, c]) pair of a merged two-segment pass)"""
+        if not BN_SUMS_FROM_DW or len(tape) < 2 or not torch.is_tensor(tape[-1]):
+            return False
+        e = tape[-2]
+        if not (isinstance(e, tuple) and len(e) == 7 and e[3] is True and e[4] is None and e[5] is None):
+            return False
+        if not (torch.is_tensor(e[1]) or (isinstance(e[1], tuple) and len(e[1]) == 2 and torch.is_tensor(e[1][0]))):
+            return False
+        return K.dwconv_dgrad_bnsums_ok(tape[-1].shape, conv_d.weight.shape, conv_d.stride, conv_d.padding)
+
+    def _dw_dgrad_expand_bwd(self, conv_d, expand, dy, tape):
+        """depthwise filter gradient; depthwise input gradient + the expand BatchNorm's (sum g, sum g xhat) from ONE kernel; that
+        BatchNorm's apply pass; the expand conv's backward"""
+        conv_e, bn_e = expand
+        a1 = tape.pop()
+        K.conv2d_wgrad(a1, dy, conv_d.weight.shape, conv_d.stride, conv_d.padding, conv_d.groups, out=grad_of(conv_d.weight), accumulate=True)
+        x1, mean, rstd, _, _, _, hw = tape.pop()
+        cexp = bn_e.num_features
+        if isinstance(mean, tuple):                          # two batch segments: ((mean[2, c], rstd[2, c]), samples of the first)
+            (m2, r2), seg = mean, rstd
+            d, sums = K.dwconv_dgrad_bnsums(dy, conv_d.weight, a1.shape, conv_d.stride, conv_d.padding, x1, m2, r2, bn_e.weight, bn_e.bias, bn_e.act,
+                                            seg, grad_of(bn_e.weight), grad_of(bn_e.bias))
+            dz = K.bn_act_bwd_apply_seg(x1, d, seg * hw, cexp, m2, r2, bn_e.weight, bn_e.bias, bn_e.act, sums)
+        else:
+            d, sums = K.dwconv_dgrad_bnsums(dy, conv_d.weight, a1.shape, conv_d.stride, conv_d.padding, x1, mean, rstd, bn_e.weight, bn_e.bias,
+                                            bn_e.act, 0, grad_of(bn_e.weight), grad_of(bn_e.bias))
+            dz = K.bn_act_bwd_apply(x1, d, cexp, mean, rstd, bn_e.weight, bn_e.bias, bn_e.act, sums, x1.numel() // cexp)
+        return conv_e.bwd(dz, tape)
 
     def _front_fwd(self, x, tape):
         # expand -> depthwise conv -> BatchNorm + SiLU + squeeze -> excitation
@@ -217,13 +255,13 @@ class MBConv(_ResidualBlock):
 
     def _front_bwd(self, dy, tape):
         if self._dw_se_fused():
+            if self.has_expand and not self._expand_folded():
+                return self._dw_se_bwd(dy, tape, expand=self.block[0])
             d = self._dw_se_bwd(dy, tape)
             if not self.has_expand:
                 return d
-            if self._expand_folded():       # d is the gradient of the activated tensor the depthwise conv recomputed
-                conv_e, bn_e = self.block[0]
-                return conv_e.bwd(bn_e.bwd(d, tape), tape)
-            return self.block[0].bwd(d, tape)
+            conv_e, bn_e = self.block[0]    # folded: d is the gradient of the activated tensor the depthwise conv recomputed
+            return conv_e.bwd(bn_e.bwd(d, tape), tape)
         return super()._front_bwd(dy, tape)
 
 

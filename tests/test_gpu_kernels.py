@@ -870,6 +870,48 @@ def test_resident_pointwise_kernel(K, cfg):
             lib.suhpe_conv2d_set_tile(ctypes.byref(d), pid, -1)
 
 
+@pytest.mark.parametrize("n,h,c,seg,act", [(160, 14, 512, 32, "silu"), (160, 7, 1536, None, "silu"), (160, 28, 256, 8, "relu"), (80, 14, 960, 5, "silu")])
+def test_depthwise_dgrad_reduces_producer_batchnorm_sums(K, n, h, c, seg, act):
+    """suhpe_dwconv_dgrad_bnsums: the depthwise input gradient is bit-equal to suhpe_dwconv_dgrad's, and the BatchNorm backward built from
+    the sums it reduces (one or two batch segments) + the apply pass equals the stand-alone three-pass BatchNorm backward (same dx up to the
+    summation order of the per-channel sums; dgamma / dbeta accumulated on top of what the buffers held)"""
+    g = torch.Generator().manual_seed(17)
+    x1 = (torch.randn(n, h, h, c, generator=g) * 1.5 + 0.3).cuda()                  # the BatchNorm's input (expand conv output)
+    dy = torch.randn(n, h, h, c, generator=g).cuda()                                 # gradient of the depthwise conv's output
+    w = K.to_filter_layout((torch.randn(c, 1, 3, 3, generator=g) / 3).cuda())
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).cuda(), (torch.randn(c, generator=g) * 0.2).cuda()
+    assert K.dwconv_dgrad_bnsums_ok(x1.shape, w.shape, 1, 1)
+    rows, hw = n * h * h, h * h
+    if seg is None:
+        mean, rstd = K.bn_stats(x1, c, 1e-3, 0.1)
+    else:
+        mean, rstd = K.bn_stats_seg(x1, seg * hw, c, 1e-3, 0.1)
+    d_ref = K.conv2d_dgrad(dy, w, x1.shape, 1, 1, c)
+    dg_ref, db_ref = torch.full((c,), 0.5, device="cuda"), torch.full((c,), -0.25, device="cuda")
+    dg, db = dg_ref.clone(), db_ref.clone()
+    if seg is None:
+        dz_ref = K.bn_act_bwd(x1, d_ref, c, mean, rstd, gamma, beta, act, True, dg_ref, db_ref, True)
+    else:
+        dz_ref = K.bn_act_bwd_seg(x1, d_ref, seg * hw, c, mean, rstd, gamma, beta, act, dg_ref, db_ref, True)
+    d, sums = K.dwconv_dgrad_bnsums(dy, w, x1.shape, 1, 1, x1, mean, rstd, gamma, beta, act, seg or 0, dg, db)
+    assert torch.equal(d, d_ref)
+    dz = (K.bn_act_bwd_apply(x1, d, c, mean, rstd, gamma, beta, act, sums, rows) if seg is None
+          else K.bn_act_bwd_apply_seg(x1, d, seg * hw, c, mean, rstd, gamma, beta, act, sums))
+    assert rel(dz, dz_ref.cpu()) < 2e-6
+    assert rel(dg, dg_ref.cpu()) < 2e-5 and rel(db, db_ref.cpu()) < 2e-5
+    # float64 reference of the sums themselves
+    xs = x1.double().cpu().reshape(rows, c)
+    parts = [(0, rows)] if seg is None else [(0, seg * hw), (seg * hw, rows)]
+    m64, r64 = mean.double().cpu().reshape(-1, c), rstd.double().cpu().reshape(-1, c)
+    for i, (lo, hi) in enumerate(parts):
+        xh = (xs[lo:hi] - m64[i]) * r64[i]
+        u = xh * gamma.double().cpu() + beta.double().cpu()
+        ga = (torch.sigmoid(u) * (1 + u * (1 - torch.sigmoid(u)))) if act == "silu" else (u > 0).double()
+        gg = d_ref.double().cpu().reshape(rows, c)[lo:hi] * ga
+        s = sums.reshape(-1, c, 2)[i].double().cpu()
+        assert rel(s[:, 0], gg.sum(0)) < 2e-5 and rel(s[:, 1], (gg * xh).sum(0)) < 2e-5
+
+
 def _db_entries(max_elems=160 * 112 * 112 * 96):
     import json, os
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "semiuhpe_amd", "tiles_mi355x.json")
