@@ -1152,7 +1152,7 @@ static void launch_nt(const NtParams& p_in, int groups, hipStream_t st) {
 enum NtTile { NT_64x64_S = 0, NT_64x64, NT_128x32, NT_128x128, NT_128x64, NT_256x32, NT_P64x64, NT_P128x32, NT_P128x64, NT_P128x128,
               NT_H64x64, NT_H128x32, NT_H128x64, NT_H128x128,
               NT_W128x128, NT_W128x64,       // four wavefronts with 64x64 / 64x32 accumulators each: half the LDS fragment reads per MFMA
-              NT_R128x16, NT_R64x8,          // operand-resident pointwise kernel (conv_resident.inl): 128 / 64 resident rows, 16 / 8 wavefronts
+              NT_R128x16, NT_R64x8, NT_R64x16,   // operand-resident pointwise kernel (conv_resident.inl): 128 / 64 resident rows, 16 / 8 / 16 wavefronts
               NT_TILES };
 static const char* kNtNames[] = {"igemm_nt_kernel<64,64,32,32,1>", "igemm_nt_kernel<64,64,32,32,4>", "igemm_nt_kernel<128,32,32,32,4>",
                                  "igemm_nt_kernel<128,128,64,32,4>", "igemm_nt_kernel<128,64,32,32,4>", "igemm_nt_kernel<256,32,64,32,4>",
@@ -1161,7 +1161,7 @@ static const char* kNtNames[] = {"igemm_nt_kernel<64,64,32,32,1>", "igemm_nt_ker
                                  "igemm_nt3x3_kernel<64,64,32,32>", "igemm_nt3x3_kernel<128,32,32,32>", "igemm_nt3x3_kernel<128,64,32,32>",
                                  "igemm_nt3x3_kernel<128,128,64,32>",
                                  "igemm_nt_kernel<128,128,64,64,4>", "igemm_nt_kernel<128,64,64,32,4>",
-                                 "gemm_nt_resident<128,2,16>", "gemm_nt_resident<64,2,8>"};
+                                 "gemm_nt_resident<128,2,16>", "gemm_nt_resident<64,2,8>", "gemm_nt_resident<64,2,16>"};
 
 struct TnTile { int bm, bn; const char* name; };
 static const TnTile kTnTiles[] = {
@@ -1236,7 +1236,7 @@ static void launch_persistent(const NtParams& p_in, int groups, hipStream_t st) 
 
 // a pinned persistent tile on a shape that is not a plain GEMM runs the igemm tile of the same size
 static NtTile effective_nt(NtTile tile, bool plain, bool halo = false, bool resident128 = false, bool resident64 = false) {
-    if (tile >= NT_R128x16) return ((tile == NT_R128x16 && resident128) || (tile == NT_R64x8 && resident64)) ? tile : NT_64x64;   // (same record height)
+    if (tile >= NT_R128x16) return ((tile == NT_R128x16 && resident128) || (tile != NT_R128x16 && resident64)) ? tile : NT_64x64;   // (same record height)
     if (tile >= NT_W128x128) return tile;
     if (tile >= NT_H64x64) {
         if (halo) return tile;
@@ -1251,6 +1251,7 @@ static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st
     if (tile >= NT_R128x16) {
         if (tile == NT_R128x16 && resident_ok(p, vec4, 128)) { launch_resident<128, 2, 16>(p, groups, st); return; }
         if (tile == NT_R64x8 && resident_ok(p, vec4, 64)) { launch_resident<64, 2, 8>(p, groups, st); return; }
+        if (tile == NT_R64x16 && resident_ok(p, vec4, 64)) { launch_resident<64, 2, 16>(p, groups, st); return; }
         tile = NT_64x64;                                    // (same statistics-record height as the resident tiles)
     }
     if (tile >= NT_W128x128 && p.a_scale) tile = tile == NT_W128x128 ? NT_128x128 : NT_128x64;     // (no input-transform form of the wide-accumulator tiles)

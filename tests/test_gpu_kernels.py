@@ -788,6 +788,42 @@ def test_attention_bias_gradient_fixed_order(ws, heads, B, H):
     assert float((db - 2 * db1).abs().max()) < 1e-6 * scale
 
 
+@pytest.mark.parametrize("pin", [None, "igemm_nt_kernel<256,32,64,32,4>", "igemm_nt_kernel<128,128,64,64,4>", "gemm_nt_resident<64,2,8>"])
+@pytest.mark.parametrize("rowscale", [False, True])
+def test_input_transform_conv_on_every_reachable_tile(K, pin, rowscale):
+    """a 1x1 conv with the loader's input transform (suhpe_conv2d_fwd_stats_xf) and a narrow output (cout = 32, M >= 2048)
+    reaches the 256x32 tile through the heuristics; that tile once had no transform instantiation (a silent no-op).  Every tile that
+    can be pinned for such a conv -- 256x32, a wide-accumulator tile, a resident tile (both without a transform form: remapped) --
+    must give the result of the unfused chain, statistics records included."""
+    import ctypes
+    from semiuhpe_amd import _lib
+    lib = _lib.load()
+    lib.suhpe_conv2d_tile_name.restype = ctypes.c_char_p
+    n, hw, cin, cout = 12, 14, 96, 32                       # M = 2352
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, hw, hw, cin, generator=g).cuda()
+    w = K.to_filter_layout((torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5).cuda())
+    sc, sh = (torch.rand(cin, generator=g) + 0.5).cuda(), (torch.randn(cin, generator=g) * 0.3).cuda()
+    rs = (torch.rand(n, cin, generator=g) + 0.5).cuda() if rowscale else None
+    a = torch.nn.functional.silu(x * sc + sh)
+    if rowscale:
+        a = a * rs[:, None, None, :]
+    y_ref, part_ref, tiles_ref = K.conv2d_fwd_stats(a.contiguous(), w, 1, 0, 1)
+    st_ref = K.bn_stats_from_partials(part_ref, tiles_ref, n * hw * hw, cout, 1e-3, 0.1)
+    d = K.conv_desc(x.shape, w.shape, 1, 0, 1)
+    names = [lib.suhpe_conv2d_tile_name(0, i).decode() for i in range(lib.suhpe_conv2d_tile_count(0))]
+    try:
+        if pin is not None:
+            assert lib.suhpe_conv2d_set_tile(ctypes.byref(d), 0, names.index(pin)) == 0
+        y, part, tiles = K.conv2d_fwd_stats(x, w, 1, 0, 1, xf=(sc, sh, rs, "silu", hw * hw, 0))
+        assert part.numel() == cout * tiles * 4
+        st = K.bn_stats_from_partials(part, tiles, n * hw * hw, cout, 1e-3, 0.1)
+    finally:
+        lib.suhpe_conv2d_set_tile(ctypes.byref(d), 0, -1)
+    assert rel(y, y_ref.cpu()) < 2e-5                        # (the loader's SiLU is v_exp / v_rcp based: ~1 ulp off torch's)
+    assert rel(st[0], st_ref[0].cpu()) < 2e-5 and rel(st[1], st_ref[1].cpu()) < 2e-5
+
+
 RESIDENT_SHAPES = [
     # (n, cin, cout, groups, h, w, seg): 1x1 / stride 1 convs as the resident kernel sees them
     (40, 160, 960, 1, 14, 14, 8),      # the C2 expand shape (M = 7840: a last partial row tile at both tile heights)
@@ -819,7 +855,7 @@ def test_resident_pointwise_kernel(K, cfg):
     res = torch.randn(n, h, w, cout, generator=g).cuda()
     d = K.conv_desc(x.shape, wg.shape, 1, 0, groups)
     tiles = [t for t in range(lib.suhpe_conv2d_tile_count(0)) if b"resident" in lib.suhpe_conv2d_tile_name(0, t)]
-    assert len(tiles) == 2
+    assert len(tiles) == 3
     igemm = [t for t in range(lib.suhpe_conv2d_tile_count(0)) if lib.suhpe_conv2d_tile_name(0, t) == b"igemm_nt_kernel<64,64,32,32,4>"][0]
     rows = n * h * w
 

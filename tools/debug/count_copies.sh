@@ -3,7 +3,7 @@
 R=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 export PYTHONPATH=$R
-rocprofv3 --kernel-trace --output-format csv -d /tmp/cc -o s -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>/tmp/cc.err
+rocprofv3 --kernel-trace --output-format csv -d /tmp/cc -o s -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-other-configs > /dev/null 2>/tmp/cc.err
 python3 - <<'PY'
 import csv, glob, re, collections
 f = glob.glob('/tmp/cc/**/*kernel_trace.csv', recursive=True)[0]

@@ -6,8 +6,8 @@
 # SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES, SQ_LDS_BANK_CONFLICT.
 R=$(pwd); cd /tmp && export TMPDIR=/tmp PYTHONPATH=$R
 for shape in "31360 960 160" "31360 160 960" "7840 1536 256" "31360 960 2048"; do
-  for tile in 1 3 4 6 8 14 15; do
-    rm -rf /tmp/pm; rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d /tmp/pm -- python3 $R/tools/gemm_pmc.py $shape 0 $tile > /dev/null 2>&1
+  for tile in 1 4 16 17 18; do   # igemm 64x64, 128x64; resident 128x16, 64x8, 64x16 (menu indices: suhpe_conv2d_tile_name)
+    rm -rf /tmp/pm; timeout 180 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d /tmp/pm -- python3 $R/tools/gemm_pmc.py $shape 0 $tile > /dev/null 2>&1
     python3 - "$shape" $tile <<'PY'
 import csv,glob,sys
 f=glob.glob('/tmp/pm/**/*counter_collection.csv',recursive=True)[0]

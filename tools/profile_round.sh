@@ -11,8 +11,8 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export PYTHONPATH=$R
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c2_serial -o s -- python3 $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --serial > $OUT/c2_serial_bench.json 2> $OUT/c2_serial.err
-rocprofv3 --kernel-trace --output-format csv -d $OUT/c2_streams -o s -- python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline > $OUT/c2_streams_bench.json 2> $OUT/c2_streams.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c2_serial -o s -- python3 $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-other-configs --serial > $OUT/c2_serial_bench.json 2> $OUT/c2_serial.err
+rocprofv3 --kernel-trace --output-format csv -d $OUT/c2_streams -o s -- python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-other-configs > $OUT/c2_streams_bench.json 2> $OUT/c2_streams.err
 export SUHPE_OVERLAP=0 SUHPE_WGRAD_OVERLAP=0
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c3_serial -o s -- python3 $R/tools/step_bench.py repvgg 64 256 2 6 > $OUT/c3_serial.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5_serial -o s -- python3 $R/tools/step_bench.py tinyvit 32 128 2 6 > $OUT/c5_serial.log 2>&1
