@@ -135,6 +135,14 @@ int suhpe_conv2d_fwd_stats_xf(const suhpe_conv_t* d, const float* x, const float
 int suhpe_conv2d_wgrad_partial_xf(const suhpe_conv_t* d, const float* x, const float* dy, void* workspace, int64_t workspace_bytes,
                                   const float* a_scale, const float* a_shift, const float* a_rowscale, int a_act, int a_hw,
                                   int64_t seg_row, suhpe_stream_t stream);
+/* Linear -> activation chains with the activation in the GEMM epilogues (TinyViT's Mlp: fc1 -> GELU -> fc2, reference
+ * src/tiny_vit.py:205-213; pointwise convs / Linear layers only).  Forward: y_pre = x w^T + bias (kept for the backward) and
+ * y_act = act(y_pre) from ONE launch -- no elementwise pass re-reads the pre-activation.  Backward: the input gradient of the layer
+ * that CONSUMED y_act, multiplied by act'(pre) in its epilogue: dx = dgrad(dy) * act'(pre) -- the gradient of the activated tensor is
+ * never stored.  Bit-identical to the unfused chain (same k order, same act / act' arithmetic). */
+int suhpe_conv2d_fwd_act2(const suhpe_conv_t* d, const float* x, const float* w, const float* bias, int act, float* y_pre, float* y_act,
+                          suhpe_stream_t stream);
+int suhpe_conv2d_dgrad_actgrad(const suhpe_conv_t* d, const float* dy, const float* wt, const float* pre, int act, float* dx, suhpe_stream_t stream);
 /* input gradient; wt is the transposed+flipped filter made by suhpe_conv2d_transpose_filter */
 int suhpe_conv2d_dgrad(const suhpe_conv_t* d, const float* dy, const float* wt, float* dx, suhpe_stream_t stream);
 /* the same input gradient with a skip connection's gradient added in the epilogue: dx = dgrad(dy) + skip (skip: the shape of dx,

@@ -113,6 +113,10 @@ struct NtParams {
     int a_act = 0, a_hw = 1;
     int64_t a_seg_row = 0;
     unsigned a_div_mul = 0, a_div_shr = 0;
+    // activation epilogues of the pointwise ACT2 instantiations (Linear -> activation chains, TinyViT's Mlp):
+    //   y2 != NULL : y = acc + bias (the pre-activation, kept for the backward) AND y2 = act(y), from one epilogue;
+    //   res_mode 4 : y = acc * act'(residual)  -- an input gradient multiplied by the activation's derivative at the saved pre-activation
+    float* y2 = nullptr;
     // start-up stagger (see stagger_wait): workgroups of the first resident generation delay their first barrier by
     // (hardware wave slot) * stagger quanta so that co-resident workgroups run out of phase
     int stagger = 0, stagger_first = 0;
@@ -140,7 +144,7 @@ template <int VEC> __device__ __forceinline__ void vload_lds(const float* p, flo
 // MODE 2: affine taps, coordinate = o*gm + sgn*tap + off (forward with any stride, dgrad with stride 1)
 // In every mode the tap of a thread's k advances incrementally (no division in the k loop), addresses are 32-bit
 // element offsets from a uniform base, and out-of-range taps are predicated (offset 0, value zeroed): no branches.
-template <int BM, int BN, int WM, int WN, int VEC, int MODE, bool AFF = false, int XF = 0>
+template <int BM, int BN, int WM, int WN, int VEC, int MODE, bool AFF = false, int XF = 0, bool ACT2 = false>
 // The second launch bound (minimum waves per SIMD) caps the register budget: left alone the compiler spends 88-148 VGPRs on
 // prefetch depth, which leaves 2 workgroups (or 1, for the wgrad kernel) per CU; at <= 80 VGPRs three 8-wave workgroups are
 // resident and the MFMA pipe sees 6 waves per SIMD.
@@ -425,7 +429,12 @@ void igemm_nt_kernel(const NtParams p) {
                         const unsigned bb = rem - a * (unsigned)g.OW;
                         orow = ((int64_t)n * g.YH + a * g.om + g.ph) * g.YW + bb * g.om + g.pw;
                     }
-                    if constexpr (!AFF_) {
+                    if constexpr (ACT2) {
+                        float v = acc[i][j][e] + bv;
+                        if (p.res_mode == 4) v *= act_grad(p.residual[orow * p.ldy + grp * p.Ng + col], p.act);
+                        y[orow * p.ldy + col] = v;
+                        if (p.y2) p.y2[orow * p.ldy + grp * p.Ng + col] = act_apply(v, p.act);
+                    } else if constexpr (!AFF_) {
                         // res_mode 3: plain skip-connection add (input gradient + the gradient that bypassed the block)
                         y[orow * p.ldy + col] = acc[i][j][e] + bv + (p.res_mode == 3 ? p.residual[orow * p.ldy + grp * p.Ng + col] : 0.f);
                     } else {
@@ -1131,7 +1140,10 @@ static void launch_nt(const NtParams& p_in, int groups, hipStream_t st) {
                     g_nt_unsupported = true;                 // never a silent no-op: the caller turns this into an error code
                 }
             } else if (p.scale) hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1, true>), grid, block, 0, st, p);
-            else hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1>), grid, block, 0, st, p);
+            else if (p.y2 || p.res_mode == 4) {
+                if constexpr (VEC == 4) hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1, false, 0, true>), grid, block, 0, st, p);
+                else g_nt_unsupported = true;
+            } else hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1>), grid, block, 0, st, p);
             break;
         case 2:
             if (p.scale) hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 2, true>), grid, block, 0, st, p);
@@ -1248,6 +1260,9 @@ static NtTile effective_nt(NtTile tile, bool plain, bool halo = false, bool resi
 
 static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st, int pinned) {
     NtTile tile = choose_nt(p.g.M, p.Ng, vec4, pinned, halo_ok(p.g, vec4));
+    const bool act2 = p.y2 || p.res_mode == 4;                 // activation epilogues live in igemm_nt_kernel's pointwise form only
+    if (act2 && tile >= NT_R128x16) tile = NT_64x64;
+    if (act2 && tile >= NT_W128x128) tile = tile == NT_W128x128 ? NT_128x128 : NT_128x64;
     if (tile >= NT_R128x16) {
         if (tile == NT_R128x16 && resident_ok(p, vec4, 128)) { launch_resident<128, 2, 16>(p, groups, st); return; }
         if (tile == NT_R64x8 && resident_ok(p, vec4, 64)) { launch_resident<64, 2, 8>(p, groups, st); return; }
@@ -1268,7 +1283,7 @@ static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st
         if (done) return;                                   // otherwise: the igemm tile of the same size (same row-tile height)
     }
     if (tile >= NT_P64x64) {
-        const bool plain = nt_mode(p.g) == 1 && p.g.M < (1LL << 31) && !p.a_scale;         // (the input transform lives in igemm_nt_kernel)
+        const bool plain = nt_mode(p.g) == 1 && p.g.M < (1LL << 31) && !p.a_scale && !act2;   // (input transform / activation epilogues live in igemm_nt_kernel)
         if (plain) {
             switch (tile) {
                 case NT_P64x64: launch_persistent<64, 64, 32, 32>(p, groups, st); return;
@@ -1362,6 +1377,45 @@ int suhpe_conv2d_fwd_affine(const suhpe_conv_t* d, const float* x, const float* 
     const bool vec4 = (cg % 4 == 0) && (d->cin % 4 == 0) && aligned16(x) && aligned16(w);
     dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 0));
     return check_launch("suhpe_conv2d_fwd_affine");
+}
+
+static bool pointwise_vec4(const suhpe_conv_t* d) {
+    return d && d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0 && d->groups == 1 && d->cin % 4 == 0 && d->cout % 4 == 0;
+}
+
+int suhpe_conv2d_fwd_act2(const suhpe_conv_t* d, const float* x, const float* w, const float* bias, int act, float* y_pre, float* y_act,
+                          suhpe_stream_t stream) {
+    int rc = check_desc(d, "suhpe_conv2d_fwd_act2");
+    if (rc) return rc;
+    SUHPE_REQUIRE(pointwise_vec4(d), "suhpe_conv2d_fwd_act2: pointwise convs / Linear layers only (1x1, stride 1, groups 1, channels %% 4 == 0)");
+    SUHPE_REQUIRE(x && w && y_pre && y_act && aligned16(x) && aligned16(w), "suhpe_conv2d_fwd_act2: null or unaligned pointer");
+    SUHPE_REQUIRE(act >= SUHPE_ACT_NONE && act <= SUHPE_ACT_SIGMOID, "suhpe_conv2d_fwd_act2: unknown activation %d", act);
+    NtParams p;
+    p.g = make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, d->cin, 1, 1, 1, 0, 0);
+    p.x = x; p.f = w; p.bias = bias; p.y = y_pre; p.y2 = y_act; p.Ng = d->cout; p.ldy = d->cout; p.ldf = p.g.K;
+    p.x_bytes = (int64_t)d->n * d->h * d->w * d->cin * 4; p.f_bytes = (int64_t)d->cout * p.g.K * 4;
+    p.stats = nullptr; p.stats_extra = nullptr; p.seg_row = 0; p.stat_gx = 0; p.stat_cout = 0; p.scale = p.shift = p.residual = nullptr; p.act = act; p.res_mode = 0;
+    g_nt_unsupported = false;
+    dispatch_nt(p, 1, true, as_stream(stream), pinned_tile(d, 0));
+    if (g_nt_unsupported) { set_error("suhpe_conv2d_fwd_act2: the selected tile has no activation-epilogue instantiation"); return SUHPE_EINVAL; }
+    return check_launch("suhpe_conv2d_fwd_act2");
+}
+
+int suhpe_conv2d_dgrad_actgrad(const suhpe_conv_t* d, const float* dy, const float* wt, const float* pre, int act, float* dx, suhpe_stream_t stream) {
+    int rc = check_desc(d, "suhpe_conv2d_dgrad_actgrad");
+    if (rc) return rc;
+    SUHPE_REQUIRE(pointwise_vec4(d), "suhpe_conv2d_dgrad_actgrad: pointwise convs / Linear layers only (1x1, stride 1, groups 1, channels %% 4 == 0)");
+    SUHPE_REQUIRE(dy && wt && pre && dx && aligned16(dy) && aligned16(wt), "suhpe_conv2d_dgrad_actgrad: null or unaligned pointer");
+    SUHPE_REQUIRE(act >= SUHPE_ACT_NONE && act <= SUHPE_ACT_SIGMOID, "suhpe_conv2d_dgrad_actgrad: unknown activation %d", act);
+    NtParams p;
+    p.g = make_geom(d->n, d->ho, d->wo, d->h, d->w, d->cout, d->cout, 1, 1, 1, 0, 1);
+    p.x = dy; p.f = wt; p.bias = nullptr; p.y = dx; p.Ng = d->cin; p.ldy = d->cin; p.ldf = p.g.K;
+    p.x_bytes = (int64_t)d->n * d->ho * d->wo * d->cout * 4; p.f_bytes = (int64_t)d->cout * d->cin * 4;
+    p.stats = nullptr; p.stats_extra = nullptr; p.seg_row = 0; p.stat_gx = 0; p.stat_cout = 0; p.scale = p.shift = nullptr; p.residual = pre; p.act = act; p.res_mode = 4;
+    g_nt_unsupported = false;
+    dispatch_nt(p, 1, true, as_stream(stream), pinned_tile(d, 1));
+    if (g_nt_unsupported) { set_error("suhpe_conv2d_dgrad_actgrad: the selected tile has no activation-epilogue instantiation"); return SUHPE_EINVAL; }
+    return check_launch("suhpe_conv2d_dgrad_actgrad");
 }
 
 int suhpe_conv2d_fwd_stats_tiles(const suhpe_conv_t* d) {

@@ -333,6 +333,42 @@ def conv2d_fwd_affine(x, w, scale, shift, act, residual=None, residual_after_act
     return y
 
 
+def conv2d_fwd_act2(x, w, bias, act):
+    """pointwise conv / Linear with the activation in the epilogue: -> (pre-activation, act(pre-activation)), one launch"""
+    _chk(x, "x")
+    assert filter_is_physical(w) or (w.shape[2] == 1 and w.shape[3] == 1)
+    d = conv_desc(x.shape, w.shape, 1, 0, 1)
+    pre = torch.empty((d.n, d.ho, d.wo, d.cout), dtype=torch.float32, device=x.device)
+    out = torch.empty_like(pre)
+    if AUTOTUNE:
+        _autotune(d, 0, lambda: call("suhpe_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(pre)))
+    with _Prof(d, 0):
+        call("suhpe_conv2d_fwd_act2", ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ACT[act], ptr(pre), ptr(out))
+    return pre, out
+
+
+def conv2d_dgrad_actgrad(dy, w, x_shape, pre, act):
+    """input gradient of a pointwise conv / Linear whose INPUT was act(pre): dx = dgrad(dy) * act'(pre) from the GEMM epilogue"""
+    _chk(dy, "dy"); _chk(pre, "pre")
+    d = conv_desc(x_shape, w.shape, 1, 0, 1)
+    assert tuple(pre.shape) == tuple(x_shape)
+    dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
+    key = (w.data_ptr(), d.cin, d.cout, d.r, d.s, d.groups)
+    wt = _WT_CACHE.get(key) if _WT_CACHE is not None else None
+    if wt is None:
+        if _WT_CACHE is not None:
+            wt = _WT_CACHE[key] = torch.empty(w.numel() * 4, dtype=torch.uint8, device=dy.device)
+            _WT_SEEN[key] = (w, (d.groups, d.cout // d.groups, d.cin // d.groups, d.r * d.s))
+        else:
+            wt = workspace("wt", w.numel() * 4, dy.device)
+        call("suhpe_conv2d_transpose_filter", ctypes.byref(d), ptr(w), ptr(wt))
+    if AUTOTUNE:
+        _autotune(d, 1, lambda: call("suhpe_conv2d_dgrad", ctypes.byref(d), ptr(dy), ptr(wt), ptr(dx)))
+    with _Prof(d, 1):
+        call("suhpe_conv2d_dgrad_actgrad", ctypes.byref(d), ptr(dy), ptr(wt), ptr(pre), ACT[act], ptr(dx))
+    return dx
+
+
 def repvgg_fuse(w3, w1, bn3, bn1, bnid, eps):
     """RepVGG deploy-mode filter and bias of one block (src/repvgg.py:104-142); bn* = (gamma, beta, running_mean, running_var)
     tensors, bnid None without an identity branch.  -> (w_eq like w3, ones (cout), b_eq (cout))"""

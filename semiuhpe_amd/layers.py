@@ -198,7 +198,9 @@ class Linear(Layer):
             tape.append(x4)
         return y.view(*shp[:-1], self.out_features)
 
-    def bwd(self, dy, tape):
+    def bwd(self, dy, tape, pre=None, act=None):
+        """pre / act: this layer's INPUT was act(pre) (see fwd_act of the layer before): the input gradient comes back already
+        multiplied by act'(pre) (GEMM epilogue), i.e. as the gradient of `pre`"""
         x4 = tape.pop()
         shp = dy.shape
         dy4 = dy.reshape(-1, 1, 1, self.out_features)
@@ -206,8 +208,23 @@ class Linear(Layer):
         K.conv2d_wgrad(x4, dy4, gw.shape, 1, 0, 1, out=gw, accumulate=True)
         if self.bias is not None:
             K.bias_grad(dy4, self.out_features, out=grad_of(self.bias), accumulate=True)
-        dx = K.conv2d_dgrad(dy4, self._w4(), x4.shape, 1, 0, 1)
+        if pre is not None:
+            dx = K.conv2d_dgrad_actgrad(dy4, self._w4(), x4.shape, pre.reshape(x4.shape), act)
+        else:
+            dx = K.conv2d_dgrad(dy4, self._w4(), x4.shape, 1, 0, 1)
         return dx.view(*shp[:-1], self.in_features)
+
+    def act_epilogue_ok(self):
+        return self.in_features % 4 == 0 and self.out_features % 4 == 0
+
+    def fwd_act(self, x, tape, act):
+        """-> (pre-activation, act(pre-activation)) from one GEMM launch (kernels.conv2d_fwd_act2)"""
+        shp = x.shape
+        x4 = x.reshape(-1, 1, 1, self.in_features)
+        pre, out = K.conv2d_fwd_act2(x4, self._w4(), self.bias, act)
+        if tape is not None:
+            tape.append(x4)
+        return pre.view(*shp[:-1], self.out_features), out.view(*shp[:-1], self.out_features)
 
 
 # Batch segments.  A training step runs the student on the labeled batch and on the strong views of the unlabeled batch

@@ -178,6 +178,9 @@ class Attention(Layer):
         return self.norm.bwd(d_xn.view(B, H, W, C), tape)
 
 
+MLP_ACT_EPILOGUE = os.environ.get("SUHPE_MLP_EPILOGUE", "1") != "0"     # GELU / GELU' in the fc1 / fc2 GEMM epilogues
+
+
 class Mlp(Layer):
     def __init__(self, in_features, hidden_features):
         super().__init__()
@@ -186,18 +189,34 @@ class Mlp(Layer):
         self.fc2 = Linear(hidden_features, in_features)
         self.hidden = hidden_features
 
+    # fc1 -> GELU -> fc2 (reference src/tiny_vit.py:205-213) with the activation in the GEMM epilogues (MLP_ACT_EPILOGUE): fc1 writes the
+    # pre-activation h (kept for the backward) and gelu(h) from one launch, and fc2's input gradient comes back multiplied by gelu'(h):
+    # the two elementwise passes over the 4x-wide tensors (read h, write a; read h and da, write dh) and the tensor da disappear.
+    def _fused(self):
+        return MLP_ACT_EPILOGUE and self.fc1.act_epilogue_ok() and self.fc2.act_epilogue_ok()
+
     def fwd(self, x, tape):
         shp = x.shape
-        h = self.fc1.fwd(self.norm.fwd(x, tape).view(-1, shp[-1]), tape)
+        xn = self.norm.fwd(x, tape).view(-1, shp[-1])
+        if self._fused():
+            h, a = self.fc1.fwd_act(xn, tape, "gelu")
+        else:
+            h = self.fc1.fwd(xn, tape)
+            a = K.act_fwd(h, self.hidden, "gelu")
         if tape is not None:
             tape.append(h)
-        return self.fc2.fwd(K.act_fwd(h, self.hidden, "gelu"), tape).view(shp)
+        return self.fc2.fwd(a, tape).view(shp)
 
     def bwd(self, dy, tape):
         shp = dy.shape
-        da = self.fc2.bwd(dy.view(-1, shp[-1]), tape)
-        h = tape.pop()
-        dh = K.act_bwd(h, da, self.hidden, "gelu")
+        h = tape[-2]                                         # (fc2's input entry is on top of it)
+        if self._fused():
+            dh = self.fc2.bwd(dy.view(-1, shp[-1]), tape, pre=h, act="gelu")
+            tape.pop()
+        else:
+            da = self.fc2.bwd(dy.view(-1, shp[-1]), tape)
+            tape.pop()
+            dh = K.act_bwd(h, da, self.hidden, "gelu")
         return self.norm.bwd(self.fc1.bwd(dh, tape).view(shp), tape)
 
 

@@ -824,6 +824,43 @@ def test_input_transform_conv_on_every_reachable_tile(K, pin, rowscale):
     assert rel(st[0], st_ref[0].cpu()) < 2e-5 and rel(st[1], st_ref[1].cpu()) < 2e-5
 
 
+@pytest.mark.parametrize("rows,cin,cout,act", [(784, 192, 768, "gelu"), (392, 576, 2304, "gelu"), (1000, 64, 72, "silu"), (6272, 384, 1536, "gelu")])
+def test_linear_activation_epilogues(K, rows, cin, cout, act):
+    """suhpe_conv2d_fwd_act2 / suhpe_conv2d_dgrad_actgrad (TinyViT's fc1 -> GELU -> fc2): pre-activation, activation and the input
+    gradient multiplied by act'(pre) from the GEMM epilogues, bit-equal to the unfused chain (Linear, act_fwd, Linear backward, act_bwd),
+    on the heuristic tile and with persistent / resident / wide tiles pinned (all remapped to the igemm tile that carries the epilogue)"""
+    import ctypes
+    from semiuhpe_amd import _lib
+    lib = _lib.load()
+    lib.suhpe_conv2d_tile_name.restype = ctypes.c_char_p
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(rows, 1, 1, cin, generator=g).cuda()
+    w1 = (torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5).cuda()
+    b1 = (torch.randn(cout, generator=g) * 0.1).cuda()
+    w2 = (torch.randn(cin, cout, 1, 1, generator=g) / cout ** 0.5).cuda()
+    dy = torch.randn(rows, 1, 1, cin, generator=g).cuda()                            # gradient of fc2's output
+    h_ref = K.conv2d_fwd(x, w1, b1, 1, 0, 1)
+    a_ref = K.act_fwd(h_ref, cout, act)
+    da_ref = K.conv2d_dgrad(dy, w2, a_ref.shape, 1, 0, 1)
+    dh_ref = K.act_bwd(h_ref, da_ref, cout, act)
+    d1, d2 = K.conv_desc(x.shape, w1.shape, 1, 0, 1), K.conv_desc(a_ref.shape, w2.shape, 1, 0, 1)
+    names = [lib.suhpe_conv2d_tile_name(0, i).decode() for i in range(lib.suhpe_conv2d_tile_count(0))]
+    pins = [None, "gemm_nt_persistent<64,64,32,32>", "gemm_nt_resident<64,2,8>", "igemm_nt_kernel<128,128,64,64,4>", "igemm_nt_kernel<128,32,32,32,4>"]
+    try:
+        for pin in pins:
+            for d, pid in ((d1, 0), (d2, 1)):
+                assert lib.suhpe_conv2d_set_tile(ctypes.byref(d), pid, -1 if pin is None else names.index(pin)) == 0 or "resident" in pin
+            h, a = K.conv2d_fwd_act2(x, w1, b1, act)
+            dh = K.conv2d_dgrad_actgrad(dy, w2, a_ref.shape, h_ref, act)
+            assert torch.equal(h, h_ref) and torch.equal(a, a_ref), pin
+            assert torch.equal(dh, dh_ref), pin
+    finally:
+        lib.suhpe_conv2d_set_tile(ctypes.byref(d1), 0, -1)
+        lib.suhpe_conv2d_set_tile(ctypes.byref(d2), 1, -1)
+    ad = torch.nn.functional.gelu(h_ref.double().cpu()) if act == "gelu" else torch.nn.functional.silu(h_ref.double().cpu())
+    assert rel(a, ad) < 1e-6
+
+
 RESIDENT_SHAPES = [
     # (n, cin, cout, groups, h, w, seg): 1x1 / stride 1 convs as the resident kernel sees them
     (40, 160, 960, 1, 14, 14, 8),      # the C2 expand shape (M = 7840: a last partial row tile at both tile heights)
