@@ -85,13 +85,20 @@ template <int VEC> __device__ __forceinline__ void buf_load(BufRsrc r, unsigned 
 }
 
 // ------------------------------------------------------------------------------------------ activations
+// sigmoid through the hardware transcendentals: v_exp_f32 (2^x) and v_rcp_f32, 1 ulp each, instead of expf's range reduction and an
+// IEEE division (~25 VALU instructions per element).  The read-only BatchNorm / SqueezeExcitation reductions were VALU-bound on the
+// accurate forms (tools/proto/ew_lab.hip: the squeeze pass over 31 360 x 960 31.0 -> 21.9 us, the BatchNorm backward sums 44.6 -> 38.8 us);
+// the error stays below 4e-7 relative for |u| <= 5 and below fp32 resolution of the result beyond.
+__device__ __forceinline__ float fast_sigmoid(float u) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * u));
+}
 __device__ __forceinline__ float act_apply(float u, int act) {
     switch (act) {
         case SUHPE_ACT_RELU: return u > 0.f ? u : 0.f;
         case SUHPE_ACT_RELU6: return fminf(fmaxf(u, 0.f), 6.f);
-        case SUHPE_ACT_SILU: return u / (1.f + expf(-u));
+        case SUHPE_ACT_SILU: return u * fast_sigmoid(u);
         case SUHPE_ACT_GELU: return 0.5f * u * (1.f + erff(u * 0.70710678118654752f));
-        case SUHPE_ACT_SIGMOID: return 1.f / (1.f + expf(-u));
+        case SUHPE_ACT_SIGMOID: return fast_sigmoid(u);
         default: return u;
     }
 }
@@ -101,7 +108,7 @@ __device__ __forceinline__ float act_grad(float u, int act) {
         case SUHPE_ACT_RELU: return u > 0.f ? 1.f : 0.f;
         case SUHPE_ACT_RELU6: return (u > 0.f && u < 6.f) ? 1.f : 0.f;
         case SUHPE_ACT_SILU: {
-            const float s = 1.f / (1.f + expf(-u));
+            const float s = fast_sigmoid(u);
             return s * (1.f + u * (1.f - s));
         }
         case SUHPE_ACT_GELU: {
@@ -109,7 +116,7 @@ __device__ __forceinline__ float act_grad(float u, int act) {
             return cdf + u * 0.3989422804014327f * expf(-0.5f * u * u);
         }
         case SUHPE_ACT_SIGMOID: {
-            const float s = 1.f / (1.f + expf(-u));
+            const float s = fast_sigmoid(u);
             return s * (1.f - s);
         }
         default: return 1.f;

@@ -424,7 +424,9 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __res
             sc[v] = rstd[ch + v] * g;
             sh[v] = b - mean[ch + v] * sc[v];
         }
-        constexpr int U = 4;
+        // one workgroup per (sample, 32 vector columns): a 7x7 sample is ONE round of 8 rows per thread, all loads issued before the
+        // first use -- with 64 columns and 4 rows per round the grid was 2.5-4 workgroups per CU with 4 KB in flight each (2.3 TB/s)
+        constexpr int U = 8;
         for (int r = r0 + rsub; r < r1; r += U * rp) {
             float xv[U][VEC];
 #pragma unroll
@@ -1836,7 +1838,7 @@ int suhpe_bn_act_pool_fwd(const float* x, int64_t rows, int64_t rows_a, int c, i
                       rows_a % hw == 0,
                   "suhpe_bn_act_pool_fwd: bad arguments (whole samples per segment: rows %% hw == 0, rows_a %% hw == 0)");
     const int vec = (vec4_ok(c, x, y) && vec4_ok(c, pool)) ? 4 : 1;
-    const int cv = c / vec, cw = cv < 64 ? cv : 64, ny = (cv + cw - 1) / cw, rp = 256 / cw;
+    const int cv = c / vec, cw = cv < 32 ? cv : 32, ny = (cv + cw - 1) / cw, rp = 256 / cw;
     const SegArgs sg{rows_a, (int)(rows_a / hw), 0};
     const dim3 grid((unsigned)(rows / hw), ny);
     if (vec == 4) LAUNCH(bn_act_pool_fwd_kernel<4>, grid, dim3(256), stream, x, (int)rows, c, cw, rp, hw, mean, rstd, gamma, beta, act, y, pool, sg);
