@@ -336,13 +336,14 @@ __global__ __launch_bounds__(256) void repvgg_fuse_kernel(const float* __restric
 // y = act(gamma*(x-mean)*rstd + beta + residual)                       (post == 0: pre-activation residual)
 // y = residual + rowscale[row / hw] * act(gamma*(x-mean)*rstd + beta)   (post == 1: the block's skip connection with
 //                                                                        StochasticDepth('row') folded in; rowscale may be NULL)
-template <int VEC>
+template <int VEC, int ACTC = -1>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, int rows, int c, int cw, int rp, int rows_per_block,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          int act, const float* __restrict__ residual, int post,
                                                          const float* __restrict__ rowscale, int hw,
                                                          float* __restrict__ y, const SegArgs sg = SegArgs{0, 0, 0}) {
+    if (ACTC >= 0) act = ACTC;                         // compile-time activation: the switch folds, the row loop is one basic block
     int64_t rows_s = rows, row_off;
     int set;
     const int bx = seg_select(sg, &rows_s, &row_off, &set);
@@ -396,11 +397,12 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
 // y = act(BN(x)) and, from the same pass, pool[sample][channel] = mean over the sample's hw rows of y (the squeeze of the
 // SqueezeExcitation block that follows the depthwise conv's BatchNorm: no second pass over y).  One row block = one sample,
 // so the pooled value is a fixed-order sum inside one workgroup (no atomics).
-template <int VEC>
+template <int VEC, int ACTC = -1>
 __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __restrict__ x, int rows, int c, int cw, int rp, int hw,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta, int act,
                                                               float* __restrict__ y, float* __restrict__ pool, const SegArgs sg) {
+    if (ACTC >= 0) act = ACTC;                         // compile-time activation: the switch folds, the row loop is one basic block
     __shared__ float pl[256 * VEC];
     int64_t rows_s = rows, row_off;
     int set;
@@ -461,13 +463,14 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __res
 }
 
 // backward pass 1: partial sums of g and g*xhat, g = dy * act'(u)
-template <int VEC>
+template <int VEC, int ACTC = -1>
 __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ x, const float* __restrict__ dy,
                                                       const float* __restrict__ yout, int64_t rows, int c, int cw, int rp,
                                                       int64_t rows_per_block, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, int act, const float* __restrict__ rowscale,
                                                       int hw, float* __restrict__ part, const SegArgs sg = SegArgs{0, 0, 0}) {
+    if (ACTC >= 0) act = ACTC;                         // compile-time activation: the switch folds, the row loop is one basic block
     __shared__ float lds[256 * 2 * VEC];
     int64_t row_off;
     int set;
@@ -555,7 +558,7 @@ __global__ __launch_bounds__(kFinThreads) void bn_bwd_finalize2(const float* __r
 }
 
 // pass 3: dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat))   [train]   or gamma*rstd*g [eval]
-template <int VEC>
+template <int VEC, int ACTC = -1>
 __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ dy,
                                                     const float* __restrict__ yout, int rows, int c, int cw, int rp, int rows_per_block,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -563,6 +566,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ x,
                                                     const float* __restrict__ sums, float inv_rows, int train_stats,
                                                     const float* __restrict__ rowscale, int hw, float* __restrict__ dx,
                                                     const SegArgs sg = SegArgs{0, 0, 0}, float inv_rows_b = 0.f) {
+    if (ACTC >= 0) act = ACTC;                         // compile-time activation: the switch folds, the row loop is one basic block
     int64_t rows_s = rows, row_off;
     int set;
     const int bx = seg_select(sg, &rows_s, &row_off, &set);
@@ -1168,11 +1172,12 @@ __global__ __launch_bounds__(256) void per_sample_scale_kernel(const float* __re
 //             expanded tensor instead of the 7 + 2 of scale-backward (two kernels) + BatchNorm backward (two passes).
 // Grids are per sample (a workgroup row never straddles samples), so the sums are fixed-order and s / dpool are per-thread
 // constants; batch segments only select the statistics set by the sample index.
-template <int VEC>
+template <int VEC, int ACTC = -1>
 __global__ __launch_bounds__(256) void bn_act_scale_fwd_kernel(const float* __restrict__ x, int hw, int c, int cw, int rp, int rows_per_block,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta, int act,
                                                                const float* __restrict__ s, int n_a, float* __restrict__ y) {
+    if (ACTC >= 0) act = ACTC;                         // compile-time activation: the switch folds, the row loop is one basic block
     const int rows = hw;
     EW_THREAD_SETUP(VEC)
     const int64_t n = blockIdx.z;
@@ -1202,11 +1207,12 @@ __global__ __launch_bounds__(256) void bn_act_scale_fwd_kernel(const float* __re
 }
 
 // sums[k][n][c], k = 0..4 (A1..A5 above); one workgroup per (sample, column chunk)
-template <int VEC>
+template <int VEC, int ACTC = -1>
 __global__ __launch_bounds__(256) void se_bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dout, int nsamp, int hw, int c,
                                                                int cw, int rp, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta, int act, int n_a,
                                                                float* __restrict__ sums) {
+    if (ACTC >= 0) act = ACTC;                         // compile-time activation: the switch folds, the row loop is one basic block
     __shared__ float lds[256 * 5 * VEC];
     const int t = threadIdx.x, col = t % cw, rsub = t / cw;
     const int col0 = blockIdx.y * cw, cv = c / VEC;
@@ -1241,10 +1247,20 @@ __global__ __launch_bounds__(256) void se_bn_bwd_reduce_kernel(const float* __re
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
                     const float xh = (xv[u][v] - mu[v]) * rs[v], uu = xh * ga[v] + be[v];
-                    const float z = ok ? act_apply(uu, act) : 0.f, ap = ok ? act_grad(uu, act) : 0.f, d = ok ? dv[u][v] : 0.f;
+                    float z, ap;
+                    if (act == SUHPE_ACT_SILU) {                     // one sigmoid serves both: z = u s, act' = s + z (1 - s)
+                        const float sg = fast_sigmoid(uu);
+                        z = uu * sg;
+                        ap = sg + z - z * sg;
+                    } else {
+                        z = act_apply(uu, act);
+                        ap = act_grad(uu, act);
+                    }
+                    ap = ok ? ap : 0.f;                              // rows past the sample: no contribution (d = 0 silences z)
+                    const float d = ok ? dv[u][v] : 0.f, dap = d * ap;
                     a[0][v] += d * z;
-                    a[1][v] += d * ap;
-                    a[2][v] += d * ap * xh;
+                    a[1][v] += dap;
+                    a[2][v] += dap * xh;
                     a[3][v] += ap;
                     a[4][v] += ap * xh;
                 }
@@ -1314,13 +1330,14 @@ __global__ __launch_bounds__(kCombCh * kCombLanes) void se_bn_bwd_combine_kernel
 }
 
 // dy = gamma rstd (g - mean(g) - xhat mean(g xhat)),  g = (dout s + dpool/hw) act'(u);   grid (row blocks of a sample, column chunks, n)
-template <int VEC>
+template <int VEC, int ACTC = -1>
 __global__ __launch_bounds__(256) void se_bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dout, int hw, int c, int cw, int rp,
                                                               int rows_per_block, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta, int act,
                                                               const float* __restrict__ s, const float* __restrict__ dpool,
                                                               const float* __restrict__ chan, int n_a, float inv_rows_a, float inv_rows_b,
                                                               int train_stats, float* __restrict__ dy) {
+    if (ACTC >= 0) act = ACTC;                         // compile-time activation: the switch folds, the row loop is one basic block
     const int rows = hw;
     EW_THREAD_SETUP(VEC)
     const int64_t n = blockIdx.z;
@@ -1575,6 +1592,12 @@ static inline bool vec4_ok(int c, const void* a, const void* b = nullptr, const 
 using namespace suhpe;
 
 #define LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL(kern, grid, block, 0, as_stream(stream), __VA_ARGS__)
+// kernels with the activation as a template constant: SiLU (every BatchNorm of EfficientNetV2) gets its own instantiation
+#define LAUNCH_ACT(kern, VEC, act, grid, block, stream, ...)                                                                       \
+    do {                                                                                                                            \
+        if ((act) == SUHPE_ACT_SILU) hipLaunchKernelGGL((kern<VEC, SUHPE_ACT_SILU>), grid, block, 0, as_stream(stream), __VA_ARGS__); \
+        else hipLaunchKernelGGL((kern<VEC, -1>), grid, block, 0, as_stream(stream), __VA_ARGS__);                                   \
+    } while (0)
 
 namespace suhpe {
 void launch_bn_bwd_finalize(const float* part, int gx_a, int gx, int c, float* sums, float* dgamma, float* dbeta, int accumulate, hipStream_t st) {
@@ -1664,11 +1687,11 @@ static int bn_act_fwd_impl(const float* x, int64_t rows, int c, const float* mea
     if (post && !(residual && hw > 0 && rows % hw == 0)) { set_error("%s: the skip form needs a skip tensor and rows %% hw == 0", who); return SUHPE_EINVAL; }
     if (vec4_ok(c, x, y, residual)) {
         const EwGeom g = ew_geom(rows, c, 4);
-        LAUNCH(bn_act_fwd_kernel<4>, dim3(g.gx, g.ny), dim3(256), stream, x, (int)rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta,
+        LAUNCH_ACT(bn_act_fwd_kernel, 4, act, dim3(g.gx, g.ny), dim3(256), stream, x, (int)rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta,
                act, residual, post, rowscale, hw, y);
     } else {
         const EwGeom g = ew_geom(rows, c, 1);
-        LAUNCH(bn_act_fwd_kernel<1>, dim3(g.gx, g.ny), dim3(256), stream, x, (int)rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta,
+        LAUNCH_ACT(bn_act_fwd_kernel, 1, act, dim3(g.gx, g.ny), dim3(256), stream, x, (int)rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta,
                act, residual, post, rowscale, hw, y);
     }
     return check_launch(who);
@@ -1697,19 +1720,19 @@ static int bn_act_bwd_impl(const float* x, const float* dy, const float* y_out, 
     const float inv_rows = 1.0f / (float)rows;
     if (vec4_ok(c, x, dy, dx) && vec4_ok(c, y_out)) {
         const ColGeom g = col_geom(rows, c, 4);
-        LAUNCH(bn_bwd_partial<4>, dim3(g.gx, g.ny), dim3(256), stream, x, dy, y_out, rows, c, g.cw, g.rp, g.rows_per_block, mean,
+        LAUNCH_ACT(bn_bwd_partial, 4, act, dim3(g.gx, g.ny), dim3(256), stream, x, dy, y_out, rows, c, g.cw, g.rp, g.rows_per_block, mean,
                rstd, gamma, beta, act, rowscale, hw, part);
         LAUNCH(bn_bwd_finalize, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
         const EwGeom e = ew_geom(rows, c, 4);
-        LAUNCH(bn_bwd_apply<4>, dim3(e.gx, e.ny), dim3(256), stream, x, dy, y_out, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd,
+        LAUNCH_ACT(bn_bwd_apply, 4, act, dim3(e.gx, e.ny), dim3(256), stream, x, dy, y_out, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd,
                gamma, beta, act, sums, inv_rows, train_stats, rowscale, hw, dx, SegArgs{0, 0, kRevSecondPass}, 0.f);
     } else {
         const ColGeom g = col_geom(rows, c, 1);
-        LAUNCH(bn_bwd_partial<1>, dim3(g.gx, g.ny), dim3(256), stream, x, dy, y_out, rows, c, g.cw, g.rp, g.rows_per_block, mean,
+        LAUNCH_ACT(bn_bwd_partial, 1, act, dim3(g.gx, g.ny), dim3(256), stream, x, dy, y_out, rows, c, g.cw, g.rp, g.rows_per_block, mean,
                rstd, gamma, beta, act, rowscale, hw, part);
         LAUNCH(bn_bwd_finalize, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
         const EwGeom e = ew_geom(rows, c, 1);
-        LAUNCH(bn_bwd_apply<1>, dim3(e.gx, e.ny), dim3(256), stream, x, dy, y_out, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd,
+        LAUNCH_ACT(bn_bwd_apply, 1, act, dim3(e.gx, e.ny), dim3(256), stream, x, dy, y_out, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd,
                gamma, beta, act, sums, inv_rows, train_stats, rowscale, hw, dx, SegArgs{0, 0, kRevSecondPass}, 0.f);
     }
     return check_launch(who);
@@ -1769,10 +1792,10 @@ int suhpe_bn_act_fwd_seg(const float* x, int64_t rows, int64_t rows_a, int c, co
     const int gx_a = (int)ceil_div(rows_a, (int64_t)g.rows_per_block), gx_b = (int)ceil_div(rows - rows_a, (int64_t)g.rows_per_block);
     const SegArgs sg{rows_a, gx_a, 0};
     if (vec == 4)
-        LAUNCH(bn_act_fwd_kernel<4>, dim3(gx_a + gx_b, g.ny), dim3(256), stream, x, (int)rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta, act,
+        LAUNCH_ACT(bn_act_fwd_kernel, 4, act, dim3(gx_a + gx_b, g.ny), dim3(256), stream, x, (int)rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta, act,
                residual, post, rowscale, hw, y, sg);
     else
-        LAUNCH(bn_act_fwd_kernel<1>, dim3(gx_a + gx_b, g.ny), dim3(256), stream, x, (int)rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta, act,
+        LAUNCH_ACT(bn_act_fwd_kernel, 1, act, dim3(gx_a + gx_b, g.ny), dim3(256), stream, x, (int)rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta, act,
                residual, post, rowscale, hw, y, sg);
     return check_launch("suhpe_bn_act_fwd_seg");
 }
@@ -1789,10 +1812,10 @@ int suhpe_bn_act_bwd_sums(const float* x, const float* dy, const float* y_out, i
     const int vec = (vec4_ok(c, x, dy) && vec4_ok(c, y_out)) ? 4 : 1;
     const ColGeom g = col_geom(rows, c, vec);
     if (vec == 4)
-        LAUNCH(bn_bwd_partial<4>, dim3(g.gx, g.ny), dim3(256), stream, x, dy, y_out, rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta, act, rowscale,
+        LAUNCH_ACT(bn_bwd_partial, 4, act, dim3(g.gx, g.ny), dim3(256), stream, x, dy, y_out, rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta, act, rowscale,
                hw, part);
     else
-        LAUNCH(bn_bwd_partial<1>, dim3(g.gx, g.ny), dim3(256), stream, x, dy, y_out, rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta, act, rowscale,
+        LAUNCH_ACT(bn_bwd_partial, 1, act, dim3(g.gx, g.ny), dim3(256), stream, x, dy, y_out, rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta, act, rowscale,
                hw, part);
     LAUNCH(bn_bwd_finalize, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, g.gx, c, sums, dgamma, dbeta, accumulate);
     return check_launch("suhpe_bn_act_bwd_sums");
@@ -1806,10 +1829,10 @@ int suhpe_bn_act_bwd_apply(const float* x, const float* dy, const float* y_out, 
     const EwGeom e = ew_geom(rows, c, vec);
     const float inv = 1.0f / (float)total_rows;
     if (vec == 4)
-        LAUNCH(bn_bwd_apply<4>, dim3(e.gx, e.ny), dim3(256), stream, x, dy, y_out, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd, gamma, beta, act, sums,
+        LAUNCH_ACT(bn_bwd_apply, 4, act, dim3(e.gx, e.ny), dim3(256), stream, x, dy, y_out, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd, gamma, beta, act, sums,
                inv, 1, rowscale, hw, dx, SegArgs{0, 0, kRevSecondPass}, 0.f);
     else
-        LAUNCH(bn_bwd_apply<1>, dim3(e.gx, e.ny), dim3(256), stream, x, dy, y_out, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd, gamma, beta, act, sums,
+        LAUNCH_ACT(bn_bwd_apply, 1, act, dim3(e.gx, e.ny), dim3(256), stream, x, dy, y_out, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd, gamma, beta, act, sums,
                inv, 1, rowscale, hw, dx, SegArgs{0, 0, kRevSecondPass}, 0.f);
     return check_launch("suhpe_bn_act_bwd_apply");
 }
@@ -1824,10 +1847,10 @@ int suhpe_bn_act_bwd_apply_seg(const float* x, const float* dy, int64_t rows, in
     const SegArgs se{rows_a, ex_a, kRevSecondPass};
     const float inv_a = 1.0f / (float)rows_a, inv_b = 1.0f / (float)(rows - rows_a);
     if (vec == 4)
-        LAUNCH(bn_bwd_apply<4>, dim3(ex_a + ex_b, e.ny), dim3(256), stream, x, dy, (const float*)nullptr, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd,
+        LAUNCH_ACT(bn_bwd_apply, 4, act, dim3(ex_a + ex_b, e.ny), dim3(256), stream, x, dy, (const float*)nullptr, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd,
                gamma, beta, act, sums, inv_a, 1, (const float*)nullptr, 1, dx, se, inv_b);
     else
-        LAUNCH(bn_bwd_apply<1>, dim3(ex_a + ex_b, e.ny), dim3(256), stream, x, dy, (const float*)nullptr, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd,
+        LAUNCH_ACT(bn_bwd_apply, 1, act, dim3(ex_a + ex_b, e.ny), dim3(256), stream, x, dy, (const float*)nullptr, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd,
                gamma, beta, act, sums, inv_a, 1, (const float*)nullptr, 1, dx, se, inv_b);
     return check_launch("suhpe_bn_act_bwd_apply_seg");
 }
@@ -1841,8 +1864,8 @@ int suhpe_bn_act_pool_fwd(const float* x, int64_t rows, int64_t rows_a, int c, i
     const int cv = c / vec, cw = cv < 32 ? cv : 32, ny = (cv + cw - 1) / cw, rp = 256 / cw;
     const SegArgs sg{rows_a, (int)(rows_a / hw), 0};
     const dim3 grid((unsigned)(rows / hw), ny);
-    if (vec == 4) LAUNCH(bn_act_pool_fwd_kernel<4>, grid, dim3(256), stream, x, (int)rows, c, cw, rp, hw, mean, rstd, gamma, beta, act, y, pool, sg);
-    else LAUNCH(bn_act_pool_fwd_kernel<1>, grid, dim3(256), stream, x, (int)rows, c, cw, rp, hw, mean, rstd, gamma, beta, act, y, pool, sg);
+    if (vec == 4) LAUNCH_ACT(bn_act_pool_fwd_kernel, 4, act, grid, dim3(256), stream, x, (int)rows, c, cw, rp, hw, mean, rstd, gamma, beta, act, y, pool, sg);
+    else LAUNCH_ACT(bn_act_pool_fwd_kernel, 1, act, grid, dim3(256), stream, x, (int)rows, c, cw, rp, hw, mean, rstd, gamma, beta, act, y, pool, sg);
     return check_launch("suhpe_bn_act_pool_fwd");
 }
 
@@ -1856,8 +1879,8 @@ int suhpe_bn_act_scale_fwd(const float* x, int64_t rows, int64_t rows_a, int c, 
     const int n = (int)(rows / hw), n_a = (int)(rows_a / hw);
     const bool v4 = vec4_ok(c, x, s, y);
     const EwGeom g = ew_geom(hw, c, v4 ? 4 : 1);
-    if (v4) LAUNCH(bn_act_scale_fwd_kernel<4>, dim3(g.gx, g.ny, n), dim3(256), stream, x, hw, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta, act, s, n_a, y);
-    else LAUNCH(bn_act_scale_fwd_kernel<1>, dim3(g.gx, g.ny, n), dim3(256), stream, x, hw, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta, act, s, n_a, y);
+    if (v4) LAUNCH_ACT(bn_act_scale_fwd_kernel, 4, act, dim3(g.gx, g.ny, n), dim3(256), stream, x, hw, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta, act, s, n_a, y);
+    else LAUNCH_ACT(bn_act_scale_fwd_kernel, 1, act, dim3(g.gx, g.ny, n), dim3(256), stream, x, hw, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta, act, s, n_a, y);
     return check_launch("suhpe_bn_act_scale_fwd");
 }
 
@@ -1867,8 +1890,8 @@ int suhpe_se_bn_bwd_reduce(const float* x, const float* dout, int64_t rows, int6
     const int n = (int)(rows / hw), n_a = (int)(rows_a / hw);
     const int vec = (vec4_ok(c, x, dout, sums)) ? 4 : 1;
     const int cv = c / vec, cw = cv < 32 ? cv : 32, ny = (cv + cw - 1) / cw, rp = 256 / cw;
-    if (vec == 4) LAUNCH(se_bn_bwd_reduce_kernel<4>, dim3(n, ny), dim3(256), stream, x, dout, n, hw, c, cw, rp, mean, rstd, gamma, beta, act, n_a, sums);
-    else LAUNCH(se_bn_bwd_reduce_kernel<1>, dim3(n, ny), dim3(256), stream, x, dout, n, hw, c, cw, rp, mean, rstd, gamma, beta, act, n_a, sums);
+    if (vec == 4) LAUNCH_ACT(se_bn_bwd_reduce_kernel, 4, act, dim3(n, ny), dim3(256), stream, x, dout, n, hw, c, cw, rp, mean, rstd, gamma, beta, act, n_a, sums);
+    else LAUNCH_ACT(se_bn_bwd_reduce_kernel, 1, act, dim3(n, ny), dim3(256), stream, x, dout, n, hw, c, cw, rp, mean, rstd, gamma, beta, act, n_a, sums);
     return check_launch("suhpe_se_bn_bwd_reduce");
 }
 
@@ -1888,9 +1911,9 @@ int suhpe_se_bn_bwd_apply(const float* x, const float* dout, int64_t rows, int64
     const bool v4 = vec4_ok(c, x, dout, dy) && vec4_ok(c, s, dpool);
     const EwGeom g = ew_geom(hw, c, v4 ? 4 : 1);
     const float inv_a = 1.0f / (float)(rows_a > 0 ? rows_a : rows), inv_b = 1.0f / (float)(rows - rows_a);
-    if (v4) LAUNCH(se_bn_bwd_apply_kernel<4>, dim3(g.gx, g.ny, n), dim3(256), stream, x, dout, hw, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta, act,
+    if (v4) LAUNCH_ACT(se_bn_bwd_apply_kernel, 4, act, dim3(g.gx, g.ny, n), dim3(256), stream, x, dout, hw, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta, act,
                    s, dpool, chan, n_a, inv_a, inv_b, train_stats, dy);
-    else LAUNCH(se_bn_bwd_apply_kernel<1>, dim3(g.gx, g.ny, n), dim3(256), stream, x, dout, hw, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta, act,
+    else LAUNCH_ACT(se_bn_bwd_apply_kernel, 1, act, dim3(g.gx, g.ny, n), dim3(256), stream, x, dout, hw, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta, act,
                 s, dpool, chan, n_a, inv_a, inv_b, train_stats, dy);
     return check_launch("suhpe_se_bn_bwd_apply");
 }
@@ -1912,16 +1935,16 @@ int suhpe_bn_act_bwd_seg(const float* x, const float* dy, const float* y_out, in
     const SegArgs se{rows_a, ex_a, kRevSecondPass};
     const float inv_a = 1.0f / (float)rows_a, inv_b = 1.0f / (float)(rows - rows_a);
     if (vec == 4) {
-        LAUNCH(bn_bwd_partial<4>, dim3(gx_a + gx_b, g.ny), dim3(256), stream, x, dy, y_out, rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta,
+        LAUNCH_ACT(bn_bwd_partial, 4, act, dim3(gx_a + gx_b, g.ny), dim3(256), stream, x, dy, y_out, rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta,
                act, rowscale, hw, part, sg);
         LAUNCH(bn_bwd_finalize2, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, gx_a, gx_a + gx_b, c, sums, dgamma, dbeta, accumulate);
-        LAUNCH(bn_bwd_apply<4>, dim3(ex_a + ex_b, e.ny), dim3(256), stream, x, dy, y_out, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd, gamma,
+        LAUNCH_ACT(bn_bwd_apply, 4, act, dim3(ex_a + ex_b, e.ny), dim3(256), stream, x, dy, y_out, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd, gamma,
                beta, act, sums, inv_a, 1, rowscale, hw, dx, se, inv_b);
     } else {
-        LAUNCH(bn_bwd_partial<1>, dim3(gx_a + gx_b, g.ny), dim3(256), stream, x, dy, y_out, rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta,
+        LAUNCH_ACT(bn_bwd_partial, 1, act, dim3(gx_a + gx_b, g.ny), dim3(256), stream, x, dy, y_out, rows, c, g.cw, g.rp, g.rows_per_block, mean, rstd, gamma, beta,
                act, rowscale, hw, part, sg);
         LAUNCH(bn_bwd_finalize2, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, gx_a, gx_a + gx_b, c, sums, dgamma, dbeta, accumulate);
-        LAUNCH(bn_bwd_apply<1>, dim3(ex_a + ex_b, e.ny), dim3(256), stream, x, dy, y_out, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd, gamma,
+        LAUNCH_ACT(bn_bwd_apply, 1, act, dim3(ex_a + ex_b, e.ny), dim3(256), stream, x, dy, y_out, (int)rows, c, e.cw, e.rp, e.rows_per_block, mean, rstd, gamma,
                beta, act, sums, inv_a, 1, rowscale, hw, dx, se, inv_b);
     }
     return check_launch("suhpe_bn_act_bwd_seg");
