@@ -448,6 +448,198 @@ __global__ __launch_bounds__(256) void dw3x3_s1_kernel(const float* __restrict__
     }
 }
 
+// ---- small square feature maps (14 x 14, 7 x 7: every MBConv stage of EfficientNetV2-S, the last two TinyViT stages): whole images in LDS.
+// The sliding-window kernel above keeps one column step of loads in flight per thread -- a dependent chain of W steps -- and
+// reached 2.6-3.7 TB/s on these shapes (tools/ewbench.py).  Here a workgroup owns a 64-channel chunk and walks groups of whole images:
+// the group's pixels are loaded with EVERY load issued up front (HW*HW*imgs/16 independent 16-byte loads per thread), written
+// into an LDS image with a zero ring (padding needs no predicate, the input transform is applied once per element on the way in),
+// and while the 3 x 3 windows of that group are computed from LDS -- thread = (channel vector, image row), the row is walked with
+// the window in registers, three ds_read_b128 per output -- the NEXT group's loads are already in flight.  tools/proto/dw_lab.hip:
+// 160 x 14 x 14 x 960: 63 -> 45 us.  LDS: 16 consecutive lanes read 256 contiguous bytes, rows are a multiple of 256 B apart: no conflicts.
+constexpr int kTileSlots = 16;                       // image rows per workgroup pass = 256 threads / 16 channel vectors
+template <int HW> struct DwTile {
+    static constexpr int imgs = kTileSlots / HW;                                   // whole images per group (14 -> 1, 7 -> 2)
+    static constexpr int npix = imgs * HW * HW;
+    static constexpr int lpt = (npix + kTileSlots - 1) / kTileSlots;               // interior loads per thread and group
+    static constexpr int wp = HW + 2;
+    static constexpr int lds_bytes = imgs * wp * wp * 64 * 4;
+};
+
+template <int HW, bool XF, bool STATS, bool BNB, int ACTC>
+__global__ __launch_bounds__(256, (HW == 14 || BNB || (XF && STATS)) ? 2 : 3) void dw3x3_tile_kernel(const float* __restrict__ src, const float* __restrict__ w, float* __restrict__ dst, int N, int C,
+                                                         int flip, int ngroups, const DwXform xform, float* __restrict__ stats, int seg_n,
+                                                         const DwBnb bnb) {
+    using T = DwTile<HW>;
+    constexpr int WP = T::wp, LPT = T::lpt;
+    extern __shared__ __attribute__((aligned(16))) float tile[];          // [imgs][HW+2][HW+2][64]
+    const int t = threadIdx.x, vc = t & 15, slot = t >> 4;
+    const int col0 = blockIdx.y * 16, c0 = (col0 + vc) * 4;
+    const bool cok = c0 < C;
+    for (int i = t; i < T::imgs * WP * WP * 16; i += 256) reinterpret_cast<float4*>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 wv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int kk = flip ? 8 - k : k;
+        wv[k] = cok ? make_float4(w[(int64_t)(c0 + 0) * 9 + kk], w[(int64_t)(c0 + 1) * 9 + kk], w[(int64_t)(c0 + 2) * 9 + kk], w[(int64_t)(c0 + 3) * 9 + kk])
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // input transform of the two batch segments (XF) / BatchNorm of the backward sums (BNB): both sets stay in registers
+    const int xact = ACTC >= 0 ? ACTC : xform.act;
+    DwXf4 xfa = dw_xf_load(xform, cok ? c0 : 0, 0), xfb = xfa;
+    if (XF && xform.seg_n > 0) xfb = dw_xf_load(xform, cok ? c0 : 0, 1);
+    // (a thread's images come in increasing order: the statistics set and the running sums switch once, at the segment boundary)
+    float b_mu[4], b_rs[4], b_ga[4], b_be[4], b_s0[4] = {0.f, 0.f, 0.f, 0.f}, b_s1[4] = {0.f, 0.f, 0.f, 0.f}, b_a0[4] = {0.f, 0.f, 0.f, 0.f},
+          b_a1[4] = {0.f, 0.f, 0.f, 0.f};
+    bool b_crossed = false;
+    if (BNB) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int ch = cok ? c0 + v : 0;
+            b_mu[v] = bnb.mean[ch]; b_rs[v] = bnb.rstd[ch];
+            b_ga[v] = bnb.gamma ? bnb.gamma[ch] : 1.f; b_be[v] = bnb.beta ? bnb.beta[ch] : 0.f;
+        }
+    }
+    const int bact = ACTC >= 0 ? ACTC : bnb.act;
+    DwStat st_a, st;
+    bool crossed = false;
+    if (STATS) { dw_stat_zero(st_a); dw_stat_zero(st); }
+
+    float4 pf[LPT];
+    auto issue = [&](int g) __attribute__((always_inline)) {
+        const int64_t p0 = (int64_t)g * T::npix;
+#pragma unroll
+        for (int k = 0; k < LPT; ++k) {
+            const int q = slot + kTileSlots * k;
+            const int64_t pix = p0 + q;
+            const bool ok = cok && q < T::npix && pix < (int64_t)N * HW * HW;
+            pf[k] = ok ? *reinterpret_cast<const float4*>(src + pix * C + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    int g = blockIdx.x;
+    if (g < ngroups) issue(g);
+    __syncthreads();
+    const int img = slot / HW, row = slot - img * HW;
+    const bool crow = slot < T::imgs * HW;
+    for (; g < ngroups; g += gridDim.x) {
+#pragma unroll
+        for (int k = 0; k < LPT; ++k) {
+            const int q = slot + kTileSlots * k;
+            if (q >= T::npix) continue;
+            const int qi = q / (HW * HW), rem = q - qi * HW * HW, h = rem / HW, x = rem - h * HW;
+            float4 v = pf[k];
+            if (XF) {
+                const int64_t n = (int64_t)g * T::imgs + qi;
+                const bool second = xform.seg_n > 0 && n >= xform.seg_n;
+                float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = dw_act(o[e] * (second ? xfb.sc[e] : xfa.sc[e]) + (second ? xfb.sh[e] : xfa.sh[e]), xact);
+                const bool ok = cok && n < N;                                  // images past the batch stay zero, not act(shift)
+                v = ok ? make_float4(o[0], o[1], o[2], o[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            *reinterpret_cast<float4*>(&tile[((qi * WP + h + 1) * WP + x + 1) * 64 + vc * 4]) = v;
+        }
+        __syncthreads();
+        if (g + (int)gridDim.x < ngroups) issue(g + gridDim.x);
+        const int64_t n = (int64_t)g * T::imgs + img;
+        if (crow && cok && n < N) {
+            if (STATS && seg_n > 0 && !crossed && n >= seg_n) { st_a = st; dw_stat_zero(st); crossed = true; }
+            if (BNB && bnb.seg_n > 0 && !b_crossed && n >= bnb.seg_n) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    b_a0[v] = b_s0[v]; b_a1[v] = b_s1[v]; b_s0[v] = 0.f; b_s1[v] = 0.f;
+                    b_mu[v] = bnb.mean[C + c0 + v]; b_rs[v] = bnb.rstd[C + c0 + v];
+                }
+                b_crossed = true;
+            }
+            // BNB: the BatchNorm input at the output positions, three column steps ahead of its use
+            const float* bxp = BNB ? bnb.x + ((n * HW + row) * HW) * C + c0 : nullptr;
+            float4 bx0 = make_float4(0.f, 0.f, 0.f, 0.f), bx1 = bx0, bx2 = bx0;
+            if (BNB) {
+                bx0 = *reinterpret_cast<const float4*>(bxp);
+                bx1 = *reinterpret_cast<const float4*>(bxp + (int64_t)1 * C);
+                bx2 = *reinterpret_cast<const float4*>(bxp + (int64_t)2 * C);
+            }
+            const float* base = &tile[((img * WP + row) * WP) * 64 + vc * 4];      // padded (row, column 0): the window's top-left corner
+            float4 a[3], b[3], c[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                a[r] = *reinterpret_cast<const float4*>(base + (r * WP + 0) * 64);
+                b[r] = *reinterpret_cast<const float4*>(base + (r * WP + 1) * 64);
+            }
+            float* out = dst + ((n * HW + row) * HW) * C + c0;
+#pragma unroll 1
+            for (int ow = 0; ow < HW; ++ow) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) c[r] = *reinterpret_cast<const float4*>(base + (r * WP + ow + 2) * 64);
+                const float4 bxc = bx0;
+                if (BNB) {
+                    bx0 = bx1; bx1 = bx2;
+                    bx2 = *reinterpret_cast<const float4*>(bxp + (int64_t)(ow + 3 < HW ? ow + 3 : HW - 1) * C);
+                }
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { fma4(acc, a[r], wv[r * 3]); fma4(acc, b[r], wv[r * 3 + 1]); fma4(acc, c[r], wv[r * 3 + 2]); }
+                *reinterpret_cast<float4*>(out + (int64_t)ow * C) = acc;
+                const float o[4] = {acc.x, acc.y, acc.z, acc.w};
+                if (STATS) dw_stat_add(st, o);
+                if (BNB) {
+                    const float xv[4] = {bxc.x, bxc.y, bxc.z, bxc.w};
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const float xh = (xv[v] - b_mu[v]) * b_rs[v];
+                        const float gg = o[v] * act_grad(xh * b_ga[v] + b_be[v], bact);
+                        b_s0[v] += gg;
+                        b_s1[v] += gg * xh;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { a[r] = b[r]; b[r] = c[r]; }
+            }
+        }
+        __syncthreads();
+    }
+    const bool active = crow && cok;
+    if (BNB) {
+        // threads that share a channel vector, added in a fixed order; records [plane][blockIdx.x][C] float2 (bn_bwd_partial's format)
+        const bool two = bnb.seg_n > 0;
+        if (two && !b_crossed) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { b_a0[v] = b_s0[v]; b_a1[v] = b_s1[v]; b_s0[v] = 0.f; b_s1[v] = 0.f; }
+        }
+        float* scratch = tile;
+        for (int plane = 0; plane < (two ? 2 : 1); ++plane) {
+            const float* q0 = (two && plane == 0) ? b_a0 : b_s0;
+            const float* q1 = (two && plane == 0) ? b_a1 : b_s1;
+            __syncthreads();
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { scratch[t * 8 + v] = active ? q0[v] : 0.f; scratch[t * 8 + 4 + v] = active ? q1[v] : 0.f; }
+            __syncthreads();
+            if (t < 16 && (col0 + t) * 4 < C) {
+                float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int r = 0; r < kTileSlots; ++r) {
+                    const float* e = &scratch[(r * 16 + t) * 8];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) { a0[v] += e[v]; a1[v] += e[4 + v]; }
+                }
+                float2* rec = reinterpret_cast<float2*>(bnb.part) + ((int64_t)plane * gridDim.x + blockIdx.x) * C + (col0 + t) * 4;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) rec[v] = make_float2(a0[v], a1[v]);
+            }
+        }
+    }
+    if (STATS) {
+        const bool two = seg_n > 0;
+        if (two && !crossed) { st_a = st; dw_stat_zero(st); }          // everything this thread produced lies in the first segment
+        float* rec = stats + (int64_t)blockIdx.x * C * 4;
+        if (two) {
+            dw_stat_emit(st_a, active, 16, kTileSlots, vc, col0, C, rec, tile);
+            dw_stat_emit(st, active, 16, kTileSlots, vc, col0, C, rec + (int64_t)gridDim.x * C * 4, tile);
+        } else {
+            dw_stat_emit(st, active, 16, kTileSlots, vc, col0, C, rec, tile);
+        }
+    }
+}
+
 // filter-gradient partials with the same sliding window: part[bx][tap][c]
 template <bool XF>
 __global__ __launch_bounds__(256) void dw3x3_wgrad_row_kernel(const float* __restrict__ x_, const float* __restrict__ dy, float* __restrict__ part,
@@ -633,6 +825,40 @@ using namespace suhpe;
         else hipLaunchKernelGGL((kern<false>), grid, block, lds, st, __VA_ARGS__);                       \
     } while (0)
 
+// ---- the image-tile kernel's descriptors and grid: 3x3 / pad 1 / stride 1 on 14 x 14 or 7 x 7 maps (SUHPE_DW_TILE=0: off)
+static const bool kDwTile = !(getenv("SUHPE_DW_TILE") && atoi(getenv("SUHPE_DW_TILE")) == 0);
+static int dw_tile_hw(const suhpe_conv_t* d) {
+    if (!kDwTile || !dw_fast(d) || d->stride != 1 || d->h != d->w || !(d->h == 14 || d->h == 7)) return 0;
+    return d->h;
+}
+// persistent workgroups: as many as stay resident at once (64 KB / 41 KB of LDS each), every one the same number of image groups
+static void dw_tile_grid(const suhpe_conv_t* d, int hw, int* gx, int* ny, int* ngroups) {
+    const int imgs = kTileSlots / hw;
+    *ngroups = (d->n + imgs - 1) / imgs;
+    *ny = (d->cin / 4 + 15) / 16;
+    const int64_t slots = 256 * (hw == 14 ? 2 : 3);
+    const int64_t iters = ceil_div((int64_t)*ngroups * *ny, slots);
+    *gx = (int)ceil_div((int64_t)*ngroups, iters < 1 ? 1 : iters);
+}
+template <int HW, bool XF, bool STATS, bool BNB>
+static void launch_dw_tile(const suhpe_conv_t* d, const float* src, const float* w, float* dst, int flip, const DwXform& xf, float* stats, int seg_n,
+                           const DwBnb& bnb, int act, hipStream_t st) {
+    int gx, ny, ngroups;
+    dw_tile_grid(d, HW, &gx, &ny, &ngroups);
+    auto go = [&](auto kern) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, DwTile<HW>::lds_bytes);
+        hipLaunchKernelGGL(kern, dim3(gx, ny), dim3(256), DwTile<HW>::lds_bytes, st, src, w, dst, d->n, d->cin, flip, ngroups, xf, stats, seg_n, bnb);
+    };
+    if ((XF || BNB) && act == SUHPE_ACT_SILU) go(dw3x3_tile_kernel<HW, XF, STATS, BNB, SUHPE_ACT_SILU>);
+    else go(dw3x3_tile_kernel<HW, XF, STATS, BNB, -1>);
+}
+template <bool XF, bool STATS, bool BNB>
+static void launch_dw_tile_hw(int hw, const suhpe_conv_t* d, const float* src, const float* w, float* dst, int flip, const DwXform& xf, float* stats,
+                              int seg_n, const DwBnb& bnb, int act, hipStream_t st) {
+    if (hw == 14) launch_dw_tile<14, XF, STATS, BNB>(d, src, w, dst, flip, xf, stats, seg_n, bnb, act, st);
+    else launch_dw_tile<7, XF, STATS, BNB>(d, src, w, dst, flip, xf, stats, seg_n, bnb, act, st);
+}
+
 extern "C" {
 
 // grid of the fast 3x3 forward kernels (shared by the launch and by suhpe_dwconv_fwd_stats_blocks)
@@ -653,6 +879,17 @@ static int dwconv_fwd_impl(const suhpe_conv_t* d, const float* x, const float* w
     const bool DW_XF_ON = xf.mean != nullptr;
     bool s1;
     int cw, rp, gx, ny;
+    if (const int thw = dw_tile_hw(d)) {
+        const DwBnb nb{};
+        if (DW_XF_ON) {
+            if (stats) launch_dw_tile_hw<true, true, false>(thw, d, x, w, y, 0, xf, stats, seg_n, nb, xf.act, as_stream(stream));
+            else launch_dw_tile_hw<true, false, false>(thw, d, x, w, y, 0, xf, stats, seg_n, nb, xf.act, as_stream(stream));
+        } else {
+            if (stats) launch_dw_tile_hw<false, true, false>(thw, d, x, w, y, 0, xf, stats, seg_n, nb, 0, as_stream(stream));
+            else launch_dw_tile_hw<false, false, false>(thw, d, x, w, y, 0, xf, stats, seg_n, nb, 0, as_stream(stream));
+        }
+        return check_launch(stats ? "suhpe_dwconv_fwd_stats" : "suhpe_dwconv_fwd");
+    }
     if (dw_fwd_fast_grid(d, &s1, &cw, &rp, &gx, &ny)) {
         if (stats) {
 #define DW_LAUNCH_STATS(kern, ...)                                                                                          \
@@ -692,6 +929,11 @@ int suhpe_dwconv_fwd_stats_blocks(const suhpe_conv_t* d) {
     if (!d || dw_check(d, "suhpe_dwconv_fwd_stats_blocks")) return 0;
     bool s1;
     int cw, rp, gx, ny;
+    if (const int thw = dw_tile_hw(d)) {
+        int ngroups;
+        dw_tile_grid(d, thw, &gx, &ny, &ngroups);
+        return gx;
+    }
     return dw_fwd_fast_grid(d, &s1, &cw, &rp, &gx, &ny) ? gx : 0;
 }
 
@@ -713,6 +955,10 @@ int suhpe_dwconv_dgrad(const suhpe_conv_t* d, const float* dy, const float* w, f
     if (rc) return rc;
     SUHPE_REQUIRE(dy && w && dx, "suhpe_dwconv_dgrad: null pointer");
     const bool DW_XF_ON = false;
+    if (const int thw = dw_tile_hw(d)) {
+        launch_dw_tile_hw<false, false, false>(thw, d, dy, w, dx, 1, kNoXform, nullptr, 0, DwBnb{}, 0, as_stream(stream));
+        return check_launch("suhpe_dwconv_dgrad");
+    }
     if (dw_fast(d) && d->stride == 1) {             // same conv on dy with the 180-degree rotated filter
         int cw, rp, gx, ny;
         const bool s1 = (int64_t)d->n * d->h * d->w * d->cin * 4 < ((int64_t)1 << 31) &&
@@ -734,6 +980,7 @@ int suhpe_dwconv_dgrad(const suhpe_conv_t* d, const float* dy, const float* w, f
 
 // which descriptors suhpe_dwconv_dgrad_bnsums serves: the sliding-window stride-1 kernel's (3x3 / pad 1 / stride 1, large tensors)
 static bool dw_bnsums_ok(const suhpe_conv_t* d) {
+    if (d && d->cin % 4 == 0 && dw_tile_hw(d)) return true;
     return d && dw_fast(d) && d->stride == 1 && d->cin % 4 == 0 && (int64_t)d->n * d->h * d->w * d->cin * 4 < ((int64_t)1 << 31) &&
            (int64_t)d->n * ((d->h + kDwRows - 1) / kDwRows) * (d->cin / 4) >= 65536;
 }
@@ -743,7 +990,12 @@ int suhpe_dwconv_dgrad_bnsums_ok(const suhpe_conv_t* d) { return dw_bnsums_ok(d)
 int64_t suhpe_dwconv_dgrad_bnsums_workspace_bytes(const suhpe_conv_t* d) {
     if (!dw_bnsums_ok(d)) return 0;
     int cw, rp, gx, ny;
-    dw_row_grid(d->cin, d->n * ((d->h + kDwRows - 1) / kDwRows), 4096, &cw, &rp, &gx, &ny);
+    if (const int thw = dw_tile_hw(d)) {
+        int ngroups;
+        dw_tile_grid(d, thw, &gx, &ny, &ngroups);
+    } else {
+        dw_row_grid(d->cin, d->n * ((d->h + kDwRows - 1) / kDwRows), 4096, &cw, &rp, &gx, &ny);
+    }
     return (int64_t)2 * gx * d->cin * 2 * sizeof(float);
 }
 
@@ -760,11 +1012,17 @@ int suhpe_dwconv_dgrad_bnsums(const suhpe_conv_t* d, const float* dy, const floa
         return SUHPE_EWORKSPACE;
     }
     int cw, rp, gx, ny;
-    dw_row_grid(d->cin, d->n * ((d->h + kDwRows - 1) / kDwRows), 4096, &cw, &rp, &gx, &ny);
     float* part = static_cast<float*>(workspace);
     const DwBnb bnb{bn_x, mean, rstd, gamma, beta, act, seg_n, part};
-    hipLaunchKernelGGL((dw3x3_s1_kernel<false, false, true>), dim3(gx, ny), dim3(256), 0, as_stream(stream), dy, (int64_t)d->n * d->h * d->w * d->cin * 4, w,
-                       dx, d->n, d->h, d->w, d->cin, 1, cw, rp, kNoXform, nullptr, 0, bnb);
+    if (const int thw = dw_tile_hw(d)) {
+        int ngroups;
+        dw_tile_grid(d, thw, &gx, &ny, &ngroups);
+        launch_dw_tile_hw<false, false, true>(thw, d, dy, w, dx, 1, kNoXform, nullptr, 0, bnb, act, as_stream(stream));
+    } else {
+        dw_row_grid(d->cin, d->n * ((d->h + kDwRows - 1) / kDwRows), 4096, &cw, &rp, &gx, &ny);
+        hipLaunchKernelGGL((dw3x3_s1_kernel<false, false, true>), dim3(gx, ny), dim3(256), 0, as_stream(stream), dy, (int64_t)d->n * d->h * d->w * d->cin * 4,
+                           w, dx, d->n, d->h, d->w, d->cin, 1, cw, rp, kNoXform, nullptr, 0, bnb);
+    }
     // finish: (sum g, sum g xhat) per channel and segment -> sums [c][2] / [2][c][2], dgamma / dbeta (nn_elem.hip's finalisers)
     launch_bn_bwd_finalize(part, seg_n > 0 ? gx : 0, seg_n > 0 ? 2 * gx : gx, d->cin, sums, dgamma, dbeta, accumulate, as_stream(stream));
     return check_launch("suhpe_dwconv_dgrad_bnsums");

@@ -1102,3 +1102,23 @@ def test_rgb_stem_direct_conv(K, n, cout, hw, stride, seg):
         m2, r2 = K.bn_stats_from_partials(res[1], res[2], rows, cout, 1e-3, 0.1)
         m0, r0 = K.bn_stats(y0, cout, 1e-3, 0.1)
     assert (m2 - m0).abs().max().item() < 2e-6 and rel(r2, r0.cpu()) < 2e-6
+
+
+@pytest.mark.parametrize("n,h,c", [(3, 7, 20), (5, 14, 96), (33, 7, 1536), (9, 14, 960), (2, 14, 64), (1, 7, 4)])
+def test_depthwise_image_tile_kernel_against_torch(K, n, h, c):
+    """dw3x3_tile_kernel (3x3 / stride 1 / pad 1 on 14 x 14 and 7 x 7 maps: whole images staged in LDS, persistent workgroups over image
+    groups): forward and input gradient against torch's fp64 depthwise convolution -- partial last groups (odd n on 7 x 7 maps), channel
+    counts that are not multiples of the 64-channel chunk, more groups than resident workgroups"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(n * 1000 + c)
+    x = torch.randn(n, c, h, h, generator=g, dtype=torch.float64)
+    w = torch.randn(c, 1, 3, 3, generator=g, dtype=torch.float64) / 3
+    dy = torch.randn(n, c, h, h, generator=g, dtype=torch.float64)
+    y_ref = F.conv2d(x, w, None, 1, 1, 1, c).permute(0, 2, 3, 1)
+    dx_ref = torch.nn.grad.conv2d_input(x.shape, w, dy, 1, 1, 1, c).permute(0, 2, 3, 1)
+    xg = x.permute(0, 2, 3, 1).contiguous().float().cuda()
+    dyg = dy.permute(0, 2, 3, 1).contiguous().float().cuda()
+    wg = K.to_filter_layout(w.float().cuda())
+    y = K.conv2d_fwd(xg, wg, None, 1, 1, c)
+    dx = K.conv2d_dgrad(dyg, wg, xg.shape, 1, 1, c)
+    assert rel(y, y_ref) < 2e-6 and rel(dx, dx_ref) < 2e-6
