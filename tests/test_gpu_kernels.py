@@ -1107,7 +1107,7 @@ def test_rgb_stem_direct_conv(K, n, cout, hw, stride, seg):
 @pytest.mark.parametrize("n,h,c", [(3, 7, 20), (5, 14, 96), (33, 7, 1536), (9, 14, 960), (2, 14, 64), (1, 7, 4)])
 def test_depthwise_image_tile_kernel_against_torch(K, n, h, c):
     """dw3x3_tile_kernel (3x3 / stride 1 / pad 1 on 14 x 14 and 7 x 7 maps: whole images staged in LDS, persistent workgroups over image
-    groups): forward and input gradient against torch's fp64 depthwise convolution -- partial last groups (odd n on 7 x 7 maps), channel
+    groups): forward, input gradient and filter gradient (dw3x3_wgrad_tile_kernel) against torch's fp64 depthwise convolution -- partial last groups (odd n on 7 x 7 maps), channel
     counts that are not multiples of the 64-channel chunk, more groups than resident workgroups"""
     import torch.nn.functional as F
     g = torch.Generator().manual_seed(n * 1000 + c)
@@ -1122,3 +1122,6 @@ def test_depthwise_image_tile_kernel_against_torch(K, n, h, c):
     y = K.conv2d_fwd(xg, wg, None, 1, 1, c)
     dx = K.conv2d_dgrad(dyg, wg, xg.shape, 1, 1, c)
     assert rel(y, y_ref) < 2e-6 and rel(dx, dx_ref) < 2e-6
+    dw_ref = torch.nn.grad.conv2d_weight(x, w.shape, dy, 1, 1, 1, c)
+    dw = K.conv2d_wgrad(xg, dyg, wg.shape, 1, 1, c)
+    assert rel(dw, dw_ref) < 5e-6
