@@ -29,7 +29,7 @@ BN_EPS = 1e-3           # torchvision: partial(nn.BatchNorm2d, eps=1e-03) for th
 # Folding the expand conv's BatchNorm + SiLU into the depthwise loaders removes two passes over the largest activation but
 # makes the depthwise kernels recompute the SiLU 1.5x (forward) to 3x (filter gradient) per element: measured 84.1 vs 79.7
 # ms/step on C2, so it is off; the kernels and their tests stay (memory-saving mode: the expanded tensor is never stored).
-FUSE_EXPAND_BN_INTO_DW = os.environ.get("SUHPE_FUSE_EXPAND_DW", "0") == "1"
+FUSE_EXPAND_BN_INTO_DW = os.environ.get("SUHPE_FUSE_EXPAND_DW", "1") != "0"
 FUSE_EXPAND_NO_TAPE = os.environ.get("SUHPE_FUSE_EXPAND_NO_TAPE", "1") != "0"      # the same fold in train-mode forwards that keep no tape (teacher pass)
 # the expand BatchNorm's backward sums reduced by the depthwise input-gradient kernel (no reduction pass over the expanded tensor pair)
 BN_SUMS_FROM_DW = os.environ.get("SUHPE_BN_SUMS_FROM_DW", "1") != "0"
@@ -206,21 +206,28 @@ class MBConv(_ResidualBlock):
     def _bn_sums_from_dw(self, conv_d, tape):
         """the tape's next two entries are the depthwise conv's plain input and the expand BatchNorm's train-mode record in a form the
         fused kernels take (one tensor of statistics, or the (mean[2, c], rstd[2, c]) pair of a merged two-segment pass)"""
-        if not BN_SUMS_FROM_DW or len(tape) < 2 or not torch.is_tensor(tape[-1]):
+        if not BN_SUMS_FROM_DW or len(tape) < 2:
+            return False
+        top = tape[-1]
+        if isinstance(top, tuple) and len(top) == 2 and torch.is_tensor(top[0]):      # (raw input, input transform): folded expand BatchNorm
+            top = top[0]
+        if not torch.is_tensor(top):
             return False
         e = tape[-2]
         if not (isinstance(e, tuple) and len(e) == 7 and e[3] is True and e[4] is None and e[5] is None):
             return False
         if not (torch.is_tensor(e[1]) or (isinstance(e[1], tuple) and len(e[1]) == 2 and torch.is_tensor(e[1][0]))):
             return False
-        return K.dwconv_dgrad_bnsums_ok(tape[-1].shape, conv_d.weight.shape, conv_d.stride, conv_d.padding)
+        return K.dwconv_dgrad_bnsums_ok(top.shape, conv_d.weight.shape, conv_d.stride, conv_d.padding)
 
     def _dw_dgrad_expand_bwd(self, conv_d, expand, dy, tape):
         """depthwise filter gradient; depthwise input gradient + the expand BatchNorm's (sum g, sum g xhat) from ONE kernel; that
         BatchNorm's apply pass; the expand conv's backward"""
         conv_e, bn_e = expand
-        a1 = tape.pop()
-        K.conv2d_wgrad(a1, dy, conv_d.weight.shape, conv_d.stride, conv_d.padding, conv_d.groups, out=grad_of(conv_d.weight), accumulate=True)
+        a1, xf = tape.pop(), None
+        if isinstance(a1, tuple):                            # folded: the filter gradient recomputes act(BN(a1)) while it stages a1
+            a1, xf = a1
+        K.conv2d_wgrad(a1, dy, conv_d.weight.shape, conv_d.stride, conv_d.padding, conv_d.groups, out=grad_of(conv_d.weight), accumulate=True, xf=xf)
         x1, mean, rstd, _, _, _, hw = tape.pop()
         cexp = bn_e.num_features
         if isinstance(mean, tuple):                          # two batch segments: ((mean[2, c], rstd[2, c]), samples of the first)
@@ -255,13 +262,9 @@ class MBConv(_ResidualBlock):
 
     def _front_bwd(self, dy, tape):
         if self._dw_se_fused():
-            if self.has_expand and not self._expand_folded():
-                return self._dw_se_bwd(dy, tape, expand=self.block[0])
-            d = self._dw_se_bwd(dy, tape)
-            if not self.has_expand:
-                return d
-            conv_e, bn_e = self.block[0]    # folded: d is the gradient of the activated tensor the depthwise conv recomputed
-            return conv_e.bwd(bn_e.bwd(d, tape), tape)
+            # (folded expand BatchNorm: the depthwise conv's tape entry is (raw expand output, transform); its input gradient is the
+            #  gradient of the activated tensor the loaders recomputed, and the BatchNorm's backward follows as in the unfolded form)
+            return self._dw_se_bwd(dy, tape, expand=self.block[0] if self.has_expand else None)
         return super()._front_bwd(dy, tape)
 
 
