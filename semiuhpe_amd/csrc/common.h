@@ -92,12 +92,24 @@ template <int VEC> __device__ __forceinline__ void buf_load(BufRsrc r, unsigned 
 __device__ __forceinline__ float fast_sigmoid(float u) {
     return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * u));
 }
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, i.e. fp32 resolution of the GELU it feeds) on the same two
+// transcendentals; *e receives exp(-x^2), which GELU' needs as well (libm's erff is ~30 VALU instructions + an expf for the density).
+__device__ __forceinline__ float fast_erf(float x, float* e) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    *e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+    return copysignf(1.f - p * t * *e, x);
+}
 __device__ __forceinline__ float act_apply(float u, int act) {
     switch (act) {
         case SUHPE_ACT_RELU: return u > 0.f ? u : 0.f;
         case SUHPE_ACT_RELU6: return fminf(fmaxf(u, 0.f), 6.f);
         case SUHPE_ACT_SILU: return u * fast_sigmoid(u);
-        case SUHPE_ACT_GELU: return 0.5f * u * (1.f + erff(u * 0.70710678118654752f));
+        case SUHPE_ACT_GELU: { float e; return 0.5f * u * (1.f + fast_erf(u * 0.70710678118654752f, &e)); }
         case SUHPE_ACT_SIGMOID: return fast_sigmoid(u);
         default: return u;
     }
@@ -112,8 +124,9 @@ __device__ __forceinline__ float act_grad(float u, int act) {
             return s * (1.f + u * (1.f - s));
         }
         case SUHPE_ACT_GELU: {
-            const float cdf = 0.5f * (1.f + erff(u * 0.70710678118654752f));
-            return cdf + u * 0.3989422804014327f * expf(-0.5f * u * u);
+            float e;                                     // exp(-(u / sqrt 2)^2) = exp(-u^2 / 2): the density's exponential
+            const float cdf = 0.5f * (1.f + fast_erf(u * 0.70710678118654752f, &e));
+            return cdf + u * 0.3989422804014327f * e;
         }
         case SUHPE_ACT_SIGMOID: {
             const float s = fast_sigmoid(u);

@@ -1592,10 +1592,11 @@ static inline bool vec4_ok(int c, const void* a, const void* b = nullptr, const 
 using namespace suhpe;
 
 #define LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL(kern, grid, block, 0, as_stream(stream), __VA_ARGS__)
-// kernels with the activation as a template constant: SiLU (every BatchNorm of EfficientNetV2) gets its own instantiation
+// kernels with the activation as a template constant: SiLU (every BatchNorm of EfficientNetV2) and GELU (TinyViT) get their own instantiations
 #define LAUNCH_ACT(kern, VEC, act, grid, block, stream, ...)                                                                       \
     do {                                                                                                                            \
         if ((act) == SUHPE_ACT_SILU) hipLaunchKernelGGL((kern<VEC, SUHPE_ACT_SILU>), grid, block, 0, as_stream(stream), __VA_ARGS__); \
+        else if ((act) == SUHPE_ACT_GELU) hipLaunchKernelGGL((kern<VEC, SUHPE_ACT_GELU>), grid, block, 0, as_stream(stream), __VA_ARGS__); \
         else hipLaunchKernelGGL((kern<VEC, -1>), grid, block, 0, as_stream(stream), __VA_ARGS__);                                   \
     } while (0)
 
