@@ -143,6 +143,18 @@ int suhpe_conv2d_wgrad_partial_xf(const suhpe_conv_t* d, const float* x, const f
 int suhpe_conv2d_fwd_act2(const suhpe_conv_t* d, const float* x, const float* w, const float* bias, int act, float* y_pre, float* y_act,
                           suhpe_stream_t stream);
 int suhpe_conv2d_dgrad_actgrad(const suhpe_conv_t* d, const float* dy, const float* wt, const float* pre, int act, float* dx, suhpe_stream_t stream);
+/* Input gradient of a pointwise conv whose INPUT was act(BatchNorm(bn_x)) of a train-mode BatchNorm -- torchvision FusedMBConv: 3x3 expand
+ * conv -> BatchNorm -> SiLU -> 1x1 project conv (src/networks.py:303), where the forward applies that BatchNorm in the project conv's
+ * loader (suhpe_conv2d_fwd_stats_xf).  ONE launch writes g = dgrad(dy) * act'(bn_x * scale + shift), the gradient of the BatchNorm's
+ * OUTPUT, and reduces the BatchNorm backward's per-channel sums (sum g, sum g xhat) from the same epilogue (records per 128-row tile and
+ * batch segment in `workspace`, finished by the BatchNorm finaliser: sums [c][2] or [2][c][2], dgamma / dbeta accumulated).  What remains
+ * of that BatchNorm's backward is the apply pass over (bn_x, g) with activation NONE (suhpe_bn_act_bwd_apply / _seg): the separate
+ * reduction pass over the expanded tensors (two reads of the widest activations of the network) disappears.
+ * mean / rstd / scale / shift: [c] or, with seg_n > 0 (samples of the first batch segment), [2][c] as suhpe_bn_affine_from_stats writes them. */
+int64_t suhpe_conv2d_dgrad_bnbwd_workspace_bytes(const suhpe_conv_t* d);
+int suhpe_conv2d_dgrad_bnbwd(const suhpe_conv_t* d, const float* dy, const float* wt, const float* bn_x, const float* mean, const float* rstd,
+                             const float* scale, const float* shift, int act, int seg_n, float* g, float* sums, float* dgamma, float* dbeta,
+                             int accumulate, void* workspace, int64_t workspace_bytes, suhpe_stream_t stream);
 /* input gradient; wt is the transposed+flipped filter made by suhpe_conv2d_transpose_filter */
 int suhpe_conv2d_dgrad(const suhpe_conv_t* d, const float* dy, const float* wt, float* dx, suhpe_stream_t stream);
 /* the same input gradient with a skip connection's gradient added in the epilogue: dx = dgrad(dy) + skip (skip: the shape of dx,

@@ -276,29 +276,40 @@ void igemm_nt3x3_kernel(const NtParams p, const HaloGeom hg) {
     auto store_out = [&](auto aff) __attribute__((always_inline)) {
         constexpr bool AFF_ = decltype(aff)::value;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
+            int64_t orow[16];
+            bool rok[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (m0 + row >= g.M) continue;
-                const int64_t orow = PATCH ? halo_patch_orow(g, hg, m0, row) : m0 + row;
+                rok[e] = m0 + row < g.M;
+                orow[e] = PATCH ? halo_patch_orow(g, hg, m0, row) : m0 + row;
+            }
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int col = n0 + wn * WN + j * 32 + r32;
-                    if (col >= p.Ng) continue;
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * WN + j * 32 + r32;
+                if (col >= p.Ng) continue;
+                // residual loads (skip gradient of the block) ahead of the stores: they may alias y as far as the compiler knows
+                float rv[16];
+                if (p.res_mode) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) rv[e] = rok[e] ? p.residual[orow[e] * p.ldy + grp * p.Ng + col] : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if (!rok[e]) continue;
                     if constexpr (!AFF_) {
-                        y[orow * p.ldy + col] = acc[i][j][e] + (p.bias ? p.bias[grp * p.Ng + col] : 0.f) +
-                                                (p.res_mode == 3 ? p.residual[orow * p.ldy + grp * p.Ng + col] : 0.f);
+                        y[orow[e] * p.ldy + col] = acc[i][j][e] + (p.bias ? p.bias[grp * p.Ng + col] : 0.f) + (p.res_mode == 3 ? rv[e] : 0.f);
                     } else {
                         float v = acc[i][j][e] * p.scale[grp * p.Ng + col] + p.shift[grp * p.Ng + col];
-                        const float rv = p.res_mode ? p.residual[orow * p.ldy + grp * p.Ng + col] : 0.f;
-                        if (p.res_mode == 1) v += rv;
+                        if (p.res_mode == 1) v += rv[e];
                         v = act_apply(v, p.act);
-                        if (p.res_mode == 2) v += rv;
-                        y[orow * p.ldy + col] = v;
+                        if (p.res_mode == 2) v += rv[e];
+                        y[orow[e] * p.ldy + col] = v;
                     }
                 }
             }
+        }
     };
     store_out(std::integral_constant<bool, AFF>{});
 

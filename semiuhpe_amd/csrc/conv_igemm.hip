@@ -117,6 +117,11 @@ struct NtParams {
     //   y2 != NULL : y = acc + bias (the pre-activation, kept for the backward) AND y2 = act(y), from one epilogue;
     //   res_mode 4 : y = acc * act'(residual)  -- an input gradient multiplied by the activation's derivative at the saved pre-activation
     float* y2 = nullptr;
+    //   res_mode 5 : the conv's INPUT was act(BatchNorm(residual)) in train mode: y = g = acc * act'(residual * scale[s][c] + shift[s][c]), the
+    //                gradient of that BatchNorm's output, AND its backward sums (sum g, sum g xhat), xhat = (residual - bn_mean[s][c]) bn_rstd[s][c],
+    //                per (row tile, channel) as float2 records in `stats`: [plane s][row tile][channel] (s = batch segment of the row, seg_row)
+    const float* bn_mean = nullptr;
+    const float* bn_rstd = nullptr;
     // start-up stagger (see stagger_wait): workgroups of the first resident generation delay their first barrier by
     // (hardware wave slot) * stagger quanta so that co-resident workgroups run out of phase
     int stagger = 0, stagger_first = 0;
@@ -406,6 +411,23 @@ void igemm_nt_kernel(const NtParams p) {
     float* __restrict__ y = p.y + (int64_t)grp * p.Ng;
     // two compile-time copies of the store loop (plain / folded affine+activation+skip) behind one uniform branch, so the
     // plain path carries no per-element tests
+    // res_mode 5 (ACT2 instantiations): per column block the two segments' (rstd, -mean rstd, scale, shift) and this lane's running sums
+    float bn5[ACT2 ? TN : 1][2][4], sum5[ACT2 ? TN : 1][4];
+    if constexpr (ACT2) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * WN + j * 32 + r32;
+            const bool on = p.res_mode == 5 && col < p.Ng;
+#pragma unroll
+            for (int sset = 0; sset < 2; ++sset) {
+                const int ci = (sset && p.seg_row > 0 ? p.Ng : 0) + (on ? col : 0);
+                const float rs = on ? p.bn_rstd[ci] : 0.f, mu = on ? p.bn_mean[ci] : 0.f;
+                bn5[j][sset][0] = rs; bn5[j][sset][1] = -mu * rs;
+                bn5[j][sset][2] = on ? p.scale[ci] : 0.f; bn5[j][sset][3] = on ? p.shift[ci] : 0.f;
+            }
+            sum5[j][0] = sum5[j][1] = sum5[j][2] = sum5[j][3] = 0.f;
+        }
+    }
     auto store_out = [&](auto aff) __attribute__((always_inline)) {
         constexpr bool AFF_ = decltype(aff)::value;
 #pragma unroll
@@ -416,39 +438,93 @@ void igemm_nt_kernel(const NtParams p) {
             const float sc = AFF_ ? p.scale[grp * p.Ng + col] : 1.f;
             const float sh = AFF_ ? p.shift[grp * p.Ng + col] : 0.f;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
+                auto out_row = [&](int e, int64_t* row) __attribute__((always_inline)) -> int64_t {
+                    *row = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (MODE != 3) return *row;
+                    // sub-grid row (n,a,b) -> pixel (n, a*om+ph, b*om+pw) of the full output
+                    const unsigned n = fast_div((unsigned)*row, g.div_hw_mul, g.div_hw_shr);
+                    const unsigned rem = (unsigned)*row - n * (unsigned)(g.OH * g.OW);
+                    const unsigned a = fast_div(rem, g.div_w_mul, g.div_w_shr);
+                    const unsigned bb = rem - a * (unsigned)g.OW;
+                    return ((int64_t)n * g.YH + a * g.om + g.ph) * g.YW + bb * g.om + g.pw;
+                };
+                // the residual operand of the block (skip gradient, pre-activation, BatchNorm input): every load is issued BEFORE the first
+                // store -- residual and y may alias as far as the compiler knows, so a load inside the store loop waits for the store ahead of it
+                float rv[16];
+                if (p.res_mode) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        int64_t row;
+                        const int64_t orow = out_row(e, &row);
+                        rv[e] = row < g.M ? p.residual[orow * p.ldy + grp * p.Ng + col] : 0.f;
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int64_t row = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    int64_t row;
+                    const int64_t orow = out_row(e, &row);
                     if (row >= g.M) continue;
-                    int64_t orow = row;
-                    if (MODE == 3) {        // sub-grid row (n,a,b) -> pixel (n, a*om+ph, b*om+pw) of the full output
-                        const unsigned n = fast_div((unsigned)row, g.div_hw_mul, g.div_hw_shr);
-                        const unsigned rem = (unsigned)row - n * (unsigned)(g.OH * g.OW);
-                        const unsigned a = fast_div(rem, g.div_w_mul, g.div_w_shr);
-                        const unsigned bb = rem - a * (unsigned)g.OW;
-                        orow = ((int64_t)n * g.YH + a * g.om + g.ph) * g.YW + bb * g.om + g.pw;
-                    }
                     if constexpr (ACT2) {
                         float v = acc[i][j][e] + bv;
-                        if (p.res_mode == 4) v *= act_grad(p.residual[orow * p.ldy + grp * p.Ng + col], p.act);
+                        if (p.res_mode == 5) {
+                            const bool second = p.seg_row > 0 && row >= p.seg_row;
+                            const float xv = rv[e];
+                            const float xh = xv * (second ? bn5[j][1][0] : bn5[j][0][0]) + (second ? bn5[j][1][1] : bn5[j][0][1]);
+                            v *= act_grad(xv * (second ? bn5[j][1][2] : bn5[j][0][2]) + (second ? bn5[j][1][3] : bn5[j][0][3]), p.act);
+                            sum5[j][second ? 2 : 0] += v;
+                            sum5[j][second ? 3 : 1] += v * xh;
+                        }
+                        if (p.res_mode == 4) v *= act_grad(rv[e], p.act);
                         y[orow * p.ldy + col] = v;
                         if (p.y2) p.y2[orow * p.ldy + grp * p.Ng + col] = act_apply(v, p.act);
                     } else if constexpr (!AFF_) {
                         // res_mode 3: plain skip-connection add (input gradient + the gradient that bypassed the block)
-                        y[orow * p.ldy + col] = acc[i][j][e] + bv + (p.res_mode == 3 ? p.residual[orow * p.ldy + grp * p.Ng + col] : 0.f);
+                        y[orow * p.ldy + col] = acc[i][j][e] + bv + (p.res_mode == 3 ? rv[e] : 0.f);
                     } else {
                         float v = acc[i][j][e] * sc + sh;
-                        const float rv = p.res_mode ? p.residual[orow * p.ldy + grp * p.Ng + col] : 0.f;
-                        if (p.res_mode == 1) v += rv;
+                        if (p.res_mode == 1) v += rv[e];
                         v = act_apply(v, p.act);
-                        if (p.res_mode == 2) v += rv;
+                        if (p.res_mode == 2) v += rv[e];
                         y[orow * p.ldy + col] = v;
                     }
                 }
+            }
         }
     };
     store_out(std::integral_constant<bool, AFF>{});       // AFF: a separate instantiation, so the plain kernel carries no affine code
+
+    if constexpr (ACT2) {
+        if (p.res_mode == 5) {                              // BatchNorm backward sums of the tile: lanes -> waves (LDS) -> one float2 record per column and plane
+            __syncthreads();
+            float* red = As;                                // [BM/WM][BN][4]
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sum5[j][q] += __shfl_xor(sum5[j][q], 32, 64);
+                if (h == 0) {
+                    const int idx = wm * BN + wn * WN + j * 32 + r32;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) red[idx * 4 + q] = sum5[j][q];
+                }
+            }
+            __syncthreads();
+            const int row_tiles = (int)((g.M + BM - 1) / BM);
+            float2* rec = reinterpret_cast<float2*>(p.stats);
+            for (int idx = t; idx < BN; idx += NT) {
+                const int col = n0 + idx;
+                if (col >= p.Ng) continue;
+                float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int w = 0; w < BM / WM; ++w)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a[q] += red[(w * BN + idx) * 4 + q];
+                rec[(int64_t)row_tile * p.Ng + col] = make_float2(a[0], a[1]);
+                if (p.seg_row > 0) rec[((int64_t)row_tiles + row_tile) * p.Ng + col] = make_float2(a[2], a[3]);
+            }
+            return;
+        }
+    }
 
     // ---- fused BatchNorm statistics.  Each tile emits (S, Q, k, n) per column: sums of (y-k) and (y-k)^2 over its n valid
     // rows, shifted by k = the tile's first-row value so the variance never forms from two large cancelling sums.
@@ -1139,11 +1215,11 @@ static void launch_nt(const NtParams& p_in, int groups, hipStream_t st) {
                 } else {
                     g_nt_unsupported = true;                 // never a silent no-op: the caller turns this into an error code
                 }
-            } else if (p.scale) hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1, true>), grid, block, 0, st, p);
-            else if (p.y2 || p.res_mode == 4) {
+            } else if (p.y2 || p.res_mode >= 4) {           // (res_mode 5 carries scale / shift of its own: tested before the folded-affine form)
                 if constexpr (VEC == 4) hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1, false, 0, true>), grid, block, 0, st, p);
                 else g_nt_unsupported = true;
-            } else hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1>), grid, block, 0, st, p);
+            } else if (p.scale) hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1, true>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 1>), grid, block, 0, st, p);
             break;
         case 2:
             if (p.scale) hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WM, WN, VEC, 2, true>), grid, block, 0, st, p);
@@ -1260,7 +1336,7 @@ static NtTile effective_nt(NtTile tile, bool plain, bool halo = false, bool resi
 
 static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st, int pinned) {
     NtTile tile = choose_nt(p.g.M, p.Ng, vec4, pinned, halo_ok(p.g, vec4));
-    const bool act2 = p.y2 || p.res_mode == 4;                 // activation epilogues live in igemm_nt_kernel's pointwise form only
+    const bool act2 = p.y2 || p.res_mode >= 4;                 // activation epilogues live in igemm_nt_kernel's pointwise form only
     if (act2 && tile >= NT_R128x16) tile = NT_64x64;
     if (act2 && tile >= NT_W128x128) tile = tile == NT_W128x128 ? NT_128x128 : NT_128x64;
     if (tile >= NT_R128x16) {
@@ -1416,6 +1492,40 @@ int suhpe_conv2d_dgrad_actgrad(const suhpe_conv_t* d, const float* dy, const flo
     dispatch_nt(p, 1, true, as_stream(stream), pinned_tile(d, 1));
     if (g_nt_unsupported) { set_error("suhpe_conv2d_dgrad_actgrad: the selected tile has no activation-epilogue instantiation"); return SUHPE_EINVAL; }
     return check_launch("suhpe_conv2d_dgrad_actgrad");
+}
+
+// rows per statistics record of suhpe_conv2d_dgrad_bnbwd (its tile is fixed: the GEMM has K = cout of a project conv, it is HBM-bound)
+constexpr int kBnbwdRows = 128;
+int64_t suhpe_conv2d_dgrad_bnbwd_workspace_bytes(const suhpe_conv_t* d) {
+    if (!d) return 0;
+    return (int64_t)2 * ceil_div((int64_t)d->n * d->h * d->w, kBnbwdRows) * d->cin * 2 * sizeof(float);
+}
+
+int suhpe_conv2d_dgrad_bnbwd(const suhpe_conv_t* d, const float* dy, const float* wt, const float* bn_x, const float* mean, const float* rstd,
+                             const float* scale, const float* shift, int act, int seg_n, float* g, float* sums, float* dgamma, float* dbeta,
+                             int accumulate, void* workspace, int64_t workspace_bytes, suhpe_stream_t stream) {
+    int rc = check_desc(d, "suhpe_conv2d_dgrad_bnbwd");
+    if (rc) return rc;
+    SUHPE_REQUIRE(pointwise_vec4(d), "suhpe_conv2d_dgrad_bnbwd: pointwise convs only (1x1, stride 1, groups 1, channels %% 4 == 0)");
+    SUHPE_REQUIRE(dy && wt && bn_x && mean && rstd && scale && shift && g && sums && workspace && aligned16(dy) && aligned16(wt),
+                  "suhpe_conv2d_dgrad_bnbwd: null or unaligned pointer");
+    SUHPE_REQUIRE(act >= SUHPE_ACT_NONE && act <= SUHPE_ACT_SIGMOID && seg_n >= 0 && seg_n < d->n, "suhpe_conv2d_dgrad_bnbwd: bad activation / segment");
+    if (workspace_bytes < suhpe_conv2d_dgrad_bnbwd_workspace_bytes(d)) {
+        set_error("suhpe_conv2d_dgrad_bnbwd: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)suhpe_conv2d_dgrad_bnbwd_workspace_bytes(d));
+        return SUHPE_EWORKSPACE;
+    }
+    NtParams p;
+    p.g = make_geom(d->n, d->ho, d->wo, d->h, d->w, d->cout, d->cout, 1, 1, 1, 0, 1);
+    p.x = dy; p.f = wt; p.bias = nullptr; p.y = g; p.Ng = d->cin; p.ldy = d->cin; p.ldf = p.g.K;
+    p.x_bytes = (int64_t)d->n * d->ho * d->wo * d->cout * 4; p.f_bytes = (int64_t)d->cout * d->cin * 4;
+    p.stats = static_cast<float*>(workspace); p.stats_extra = nullptr; p.seg_row = (int64_t)seg_n * d->h * d->w; p.stat_gx = 0; p.stat_cout = d->cin;
+    p.scale = scale; p.shift = shift; p.residual = bn_x; p.act = act; p.res_mode = 5; p.bn_mean = mean; p.bn_rstd = rstd;
+    g_nt_unsupported = false;
+    dispatch_nt(p, 1, true, as_stream(stream), NT_128x64);
+    if (g_nt_unsupported) { set_error("suhpe_conv2d_dgrad_bnbwd: no activation-epilogue instantiation of the tile"); return SUHPE_EINVAL; }
+    const int row_tiles = (int)ceil_div(p.g.M, kBnbwdRows);
+    launch_bn_bwd_finalize(p.stats, seg_n > 0 ? row_tiles : 0, seg_n > 0 ? 2 * row_tiles : row_tiles, d->cin, sums, dgamma, dbeta, accumulate, as_stream(stream));
+    return check_launch("suhpe_conv2d_dgrad_bnbwd");
 }
 
 int suhpe_conv2d_fwd_stats_tiles(const suhpe_conv_t* d) {

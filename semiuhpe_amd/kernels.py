@@ -369,6 +369,35 @@ def conv2d_dgrad_actgrad(dy, w, x_shape, pre, act):
     return dx
 
 
+def conv2d_dgrad_bnbwd(dy, w, x_shape, bn_x, mean, rstd, scale, shift, act, seg_n, dgamma, dbeta):
+    """input gradient of a pointwise conv whose input was act(BN(bn_x)) (train mode): -> (g, sums) with g = dgrad(dy) * act'(BN(bn_x)), the
+    gradient of the BatchNorm's output, and that BatchNorm's backward sums [2c] / [2, 2c] reduced by the same GEMM epilogue
+    (suhpe_conv2d_dgrad_bnbwd); dgamma / dbeta are accumulated into.  The BatchNorm's apply pass then runs with activation 'none'."""
+    _chk(dy, "dy"); _chk(bn_x, "bn_x")
+    d = conv_desc(x_shape, w.shape, 1, 0, 1)
+    assert tuple(bn_x.shape) == tuple(x_shape)
+    c = d.cin
+    two = seg_n > 0
+    assert mean.numel() == rstd.numel() == scale.numel() == shift.numel() == (2 if two else 1) * c
+    g = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
+    sums = torch.empty(((2, 2 * c) if two else (2 * c,)), dtype=torch.float32, device=dy.device)
+    key = (w.data_ptr(), d.cin, d.cout, d.r, d.s, d.groups)
+    wt = _WT_CACHE.get(key) if _WT_CACHE is not None else None
+    if wt is None:
+        if _WT_CACHE is not None:
+            wt = _WT_CACHE[key] = torch.empty(w.numel() * 4, dtype=torch.uint8, device=dy.device)
+            _WT_SEEN[key] = (w, (d.groups, d.cout // d.groups, d.cin // d.groups, d.r * d.s))
+        else:
+            wt = workspace("wt", w.numel() * 4, dy.device)
+        call("suhpe_conv2d_transpose_filter", ctypes.byref(d), ptr(w), ptr(wt))
+    nbytes = _lib.load().suhpe_conv2d_dgrad_bnbwd_workspace_bytes(ctypes.byref(d))
+    ws = workspace("dgrad_bnbwd", nbytes, dy.device)
+    with _Prof(d, 1):
+        call("suhpe_conv2d_dgrad_bnbwd", ctypes.byref(d), ptr(dy), ptr(wt), ptr(bn_x), ptr(mean), ptr(rstd), ptr(scale), ptr(shift), ACT[act],
+             int(seg_n) if two else 0, ptr(g), ptr(sums), ptr(dgamma), ptr(dbeta), 1, ptr(ws), nbytes)
+    return g, sums
+
+
 def repvgg_fuse(w3, w1, bn3, bn1, bnid, eps):
     """RepVGG deploy-mode filter and bias of one block (src/repvgg.py:104-142); bn* = (gamma, beta, running_mean, running_var)
     tensors, bnid None without an identity branch.  -> (w_eq like w3, ones (cout), b_eq (cout))"""

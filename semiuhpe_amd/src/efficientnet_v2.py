@@ -30,6 +30,7 @@ BN_EPS = 1e-3           # torchvision: partial(nn.BatchNorm2d, eps=1e-03) for th
 # makes the depthwise kernels recompute the SiLU 1.5x (forward) to 3x (filter gradient) per element: measured 84.1 vs 79.7
 # ms/step on C2, so it is off; the kernels and their tests stay (memory-saving mode: the expanded tensor is never stored).
 FUSE_EXPAND_BN_INTO_DW = os.environ.get("SUHPE_FUSE_EXPAND_DW", "1") != "0"
+BN_SUMS_FROM_PROJECT = os.environ.get("SUHPE_BN_SUMS_PROJECT", "1") != "0"     # FusedMBConv: expand BatchNorm's backward sums from the project conv's dgrad epilogue
 FUSE_EXPAND_NO_TAPE = os.environ.get("SUHPE_FUSE_EXPAND_NO_TAPE", "1") != "0"      # the same fold in train-mode forwards that keep no tape (teacher pass)
 # the expand BatchNorm's backward sums reduced by the depthwise input-gradient kernel (no reduction pass over the expanded tensor pair)
 BN_SUMS_FROM_DW = os.environ.get("SUHPE_BN_SUMS_FROM_DW", "1") != "0"
@@ -84,13 +85,17 @@ class _ResidualBlock(Layer):
         from .. import layers as L
         fused = self.use_res_connect and park_skip(first[0] if isinstance(first, ConvNormActivation) else None, dy)
         try:
-            d = self._front_bwd(self.block[-1].bwd(dy, tape), tape)     # (the last BatchNorm's backward applies the keep scale)
+            d = self._front_bwd(self._last_bwd(dy, tape), tape)         # (the last BatchNorm's backward applies the keep scale)
             if fused:                       # the first conv's input-gradient epilogue added dy
                 assert L._PENDING_SKIP is None, "the parked skip gradient was not consumed"
                 return d
         finally:
             L._PENDING_SKIP = None          # an exception between park and take must not poison every later backward of the process
         return K.add(d, dy) if self.use_res_connect else d
+
+
+    def _last_bwd(self, dy, tape):
+        return self.block[-1].bwd(dy, tape)
 
 
 class FusedMBConv(_ResidualBlock):
@@ -123,6 +128,38 @@ class FusedMBConv(_ResidualBlock):
             tape.append((y0, (mean, rstd), rows_a // hw, True, None, None, hw) if rows_a else (y0, mean, rstd, True, None, None, hw))
         sc, sh = K.bn_affine_from_stats(mean, rstd, b0.weight, b0.bias)
         return y0, (sc, sh, None, b0.act, hw, rows_a)
+
+
+    # Backward of the folded form: the project conv's input-gradient GEMM multiplies by SiLU'(BN(y0)) in its epilogue and reduces the expand
+    # BatchNorm's backward sums there (suhpe_conv2d_dgrad_bnbwd), so that BatchNorm's backward is ONE apply pass over (y0, g) instead of a
+    # reduction pass + an apply pass over the two widest tensors of the network.  SUHPE_BN_SUMS_PROJECT=0: the layer-by-layer backward.
+    def _last_bwd(self, dy, tape):
+        if not (BN_SUMS_FROM_PROJECT and len(self.block) == 2 and len(tape) >= 3):
+            return super()._last_bwd(dy, tape)
+        (conv0, bn0), (conv1, bn1) = self.block[0], self.block[1]
+        top, rec = tape[-2], tape[-3]          # (y0, input transform) of the project conv; the expand BatchNorm's train-mode record
+        if not (isinstance(top, tuple) and len(top) == 2 and torch.is_tensor(top[0]) and isinstance(rec, tuple) and len(rec) == 7 and rec[0] is top[0] and
+                rec[3] is True and rec[4] is None and rec[5] is None and conv1.need_input_grad and conv1.bias is None):
+            return super()._last_bwd(dy, tape)
+        dt = bn1.bwd(dy, tape)
+        y0, xf = tape.pop()
+        K.conv2d_wgrad(y0, dt, conv1.weight.shape, conv1.stride, conv1.padding, conv1.groups, out=grad_of(conv1.weight), accumulate=True, xf=xf)
+        sc, sh = xf[0], xf[1]
+        _, mean, rstd, _, _, _, hw = tape.pop()
+        c = bn0.num_features
+        if isinstance(mean, tuple):                          # two batch segments: ((mean[2, c], rstd[2, c]), samples of the first)
+            (m2, r2), seg = mean, rstd
+            g, sums = K.conv2d_dgrad_bnbwd(dt, conv1.weight, y0.shape, y0, m2, r2, sc, sh, bn0.act, seg, grad_of(bn0.weight), grad_of(bn0.bias))
+            dz = K.bn_act_bwd_apply_seg(y0, g, seg * hw, c, m2, r2, bn0.weight, bn0.bias, "none", sums)
+        else:
+            g, sums = K.conv2d_dgrad_bnbwd(dt, conv1.weight, y0.shape, y0, mean, rstd, sc, sh, bn0.act, 0, grad_of(bn0.weight), grad_of(bn0.bias))
+            dz = K.bn_act_bwd_apply(y0, g, c, mean, rstd, bn0.weight, bn0.bias, "none", sums, y0.numel() // c)
+        return ("expand_bn_done", dz)
+
+    def _front_bwd(self, dy, tape):
+        if isinstance(dy, tuple) and dy[0] == "expand_bn_done":
+            return self.block[0][0].bwd(dy[1], tape)
+        return super()._front_bwd(dy, tape)
 
 
 class MBConv(_ResidualBlock):

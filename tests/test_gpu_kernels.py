@@ -1125,3 +1125,49 @@ def test_depthwise_image_tile_kernel_against_torch(K, n, h, c):
     dw_ref = torch.nn.grad.conv2d_weight(x, w.shape, dy, 1, 1, 1, c)
     dw = K.conv2d_wgrad(xg, dyg, wg.shape, 1, 1, c)
     assert rel(dw, dw_ref) < 5e-6
+
+
+@pytest.mark.parametrize("n,h,cexp,cout,seg,act", [(6, 28, 192, 48, 0, "silu"), (9, 14, 256, 64, 4, "silu"), (160, 28, 256, 64, 32, "silu"), (3, 7, 96, 24, 1, "relu")])
+def test_pointwise_dgrad_reduces_batchnorm_backward_sums(K, n, h, cexp, cout, seg, act):
+    """suhpe_conv2d_dgrad_bnbwd (FusedMBConv backward): the project conv's input-gradient GEMM returns g = dgrad(dt) * act'(BN(y0)) and the
+    expand BatchNorm's backward sums from its epilogue; g, the sums (fp64 reference, one and two batch segments, a segment boundary inside a
+    128-row tile) and the BatchNorm backward assembled from them (apply pass with activation 'none') equal the unfused chain
+    dgrad -> three-pass BatchNorm backward; dgamma / dbeta are accumulated on top of what the buffers held"""
+    g_ = torch.Generator().manual_seed(n * 7 + cexp)
+    y0 = (torch.randn(n, h, h, cexp, generator=g_) * 1.4 + 0.2).cuda()              # expand conv output = the BatchNorm's input
+    dt = torch.randn(n, h, h, cout, generator=g_).cuda()                             # gradient of the project conv's output
+    w = K.to_filter_layout((torch.randn(cout, cexp, 1, 1, generator=g_) / 8).cuda())
+    gamma, beta = (torch.rand(cexp, generator=g_) + 0.5).cuda(), (torch.randn(cexp, generator=g_) * 0.2).cuda()
+    rows, hw = n * h * h, h * h
+    if seg:
+        y0[seg:] = y0[seg:] * 0.7 - 0.3
+        mean, rstd = K.bn_stats_seg(y0, seg * hw, cexp, 1e-3, 0.1)
+    else:
+        mean, rstd = K.bn_stats(y0, cexp, 1e-3, 0.1)
+    sc, sh = K.bn_affine_from_stats(mean, rstd, gamma, beta)
+    dz_ref = K.conv2d_dgrad(dt, w, y0.shape, 1, 0, 1)                                # gradient of the activated tensor
+    dg_ref, db_ref = torch.full((cexp,), 0.5, device="cuda"), torch.full((cexp,), -0.25, device="cuda")
+    dg, db = dg_ref.clone(), db_ref.clone()
+    if seg:
+        dy_ref = K.bn_act_bwd_seg(y0, dz_ref, seg * hw, cexp, mean, rstd, gamma, beta, act, dg_ref, db_ref, True)
+    else:
+        dy_ref = K.bn_act_bwd(y0, dz_ref, cexp, mean, rstd, gamma, beta, act, True, dg_ref, db_ref, True)
+    g, sums = K.conv2d_dgrad_bnbwd(dt, w, y0.shape, y0, mean, rstd, sc, sh, act, seg, dg, db)
+    if seg:
+        dy = K.bn_act_bwd_apply_seg(y0, g, seg * hw, cexp, mean, rstd, gamma, beta, "none", sums)
+    else:
+        dy = K.bn_act_bwd_apply(y0, g, cexp, mean, rstd, gamma, beta, "none", sums, rows)
+    assert rel(dy, dy_ref.cpu()) < 5e-6
+    assert rel(dg, dg_ref.cpu()) < 2e-5 and rel(db, db_ref.cpu()) < 2e-5
+    xs = y0.double().cpu().reshape(rows, cexp)
+    parts = [(0, rows)] if not seg else [(0, seg * hw), (seg * hw, rows)]
+    m64, r64 = mean.double().cpu().reshape(-1, cexp), rstd.double().cpu().reshape(-1, cexp)
+    g64 = torch.empty(rows, cexp, dtype=torch.float64)
+    for i, (lo, hi) in enumerate(parts):
+        xh = (xs[lo:hi] - m64[i]) * r64[i]
+        u = xh * gamma.double().cpu() + beta.double().cpu()
+        ga = (torch.sigmoid(u) * (1 + u * (1 - torch.sigmoid(u)))) if act == "silu" else (u > 0).double()
+        g64[lo:hi] = dz_ref.double().cpu().reshape(rows, cexp)[lo:hi] * ga
+        s = sums.reshape(-1, cexp, 2)[i].double().cpu()
+        assert rel(s[:, 0], g64[lo:hi].sum(0)) < 2e-5 and rel(s[:, 1], (g64[lo:hi] * xh).sum(0)) < 2e-5
+    assert rel(g.reshape(rows, cexp), g64) < 3e-6

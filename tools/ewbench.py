@@ -55,6 +55,11 @@ for hw_side, c in ((14, 512), (14, 960), (7, 1536)):
     line("bn_act_bwd_sums (silu)", timed(lambda: K.bn_act_bwd_sums(x, dy, c, mean1, rstd1, gamma, beta, "silu"), [x, dy]), 2, nb)
     bsums = K.bn_act_bwd_sums(x, dy, c, mean1, rstd1, gamma, beta, "silu")
     line("bn_act_bwd_apply (silu)", timed(lambda: K.bn_act_bwd_apply(x, dy, c, mean1, rstd1, gamma, beta, "silu", bsums, rows), [x, dy]), 3, nb)
+    csq = {512: 32, 960: 40, 1536: 64}[c]
+    w1 = torch.randn(csq, c, device="cuda") * 0.05; b1 = torch.zeros(csq, device="cuda"); w2 = torch.randn(c, csq, device="cuda") * 0.05; b2 = torch.zeros(c, device="cuda")
+    pl = torch.randn(N, c, device="cuda")
+    us = timed(lambda: K.se_mlp_fwd(pl, w1, b1, w2, b2), [pl])
+    print(f"  {'se_mlp_fwd':34s} {us:8.1f} us", flush=True)
     line("dwconv_fwd_stats", timed(lambda: K.dwconv_fwd_stats(x, w, 1, 1, seg=seg or None), [x]), 2, nb)
     if K.dwconv_dgrad_bnsums_ok(tuple(x.shape), tuple(w.shape), 1, 1):
         line("dwconv_dgrad_bnsums", timed(lambda: K.dwconv_dgrad_bnsums(dy, w, tuple(x.shape), 1, 1, x, m, r, gamma, beta, "silu", seg, dg, db), [x, dy]), 3, nb)
