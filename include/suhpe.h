@@ -361,6 +361,10 @@ int suhpe_layernorm_fwd(const float* x, int64_t rows, int c, float eps, const fl
 int suhpe_layernorm_bwd(const float* x, const float* dy, int64_t rows, int c, const float* mean, const float* rstd,
                         const float* gamma, float* dx, float* dgamma, float* dbeta, int accumulate,
                         void* workspace, suhpe_stream_t stream);
+/* the same backward with the gradient that bypassed the normalised sub-block added to dx (x + drop_path(f(LN(x))), src/tiny_vit.py:366,378):
+ * dx = LayerNorm'(dy) + skip, no separate add pass (skip: the shape of dx, or NULL) */
+int suhpe_layernorm_bwd_skip(const float* x, const float* dy, int64_t rows, int c, const float* mean, const float* rstd, const float* gamma,
+                             const float* skip, float* dx, float* dgamma, float* dbeta, int accumulate, void* workspace, suhpe_stream_t stream);
 /* plain activation y = act(x + bias[c]) and its backward dx = dy * act'(x + bias) */
 int suhpe_act_fwd(const float* x, int64_t rows, int c, const float* bias, int act, float* y, suhpe_stream_t stream);
 int suhpe_act_bwd(const float* x, const float* dy, int64_t rows, int c, const float* bias, int act, float* dx,

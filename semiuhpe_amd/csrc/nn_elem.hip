@@ -896,11 +896,87 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     if (lane == 0) { mean[row] = m; rstd[row] = rs; }
 }
 
+// 16-byte form (c % 4 == 0, c <= 256 NV): the row lives in registers between the statistics and the normalisation -- one pass over
+// memory, NV independent float4 loads per lane issued together (the scalar kernel above reads the row three times from L1 / L2)
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_fwd_v4(const float* __restrict__ x, int64_t rows, int c, float eps, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ mean,
+                                                        float* __restrict__ rstd) {
+    const int lane = threadIdx.x & 63, cv = c / 4;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float4* xr = reinterpret_cast<const float4*>(x + row * c);
+    float4 v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = lane + 64 * k < cv ? xr[lane + 64 * k] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    const float m = wave_sum(s) / c;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+        if (lane + 64 * k < cv) {
+            const float a = v[k].x - m, b = v[k].y - m, cc = v[k].z - m, d = v[k].w - m;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    const float rs = 1.f / sqrtf(wave_sum(q) / c + eps);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int j = lane + 64 * k;
+        if (j >= cv) continue;
+        const float4 ga = gamma ? reinterpret_cast<const float4*>(gamma)[j] : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 be = beta ? reinterpret_cast<const float4*>(beta)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4*>(y + row * c)[j] = make_float4((v[k].x - m) * rs * ga.x + be.x, (v[k].y - m) * rs * ga.y + be.y,
+                                                                (v[k].z - m) * rs * ga.z + be.z, (v[k].w - m) * rs * ga.w + be.w);
+    }
+    if (lane == 0) { mean[row] = m; rstd[row] = rs; }
+}
+
+// dx = rstd (g - mean(g) - xhat mean(g xhat)) [+ skip]: the gradient that bypassed the sub-block through its residual connection
+// (TinyViTBlock: x + drop_path(attn(x)), x + drop_path(mlp(x)), src/tiny_vit.py:366,378) is added here instead of by a pass of its own
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_dx_v4(const float* __restrict__ x, const float* __restrict__ dy, int64_t rows, int c,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ skip, float* __restrict__ dx) {
+    const int lane = threadIdx.x & 63, cv = c / 4;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float m = mean[row], rs = rstd[row];
+    float g[NV][4], xh[NV][4], sk[NV][4];
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int j = lane + 64 * k;
+        const bool ok = j < cv;
+        const float4 xv = ok ? reinterpret_cast<const float4*>(x + row * c)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 dv = ok ? reinterpret_cast<const float4*>(dy + row * c)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 ga = (ok && gamma) ? reinterpret_cast<const float4*>(gamma)[j] : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 sv = (ok && skip) ? reinterpret_cast<const float4*>(skip + row * c)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        g[k][0] = dv.x * ga.x; g[k][1] = dv.y * ga.y; g[k][2] = dv.z * ga.z; g[k][3] = dv.w * ga.w;
+        xh[k][0] = (xv.x - m) * rs; xh[k][1] = (xv.y - m) * rs; xh[k][2] = (xv.z - m) * rs; xh[k][3] = (xv.w - m) * rs;
+        sk[k][0] = sv.x; sk[k][1] = sv.y; sk[k][2] = sv.z; sk[k][3] = sv.w;
+        if (ok) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s0 += g[k][e]; s1 += g[k][e] * xh[k][e]; }
+        }
+    }
+    s0 = wave_sum(s0) / c;
+    s1 = wave_sum(s1) / c;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int j = lane + 64 * k;
+        if (j >= cv) continue;
+        reinterpret_cast<float4*>(dx + row * c)[j] = make_float4(rs * (g[k][0] - s0 - xh[k][0] * s1) + sk[k][0], rs * (g[k][1] - s0 - xh[k][1] * s1) + sk[k][1],
+                                                                 rs * (g[k][2] - s0 - xh[k][2] * s1) + sk[k][2], rs * (g[k][3] - s0 - xh[k][3] * s1) + sk[k][3]);
+    }
+}
+
 // dx per row; dgamma/dbeta partials via the column-reduction machinery (VEC=1 form, g = dy, xhat from saved stats)
 __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                int64_t rows, int c, const float* __restrict__ mean,
                                                                const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                               float* __restrict__ dx) {
+                                                               const float* __restrict__ skip, float* __restrict__ dx) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -917,7 +993,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __re
     for (int j = lane; j < c; j += 64) {
         const float g = dy[row * c + j] * (gamma ? gamma[j] : 1.f);
         const float xh = (x[row * c + j] - m) * rs;
-        dx[row * c + j] = rs * (g - s0 - xh * s1);
+        dx[row * c + j] = rs * (g - s0 - xh * s1) + (skip ? skip[row * c + j] : 0.f);
     }
 }
 
@@ -2032,15 +2108,34 @@ int suhpe_repvgg_bn_bwd(const float* const* x, const float* const* mean, const f
 int suhpe_layernorm_fwd(const float* x, int64_t rows, int c, float eps, const float* gamma, const float* beta, float* y,
                         float* mean, float* rstd, suhpe_stream_t stream) {
     SUHPE_REQUIRE(x && y && mean && rstd && rows > 0 && c > 0, "suhpe_layernorm_fwd: bad arguments");
-    LAUNCH(layernorm_fwd_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), stream, x, rows, c, eps, gamma, beta, y, mean, rstd);
+    const dim3 grid((unsigned)ceil_div(rows, 4));
+    if (vec4_ok(c, x, y) && (!gamma || vec4_ok(c, gamma)) && (!beta || vec4_ok(c, beta)) && c <= 768) {
+        if (c <= 256) LAUNCH(layernorm_fwd_v4<1>, grid, dim3(256), stream, x, rows, c, eps, gamma, beta, y, mean, rstd);
+        else if (c <= 512) LAUNCH(layernorm_fwd_v4<2>, grid, dim3(256), stream, x, rows, c, eps, gamma, beta, y, mean, rstd);
+        else LAUNCH(layernorm_fwd_v4<3>, grid, dim3(256), stream, x, rows, c, eps, gamma, beta, y, mean, rstd);
+        return check_launch("suhpe_layernorm_fwd");
+    }
+    LAUNCH(layernorm_fwd_kernel, grid, dim3(256), stream, x, rows, c, eps, gamma, beta, y, mean, rstd);
     return check_launch("suhpe_layernorm_fwd");
 }
 
 int suhpe_layernorm_bwd(const float* x, const float* dy, int64_t rows, int c, const float* mean, const float* rstd,
                         const float* gamma, float* dx, float* dgamma, float* dbeta, int accumulate, void* workspace,
                         suhpe_stream_t stream) {
+    return suhpe_layernorm_bwd_skip(x, dy, rows, c, mean, rstd, gamma, nullptr, dx, dgamma, dbeta, accumulate, workspace, stream);
+}
+
+int suhpe_layernorm_bwd_skip(const float* x, const float* dy, int64_t rows, int c, const float* mean, const float* rstd, const float* gamma,
+                             const float* skip, float* dx, float* dgamma, float* dbeta, int accumulate, void* workspace, suhpe_stream_t stream) {
     SUHPE_REQUIRE(x && dy && dx && mean && rstd && workspace && rows > 0 && c > 0, "suhpe_layernorm_bwd: bad arguments");
-    LAUNCH(layernorm_bwd_dx_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), stream, x, dy, rows, c, mean, rstd, gamma, dx);
+    const dim3 grid((unsigned)ceil_div(rows, 4));
+    if (vec4_ok(c, x, dy) && vec4_ok(c, dx) && (!gamma || vec4_ok(c, gamma)) && (!skip || vec4_ok(c, skip)) && c <= 768) {
+        if (c <= 256) LAUNCH(layernorm_bwd_dx_v4<1>, grid, dim3(256), stream, x, dy, rows, c, mean, rstd, gamma, skip, dx);
+        else if (c <= 512) LAUNCH(layernorm_bwd_dx_v4<2>, grid, dim3(256), stream, x, dy, rows, c, mean, rstd, gamma, skip, dx);
+        else LAUNCH(layernorm_bwd_dx_v4<3>, grid, dim3(256), stream, x, dy, rows, c, mean, rstd, gamma, skip, dx);
+    } else {
+        LAUNCH(layernorm_bwd_dx_kernel, grid, dim3(256), stream, x, dy, rows, c, mean, rstd, gamma, skip, dx);
+    }
     if (dgamma || dbeta) {
         float* part = static_cast<float*>(workspace);
         float* sums = bn_sums_of(workspace, c);

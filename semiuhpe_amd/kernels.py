@@ -1010,11 +1010,13 @@ def layernorm_fwd(x, c, eps, gamma, beta):
 
 
 @_memop
-def layernorm_bwd(x, dy, c, mean, rstd, gamma, dgamma=None, dbeta=None, accumulate=False):
-    _chk(x, "x"); _chk(dy, "dy")
+def layernorm_bwd(x, dy, c, mean, rstd, gamma, dgamma=None, dbeta=None, accumulate=False, skip=None):
+    """skip: a tensor of x's shape added to dx (the gradient that bypassed the normalised sub-block through its residual connection)"""
+    _chk(x, "x"); _chk(dy, "dy"); _chk(skip, "skip")
     dx = torch.empty_like(x)
+    assert skip is None or skip.numel() == x.numel()
     ws = workspace("bn", _lib.load().suhpe_bn_workspace_bytes(c), x.device)
-    call("suhpe_layernorm_bwd", ptr(x), ptr(dy), x.numel() // c, c, ptr(mean), ptr(rstd), ptr(gamma), ptr(dx), ptr(dgamma),
+    call("suhpe_layernorm_bwd_skip", ptr(x), ptr(dy), x.numel() // c, c, ptr(mean), ptr(rstd), ptr(gamma), ptr(skip), ptr(dx), ptr(dgamma),
          ptr(dbeta), int(accumulate), ptr(ws))
     return dx
 

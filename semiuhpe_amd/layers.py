@@ -470,9 +470,9 @@ class LayerNorm(Layer):
             tape.append((x, mean, rstd))
         return y
 
-    def bwd(self, dy, tape):
+    def bwd(self, dy, tape, skip=None):
         x, mean, rstd = tape.pop()
-        return K.layernorm_bwd(x, dy, self.dim, mean, rstd, self.weight, grad_of(self.weight), grad_of(self.bias), True)
+        return K.layernorm_bwd(x, dy, self.dim, mean, rstd, self.weight, grad_of(self.weight), grad_of(self.bias), True, skip=skip)
 
 
 class Activation(Layer):

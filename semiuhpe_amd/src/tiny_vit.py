@@ -167,7 +167,8 @@ class Attention(Layer):
             tape.append((qkv, probs, (B, H, W)))
         return self.proj.fwd(out, tape).view(B, H, W, C)
 
-    def bwd(self, dy, tape):
+    def bwd(self, dy, tape, skip=None):
+        """skip: the gradient of the residual connection around the block, added by the LayerNorm backward's kernel"""
         B, H, W, C = dy.shape
         d_out = self.proj.bwd(dy.view(-1, C), tape)
         qkv, probs, _ = tape.pop()
@@ -175,7 +176,7 @@ class Attention(Layer):
                                  self.attention_biases.shape[1], self.scale, grad_of(self.attention_biases),
                                  inverse=self._inverse_index(dy.device) if DETERMINISTIC_DBIAS else None)
         d_xn = self.qkv.bwd(dqkv, tape)
-        return self.norm.bwd(d_xn.view(B, H, W, C), tape)
+        return self.norm.bwd(d_xn.view(B, H, W, C), tape, skip=skip)
 
 
 MLP_ACT_EPILOGUE = os.environ.get("SUHPE_MLP_EPILOGUE", "1") != "0"     # GELU / GELU' in the fc1 / fc2 GEMM epilogues
@@ -207,7 +208,7 @@ class Mlp(Layer):
             tape.append(h)
         return self.fc2.fwd(a, tape).view(shp)
 
-    def bwd(self, dy, tape):
+    def bwd(self, dy, tape, skip=None):
         shp = dy.shape
         h = tape[-2]                                         # (fc2's input entry is on top of it)
         if self._fused():
@@ -217,7 +218,7 @@ class Mlp(Layer):
             da = self.fc2.bwd(dy.view(-1, shp[-1]), tape)
             tape.pop()
             dh = K.act_bwd(h, da, self.hidden, "gelu")
-        return self.norm.bwd(self.fc1.bwd(dh, tape).view(shp), tape)
+        return self.norm.bwd(self.fc1.bwd(dh, tape).view(shp), tape, skip=skip)
 
 
 class TinyViTBlock(Layer):
@@ -240,10 +241,10 @@ class TinyViTBlock(Layer):
 
     def bwd(self, dy, tape):
         d_m, d_x2 = self.drop_path.bwd2(dy, tape)
-        d_x2 = K.add(d_x2, self.mlp.bwd(d_m, tape))
+        d_x2 = self.mlp.bwd(d_m, tape, skip=d_x2)            # (+ the skip gradient: in the LayerNorm backward's kernel)
         d_x1 = self.local_conv.bwd(d_x2, tape)
         d_a, d_x = self.drop_path.bwd2(d_x1, tape)
-        return K.add(d_x, self.attn.bwd(d_a, tape))
+        return self.attn.bwd(d_a, tape, skip=d_x)
 
 
 class _Stage(Layer):

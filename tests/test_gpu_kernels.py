@@ -397,8 +397,10 @@ def test_bn_residual_relu(K):
     assert rel(dx.reshape(-1, c), xd.grad) < 5e-5
 
 
-@pytest.mark.parametrize("rows,c", [(98, 192), (392, 576), (10, 6)])
+@pytest.mark.parametrize("rows,c", [(98, 192), (392, 576), (10, 6), (77, 384), (5, 96), (9, 1024), (31, 260)])
 def test_layernorm(K, rows, c):
+    """the register-resident 16-byte kernels (c % 4 == 0, c <= 768: one, two or three vectors per lane, a partial last vector for c = 260)
+    and the scalar fallback (c = 6, c = 1024); the backward with and without the fused skip-connection add"""
     g = torch.Generator().manual_seed(c)
     x, dy = torch.randn(rows, c, generator=g) * 3, torch.randn(rows, c, generator=g)
     gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
@@ -410,6 +412,9 @@ def test_layernorm(K, rows, c):
     dg, db = torch.zeros(c).cuda(), torch.zeros(c).cuda()
     dx = K.layernorm_bwd(x.cuda(), dy.cuda(), c, mean, rstd, gamma.cuda(), dg, db)
     assert rel(dx, xd.grad) < 5e-5 and rel(dg, gd.grad) < 5e-5 and rel(db, bd.grad) < 5e-5
+    skip = torch.randn(rows, c, generator=g)
+    dx2 = K.layernorm_bwd(x.cuda(), dy.cuda(), c, mean, rstd, gamma.cuda(), None, None, skip=skip.cuda())
+    assert torch.equal(dx2, dx + skip.cuda()) or rel(dx2, xd.grad + skip.double()) < 5e-5
 
 
 @pytest.mark.parametrize("act", ["relu", "relu6", "silu", "gelu", "sigmoid"])
