@@ -45,6 +45,46 @@ def _make_divisible(v, divisor=8):
     return new_v
 
 
+def bn_sums_from_dw_ok(conv_d, tape):
+    """the tape's next two entries are the depthwise conv's plain input and the expand BatchNorm's train-mode record in a form the
+    fused kernels take (one tensor of statistics, or the (mean[2, c], rstd[2, c]) pair of a merged two-segment pass)"""
+    if not BN_SUMS_FROM_DW or len(tape) < 2:
+        return False
+    top = tape[-1]
+    if isinstance(top, tuple) and len(top) == 2 and torch.is_tensor(top[0]):      # (raw input, input transform): folded expand BatchNorm
+        top = top[0]
+    if not torch.is_tensor(top):
+        return False
+    e = tape[-2]
+    if not (isinstance(e, tuple) and len(e) == 7 and e[3] is True and e[4] is None and e[5] is None):
+        return False
+    if not (torch.is_tensor(e[1]) or (isinstance(e[1], tuple) and len(e[1]) == 2 and torch.is_tensor(e[1][0]))):
+        return False
+    return K.dwconv_dgrad_bnsums_ok(top.shape, conv_d.weight.shape, conv_d.stride, conv_d.padding)
+
+def dw_dgrad_expand_bwd(conv_d, expand, dy, tape):
+    """depthwise filter gradient; depthwise input gradient + the expand BatchNorm's (sum g, sum g xhat) from ONE kernel; that
+    BatchNorm's apply pass; the expand conv's backward"""
+    conv_e, bn_e = expand
+    a1, xf = tape.pop(), None
+    if isinstance(a1, tuple):                            # folded: the filter gradient recomputes act(BN(a1)) while it stages a1
+        a1, xf = a1
+    K.conv2d_wgrad(a1, dy, conv_d.weight.shape, conv_d.stride, conv_d.padding, conv_d.groups, out=grad_of(conv_d.weight), accumulate=True, xf=xf)
+    x1, mean, rstd, _, _, _, hw = tape.pop()
+    cexp = bn_e.num_features
+    if isinstance(mean, tuple):                          # two batch segments: ((mean[2, c], rstd[2, c]), samples of the first)
+        (m2, r2), seg = mean, rstd
+        d, sums = K.dwconv_dgrad_bnsums(dy, conv_d.weight, a1.shape, conv_d.stride, conv_d.padding, x1, m2, r2, bn_e.weight, bn_e.bias, bn_e.act,
+                                        seg, grad_of(bn_e.weight), grad_of(bn_e.bias))
+        dz = K.bn_act_bwd_apply_seg(x1, d, seg * hw, cexp, m2, r2, bn_e.weight, bn_e.bias, bn_e.act, sums)
+    else:
+        d, sums = K.dwconv_dgrad_bnsums(dy, conv_d.weight, a1.shape, conv_d.stride, conv_d.padding, x1, mean, rstd, bn_e.weight, bn_e.bias,
+                                        bn_e.act, 0, grad_of(bn_e.weight), grad_of(bn_e.bias))
+        dz = K.bn_act_bwd_apply(x1, d, cexp, mean, rstd, bn_e.weight, bn_e.bias, bn_e.act, sums, x1.numel() // cexp)
+    return conv_e.bwd(dz, tape)
+
+
+
 class _ResidualBlock(Layer):
     """Shared tail: x + StochasticDepth('row')(block(x)).  The add and the per-sample keep scale run inside the last
     BatchNorm's apply kernel (and its backward), so the skip costs no pass of its own."""
@@ -241,42 +281,10 @@ class MBConv(_ResidualBlock):
         return d if expand is None else expand.bwd(d, tape)
 
     def _bn_sums_from_dw(self, conv_d, tape):
-        """the tape's next two entries are the depthwise conv's plain input and the expand BatchNorm's train-mode record in a form the
-        fused kernels take (one tensor of statistics, or the (mean[2, c], rstd[2, c]) pair of a merged two-segment pass)"""
-        if not BN_SUMS_FROM_DW or len(tape) < 2:
-            return False
-        top = tape[-1]
-        if isinstance(top, tuple) and len(top) == 2 and torch.is_tensor(top[0]):      # (raw input, input transform): folded expand BatchNorm
-            top = top[0]
-        if not torch.is_tensor(top):
-            return False
-        e = tape[-2]
-        if not (isinstance(e, tuple) and len(e) == 7 and e[3] is True and e[4] is None and e[5] is None):
-            return False
-        if not (torch.is_tensor(e[1]) or (isinstance(e[1], tuple) and len(e[1]) == 2 and torch.is_tensor(e[1][0]))):
-            return False
-        return K.dwconv_dgrad_bnsums_ok(top.shape, conv_d.weight.shape, conv_d.stride, conv_d.padding)
+        return bn_sums_from_dw_ok(conv_d, tape)
 
     def _dw_dgrad_expand_bwd(self, conv_d, expand, dy, tape):
-        """depthwise filter gradient; depthwise input gradient + the expand BatchNorm's (sum g, sum g xhat) from ONE kernel; that
-        BatchNorm's apply pass; the expand conv's backward"""
-        conv_e, bn_e = expand
-        a1, xf = tape.pop(), None
-        if isinstance(a1, tuple):                            # folded: the filter gradient recomputes act(BN(a1)) while it stages a1
-            a1, xf = a1
-        K.conv2d_wgrad(a1, dy, conv_d.weight.shape, conv_d.stride, conv_d.padding, conv_d.groups, out=grad_of(conv_d.weight), accumulate=True, xf=xf)
-        x1, mean, rstd, _, _, _, hw = tape.pop()
-        cexp = bn_e.num_features
-        if isinstance(mean, tuple):                          # two batch segments: ((mean[2, c], rstd[2, c]), samples of the first)
-            (m2, r2), seg = mean, rstd
-            d, sums = K.dwconv_dgrad_bnsums(dy, conv_d.weight, a1.shape, conv_d.stride, conv_d.padding, x1, m2, r2, bn_e.weight, bn_e.bias, bn_e.act,
-                                            seg, grad_of(bn_e.weight), grad_of(bn_e.bias))
-            dz = K.bn_act_bwd_apply_seg(x1, d, seg * hw, cexp, m2, r2, bn_e.weight, bn_e.bias, bn_e.act, sums)
-        else:
-            d, sums = K.dwconv_dgrad_bnsums(dy, conv_d.weight, a1.shape, conv_d.stride, conv_d.padding, x1, mean, rstd, bn_e.weight, bn_e.bias,
-                                            bn_e.act, 0, grad_of(bn_e.weight), grad_of(bn_e.bias))
-            dz = K.bn_act_bwd_apply(x1, d, cexp, mean, rstd, bn_e.weight, bn_e.bias, bn_e.act, sums, x1.numel() // cexp)
-        return conv_e.bwd(dz, tape)
+        return dw_dgrad_expand_bwd(conv_d, expand, dy, tape)
 
     def _front_fwd(self, x, tape):
         # expand -> depthwise conv -> BatchNorm + SiLU + squeeze -> excitation

@@ -15,7 +15,7 @@ import torch.nn as nn
 from .. import kernels as K
 from ..layers import (BatchNorm2d, Conv2d, Dropout, Identity, Layer, LayerNorm, Linear, Network, Sequential, conv_bn_fwd, draw_mask,
                       grad_of)
-from .efficientnet_v2 import init_regression_head_, regression_head
+from .efficientnet_v2 import bn_sums_from_dw_ok, dw_dgrad_expand_bwd, init_regression_head_, regression_head
 
 
 class Conv2d_BN(Layer):
@@ -89,7 +89,14 @@ class MBConv(Layer):
         z = tape.pop()
         dz = K.act_bwd(z, dy, z.shape[-1], "gelu")
         d_branch, d_skip = self.drop_path.bwd2(dz, tape)
-        dx = self.conv1.bwd(self.conv2.bwd(self.conv3.bwd(d_branch, tape), tape), tape)
+        d3 = self.conv3.bwd(d_branch, tape)
+        dy2 = self.conv2.bn.bwd(d3, tape)
+        if bn_sums_from_dw_ok(self.conv2.c, tape):
+            # the depthwise input-gradient kernel also reduces conv1's BatchNorm backward sums (one read of conv1's raw output there
+            # instead of a reduction pass over it and the gradient: the 4x-expanded 56 x 56 tensors are the largest of the network)
+            dx = dw_dgrad_expand_bwd(self.conv2.c, (self.conv1.c, self.conv1.bn), dy2, tape)
+        else:
+            dx = self.conv1.bwd(self.conv2.c.bwd(dy2, tape), tape)
         return K.add(dx, d_skip)
 
 
