@@ -410,6 +410,12 @@ int suhpe_add3(const float* a, const float* b, const float* c, int64_t count, fl
  * draw fresh numbers); with advance == 0 the caller tracks the position in host_offset and saves the extra launch. */
 int suhpe_dropout_mask(uint64_t* counter, uint64_t host_offset, int advance, float keep, int64_t count, float* mask,
                        suhpe_stream_t stream);
+/* every mask of a forward pass (StochasticDepth('row') of each residual block, reference src/networks.py:303 / torchvision MBConv) from ONE
+ * launch: request k draws count[k] values with keep[k] at stream position counter[1] + host_offset + rel[k] into out + out_off[k]
+ * (device arrays of nreq entries).  With rel[k] = the cumulative ceil(count / 4) of the requests before it the values equal those of
+ * nreq consecutive suhpe_dropout_mask calls. */
+int suhpe_dropout_mask_batch(const uint64_t* counter, uint64_t host_offset, const int64_t* rel, const float* keep, const int64_t* count,
+                             const int64_t* out_off, int nreq, int64_t max_count, float* out, suhpe_stream_t stream);
 
 /* ------------------------------------------------------------------ reductions for the loss ------------- */
 /* out[0] = scale * sum_i x[i]*(w ? w[i] : 1) */

@@ -1552,6 +1552,28 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(const uint64_t* __res
     }
 }
 __global__ void advance_counter_kernel(uint64_t* counter, uint64_t by) { counter[1] += by; }
+// the masks of a whole forward pass from one launch: request k = blockIdx.y draws count[k] values at stream position + rel[k] into
+// out + out_off[k]; with rel[k] = the positions a sequence of suhpe_dropout_mask calls would have used, the values are the same
+__global__ __launch_bounds__(256) void dropout_mask_batch_kernel(const uint64_t* __restrict__ counter, uint64_t extra, const int64_t* __restrict__ rel,
+                                                                 const float* __restrict__ keep_k, const int64_t* __restrict__ count_k,
+                                                                 const int64_t* __restrict__ out_off, float* __restrict__ out) {
+    const int k = blockIdx.y;
+    const uint64_t seed = counter[0], offset = counter[1] + extra + (uint64_t)rel[k];
+    const float keep = keep_k[k], inv = keep > 0.f ? 1.f / keep : 0.f;
+    const int64_t count = count_k[k];
+    float* mask = out + out_off[k];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i * 4 < count; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t ctr = offset + (uint64_t)i;
+        uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x5355u, c3 = 0x4850u;
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) { philox_round(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+        const uint32_t rr[4] = {c0, c1, c2, c3};
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            if (i * 4 + v < count) mask[i * 4 + v] = ((rr[v] >> 8) * (1.0f / 16777216.0f)) < keep ? inv : 0.f;
+    }
+}
 
 // ------------------------------------------------------------------------------------------ loss reductions
 __global__ __launch_bounds__(256) void weighted_sum_kernel(const float* __restrict__ x, const float* __restrict__ w, int64_t count,
@@ -2270,6 +2292,16 @@ int suhpe_dropout_mask(uint64_t* counter, uint64_t host_offset, int advance, flo
     LAUNCH(dropout_mask_kernel, dim3(grid_for(n4, 256)), dim3(256), stream, counter, host_offset, keep, count, mask);
     if (advance) LAUNCH(advance_counter_kernel, dim3(1), dim3(1), stream, counter, (uint64_t)n4);
     return check_launch("suhpe_dropout_mask");
+}
+
+int suhpe_dropout_mask_batch(const uint64_t* counter, uint64_t host_offset, const int64_t* rel, const float* keep, const int64_t* count,
+                             const int64_t* out_off, int nreq, int64_t max_count, float* out, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(counter && rel && keep && count && out_off && out && nreq > 0 && max_count > 0, "suhpe_dropout_mask_batch: bad arguments");
+    const int64_t n4 = ceil_div(max_count, 4);
+    int64_t gx = ceil_div(n4, 256);
+    if (gx > 64) gx = 64;
+    LAUNCH(dropout_mask_batch_kernel, dim3((unsigned)gx, (unsigned)nreq), dim3(256), stream, counter, host_offset, rel, keep, count, out_off, out);
+    return check_launch("suhpe_dropout_mask_batch");
 }
 
 int suhpe_weighted_sum(const float* x, const float* w, int64_t count, float scale, float* out, suhpe_stream_t stream) {

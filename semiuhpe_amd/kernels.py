@@ -1185,6 +1185,34 @@ def dropout_mask(shape, keep, device):
     return m
 
 
+_MASK_TABLES = {}
+
+
+def dropout_masks(requests, device):
+    """requests: [(shape, keep)] -> list of masks, the values consecutive dropout_mask calls would have drawn, from ONE launch
+    (suhpe_dropout_mask_batch); the request table lives on the device and is reused while the sequence repeats"""
+    key = (torch.device(device), tuple((tuple(s), float(k)) for s, k in requests))
+    tab = _MASK_TABLES.get(key)
+    if tab is None:
+        counts = [int(torch.Size(s).numel()) for s, _ in requests]
+        rel, off, r, o = [], [], 0, 0
+        for c in counts:
+            rel.append(r); off.append(o)
+            r += (c + 3) // 4
+            o += (c + 3) // 4 * 4                            # 16-byte aligned sub-buffers
+        dev = torch.device(device)
+        tab = (torch.tensor(rel, dtype=torch.int64, device=dev), torch.tensor([float(k) for _, k in requests], dtype=torch.float32, device=dev),
+               torch.tensor(counts, dtype=torch.int64, device=dev), torch.tensor(off, dtype=torch.int64, device=dev), counts, off, r, o)
+        _MASK_TABLES[key] = tab
+    rel_t, keep_t, count_t, off_t, counts, off, total4, total = tab
+    out = torch.empty(total, dtype=torch.float32, device=device)
+    ctr = rng_counter(device)
+    dkey = torch.device(device)
+    call("suhpe_dropout_mask_batch", ptr(ctr), _host_offsets[dkey], ptr(rel_t), ptr(keep_t), ptr(count_t), ptr(off_t), len(counts), max(counts), ptr(out))
+    _host_offsets[dkey] += total4
+    return [out[o:o + c].view(tuple(s)) for (s, _), c, o in zip(requests, counts, off)]
+
+
 def weighted_sum(x, w=None, scale=1.0):
     out = torch.empty(1, dtype=torch.float32, device=x.device)
     call("suhpe_weighted_sum", ptr(x), ptr(w), x.numel(), float(scale), ptr(out))

@@ -29,7 +29,31 @@ def set_mask_hook(fn):
     _mask_hook = fn
 
 
+# The masks of a forward pass drawn ahead by ONE launch (a network that knows its sequence of draws calls prefetch_masks): draw_mask hands
+# them out in order; a draw that does not match the head of the queue drops the queue (the generator position has moved on, the values
+# stay valid random numbers).  Sequential and prefetched draws of the same sequence give the same values (same stream positions).
+_mask_queue = None
+
+
+def prefetch_masks(requests, device):
+    """requests: [(kind, shape, keep)] in the order the forward pass will draw them"""
+    global _mask_queue
+    _mask_queue = None
+    if _mask_hook is not None or len(requests) < 2:
+        return
+    import collections
+    masks = K.dropout_masks([(shape, keep) for _, shape, keep in requests], device)
+    _mask_queue = collections.deque(zip(requests, masks))
+
+
 def draw_mask(kind, shape, keep, device):
+    global _mask_queue
+    if _mask_queue:
+        (k0, s0, p0), m = _mask_queue[0]
+        if _mask_hook is None and k0 == kind and tuple(s0) == tuple(shape) and p0 == keep:
+            _mask_queue.popleft()
+            return m
+        _mask_queue = None
     if _mask_hook is not None:
         m = _mask_hook(kind, tuple(shape), keep)
         if m is not None:

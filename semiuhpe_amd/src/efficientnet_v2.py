@@ -355,6 +355,11 @@ class EfficientNetV2S(Network):
         init_regression_head_(self.classifier)
 
     def fwd(self, x, tape):
+        if self.training:                   # every StochasticDepth mask of the pass from one launch (same values as block-by-block draws)
+            from ..layers import prefetch_masks
+            reqs = [("stochastic_depth", (x.shape[0],), 1.0 - blk.stochastic_depth.p) for stage in list(self.features)[1:-1] for blk in stage
+                    if blk.use_res_connect and blk.stochastic_depth.training and blk.stochastic_depth.p > 0.0]
+            prefetch_masks(reqs, x.device)
         x = self.features.fwd(x, tape)
         x = self.avgpool.fwd(x, tape)
         return self.classifier.fwd(x, tape)

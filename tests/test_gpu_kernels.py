@@ -1176,3 +1176,28 @@ def test_pointwise_dgrad_reduces_batchnorm_backward_sums(K, n, h, cexp, cout, se
         s = sums.reshape(-1, cexp, 2)[i].double().cpu()
         assert rel(s[:, 0], g64[lo:hi].sum(0)) < 2e-5 and rel(s[:, 1], (g64[lo:hi] * xh).sum(0)) < 2e-5
     assert rel(g.reshape(rows, cexp), g64) < 3e-6
+
+
+def test_masks_of_a_pass_from_one_launch_equal_consecutive_draws(K):
+    """suhpe_dropout_mask_batch / layers.prefetch_masks: the StochasticDepth masks of a forward pass drawn ahead by one launch are the values
+    block-by-block draws give (same stream positions), the stream position after them is the same, a request of odd length included; a draw
+    that does not match the head of the queue falls back to an ordinary draw"""
+    from semiuhpe_amd import layers as L
+    dev = torch.device("cuda", torch.cuda.current_device())
+    reqs = [((160,), 0.995), ((160,), 0.9), ((7,), 0.5), ((160, 3), 0.8), ((160,), 0.85)]
+    K.rng_counter(dev, seed=77)
+    seq = [K.dropout_mask(s, k, dev).cpu() for s, k in reqs]
+    after_seq = K.dropout_mask((64,), 0.5, dev).cpu()
+    K.rng_counter(dev, seed=77)
+    bat = [m.cpu() for m in K.dropout_masks(reqs, dev)]
+    after_bat = K.dropout_mask((64,), 0.5, dev).cpu()
+    for a, b in zip(seq, bat):
+        assert a.shape == b.shape and torch.equal(a, b)
+    assert torch.equal(after_seq, after_bat)
+    K.rng_counter(dev, seed=77)
+    L.prefetch_masks([("stochastic_depth", s, k) for s, k in reqs], dev)
+    got = [L.draw_mask("stochastic_depth", s, k, dev).cpu() for s, k in reqs[:3]]
+    for a, b in zip(seq, got):
+        assert torch.equal(a, b)
+    other = L.draw_mask("dropout", (5, 5), 0.5, dev)       # not the head of the queue: ordinary draw
+    assert other.shape == (5, 5) and L._mask_queue is None
