@@ -300,6 +300,15 @@ class TinyViT21M(Network):
         init_regression_head_(self.head)
 
     def fwd(self, x, tape):
+        if self.training:                   # every DropPath mask of the pass from one launch (same values as draw-by-draw)
+            from ..layers import prefetch_masks
+            reqs = []
+            for stage in self.layers:
+                for blk in stage.blocks:
+                    dp = blk.drop_path
+                    if dp.training and dp.drop_prob > 0.0:
+                        reqs += [("drop_path", (x.shape[0],), 1.0 - dp.drop_prob)] * (2 if isinstance(blk, TinyViTBlock) else 1)
+            prefetch_masks(reqs, x.device)
         x = self.layers.fwd(self.patch_embed.fwd(x, tape), tape)
         if tape is not None:
             tape.append(x.shape)
