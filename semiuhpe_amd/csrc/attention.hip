@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void window_attn_fwd_kernel(const AttnGeom g, 
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int j = jj * 64 + lane;
-            s[jj] = (active && j < g.N) ? expf(s[jj] - m) : 0.f;
+            s[jj] = (active && j < g.N) ? __builtin_amdgcn_exp2f((s[jj] - m) * 1.4426950408889634f) : 0.f;
             sum += s[jj];
         }
         sum = wave_sum(sum);
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(NP == 64 ? 128 : 256, 2) void window_attn_fwd_mfma(
             const int j = kt * 32 + r32;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float pv = j < g.N ? expf(sc[kt][e] - rmax[e]) : 0.f;      // rows beyond N: exp(0) = 1, never stored
+                const float pv = j < g.N ? __builtin_amdgcn_exp2f((sc[kt][e] - rmax[e]) * 1.4426950408889634f) : 0.f;      // (v_exp_f32: 1 ulp; libm's expf is ~10 VALU instructions per probability)  rows beyond N: exp(0) = 1, never stored
                 sc[kt][e] = pv;
                 rsum[e] += pv;
             }
