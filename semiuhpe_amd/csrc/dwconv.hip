@@ -457,6 +457,7 @@ __global__ __launch_bounds__(256) void dw3x3_s1_kernel(const float* __restrict__
 // the window in registers, three ds_read_b128 per output -- the NEXT group's loads are already in flight.  tools/proto/dw_lab.hip:
 // 160 x 14 x 14 x 960: 63 -> 45 us.  LDS: 16 consecutive lanes read 256 contiguous bytes, rows are a multiple of 256 B apart: no conflicts.
 constexpr int kTileSlots = 16;                       // image rows per workgroup pass = 256 threads / 16 channel vectors
+constexpr int kTileAhead = 6;                        // column steps between a per-row operand's load (BatchNorm input, dy) and its use
 template <int HW> struct DwTile {
     static constexpr int imgs = kTileSlots / HW;                                   // whole images per group (14 -> 1, 7 -> 2)
     static constexpr int npix = imgs * HW * HW;
@@ -551,13 +552,12 @@ __global__ __launch_bounds__(256, (HW == 14 || BNB || (XF && STATS)) ? 2 : 3) vo
                 }
                 b_crossed = true;
             }
-            // BNB: the BatchNorm input at the output positions, three column steps ahead of its use
+            // BNB: the BatchNorm input at the output positions, kTileAhead column steps ahead of its use
             const float* bxp = BNB ? bnb.x + ((n * HW + row) * HW) * C + c0 : nullptr;
-            float4 bx0 = make_float4(0.f, 0.f, 0.f, 0.f), bx1 = bx0, bx2 = bx0;
+            float4 bq[kTileAhead];
             if (BNB) {
-                bx0 = *reinterpret_cast<const float4*>(bxp);
-                bx1 = *reinterpret_cast<const float4*>(bxp + (int64_t)1 * C);
-                bx2 = *reinterpret_cast<const float4*>(bxp + (int64_t)2 * C);
+#pragma unroll
+                for (int d = 0; d < kTileAhead; ++d) bq[d] = *reinterpret_cast<const float4*>(bxp + (int64_t)(d < HW ? d : HW - 1) * C);
             }
             const float* base = &tile[((img * WP + row) * WP) * 64 + vc * 4];      // padded (row, column 0): the window's top-left corner
             float4 a[3], b[3], c[3];
@@ -571,10 +571,11 @@ __global__ __launch_bounds__(256, (HW == 14 || BNB || (XF && STATS)) ? 2 : 3) vo
             for (int ow = 0; ow < HW; ++ow) {
 #pragma unroll
                 for (int r = 0; r < 3; ++r) c[r] = *reinterpret_cast<const float4*>(base + (r * WP + ow + 2) * 64);
-                const float4 bxc = bx0;
+                const float4 bxc = BNB ? bq[0] : make_float4(0.f, 0.f, 0.f, 0.f);
                 if (BNB) {
-                    bx0 = bx1; bx1 = bx2;
-                    bx2 = *reinterpret_cast<const float4*>(bxp + (int64_t)(ow + 3 < HW ? ow + 3 : HW - 1) * C);
+#pragma unroll
+                    for (int d = 0; d + 1 < kTileAhead; ++d) bq[d] = bq[d + 1];
+                    bq[kTileAhead - 1] = *reinterpret_cast<const float4*>(bxp + (int64_t)(ow + kTileAhead < HW ? ow + kTileAhead : HW - 1) * C);
                 }
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -641,7 +642,7 @@ __global__ __launch_bounds__(256, (HW == 14 || BNB || (XF && STATS)) ? 2 : 3) vo
 }
 
 // Filter gradient on the same image tiles: x (through the input transform, once per element) is staged in LDS with its zero ring, a
-// thread = (channel vector, image row) walks its row with the 3 x 3 window of x in registers and the row's dy values arriving three steps
+// thread = (channel vector, image row) walks its row with the 3 x 3 window of x in registers and the row's dy values arriving kTileAhead steps
 // ahead, and keeps the nine tap sums of its four channels in registers ACROSS the image groups of its persistent workgroup: one LDS
 // reduction and one part[bx][tap][c] record set per workgroup at the end (dw_wgrad_finalize adds the workgroups in fp64).
 // The row kernel below loads and uses x / dy in the same step (no prefetch): 2.4-3.0 TB/s on these shapes.
@@ -700,8 +701,9 @@ __global__ __launch_bounds__(256, 2) void dw3x3_wgrad_tile_kernel(const float* _
         const int64_t n = (int64_t)g * T::imgs + img;
         if (crow && cok && n < N) {
             const float* dp = dy + ((n * HW + row) * HW) * C + c0;
-            float4 d0 = *reinterpret_cast<const float4*>(dp), d1 = *reinterpret_cast<const float4*>(dp + (int64_t)1 * C),
-                   d2 = *reinterpret_cast<const float4*>(dp + (int64_t)2 * C);
+            float4 dq[kTileAhead];
+#pragma unroll
+            for (int d = 0; d < kTileAhead; ++d) dq[d] = *reinterpret_cast<const float4*>(dp + (int64_t)(d < HW ? d : HW - 1) * C);
             const float* base = &tile[((img * WP + row) * WP) * 64 + vc * 4];
             float4 a[3], b[3], c[3];
 #pragma unroll
@@ -713,9 +715,10 @@ __global__ __launch_bounds__(256, 2) void dw3x3_wgrad_tile_kernel(const float* _
             for (int ow = 0; ow < HW; ++ow) {
 #pragma unroll
                 for (int r = 0; r < 3; ++r) c[r] = *reinterpret_cast<const float4*>(base + (r * WP + ow + 2) * 64);
-                const float4 dv = d0;
-                d0 = d1; d1 = d2;
-                d2 = *reinterpret_cast<const float4*>(dp + (int64_t)(ow + 3 < HW ? ow + 3 : HW - 1) * C);
+                const float4 dv = dq[0];
+#pragma unroll
+                for (int d = 0; d + 1 < kTileAhead; ++d) dq[d] = dq[d + 1];
+                dq[kTileAhead - 1] = *reinterpret_cast<const float4*>(dp + (int64_t)(ow + kTileAhead < HW ? ow + kTileAhead : HW - 1) * C);
 #pragma unroll
                 for (int r = 0; r < 3; ++r) { fma4(acc[r * 3], a[r], dv); fma4(acc[r * 3 + 1], b[r], dv); fma4(acc[r * 3 + 2], c[r], dv); }
 #pragma unroll
