@@ -130,7 +130,8 @@ __global__ __launch_bounds__(NP == 64 ? 128 : 256, 2) void window_attn_fwd_mfma(
                                                                             const float* __restrict__ dense_bias, float* __restrict__ out,
                                                                             float* __restrict__ probs) {
     constexpr int QB = NP / 32;                         // query / key tiles
-    constexpr int NW = NP == 64 ? 2 : 4;                // wavefronts
+    constexpr int NW = NP == 64 ? 2 : 4;                // wavefronts (eight, one per query block of a 196-token window, were measured: 228 vs 221 us --
+                                                        // the forward is bound by its probability stores, not by the imbalance of 7 blocks over 4 wavefronts)
     constexpr int VP = NP + 4;                          // row pitch of V^T
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;                                   // [NP][KP]
@@ -337,23 +338,27 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const AttnGeom g, 
 
 // ---- backward on the matrix cores (probabilities P from the forward pass).
 //   dP = dO V^T,  delta_i = sum_j P_ij dP_ij,  dS = P o (dP - delta),  dQ = scale dS K,  dK = scale dS^T Q,  dV = P^T dO
-// Phase A, a wavefront per 32 query rows: dP tiles for the whole window in registers, delta by xor-shuffles, dS written to the
-// scratch matrix (for the bias gradient) and, tile by tile through a wave-private LDS tile, used as the A operand of dS K.
-// Phase B, a wavefront per 32 keys: the dP / dS tiles are recomputed (16 MFMAs) and dK, dV accumulate in the "TN" form
-// (reduction index = query = row index of both operands, read from LDS one value per lane: A[k][m] = dS[query][key]).
-// LDS: V, dO and (K, then Q in the same buffer) as [token][32+4]; two staging tiles per wavefront; delta.
+// One wavefront per 32-row block in both phases (QB blocks: 2 wavefronts for 64-token windows, 7 of 8 for 196-token ones), two wavefronts
+// per SIMD on the large windows.  Round 3: the first version kept all dP and P tiles of a query block in registers (256 VGPRs + 153
+// AGPRs: ONE workgroup of four wavefronts per CU, every P load used right behind its issue) and ran at 29 TF/s; now
+// Phase A, a wavefront per 32 query rows, in TWO sweeps over the key tiles: sweep 1 accumulates delta alone (dP tile, P tile, multiply-add:
+//   nothing kept), sweep 2 recomputes each dP tile (16 MFMAs), forms dS, writes it to the scratch matrix (for the bias gradient) and feeds
+//   it, through a wave-private LDS tile, to dQ += dS K.  The P tile of the NEXT key tile is requested before the current tile's MFMAs.
+// Phase B, a wavefront per 32 keys: dP / dS tiles recomputed per query block; dK, dV accumulate in the "TN" form (reduction index = query =
+//   row index of both operands): dS^T from the LDS tile one value per lane, P^T from registers (the P tile is turned through the same LDS
+//   tile before dS overwrites it -- one staging tile per wavefront instead of two).
+// LDS: V, dO and (K, then Q in the same buffer) as [token][32+4]; one staging tile per wavefront; delta.
 template <int NP>
-__global__ __launch_bounds__(NP == 64 ? 128 : 256) void window_attn_bwd_mfma(const AttnGeom g, const float* __restrict__ qkv,
-                                                                            const float* __restrict__ probs, const float* __restrict__ dout,
-                                                                            float* __restrict__ dS_out, float* __restrict__ dqkv) {
+__global__ __launch_bounds__(NP == 64 ? 128 : 512, 2) void window_attn_bwd_mfma(const AttnGeom g, const float* __restrict__ qkv,
+                                                                               const float* __restrict__ probs, const float* __restrict__ dout,
+                                                                               float* __restrict__ dS_out, float* __restrict__ dqkv) {
     constexpr int QB = NP / 32;
-    constexpr int NW = NP == 64 ? 2 : 4;
+    constexpr int NW = NP == 64 ? 2 : 8;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* KQ = smem;                                   // [NP][KP]: K during phase A, Q during phase B
     float* Vs = KQ + NP * KP;                           // [NP][KP]
     float* Os = Vs + NP * KP;                           // [NP][KP]  dO
-    float* stP = Os + NP * KP;                          // [NW][32][PP]
-    float* stS = stP + NW * 32 * PP;                    // [NW][32][PP]
+    float* stS = Os + NP * KP;                          // [NW][32][PP]
     float* delta = stS + NW * 32 * PP;                  // [NP]
     const int win = blockIdx.x / g.heads, hd = blockIdx.x - win * g.heads;
     const int ld = g.heads * 3 * DH, lo = g.heads * DH, t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -365,7 +370,6 @@ __global__ __launch_bounds__(NP == 64 ? 128 : 256) void window_attn_bwd_mfma(con
     const BufRsrc ro = make_rsrc(dout, (int64_t)g.B * g.H * g.W * lo * 4);
     const BufRsrc rp = make_rsrc(P, (int64_t)g.N * g.N * 4);
     auto load_rows = [&](BufRsrc src, int ldsrc, int off, float* dst) __attribute__((always_inline)) {
-#pragma unroll
         for (int e = t; e < NP * (DH / 4); e += NW * 64) {
             const int tok = e / (DH / 4), c4 = (e - tok * (DH / 4)) * 4;
             float4 v;
@@ -378,38 +382,51 @@ __global__ __launch_bounds__(NP == 64 ? 128 : 256) void window_attn_bwd_mfma(con
     load_rows(ro, lo, hd * DH, Os);
     __syncthreads();
     float* sS = stS + wave * 32 * PP;
-    float* sP = stP + wave * 32 * PP;
+    // the P tile (query block qb, key tile kt) in the MFMA C layout: element e of this lane = P[qb*32 + (e&3) + 8(e>>2) + 4h][kt*32 + r32]
+    auto load_p = [&](int qb, int kt, float (&pv)[16]) __attribute__((always_inline)) {
+        const int j = kt * 32 + r32;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            buf_load<1>(rp, ((i < g.N) & (j < g.N) & (kt < QB) & (qb < QB)) ? (unsigned)((i * g.N + j) * 4) : kOob, &pv[e]);
+        }
+    };
+    // dP tile = dO[query block] V[key tile]^T (16 MFMAs, operands from LDS)
+    auto dp_tile = [&](const float4 (&of)[DH / 8], int kt) __attribute__((always_inline)) -> floatx16 {
+        floatx16 dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dp[e] = 0.f;
+#pragma unroll
+        for (int kg = 0; kg < DH / 8; ++kg) {
+            const float4 vf = *reinterpret_cast<const float4*>(&Vs[(kt * 32 + r32) * KP + kg * 8 + h * 4]);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(of[kg].x, vf.x, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(of[kg].y, vf.y, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(of[kg].z, vf.z, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(of[kg].w, vf.w, dp, 0, 0, 0);
+        }
+        return dp;
+    };
 
     // ---------------- phase A: query blocks
     for (int qb = wave; qb < QB; qb += NW) {
         float4 of[DH / 8];
 #pragma unroll
         for (int kg = 0; kg < DH / 8; ++kg) of[kg] = *reinterpret_cast<const float4*>(&Os[(qb * 32 + r32) * KP + kg * 8 + h * 4]);
-        floatx16 dp[QB], pt[QB];
-        float dl[16];
+        float dl[16], pa[16], pb[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) dl[e] = 0.f;
+        // sweep 1: delta
+        load_p(qb, 0, pa);
+        for (int kt = 0; kt < QB; kt += 2) {
+            load_p(qb, kt + 1, pb);
+            floatx16 dp = dp_tile(of, kt);
 #pragma unroll
-        for (int kt = 0; kt < QB; ++kt) {
+            for (int e = 0; e < 16; ++e) dl[e] += pa[e] * dp[e];
+            if (kt + 1 >= QB) break;
+            load_p(qb, kt + 2, pa);
+            dp = dp_tile(of, kt + 1);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) dp[kt][e] = 0.f;
-#pragma unroll
-            for (int kg = 0; kg < DH / 8; ++kg) {
-                const float4 vf = *reinterpret_cast<const float4*>(&Vs[(kt * 32 + r32) * KP + kg * 8 + h * 4]);
-                dp[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(of[kg].x, vf.x, dp[kt], 0, 0, 0);
-                dp[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(of[kg].y, vf.y, dp[kt], 0, 0, 0);
-                dp[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(of[kg].z, vf.z, dp[kt], 0, 0, 0);
-                dp[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(of[kg].w, vf.w, dp[kt], 0, 0, 0);
-            }
-            const int j = kt * 32 + r32;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int i = qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                float pv;
-                buf_load<1>(rp, ((i < g.N) & (j < g.N)) ? (unsigned)((i * g.N + j) * 4) : kOob, &pv);
-                pt[kt][e] = pv;
-                dl[e] += pv * dp[kt][e];
-            }
+            for (int e = 0; e < 16; ++e) dl[e] += pb[e] * dp[e];
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -417,16 +434,17 @@ __global__ __launch_bounds__(NP == 64 ? 128 : 256) void window_attn_bwd_mfma(con
             for (int m = 1; m < 32; m <<= 1) dl[e] += __shfl_xor(dl[e], m, 64);
             if (r32 == 0) delta[qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] = dl[e];
         }
+        // sweep 2: dS tiles and dQ
         floatx16 dq;
 #pragma unroll
         for (int e = 0; e < 16; ++e) dq[e] = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < QB; ++kt) {
+        auto ds_dq = [&](int kt, const float (&pv)[16]) __attribute__((always_inline)) {
+            const floatx16 dp = dp_tile(of, kt);
             const int j = kt * 32 + r32;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int rl = (e & 3) + 8 * (e >> 2) + 4 * h, i = qb * 32 + rl;
-                const float ds = pt[kt][e] * (dp[kt][e] - dl[e]);
+                const float ds = pv[e] * (dp[e] - dl[e]);
                 sS[rl * PP + r32] = ds;
                 if (i < g.N && j < g.N) S[i * g.N + j] = ds;
             }
@@ -441,6 +459,14 @@ __global__ __launch_bounds__(NP == 64 ? 128 : 256) void window_attn_bwd_mfma(con
                 dq = __builtin_amdgcn_mfma_f32_32x32x2f32(sf.w, KQ[(key + 3) * KP + r32], dq, 0, 0, 0);
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
+        };
+        load_p(qb, 0, pa);
+        for (int kt = 0; kt < QB; kt += 2) {
+            load_p(qb, kt + 1, pb);
+            ds_dq(kt, pa);
+            if (kt + 1 >= QB) break;
+            load_p(qb, kt + 2, pa);
+            ds_dq(kt + 1, pb);
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -457,36 +483,42 @@ __global__ __launch_bounds__(NP == 64 ? 128 : 256) void window_attn_bwd_mfma(con
         floatx16 dk, dv;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { dk[e] = 0.f; dv[e] = 0.f; }
-        const int j = kt * 32 + r32;
-        for (int qb = 0; qb < QB; ++qb) {
-            floatx16 dp;
+        float pa[16], pb[16];
+        auto dk_dv = [&](int qb, const float (&pv)[16]) __attribute__((always_inline)) {
+            float4 of[DH / 8];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) dp[e] = 0.f;
+            for (int kg = 0; kg < DH / 8; ++kg) of[kg] = *reinterpret_cast<const float4*>(&Os[(qb * 32 + r32) * KP + kg * 8 + h * 4]);
+            const floatx16 dp = dp_tile(of, kt);
+            // turn the P tile into the A-operand layout of P^T dO: lane (key r32, half h) takes P[query 2 kk + h][key] for kk = 0..15
+            // (reading the tile a second time from L1 / L2 in that layout instead was measured slower: 650 vs 611 us)
 #pragma unroll
-            for (int kg = 0; kg < DH / 8; ++kg) {
-                const float4 of = *reinterpret_cast<const float4*>(&Os[(qb * 32 + r32) * KP + kg * 8 + h * 4]);
-                const float4 vf = *reinterpret_cast<const float4*>(&Vs[(kt * 32 + r32) * KP + kg * 8 + h * 4]);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(of.x, vf.x, dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(of.y, vf.y, dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(of.z, vf.z, dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(of.w, vf.w, dp, 0, 0, 0);
-            }
+            for (int e = 0; e < 16; ++e) sS[((e & 3) + 8 * (e >> 2) + 4 * h) * PP + r32] = pv[e];
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            float pt[16];
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) pt[kk] = sS[(2 * kk + h) * PP + r32];
+            __builtin_amdgcn_s_waitcnt(0xc07f);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int rl = (e & 3) + 8 * (e >> 2) + 4 * h, i = qb * 32 + rl;
-                float pv;
-                buf_load<1>(rp, ((i < g.N) & (j < g.N)) ? (unsigned)((i * g.N + j) * 4) : kOob, &pv);
-                sP[rl * PP + r32] = pv;
-                sS[rl * PP + r32] = pv * (dp[e] - delta[i]);
+                const int rl = (e & 3) + 8 * (e >> 2) + 4 * h;
+                sS[rl * PP + r32] = pv[e] * (dp[e] - delta[qb * 32 + rl]);
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
                 const int q = 2 * kk + h;               // query inside the block = reduction index
                 dk = __builtin_amdgcn_mfma_f32_32x32x2f32(sS[q * PP + r32], KQ[(qb * 32 + q) * KP + r32], dk, 0, 0, 0);
-                dv = __builtin_amdgcn_mfma_f32_32x32x2f32(sP[q * PP + r32], Os[(qb * 32 + q) * KP + r32], dv, 0, 0, 0);
+                dv = __builtin_amdgcn_mfma_f32_32x32x2f32(pt[kk], Os[(qb * 32 + q) * KP + r32], dv, 0, 0, 0);
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
+        };
+        load_p(0, kt, pa);
+        for (int qb = 0; qb < QB; qb += 2) {
+            load_p(qb + 1, kt, pb);
+            dk_dv(qb, pa);
+            if (qb + 1 >= QB) break;
+            load_p(qb + 2, kt, pa);
+            dk_dv(qb + 1, pb);
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -613,16 +645,13 @@ int suhpe_window_attn_bwd(const float* qkv, const float* probs, const float* dou
     float* dS = static_cast<float*>(workspace);
     const int nwin = B * g.nwy * g.nwx;
     if (g.N <= 64) {
-        const size_t l2 = (size_t)(3 * 64 * KP + 2 * 2 * 32 * PP + 64) * sizeof(float);
+        const size_t l2 = (size_t)(3 * 64 * KP + 2 * 32 * PP + 64) * sizeof(float);
         hipLaunchKernelGGL(window_attn_bwd_mfma<64>, dim3(nwin * heads), dim3(128), l2, as_stream(stream), g, qkv, probs, dout, dS, dqkv);
     } else if (g.N <= 224) {
-        const size_t l2 = (size_t)(3 * 224 * KP + 2 * 4 * 32 * PP + 224) * sizeof(float);
-        static bool attr2 = false;
-        if (!attr2) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_bwd_mfma<224>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr2 = true;
-        }
-        hipLaunchKernelGGL(window_attn_bwd_mfma<224>, dim3(nwin * heads), dim3(256), l2, as_stream(stream), g, qkv, probs, dout, dS, dqkv);
+        const size_t l2 = (size_t)(3 * 224 * KP + 8 * 32 * PP + 224) * sizeof(float);
+        // (the attribute is per device: set before every launch, no process-wide flag to go stale on a second GPU)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_bwd_mfma<224>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(window_attn_bwd_mfma<224>, dim3(nwin * heads), dim3(512), l2, as_stream(stream), g, qkv, probs, dout, dS, dqkv);
     } else {
         hipLaunchKernelGGL(window_attn_bwd_kernel, dim3(nwin * heads), dim3(256), lds, as_stream(stream), g, qkv, probs, dout, dS, dqkv);
     }
