@@ -368,6 +368,219 @@ void igemm_nt3x3_kernel(const NtParams p, const HaloGeom hg) {
     }
 }
 
+// ---- 48-column PATCH tile: 128 rows x 48 columns, four wavefronts of 32 rows each: columns 0-31 on the 32x32x2 MFMA as above, columns
+// 32-47 on two v_mfma_f32_16x16x4_f32 blocks (rows 0-15 / 16-31 of the wavefront's 32) -- an output with 48 channels (the input gradient
+// of EfficientNetV2-S's 48 -> 192 FusedMBConv expand convs: 1.7 TFLOP per step) wastes a quarter of a 64-column tile's matrix work.
+// 16x16x4 operands: lane l supplies A[row l & 15][k] and B[k][column l & 15] for the k of its 16-lane group q = l >> 4; a ds_read_b128 hands
+// it four consecutive k, used by four MFMAs: group q of read g takes k = 4 (q * CC/16 + g) .. +3 of the slab (any assignment works as long as
+// A and B agree).  Two-way LDS conflicts on these reads (no lane -> row permutation serves both fragment shapes), which the matrix pipe hides.
+// Forward or input gradient without statistics / folded affine; bias and the skip-connection add (res_mode 3) in the epilogue.
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+template <int CC>
+__global__ __launch_bounds__(256, 2) void igemm_nt3x3_n48_kernel(const NtParams p, const HaloGeom hg) {
+    constexpr int BM = 128, BN = 48, NT = 256;
+    constexpr int LDP = CC + 4, VC = CC / 4, KG = CC / 8, NG16 = CC / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                // [240][LDP]
+    float* Bs = smem + (size_t)hg.nslots * LDP;      // [48][LDP]
+    const GatherGeom& g = p.g;
+    const int t = threadIdx.x, lane = t & 63, wm = t >> 6;
+    const int grp = blockIdx.z;
+    const int b = blockIdx.x, jx = b >> 3, col_tile = jx % p.col_tiles;
+    int row_tile;
+    {
+        const int row_tiles = (int)((g.M + BM - 1) / BM), q = row_tiles >> 3, rem = row_tiles & 7, xcd = b & 7, jl = jx / p.col_tiles;
+        if (jl >= q + (xcd < rem ? 1 : 0)) return;
+        row_tile = xcd * q + (xcd < rem ? xcd : rem) + jl;
+    }
+    const int64_t m0 = (int64_t)row_tile * BM;
+    const int n0 = col_tile * BN;
+    const BufRsrc xr = make_rsrc(p.x + (int64_t)grp * g.Cg, p.x_bytes - (int64_t)grp * g.Cg * 4);
+    const BufRsrc fr = make_rsrc(p.f + (int64_t)grp * p.Ng * p.ldf, p.f_bytes - (int64_t)grp * p.Ng * p.ldf * 4);
+    const int sgn = g.mode == 0 ? 1 : -1;
+    // ---- A image loader (PATCH tiles: two 10 x 10 halo patches)
+    constexpr int LPT_MAX = (2 * 100 * VC + NT - 1) / NT;
+    int a_goff[LPT_MAX], a_loff[LPT_MAX];
+#pragma unroll
+    for (int i = 0; i < LPT_MAX; ++i) {
+        const int pair = t + i * NT;
+        const int idx = pair / VC, vcol = pair - idx * VC;
+        a_goff[i] = -1;
+        a_loff[i] = -1;
+        if (idx < 200) {
+            const int bq = idx / 100, rem = idx - bq * 100, py = rem / 10, px = rem - py * 10;
+            const unsigned pidx = (unsigned)(m0 >> 6) + (unsigned)bq;
+            const unsigned nn = fast_div(pidx, hg.div_pxy_mul, hg.div_pxy_shr);
+            const unsigned pr = pidx - nn * (unsigned)hg.PXY;
+            const unsigned pyy = fast_div(pr, hg.div_px_mul, hg.div_px_shr), pxx = pr - pyy * (unsigned)hg.PX;
+            const int n = (int)nn, oh = (int)pyy * 8 + py - 1, ow = (int)pxx * 8 + px - 1;
+            const bool ok = (unsigned)oh < (unsigned)g.OH && (unsigned)ow < (unsigned)g.OW && n < g.N;
+            a_goff[i] = ok ? ((n * g.OH + oh) * g.OW + ow) * g.ldg + vcol * 4 : -1;
+            a_loff[i] = (bq * 120 + py * 12 + px) * LDP + vcol * 4;
+        }
+    }
+    constexpr int BPT = (BN * VC + NT - 1) / NT;
+    int b_goff[BPT], b_loff[BPT];
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) {
+        const int pair = t + i * NT;
+        const int brow = pair / VC, vcol = pair - brow * VC;
+        const int col = n0 + brow;
+        b_goff[i] = (brow < BN && col < p.Ng) ? col * p.ldf + vcol * 4 : -1;
+        b_loff[i] = brow < BN ? brow * LDP + vcol * 4 : -1;
+    }
+    // ---- fragment bases (tap (1,1) position): the 32-row block of the wavefront, and its two 16-row blocks in the 16x16x4 lane order
+    const int r32 = lane & 31, h = lane >> 5, i16 = lane & 15, q16 = lane >> 4;
+    auto slot_of = [&](int row) __attribute__((always_inline)) {
+        int iy, ix;
+        halo_pi(row & 31, &iy, &ix);
+        iy += ((row >> 5) & 1) * 4;
+        return (row >> 6) * 120 + (iy + 1) * 12 + ix + 1;
+    };
+    const int arow32 = slot_of(wm * 32 + r32) * LDP + h * 4;
+    int arow16[2];
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) arow16[bb] = slot_of(wm * 32 + bb * 16 + i16) * LDP + q16 * NG16 * 4;
+    const int brow32 = r32 * LDP + h * 4, brow16 = (32 + i16) * LDP + q16 * NG16 * 4;
+
+    float a_stage[LPT_MAX][4];
+    float b_stage[2][BPT][4];
+    auto load_a = [&](int chunk) __attribute__((always_inline)) {
+        const int c0 = chunk * CC;
+#pragma unroll
+        for (int i = 0; i < LPT_MAX; ++i) {
+            const int vcol4 = ((t + i * NT) % VC) * 4;
+            const bool ok = (a_goff[i] >= 0) & (c0 + vcol4 < g.Cg);
+            buf_load<4>(xr, ok ? ((unsigned)a_goff[i] + (unsigned)c0) * 4u : kOob, a_stage[i]);
+        }
+    };
+    auto store_a = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < LPT_MAX; ++i) {
+            if (a_loff[i] < 0) continue;
+            *reinterpret_cast<float4*>(&As[a_loff[i]]) = make_float4(a_stage[i][0], a_stage[i][1], a_stage[i][2], a_stage[i][3]);
+        }
+    };
+    auto load_b = [&](auto stage, int chunk, int tap) __attribute__((always_inline)) {
+        auto& b_reg = b_stage[decltype(stage)::value];
+        const int c0 = chunk * CC, k0 = tap * g.Cg + c0;
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) {
+            const int vcol4 = ((t + i * NT) % VC) * 4;
+            const bool ok = (b_goff[i] >= 0) & (c0 + vcol4 < g.Cg);
+            buf_load<4>(fr, ok ? ((unsigned)b_goff[i] + (unsigned)k0) * 4u : kOob, b_reg[i]);
+        }
+    };
+    auto store_b = [&](auto stage) __attribute__((always_inline)) {
+        auto& b_reg = b_stage[decltype(stage)::value];
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) {
+            if (b_loff[i] < 0) continue;
+            *reinterpret_cast<float4*>(&Bs[b_loff[i]]) = make_float4(b_reg[i][0], b_reg[i][1], b_reg[i][2], b_reg[i][3]);
+        }
+    };
+    floatx16 acc32;
+    floatx4 acc16[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc32[e] = 0.f;
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc16[bb][e] = 0.f;
+    auto mma_slab = [&](int shift) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+            const float4 af = *reinterpret_cast<const float4*>(&As[arow32 + shift + kg * 8]);
+            const float4 bf = *reinterpret_cast<const float4*>(&Bs[brow32 + kg * 8]);
+            acc32 = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc32, 0, 0, 0);
+            acc32 = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc32, 0, 0, 0);
+            acc32 = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc32, 0, 0, 0);
+            acc32 = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc32, 0, 0, 0);
+        }
+#pragma unroll
+        for (int gg = 0; gg < NG16; ++gg) {
+            const float4 bf = *reinterpret_cast<const float4*>(&Bs[brow16 + gg * 4]);
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const float4 af = *reinterpret_cast<const float4*>(&As[arow16[bb] + shift + gg * 4]);
+                acc16[bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf.x, acc16[bb], 0, 0, 0);
+                acc16[bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf.y, acc16[bb], 0, 0, 0);
+                acc16[bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf.z, acc16[bb], 0, 0, 0);
+                acc16[bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf.w, acc16[bb], 0, 0, 0);
+            }
+        }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    const int nslabs = hg.nchunks * 9;
+    int c_chunk = 0, c_tap = 0, l_chunk = 0, l_tap = 0;
+    auto advance = [](int& chunk, int& tap) __attribute__((always_inline)) { if (++tap == 9) { tap = 0; ++chunk; } };
+    auto step = [&](int s_, auto cur, auto nxt) __attribute__((always_inline)) {
+        if (s_ + 2 < nslabs) { load_b(cur, l_chunk, l_tap); advance(l_chunk, l_tap); }
+        if (c_tap == 5 && c_chunk + 1 < hg.nchunks) load_a(c_chunk + 1);
+        const int tr = c_tap / 3, ts = c_tap - tr * 3;
+        mma_slab(sgn * ((tr - 1) * hg.P + (ts - 1)) * LDP);
+        __syncthreads();
+        if (s_ + 1 < nslabs) {
+            store_b(nxt);
+            if (c_tap == 8) store_a();
+            __syncthreads();
+        }
+        advance(c_chunk, c_tap);
+    };
+    load_a(0);
+    load_b(S0{}, 0, 0);
+    advance(l_chunk, l_tap);
+    store_a();
+    store_b(S0{});
+    __syncthreads();
+    if (nslabs > 1) { load_b(S1{}, l_chunk, l_tap); advance(l_chunk, l_tap); }
+    for (int s_ = 0; s_ < nslabs; s_ += 2) {
+        step(s_, S0{}, S1{});
+        if (s_ + 1 < nslabs) step(s_ + 1, S1{}, S0{});
+    }
+    // ---- epilogue: the 32-column block in the 32x32 C layout, the 16-column blocks in the 16x16 one (row = 4 (lane >> 4) + e, column = lane & 15)
+    float* __restrict__ y = p.y + (int64_t)grp * p.Ng;
+    {
+        const int col = n0 + r32;
+        int64_t orow[16];
+        bool rok[16];
+        float rv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            rok[e] = m0 + row < g.M && col < p.Ng;
+            orow[e] = halo_patch_orow(g, hg, m0, row);
+            rv[e] = (p.res_mode == 3 && rok[e]) ? p.residual[orow[e] * p.ldy + grp * p.Ng + col] : 0.f;
+        }
+        const float bv = (p.bias && col < p.Ng) ? p.bias[grp * p.Ng + col] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            if (rok[e]) y[orow[e] * p.ldy + col] = acc32[e] + bv + rv[e];
+    }
+    {
+        const int col = n0 + 32 + i16;
+        int64_t orow[8];
+        bool rok[8];
+        float rv[8];
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = wm * 32 + bb * 16 + 4 * q16 + e;
+                rok[bb * 4 + e] = m0 + row < g.M && col < p.Ng;
+                orow[bb * 4 + e] = halo_patch_orow(g, hg, m0, row);
+                rv[bb * 4 + e] = (p.res_mode == 3 && rok[bb * 4 + e]) ? p.residual[orow[bb * 4 + e] * p.ldy + grp * p.Ng + col] : 0.f;
+            }
+        const float bv = (p.bias && col < p.Ng) ? p.bias[grp * p.Ng + col] : 0.f;
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (rok[bb * 4 + e]) y[orow[bb * 4 + e] * p.ldy + col] = acc16[bb][e] + bv + rv[bb * 4 + e];
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------------------
 // eligible: 3x3, stride 1, pad 1 forward (mode 0) or input gradient (mode 1), 16-byte vector channels
 static bool halo_eligible(const GatherGeom& g) {
@@ -421,6 +634,27 @@ static bool launch_halo_cc(const NtParams& p_in, int groups, hipStream_t st) {
     else if constexpr (CC == 32) { if (p.scale) HALO_LAUNCH(false, true); else HALO_LAUNCH(false, false); }
     else return false;
 #undef HALO_LAUNCH
+    return true;
+}
+
+// the 48-column tile: PATCH geometries (output sizes that are multiples of 8), 32- or 48-channel chunks, no statistics / folded affine
+static bool launch_halo_n48(const NtParams& p_in, int groups, hipStream_t st) {
+    if (!halo_eligible(p_in.g) || p_in.stats || p_in.scale || p_in.y2 || p_in.a_scale || (p_in.res_mode != 0 && p_in.res_mode != 3)) return false;
+    const int cc = halo_chunk(p_in.g.Cg);
+    HaloGeom hg;
+    if (!(cc == 32 || cc == 48) || !halo_geom(p_in.g, 128, cc, &hg) || !hg.patch) return false;
+    NtParams p = p_in;
+    p.col_tiles = (int)ceil_div(p.Ng, 48);
+    const int64_t row_tiles8 = ceil_div(ceil_div(p.g.M, 128), 8) * 8;
+    const dim3 grid((unsigned)(row_tiles8 * p.col_tiles), 1, groups), block(256);
+    const size_t lds = ((size_t)hg.nslots + 48) * (cc + 4) * sizeof(float);
+    if (cc == 32) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_nt3x3_n48_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(igemm_nt3x3_n48_kernel<32>, grid, block, lds, st, p, hg);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_nt3x3_n48_kernel<48>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(igemm_nt3x3_n48_kernel<48>, grid, block, lds, st, p, hg);
+    }
     return true;
 }
 

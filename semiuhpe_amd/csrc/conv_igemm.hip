@@ -1239,6 +1239,7 @@ static void launch_nt(const NtParams& p_in, int groups, hipStream_t st) {
 // NT_H*: the 3x3 / stride 1 halo-tile kernel (conv_halo.inl); on any other geometry a pinned NT_H* tile runs the igemm tile of the same size
 enum NtTile { NT_64x64_S = 0, NT_64x64, NT_128x32, NT_128x128, NT_128x64, NT_256x32, NT_P64x64, NT_P128x32, NT_P128x64, NT_P128x128,
               NT_H64x64, NT_H128x32, NT_H128x64, NT_H128x128,
+              NT_H128x48,                    // halo tile of 48 columns: 32 on the 32x32x2 MFMA + 16 on the 16x16x4 MFMA (outputs with 48 channels)
               NT_W128x128, NT_W128x64,       // four wavefronts with 64x64 / 64x32 accumulators each: half the LDS fragment reads per MFMA
               NT_R128x16, NT_R64x8, NT_R64x16,   // operand-resident pointwise kernel (conv_resident.inl): 128 / 64 resident rows, 16 / 8 / 16 wavefronts
               NT_TILES };
@@ -1247,7 +1248,7 @@ static const char* kNtNames[] = {"igemm_nt_kernel<64,64,32,32,1>", "igemm_nt_ker
                                  "gemm_nt_persistent<64,64,32,32>", "gemm_nt_persistent<128,32,32,32>", "gemm_nt_persistent<128,64,32,32>",
                                  "gemm_nt_persistent<128,128,64,32>",
                                  "igemm_nt3x3_kernel<64,64,32,32>", "igemm_nt3x3_kernel<128,32,32,32>", "igemm_nt3x3_kernel<128,64,32,32>",
-                                 "igemm_nt3x3_kernel<128,128,64,32>",
+                                 "igemm_nt3x3_kernel<128,128,64,32>", "igemm_nt3x3_n48_kernel<128,48>",
                                  "igemm_nt_kernel<128,128,64,64,4>", "igemm_nt_kernel<128,64,64,32,4>",
                                  "gemm_nt_resident<128,2,16>", "gemm_nt_resident<64,2,8>", "gemm_nt_resident<64,2,16>"};
 
@@ -1328,7 +1329,7 @@ static NtTile effective_nt(NtTile tile, bool plain, bool halo = false, bool resi
     if (tile >= NT_W128x128) return tile;
     if (tile >= NT_H64x64) {
         if (halo) return tile;
-        return tile == NT_H64x64 ? NT_64x64 : (tile == NT_H128x32 ? NT_128x32 : (tile == NT_H128x64 ? NT_128x64 : NT_128x128));
+        return tile == NT_H64x64 ? NT_64x64 : (tile == NT_H128x32 ? NT_128x32 : ((tile == NT_H128x64 || tile == NT_H128x48) ? NT_128x64 : NT_128x128));
     }
     if (tile < NT_P64x64 || plain) return tile;
     return tile == NT_P64x64 ? NT_64x64 : (tile == NT_P128x32 ? NT_128x32 : (tile == NT_P128x64 ? NT_128x64 : NT_128x128));
@@ -1354,6 +1355,7 @@ static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st
             case NT_H64x64: done = launch_halo<64, 64, 32, 32>(p, groups, st); tile = NT_64x64; break;
             case NT_H128x32: done = launch_halo<128, 32, 32, 32>(p, groups, st); tile = NT_128x32; break;
             case NT_H128x64: done = launch_halo<128, 64, 32, 32>(p, groups, st); tile = NT_128x64; break;
+            case NT_H128x48: done = launch_halo_n48(p, groups, st); tile = NT_128x64; break;
             default: done = launch_halo<128, 128, 64, 32>(p, groups, st); tile = NT_128x128; break;
         }
         if (done) return;                                   // otherwise: the igemm tile of the same size (same row-tile height)
