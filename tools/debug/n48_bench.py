@@ -31,3 +31,16 @@ for n, hw, cin, cout in ((160, 56, 48, 192), (160, 56, 24, 96)):
         us = timed(lambda: K.conv2d_dgrad(dy, w, x_shape, 1, 1, 1, skip=skip))
         print(f"{n}x{hw}x{hw} {cin}<-{cout} dgrad+skip  {pin:40s} {us:8.1f} us  {flops / us / 1e6:6.1f} TF/s", flush=True)
     lib.suhpe_conv2d_set_tile(ctypes.byref(d), 1, -1)
+print("forward (no statistics epilogue):")
+for n in (160, 128):
+    hw, cin, cout = 56, 48, 192
+    x = torch.randn(n, hw, hw, cin, device="cuda")
+    w = K.to_filter_layout(torch.randn(cout, cin, 3, 3, device="cuda") / 20)
+    d = K.conv_desc(x.shape, w.shape, 1, 1, 1)
+    flops = 2.0 * n * hw * hw * cin * cout * 9
+    for pin in ("igemm_nt3x3_kernel<64,64,32,32>", "igemm_nt3x3_kernel<128,64,32,32>", "igemm_nt_kernel<128,64,32,32,4>", "igemm_nt_kernel<64,64,32,32,4>", "igemm_nt3x3_n48_kernel<128,48>"):
+        if lib.suhpe_conv2d_set_tile(ctypes.byref(d), 0, names.index(pin)) != 0:
+            continue
+        us = timed(lambda: K.conv2d_fwd(x, w, None, 1, 1, 1))
+        print(f"{n}x{hw}x{hw} {cin}->{cout} fwd  {pin:40s} {us:8.1f} us  {flops / us / 1e6:6.1f} TF/s", flush=True)
+    lib.suhpe_conv2d_set_tile(ctypes.byref(d), 0, -1)
