@@ -142,6 +142,11 @@ int suhpe_conv2d_wgrad_partial_xf(const suhpe_conv_t* d, const float* x, const f
  * never stored.  Bit-identical to the unfused chain (same k order, same act / act' arithmetic). */
 int suhpe_conv2d_fwd_act2(const suhpe_conv_t* d, const float* x, const float* w, const float* bias, int act, float* y_pre, float* y_act,
                           suhpe_stream_t stream);
+/* Linear / 1x1 conv whose output closes a residual connection (TinyViT: x + drop_path(proj(...)), x + drop_path(fc2(...)), reference
+ * src/tiny_vit.py:366,378; timm DropPath): y = (x w^T + bias) * rowscale[row / rows_per_sample] + skip from the GEMM epilogue -- no add pass over
+ * the activations.  rowscale: one keep scale per sample (mask / keep_prob) or NULL (scale 1); skip has y's shape. */
+int suhpe_conv2d_fwd_skip(const suhpe_conv_t* d, const float* x, const float* w, const float* bias, const float* skip, const float* rowscale,
+                          int rows_per_sample, float* y, suhpe_stream_t stream);
 int suhpe_conv2d_dgrad_actgrad(const suhpe_conv_t* d, const float* dy, const float* wt, const float* pre, int act, float* dx, suhpe_stream_t stream);
 /* Input gradient of a pointwise conv whose INPUT was act(BatchNorm(bn_x)) of a train-mode BatchNorm -- torchvision FusedMBConv: 3x3 expand
  * conv -> BatchNorm -> SiLU -> 1x1 project conv (src/networks.py:303), where the forward applies that BatchNorm in the project conv's

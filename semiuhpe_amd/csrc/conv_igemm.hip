@@ -122,6 +122,10 @@ struct NtParams {
     //                per (row tile, channel) as float2 records in `stats`: [plane s][row tile][channel] (s = batch segment of the row, seg_row)
     const float* bn_mean = nullptr;
     const float* bn_rstd = nullptr;
+    // residual connection with a per-sample keep scale (timm DropPath / torchvision StochasticDepth 'row') in the epilogue of the plain igemm
+    // tiles: y = (acc + bias) * o_rowscale[row / rows per sample] + residual   (res_mode 3; o_rowscale == NULL: scale 1)
+    const float* o_rowscale = nullptr;
+    unsigned o_div_mul = 0, o_div_shr = 0;
     // start-up stagger (see stagger_wait): workgroups of the first resident generation delay their first barrier by
     // (hardware wave slot) * stagger quanta so that co-resident workgroups run out of phase
     int stagger = 0, stagger_first = 0;
@@ -479,8 +483,10 @@ void igemm_nt_kernel(const NtParams p) {
                         y[orow * p.ldy + col] = v;
                         if (p.y2) p.y2[orow * p.ldy + grp * p.Ng + col] = act_apply(v, p.act);
                     } else if constexpr (!AFF_) {
-                        // res_mode 3: plain skip-connection add (input gradient + the gradient that bypassed the block)
-                        y[orow * p.ldy + col] = acc[i][j][e] + bv + (p.res_mode == 3 ? rv[e] : 0.f);
+                        // res_mode 3: plain skip-connection add (input gradient + the gradient that bypassed the block; forward: x + keep * f(x))
+                        float v = acc[i][j][e] + bv;
+                        if (p.o_rowscale) v *= p.o_rowscale[fast_div((unsigned)row, p.o_div_mul, p.o_div_shr)];
+                        y[orow * p.ldy + col] = v + (p.res_mode == 3 ? rv[e] : 0.f);
                     } else {
                         float v = acc[i][j][e] * sc + sh;
                         if (p.res_mode == 1) v += rv[e];
@@ -1337,7 +1343,7 @@ static NtTile effective_nt(NtTile tile, bool plain, bool halo = false, bool resi
 
 static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st, int pinned) {
     NtTile tile = choose_nt(p.g.M, p.Ng, vec4, pinned, halo_ok(p.g, vec4));
-    const bool act2 = p.y2 || p.res_mode >= 4;                 // activation epilogues live in igemm_nt_kernel's pointwise form only
+    const bool act2 = p.y2 || p.res_mode >= 4 || p.o_rowscale; // activation / keep-scale epilogues live in igemm_nt_kernel's pointwise form only
     if (act2 && tile >= NT_R128x16) tile = NT_64x64;
     if (act2 && tile >= NT_W128x128) tile = tile == NT_W128x128 ? NT_128x128 : NT_128x64;
     if (tile >= NT_R128x16) {
@@ -1437,6 +1443,27 @@ int suhpe_conv2d_fwd(const suhpe_conv_t* d, const float* x, const float* w, cons
     const bool vec4 = (cg % 4 == 0) && (d->cin % 4 == 0) && aligned16(x) && aligned16(w);
     dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 0));
     return check_launch("suhpe_conv2d_fwd");
+}
+
+static bool pointwise_vec4(const suhpe_conv_t* d);
+int suhpe_conv2d_fwd_skip(const suhpe_conv_t* d, const float* x, const float* w, const float* bias, const float* skip, const float* rowscale,
+                          int rows_per_sample, float* y, suhpe_stream_t stream) {
+    int rc = check_desc(d, "suhpe_conv2d_fwd_skip");
+    if (rc) return rc;
+    SUHPE_REQUIRE(pointwise_vec4(d), "suhpe_conv2d_fwd_skip: pointwise convs / Linear layers only (1x1, stride 1, groups 1, channels %% 4 == 0)");
+    SUHPE_REQUIRE(x && w && skip && y && aligned16(x) && aligned16(w), "suhpe_conv2d_fwd_skip: null or unaligned pointer");
+    SUHPE_REQUIRE(!rowscale || (rows_per_sample > 0 && ((int64_t)d->n * d->h * d->w) % rows_per_sample == 0 && (int64_t)d->n * d->h * d->w < (1LL << 31)),
+                  "suhpe_conv2d_fwd_skip: rows_per_sample must divide the row count");
+    NtParams p;
+    p.g = make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, d->cin, 1, 1, 1, 0, 0);
+    p.x = x; p.f = w; p.bias = bias; p.y = y; p.Ng = d->cout; p.ldy = d->cout; p.ldf = p.g.K;
+    p.x_bytes = (int64_t)d->n * d->h * d->w * d->cin * 4; p.f_bytes = (int64_t)d->cout * p.g.K * 4;
+    p.stats = nullptr; p.stats_extra = nullptr; p.seg_row = 0; p.stat_gx = 0; p.stat_cout = 0; p.scale = p.shift = nullptr; p.residual = skip; p.act = 0; p.res_mode = 3;
+    if (rowscale) { p.o_rowscale = rowscale; magic_div((unsigned)rows_per_sample, &p.o_div_mul, &p.o_div_shr); }
+    g_nt_unsupported = false;
+    dispatch_nt(p, 1, true, as_stream(stream), pinned_tile(d, 0));
+    if (g_nt_unsupported) { set_error("suhpe_conv2d_fwd_skip: the selected tile has no instantiation for this epilogue"); return SUHPE_EINVAL; }
+    return check_launch("suhpe_conv2d_fwd_skip");
 }
 
 int suhpe_conv2d_fwd_affine(const suhpe_conv_t* d, const float* x, const float* w, const float* scale, const float* shift, int act,

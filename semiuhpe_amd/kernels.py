@@ -227,6 +227,20 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, groups=1):
     return y
 
 
+def conv2d_fwd_skip(x, w, bias, skip, rowscale=None, rows_per_sample=1):
+    """pointwise conv / Linear closing a residual connection: (x w^T + bias) * rowscale[sample] + skip from the GEMM epilogue"""
+    _chk(x, "x"); _chk(bias, "bias"); _chk(skip, "skip"); _chk(rowscale, "rowscale")
+    assert filter_is_physical(w)
+    d = conv_desc(x.shape, w.shape, 1, 0, 1)
+    y = torch.empty((d.n, d.ho, d.wo, d.cout), dtype=torch.float32, device=x.device)
+    assert skip.numel() == y.numel()
+    if AUTOTUNE:
+        _autotune(d, 0, lambda: call("suhpe_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(y)))
+    with _Prof(d, 0):
+        call("suhpe_conv2d_fwd_skip", ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(skip), ptr(rowscale), int(rows_per_sample), ptr(y))
+    return y
+
+
 @_memop
 def _dw_fwd(d, x, w, y):
     call("suhpe_dwconv_fwd", ctypes.byref(d), ptr(x), ptr(w), ptr(y))

@@ -214,10 +214,18 @@ class Linear(Layer):
     def _w4(self):
         return self.weight.view(self.out_features, self.in_features, 1, 1)
 
-    def fwd(self, x, tape):
+    def fwd(self, x, tape, skip=None, rowscale=None, rows_per_sample=1):
+        """skip / rowscale: the layer closes a residual connection -- y = skip + rowscale[sample] * (x W^T + b) from the GEMM epilogue
+        (suhpe_conv2d_fwd_skip); rows_per_sample = rows of x per entry of rowscale"""
         shp = x.shape
         x4 = x.reshape(-1, 1, 1, self.in_features)
-        y = K.conv2d_fwd(x4, self._w4(), self.bias, 1, 0, 1)
+        if skip is not None and self.in_features % 4 == 0 and self.out_features % 4 == 0:
+            y = K.conv2d_fwd_skip(x4, self._w4(), self.bias, skip, rowscale, rows_per_sample)
+        else:
+            y = K.conv2d_fwd(x4, self._w4(), self.bias, 1, 0, 1)
+            if skip is not None:                             # (channel counts the vector tiles cannot take: separate pass)
+                ns = y.shape[0] // rows_per_sample if rowscale is not None else y.shape[0]
+                y = K.add_rowscale(skip.reshape(ns, -1), y.reshape(ns, -1), rowscale)
         if tape is not None:
             tape.append(x4)
         return y.view(*shp[:-1], self.out_features)

@@ -41,10 +41,15 @@ class DropPath(Layer):
         super().__init__()
         self.drop_prob = drop_prob
 
-    def fwd2(self, branch, skip, tape):
-        rs = None
+    def draw(self, n, device):
+        """the keep scale of this call (or None): for callers that fold `skip + scale * branch` into the branch's last GEMM (RESIDUAL_EPILOGUE)
+        and push it on the tape themselves, after the branch's own entries"""
         if self.training and self.drop_prob > 0.0:
-            rs = draw_mask("drop_path", (branch.shape[0],), 1.0 - self.drop_prob, branch.device)
+            return draw_mask("drop_path", (n,), 1.0 - self.drop_prob, device)
+        return None
+
+    def fwd2(self, branch, skip, tape):
+        rs = self.draw(branch.shape[0], branch.device)
         if tape is not None:
             tape.append(rs)
         return K.add_rowscale(skip, branch, rs)
@@ -164,7 +169,8 @@ class Attention(Layer):
             self._idx32 = self.attention_bias_idxs.to(device=device, dtype=torch.int32).contiguous()
         return self._idx32
 
-    def fwd(self, x, tape):
+    def fwd(self, x, tape, residual=None):
+        """residual = (skip, keep scale per sample or None): x + drop_path(attn(x)) closed by the proj GEMM's epilogue (src/tiny_vit.py:366)"""
         B, H, W, C = x.shape
         xn = self.norm.fwd(x, tape)
         qkv = self.qkv.fwd(xn.view(-1, C), tape)
@@ -172,6 +178,8 @@ class Attention(Layer):
                                        self.scale, save_probs=tape is not None)
         if tape is not None:
             tape.append((qkv, probs, (B, H, W)))
+        if residual is not None:
+            return self.proj.fwd(out, tape, skip=residual[0], rowscale=residual[1], rows_per_sample=H * W).view(B, H, W, C)
         return self.proj.fwd(out, tape).view(B, H, W, C)
 
     def bwd(self, dy, tape, skip=None):
@@ -187,6 +195,7 @@ class Attention(Layer):
 
 
 MLP_ACT_EPILOGUE = os.environ.get("SUHPE_MLP_EPILOGUE", "1") != "0"     # GELU / GELU' in the fc1 / fc2 GEMM epilogues
+RESIDUAL_EPILOGUE = os.environ.get("SUHPE_RESIDUAL_EPILOGUE", "1") != "0"   # x + drop_path(branch) in the proj / fc2 GEMM epilogues
 
 
 class Mlp(Layer):
@@ -203,7 +212,8 @@ class Mlp(Layer):
     def _fused(self):
         return MLP_ACT_EPILOGUE and self.fc1.act_epilogue_ok() and self.fc2.act_epilogue_ok()
 
-    def fwd(self, x, tape):
+    def fwd(self, x, tape, residual=None):
+        """residual = (skip, keep scale per sample or None): x + drop_path(mlp(x)) closed by the fc2 GEMM's epilogue (src/tiny_vit.py:378)"""
         shp = x.shape
         xn = self.norm.fwd(x, tape).view(-1, shp[-1])
         if self._fused():
@@ -213,6 +223,8 @@ class Mlp(Layer):
             a = K.act_fwd(h, self.hidden, "gelu")
         if tape is not None:
             tape.append(h)
+        if residual is not None:
+            return self.fc2.fwd(a, tape, skip=residual[0], rowscale=residual[1], rows_per_sample=x.numel() // (shp[0] * shp[-1])).view(shp)
         return self.fc2.fwd(a, tape).view(shp)
 
     def bwd(self, dy, tape, skip=None):
@@ -240,11 +252,24 @@ class TinyViTBlock(Layer):
         self.local_conv = Conv2d_BN(dim, dim, 3, 1, 1, groups=dim)
 
     def fwd(self, x, tape):
-        a = self.attn.fwd(x, tape)
-        x1 = self.drop_path.fwd2(a, x, tape)
+        if not RESIDUAL_EPILOGUE:
+            a = self.attn.fwd(x, tape)
+            x1 = self.drop_path.fwd2(a, x, tape)
+            x2 = self.local_conv.fwd(x1, tape)
+            m = self.mlp.fwd(x2, tape)
+            return self.drop_path.fwd2(m, x2, tape)
+        # x + drop_path(attn(x)) and x + drop_path(mlp(x)) from the proj / fc2 GEMM epilogues: the keep scales are drawn in the same order as
+        # by fwd2 and pushed on the tape where fwd2 pushes them (after the branch's entries), so the backward is unchanged
+        rs = self.drop_path.draw(x.shape[0], x.device)
+        x1 = self.attn.fwd(x, tape, residual=(x, rs))
+        if tape is not None:
+            tape.append(rs)
         x2 = self.local_conv.fwd(x1, tape)
-        m = self.mlp.fwd(x2, tape)
-        return self.drop_path.fwd2(m, x2, tape)
+        rs = self.drop_path.draw(x2.shape[0], x2.device)
+        y = self.mlp.fwd(x2, tape, residual=(x2, rs))
+        if tape is not None:
+            tape.append(rs)
+        return y
 
     def bwd(self, dy, tape):
         d_m, d_x2 = self.drop_path.bwd2(dy, tape)

@@ -1253,3 +1253,35 @@ def test_halo_tile_of_48_columns(K, n, hw, cin, cout):
     assert rel(y, y0.cpu()) < 3e-6 and rel(dx, dx0.cpu()) < 3e-6 and rel(dxs, dxs0.cpu()) < 3e-6
     assert rel(y, y_ref) < 1e-5 and rel(dx, dx_ref) < 1e-5 and rel(dxs, dx_ref + skip.permute(0, 2, 3, 1)) < 1e-5
     assert rel(ys, y_ref) < 1e-5 and tiles == (n * hw * hw + 127) // 128
+
+
+@pytest.mark.parametrize("n,tokens,cin,cout,keep", [(12, 196, 384, 384, 0.8), (9, 49, 1536, 384, None), (5, 196, 576, 576, 0.9), (3, 64, 100, 36, 0.5)])
+def test_linear_closes_residual_connection_in_epilogue(K, n, tokens, cin, cout, keep):
+    """suhpe_conv2d_fwd_skip (TinyViT: x + drop_path(proj(.)), x + drop_path(fc2(.))): y = (x W^T + b) * keep_scale[sample] + skip from the GEMM
+    epilogue equals Linear followed by the add pass (kernels.add_rowscale), with and without a keep scale, on the heuristic tile and with
+    persistent / resident / wide tiles pinned (remapped to the igemm tile that carries the epilogue when a scale is present)"""
+    import ctypes
+    from semiuhpe_amd import _lib
+    lib = _lib.load()
+    lib.suhpe_conv2d_tile_name.restype = ctypes.c_char_p
+    g = torch.Generator().manual_seed(n + cin)
+    x = torch.randn(n * tokens, 1, 1, cin, generator=g).cuda()
+    w = (torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5).cuda()
+    b = (torch.randn(cout, generator=g) * 0.1).cuda()
+    skip = torch.randn(n, tokens, cout, generator=g).cuda()
+    rs = None if keep is None else ((torch.rand(n, generator=g) < keep).float() / keep).cuda()
+    y_ref = K.add_rowscale(skip, K.conv2d_fwd(x, w, b, 1, 0, 1).view(n, tokens, cout), rs)
+    d = K.conv_desc(x.shape, w.shape, 1, 0, 1)
+    names = [lib.suhpe_conv2d_tile_name(0, i).decode() for i in range(lib.suhpe_conv2d_tile_count(0))]
+    try:
+        for pin in (None, "gemm_nt_persistent<64,64,32,32>", "gemm_nt_resident<64,2,8>", "igemm_nt_kernel<128,128,64,64,4>", "igemm_nt_kernel<128,32,32,32,4>"):
+            if pin is not None and lib.suhpe_conv2d_set_tile(ctypes.byref(d), 0, names.index(pin)) != 0:
+                continue
+            y = K.conv2d_fwd_skip(x, w, b, skip, rs, tokens)
+            assert rel(y.view(n, tokens, cout), y_ref.cpu()) < 1e-6, pin
+    finally:
+        lib.suhpe_conv2d_set_tile(ctypes.byref(d), 0, -1)
+    yd = (x.double().cpu().view(-1, cin) @ w.double().cpu().view(cout, cin).t() + b.double().cpu()).view(n, tokens, cout)
+    if rs is not None:
+        yd = yd * rs.double().cpu()[:, None, None]
+    assert rel(y.view(n, tokens, cout), yd + skip.double().cpu()) < 2e-5
