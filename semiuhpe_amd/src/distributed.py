@@ -103,7 +103,9 @@ _NATIVE = None
 
 
 def native():
-    """the process-wide NativeComm when SUHPE_COMM=native and more than one rank runs (created on first use), else None"""
+    """the process-wide NativeComm when SUHPE_COMM=native and more than one rank runs (created on first use), else None.
+    EXPERIMENTAL: a second RCCL communicator beside torch.distributed's (which keeps gather_varlen, the object gathers and barriers): collectives
+    on the two communicators are not ordered against each other, and the mode has only run with one rank -- keep the default on multi-GPU jobs."""
     global _NATIVE
     if _NATIVE is None and os.environ.get("SUHPE_COMM", "") == "native" and world()[1] > 1 and torch.cuda.is_available():
         _NATIVE = NativeComm()
