@@ -120,6 +120,27 @@ int suhpe_conv2d_tile_count(int pass);
 int suhpe_conv2d_set_stagger(int quanta, int first_gen);
 const char* suhpe_conv2d_tile_name(int pass, int tile);
 int suhpe_conv2d_set_tile(const suhpe_conv_t* d, int pass, int tile);
+/* Winograd F(2x2, 3x3) tile (csrc/conv_wino.hip; menu name "wino_nt_kernel<64,64>"): 3x3 / stride 1 / pad 1 forward and input-gradient
+ * convolutions on even output sizes with 2.25x fewer multiplies -- what cuDNN does behind the reference's 3x3 convs (src/networks.py:303
+ * FusedMBConv, src/repvgg.py:28-32 rbr_dense).  The tile runs fastest on a filter that is already in the Winograd domain:
+ *   suhpe_conv2d_wino_pinned(d, pass)        1 when the tile selected for (d, pass) is the Winograd one (and this geometry can run it)
+ *   suhpe_conv2d_wino_filter_bytes(d, pass)  size of the transformed filter
+ *   suhpe_conv2d_wino_filter(d, pass, w, fw) fw <- G g G^T of the filter AS STORED (w, [cout][3][3][cin/groups]) for pass 0 (forward) or of
+ *                                            its transposed / 180-degree rotated form for pass 1 (input gradient: no transposed copy needed),
+ *                                            in the kernel's LDS image order; redo after every weight update
+ *   suhpe_conv2d_fwd_wino                    suhpe_conv2d_fwd / _fwd_stats / _fwd_stats_seg in one: bias may be NULL; stats NULL = no records;
+ *                                            stats_extra / seg_row as suhpe_conv2d_fwd_stats_seg.  fw NULL = the tile transforms the filter rows
+ *                                            itself (slower); on a (d, pass) whose tile is not the Winograd one, fw is ignored and w is used
+ *   suhpe_conv2d_dgrad_wino                  suhpe_conv2d_dgrad_add with the same rule; wt (the transposed filter) may be NULL when fw is given
+ *                                            and suhpe_conv2d_wino_pinned(d, 1) holds
+ * Results differ from the direct tiles by rounding (measured: closer to float64 than the direct sum).  SUHPE_WINOGRAD=0 disables the tile. */
+int suhpe_conv2d_wino_pinned(const suhpe_conv_t* d, int pass);
+int64_t suhpe_conv2d_wino_filter_bytes(const suhpe_conv_t* d, int pass);
+int suhpe_conv2d_wino_filter(const suhpe_conv_t* d, int pass, const float* w, float* fw, suhpe_stream_t stream);
+int suhpe_conv2d_fwd_wino(const suhpe_conv_t* d, const float* x, const float* w, const float* fw, const float* bias, float* y, float* stats,
+                          float* stats_extra, int64_t seg_row, suhpe_stream_t stream);
+int suhpe_conv2d_dgrad_wino(const suhpe_conv_t* d, const float* dy, const float* wt, const float* fw, const float* skip, float* dx,
+                            suhpe_stream_t stream);
 /* Pointwise conv whose INPUT is act(BN(x)) [* per-sample scale] of a tensor x that was never normalised in memory: the loader of
  * the GEMM applies  a <- act(a * a_scale[s][k] + a_shift[s][k]) * a_rowscale[row / a_hw][k]  while it stages the operand
  * (s = batch segment of the row: rows < seg_row -> 0; a_rowscale (n, cin) may be NULL).  Used for torchvision's

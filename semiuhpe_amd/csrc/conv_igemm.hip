@@ -14,6 +14,7 @@
 // Replaces the cuDNN / cuBLAS calls behind nn.Conv2d / nn.Linear in src/networks.py:229-332,407-441,
 // src/repvgg.py:28-32,67-76 and src/tiny_vit.py:28-50,84-151 (forward, input gradient, filter gradient).
 #include "common.h"
+#include "conv_params.h"
 #include <cstdlib>
 #ifndef SUHPE_STAGES
 #define SUHPE_STAGES 2     // register stages of the persistent kernel (3 = one more slab of prefetch distance; experiment)
@@ -28,46 +29,6 @@
 
 namespace suhpe {
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-
-constexpr int BK = 32;          // reduction chunk staged per LDS tile
-constexpr int LDK = BK + 4;     // padded LDS row (floats): 144 B keeps 16-B alignment and spreads banks
-
-// activation of the input transforms (XF loaders): SiLU on the hardware exponential (v_exp_f32, ~1 ulp of exp2) -- the accurate
-// expf / erff paths of act_apply cost the GEMM loaders dozens of VGPRs and scratch; none / ReLU / SiLU are what the producers of
-// a pointwise conv's input use (torchvision MBConv / FusedMBConv)
-__device__ __forceinline__ float xf_act(float u, int act) {
-    const float s = u * __builtin_amdgcn_rcpf(1.f + __expf(-u));       // v_exp_f32 + v_rcp_f32: ~1 ulp each
-    return act == SUHPE_ACT_SILU ? s : (act == SUHPE_ACT_RELU ? fmaxf(u, 0.f) : u);
-}
-
-struct GatherGeom {
-    int N, GH, GW;       // gathered tensor spatial dims
-    int OH, OW;          // GEMM-row enumeration: m = (n, oh, ow)
-    int ldg;             // gathered tensor pixel stride (elements)
-    int Cg;              // channels per group in the gathered tensor (k = tap*Cg + c)
-    int R, S;
-    int stride, pad;
-    int mode;            // 0: gh = oh*stride - pad + r      (forward / wgrad gather of x)
-                         // 1: gh = (oh + pad - r)/stride     (dgrad gather of dy; only exact multiples)
-    int K;               // R*S*Cg
-    int64_t M;           // N*OH*OW
-    // affine form used by the fast paths: coordinate = o*gm + sgn*tap + off
-    //   forward (any stride): gm = stride, sgn = +1, off = -pad ;  dgrad stride 1: gm = 1, sgn = -1, off = +pad
-    int gm, sgn, off;
-    // magic numbers for n / (OH*OW) and rem / OW on dividends < 2^31 (q = umulhi(n, mul) >> shr)
-    unsigned div_hw_mul, div_hw_shr, div_w_mul, div_w_shr;
-    // MODE 3 (dgrad of a strided conv, one launch per output parity class (ph,pw)): rows enumerate the sub-grid
-    // (n, a, b) -> output pixel (a*om+ph, b*om+pw) of a (YH,YW) tensor; taps enumerate only the filter rows/cols
-    // r = r0 + om*th, s = s0 + om*tw that hit this parity (R,S hold the enumerated counts, Sfull the filter width);
-    // gathered coordinate = a - th + off_h, b - tw + off_w.
-    int om, ph, pw, YH, YW, r0, s0, Sfull, off_h, off_w;
-};
-
-__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned mul, unsigned shr) {
-    return mul ? (__umulhi(n, mul) >> shr) : n;       // mul == 0 encodes divisor 1
-}
-
 __device__ __forceinline__ bool gather_coord(const GatherGeom& g, int o, int tap, int extent, int* out) {
     if (g.mode == 0) {
         const int v = o * g.stride - g.pad + tap;
@@ -81,55 +42,6 @@ __device__ __forceinline__ bool gather_coord(const GatherGeom& g, int o, int tap
     *out = q;
     return (q * g.stride == t) && q < extent;
 }
-
-struct NtParams {
-    GatherGeom g;
-    const float* x;      // gathered tensor
-    const float* f;      // filter rows [Ng_total][K]
-    const float* bias;   // per output column or null
-    float* y;            // [M][ldy]
-    int Ng;              // output columns per group
-    int ldy;
-    int col_tiles;       // ceil(Ng / BN), set by the launcher
-    int ldf;             // filter row length in elements (== g.K except in MODE 3)
-    int64_t x_bytes, f_bytes;   // extents of the gathered tensor and of the filter matrix (buffer descriptors)
-    const float* scale;  // optional per-channel affine + activation + residual in the epilogue (eval-mode BatchNorm folded into
-    const float* shift;  // the conv): y = act(acc*scale + shift [+ res]) [+ res], res_mode 1 = before / 2 = after the activation
-    const float* residual;
-    int act, res_mode;
-    float* stats;        // optional BatchNorm statistics from the epilogue: records [stat_gx][stat_cout][4] = (S, Q, k, n)
-    float* stats_extra;  // [stat_cout][4]: second record of the one row tile that straddles seg_row (see below), or NULL
-    int64_t seg_row;     // batch segments (two sub-batches normalised separately): rows < seg_row belong to the first; a tile
-                         // that contains the boundary emits its first-segment rows to `stats` and the rest to `stats_extra`
-    int stat_cout;       // channels of the whole output (record pitch)
-    int stat_gx;         // row tiles = ceil(M / BM)
-    // optional transform of the GATHERED operand while it is staged (pointwise GEMMs only, XF instantiations):
-    //   a[m][k] <- act(a[m][k] * a_scale[s][k] + a_shift[s][k]) * a_rowscale[m / a_hw][k]      (s = segment of row m, a_rowscale may be NULL)
-    // i.e. the producer's BatchNorm + activation (+ SqueezeExcitation scale) applied by the consumer's loader: the activated
-    // tensor is never written to or read from HBM (a_scale / a_shift are [segments][K] as suhpe_bn_affine_from_stats writes them)
-    const float* a_scale = nullptr;
-    const float* a_shift = nullptr;
-    const float* a_rowscale = nullptr;
-    int a_act = 0, a_hw = 1;
-    int64_t a_seg_row = 0;
-    unsigned a_div_mul = 0, a_div_shr = 0;
-    // activation epilogues of the pointwise ACT2 instantiations (Linear -> activation chains, TinyViT's Mlp):
-    //   y2 != NULL : y = acc + bias (the pre-activation, kept for the backward) AND y2 = act(y), from one epilogue;
-    //   res_mode 4 : y = acc * act'(residual)  -- an input gradient multiplied by the activation's derivative at the saved pre-activation
-    float* y2 = nullptr;
-    //   res_mode 5 : the conv's INPUT was act(BatchNorm(residual)) in train mode: y = g = acc * act'(residual * scale[s][c] + shift[s][c]), the
-    //                gradient of that BatchNorm's output, AND its backward sums (sum g, sum g xhat), xhat = (residual - bn_mean[s][c]) bn_rstd[s][c],
-    //                per (row tile, channel) as float2 records in `stats`: [plane s][row tile][channel] (s = batch segment of the row, seg_row)
-    const float* bn_mean = nullptr;
-    const float* bn_rstd = nullptr;
-    // residual connection with a per-sample keep scale (timm DropPath / torchvision StochasticDepth 'row') in the epilogue of the plain igemm
-    // tiles: y = (acc + bias) * o_rowscale[row / rows per sample] + residual   (res_mode 3; o_rowscale == NULL: scale 1)
-    const float* o_rowscale = nullptr;
-    unsigned o_div_mul = 0, o_div_shr = 0;
-    // start-up stagger (see stagger_wait): workgroups of the first resident generation delay their first barrier by
-    // (hardware wave slot) * stagger quanta so that co-resident workgroups run out of phase
-    int stagger = 0, stagger_first = 0;
-};
 
 // Workgroups that start together on a CU finish together: their epilogues (no MFMA work) and the prologues of the workgroups
 // that replace them coincide, and the matrix pipes idle for that whole interval every generation.  The first generation is
@@ -1145,8 +1057,6 @@ __global__ __launch_bounds__(256) void transpose_filters_batched_kernel(const Tr
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-
 static int check_desc(const suhpe_conv_t* d, const char* who) {
     if (!d) { set_error("%s: null descriptor", who); return SUHPE_EINVAL; }
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cin <= 0 || d->cout <= 0 || d->r <= 0 || d->s <= 0 || d->stride <= 0 || d->pad < 0 ||
@@ -1163,15 +1073,6 @@ static int check_desc(const suhpe_conv_t* d, const char* who) {
         return SUHPE_EINVAL;
     }
     return SUHPE_OK;
-}
-
-static void magic_div(unsigned d, unsigned* mul, unsigned* shr) {
-    if (d <= 1) { *mul = 0; *shr = 0; return; }
-    unsigned lg = 0;
-    while ((1ull << lg) < d) ++lg;
-    const unsigned pw = 31 + lg;
-    *mul = (unsigned)(((1ull << pw) + d - 1) / d);
-    *shr = pw - 32;
 }
 
 static GatherGeom make_geom(int N, int GH, int GW, int OH, int OW, int ldg, int Cg, int R, int S, int stride, int pad, int mode) {
@@ -1248,6 +1149,7 @@ enum NtTile { NT_64x64_S = 0, NT_64x64, NT_128x32, NT_128x128, NT_128x64, NT_256
               NT_H128x48,                    // halo tile of 48 columns: 32 on the 32x32x2 MFMA + 16 on the 16x16x4 MFMA (outputs with 48 channels)
               NT_W128x128, NT_W128x64,       // four wavefronts with 64x64 / 64x32 accumulators each: half the LDS fragment reads per MFMA
               NT_R128x16, NT_R64x8, NT_R64x16,   // operand-resident pointwise kernel (conv_resident.inl): 128 / 64 resident rows, 16 / 8 / 16 wavefronts
+              NT_G64x64,                     // Winograd F(2x2, 3x3) kernel (conv_wino.inl): 64 tiles (256 output pixels) x 64 output channels
               NT_TILES };
 static const char* kNtNames[] = {"igemm_nt_kernel<64,64,32,32,1>", "igemm_nt_kernel<64,64,32,32,4>", "igemm_nt_kernel<128,32,32,32,4>",
                                  "igemm_nt_kernel<128,128,64,32,4>", "igemm_nt_kernel<128,64,32,32,4>", "igemm_nt_kernel<256,32,64,32,4>",
@@ -1256,7 +1158,8 @@ static const char* kNtNames[] = {"igemm_nt_kernel<64,64,32,32,1>", "igemm_nt_ker
                                  "igemm_nt3x3_kernel<64,64,32,32>", "igemm_nt3x3_kernel<128,32,32,32>", "igemm_nt3x3_kernel<128,64,32,32>",
                                  "igemm_nt3x3_kernel<128,128,64,32>", "igemm_nt3x3_n48_kernel<128,48>",
                                  "igemm_nt_kernel<128,128,64,64,4>", "igemm_nt_kernel<128,64,64,32,4>",
-                                 "gemm_nt_resident<128,2,16>", "gemm_nt_resident<64,2,8>", "gemm_nt_resident<64,2,16>"};
+                                 "gemm_nt_resident<128,2,16>", "gemm_nt_resident<64,2,8>", "gemm_nt_resident<64,2,16>",
+                                 "wino_nt_kernel<64,64>"};
 
 struct TnTile { int bm, bn; const char* name; };
 static const TnTile kTnTiles[] = {
@@ -1302,7 +1205,7 @@ static NtTile choose_nt(int64_t M, int ng, bool vec4, int pinned, bool halo = fa
 }
 
 // (row-tile height = rows per BatchNorm statistics record; the resident tiles emit one record per 64-row unit)
-static int nt_tile_bm(NtTile t) { return (t == NT_64x64_S || t == NT_64x64 || t == NT_P64x64 || t == NT_H64x64 || t >= NT_R128x16) ? 64 : (t == NT_256x32 ? 256 : 128); }
+static int nt_tile_bm(NtTile t) { return t == NT_G64x64 ? 256 : (t == NT_64x64_S || t == NT_64x64 || t == NT_P64x64 || t == NT_H64x64 || t >= NT_R128x16) ? 64 : (t == NT_256x32 ? 256 : 128); }    // (the Winograd tile's record = 64 tiles of 2x2 pixels)
 // the halo kernel runs 3x3 / stride 1 / pad 1 forward and input-gradient GEMMs whose channel counts chunk evenly
 static bool halo_ok(const GatherGeom& g, bool vec4) { return vec4 && halo_capable(g, 128) && halo_capable(g, 64); }
 
@@ -1330,7 +1233,8 @@ static void launch_persistent(const NtParams& p_in, int groups, hipStream_t st) 
 }
 
 // a pinned persistent tile on a shape that is not a plain GEMM runs the igemm tile of the same size
-static NtTile effective_nt(NtTile tile, bool plain, bool halo = false, bool resident128 = false, bool resident64 = false) {
+static NtTile effective_nt(NtTile tile, bool plain, bool halo = false, bool resident128 = false, bool resident64 = false, bool wino = false) {
+    if (tile == NT_G64x64) return wino ? tile : NT_128x64;
     if (tile >= NT_R128x16) return ((tile == NT_R128x16 && resident128) || (tile != NT_R128x16 && resident64)) ? tile : NT_64x64;   // (same record height)
     if (tile >= NT_W128x128) return tile;
     if (tile >= NT_H64x64) {
@@ -1344,6 +1248,10 @@ static NtTile effective_nt(NtTile tile, bool plain, bool halo = false, bool resi
 static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st, int pinned) {
     NtTile tile = choose_nt(p.g.M, p.Ng, vec4, pinned, halo_ok(p.g, vec4));
     const bool act2 = p.y2 || p.res_mode >= 4 || p.o_rowscale; // activation / keep-scale epilogues live in igemm_nt_kernel's pointwise form only
+    if (tile == NT_G64x64) {
+        if (launch_wino(p, groups, st)) return;
+        tile = p.stats ? NT_256x32 : NT_128x64;             // (a form the Winograd kernel lacks: the direct tile with the same statistics-record height)
+    }
     if (act2 && tile >= NT_R128x16) tile = NT_64x64;
     if (act2 && tile >= NT_W128x128) tile = tile == NT_W128x128 ? NT_128x128 : NT_128x64;
     if (tile >= NT_R128x16) {
@@ -1395,6 +1303,15 @@ static bool halo_ok_desc(const suhpe_conv_t* d, int pass) {
     const int cg = d->cin / d->groups, ng = d->cout / d->groups;
     if (pass == 0) return halo_ok(make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0), cg % 4 == 0 && d->cin % 4 == 0);
     return halo_ok(make_geom(d->n, d->ho, d->wo, d->h, d->w, d->cout, ng, d->r, d->s, d->stride, d->pad, 1), ng % 4 == 0 && d->cout % 4 == 0);
+}
+
+// Winograd-kernel capability of a (descriptor, pass): pass 0 = forward, 1 = input gradient
+static bool wino_ok_desc(const suhpe_conv_t* d, int pass) {
+    if (!d || d->groups <= 0 || pass > 1 || d->stride != 1) return false;
+    const int cg = d->cin / d->groups, ng = d->cout / d->groups;
+    if (d->cin % 4 || d->cout % 4) return false;
+    if (pass == 0) return wino_geom_ok(make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0), ng);
+    return wino_geom_ok(make_geom(d->n, d->ho, d->wo, d->h, d->w, d->cout, ng, d->r, d->s, d->stride, d->pad, 1), cg);
 }
 
 // resident-kernel capability of a (descriptor, pass): pass 0 = forward, 1 = input gradient (plain pointwise GEMMs only)
@@ -1603,6 +1520,73 @@ int suhpe_conv2d_fwd_stats_seg(const suhpe_conv_t* d, const float* x, const floa
     return conv2d_fwd_stats_impl(d, x, w, y, stats, stats_extra, seg_row, stream);
 }
 
+// ---- Winograd tile with a pre-transformed filter (conv_wino.hip)
+int suhpe_conv2d_wino_pinned(const suhpe_conv_t* d, int pass) {
+    if (!d || d->groups <= 0 || pass < 0 || pass > 1 || !wino_ok_desc(d, pass)) return 0;
+    const int cg = d->cin / d->groups, ng = d->cout / d->groups;
+    const int64_t M = (int64_t)d->n * d->ho * d->wo;
+    const NtTile tile = pass == 0 ? choose_nt(M, ng, true, pinned_tile(d, 0), halo_ok_desc(d, 0)) : choose_nt(M, cg, true, pinned_tile(d, 1), halo_ok_desc(d, 1));
+    return tile == NT_G64x64 ? 1 : 0;
+}
+
+int64_t suhpe_conv2d_wino_filter_bytes(const suhpe_conv_t* d, int pass) {
+    if (!d || d->groups <= 0 || pass < 0 || pass > 1) return 0;
+    const int cg = d->cin / d->groups, ng = d->cout / d->groups;
+    return (pass == 0 ? wino_filter_floats(d->groups, ng, cg) : wino_filter_floats(d->groups, cg, ng)) * 4;
+}
+
+int suhpe_conv2d_wino_filter(const suhpe_conv_t* d, int pass, const float* w, float* fw, suhpe_stream_t stream) {
+    int rc = check_desc(d, "suhpe_conv2d_wino_filter");
+    if (rc) return rc;
+    SUHPE_REQUIRE((pass == 0 || pass == 1) && d->r == 3 && d->s == 3 && w && fw && aligned16(fw), "suhpe_conv2d_wino_filter: 3x3 filters, pass 0 / 1, non-null 16-byte aligned output");
+    const int cg = d->cin / d->groups, ng = d->cout / d->groups;
+    if (pass == 0) launch_wino_filter(w, fw, d->groups, ng, cg, ng, cg, 0, as_stream(stream));
+    else launch_wino_filter(w, fw, d->groups, cg, ng, ng, cg, 1, as_stream(stream));
+    return check_launch("suhpe_conv2d_wino_filter");
+}
+
+int suhpe_conv2d_fwd_wino(const suhpe_conv_t* d, const float* x, const float* w, const float* fw, const float* bias, float* y, float* stats,
+                          float* stats_extra, int64_t seg_row, suhpe_stream_t stream) {
+    int rc = check_desc(d, "suhpe_conv2d_fwd_wino");
+    if (rc) return rc;
+    SUHPE_REQUIRE(x && w && y, "suhpe_conv2d_fwd_wino: null pointer");
+    SUHPE_REQUIRE(!stats_extra || (stats && seg_row > 0), "suhpe_conv2d_fwd_wino: stats_extra needs stats and a positive seg_row");
+    NtParams p;
+    const int cg = d->cin / d->groups;
+    p.g = make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0);
+    p.x = x; p.f = w; p.bias = bias; p.y = y; p.Ng = d->cout / d->groups; p.ldy = d->cout; p.ldf = p.g.K;
+    p.x_bytes = (int64_t)d->n * d->h * d->w * d->cin * 4; p.f_bytes = (int64_t)d->cout * p.g.K * 4;
+    p.stats = stats; p.stats_extra = stats_extra; p.seg_row = stats ? seg_row : 0; p.stat_gx = stats ? suhpe_conv2d_fwd_stats_tiles(d) : 0; p.stat_cout = d->cout;
+    p.scale = p.shift = p.residual = nullptr; p.act = 0; p.res_mode = 0;
+    p.fw = fw;
+    const bool vec4 = (cg % 4 == 0) && (d->cin % 4 == 0) && aligned16(x) && aligned16(w);
+    dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 0));
+    return check_launch("suhpe_conv2d_fwd_wino");
+}
+
+int suhpe_conv2d_dgrad_wino(const suhpe_conv_t* d, const float* dy, const float* wt, const float* fw, const float* skip, float* dx,
+                            suhpe_stream_t stream) {
+    int rc = check_desc(d, "suhpe_conv2d_dgrad_wino");
+    if (rc) return rc;
+    SUHPE_REQUIRE(dy && dx && (wt || (fw && suhpe_conv2d_wino_pinned(d, 1))), "suhpe_conv2d_dgrad_wino: null pointer (wt may be NULL only with fw on a Winograd-pinned conv)");
+    SUHPE_REQUIRE(d->stride == 1, "suhpe_conv2d_dgrad_wino: stride 1 only");
+    NtParams p;
+    const int ng = d->cout / d->groups, cg = d->cin / d->groups;
+    const bool vec4 = (ng % 4 == 0) && (d->cout % 4 == 0) && aligned16(dy) && aligned16(wt);
+    p.g = make_geom(d->n, d->ho, d->wo, d->h, d->w, d->cout, ng, d->r, d->s, d->stride, d->pad, 1);
+    p.x = dy; p.f = wt; p.bias = nullptr; p.y = dx; p.Ng = cg; p.ldy = d->cin; p.ldf = p.g.K;
+    p.x_bytes = (int64_t)d->n * d->ho * d->wo * d->cout * 4; p.f_bytes = (int64_t)d->cout * cg * d->r * d->s * 4;
+    p.stats = nullptr; p.stats_extra = nullptr; p.seg_row = 0; p.stat_gx = 0; p.stat_cout = 0; p.scale = p.shift = nullptr; p.residual = skip; p.act = 0; p.res_mode = skip ? 3 : 0;
+    p.fw = fw;
+    g_nt_unsupported = false;
+    if (!wt) {                                                // no direct-tile operand: the Winograd kernel must take this launch
+        if (!launch_wino(p, d->groups, as_stream(stream))) { set_error("suhpe_conv2d_dgrad_wino: the Winograd kernel cannot run these operands and wt is NULL"); return SUHPE_EINVAL; }
+    } else {
+        dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 1));
+    }
+    return check_launch("suhpe_conv2d_dgrad_wino");
+}
+
 static bool xf_desc_ok(const suhpe_conv_t* d) {
     return d && d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0 && d->groups == 1 && d->cin % 4 == 0 && d->cout % 4 == 0;
 }
@@ -1733,7 +1717,8 @@ int suhpe_conv2d_set_tile(const suhpe_conv_t* d, int pass, int tile) {
     const bool v4 = ng % 4 == 0 && d->cout % 4 == 0 && cg % 4 == 0 && d->cin % 4 == 0;
     SUHPE_REQUIRE(tile < 0 || (v4 && !(pass != 2 && tile == (int)NT_64x64_S)), "suhpe_conv2d_set_tile: the vector tiles need channel counts that are multiples of 4");
     SUHPE_REQUIRE(pass == 2 || tile < (int)NT_H64x64 || tile >= (int)NT_W128x128 || halo_ok_desc(d, pass), "suhpe_conv2d_set_tile: the halo tiles need a 3x3 / stride 1 / pad 1 conv with evenly chunked channels");
-    SUHPE_REQUIRE(pass == 2 || tile < (int)NT_R128x16 || resident_ok_desc(d, pass, tile == (int)NT_R128x16 ? 128 : 64),
+    SUHPE_REQUIRE(pass == 2 || tile != (int)NT_G64x64 || wino_ok_desc(d, pass), "suhpe_conv2d_set_tile: the Winograd tile needs a 3x3 / stride 1 / pad 1 conv on even output sizes");
+    SUHPE_REQUIRE(pass == 2 || tile < (int)NT_R128x16 || tile == (int)NT_G64x64 || resident_ok_desc(d, pass, tile == (int)NT_R128x16 ? 128 : 64),
                   "suhpe_conv2d_set_tile: the resident tiles need a 1x1 / stride 1 conv whose BM x K block fits the LDS");
     std::lock_guard<std::mutex> lock(tile_mutex());
     if (tile < 0) tile_table().erase(tile_key(d, pass));
@@ -1746,10 +1731,10 @@ const char* suhpe_conv2d_kernel_name(const suhpe_conv_t* d, int pass) {
     const int ng = d->cout / d->groups, cg = d->cin / d->groups;
     const bool plain = d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0;
     if (pass == 0 && stem_ok(d) && pinned_tile(d, 0) < 0) return d->cout == 24 ? "rgb_conv3x3_kernel<24>" : (d->cout == 48 ? "rgb_conv3x3_kernel<48>" : "rgb_conv3x3_kernel<64>");
-    if (pass == 0) return kNtNames[effective_nt(choose_nt((int64_t)d->n * d->ho * d->wo, ng, cg % 4 == 0 && d->cin % 4 == 0, pinned_tile(d, 0), halo_ok_desc(d, 0)), plain, halo_ok_desc(d, 0), resident_ok_desc(d, 0, 128), resident_ok_desc(d, 0, 64))];
+    if (pass == 0) return kNtNames[effective_nt(choose_nt((int64_t)d->n * d->ho * d->wo, ng, cg % 4 == 0 && d->cin % 4 == 0, pinned_tile(d, 0), halo_ok_desc(d, 0)), plain, halo_ok_desc(d, 0), resident_ok_desc(d, 0, 128), resident_ok_desc(d, 0, 64), wino_ok_desc(d, 0))];
     if (pass == 1) {
         const int st = d->stride;
-        return kNtNames[effective_nt(choose_nt((int64_t)d->n * ((d->h + st - 1) / st) * ((d->w + st - 1) / st), cg, ng % 4 == 0 && d->cout % 4 == 0, pinned_tile(d, 1), halo_ok_desc(d, 1)), plain, halo_ok_desc(d, 1), resident_ok_desc(d, 1, 128), resident_ok_desc(d, 1, 64))];
+        return kNtNames[effective_nt(choose_nt((int64_t)d->n * ((d->h + st - 1) / st) * ((d->w + st - 1) / st), cg, ng % 4 == 0 && d->cout % 4 == 0, pinned_tile(d, 1), halo_ok_desc(d, 1)), plain, halo_ok_desc(d, 1), resident_ok_desc(d, 1, 128), resident_ok_desc(d, 1, 64), wino_ok_desc(d, 1))];
     }
     const bool va = ng % 4 == 0 && d->cout % 4 == 0, vb = cg % 4 == 0 && d->cin % 4 == 0;
     if (!(va && vb)) return va ? "igemm_tn_kernel<64,64,32,32,4,1>" : (vb ? "igemm_tn_kernel<64,64,32,32,1,4>" : "igemm_tn_kernel<64,64,32,32,1,1>");

@@ -1,0 +1,119 @@
+// Parameter blocks shared by the dense-convolution translation units (conv_igemm.hip, conv_wino.hip).
+#pragma once
+#include "common.h"
+#include <cstring>
+
+namespace suhpe {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;          // reduction chunk staged per LDS tile
+constexpr int LDK = BK + 4;     // padded LDS row (floats): 144 B keeps 16-B alignment and spreads banks
+
+// activation of the input transforms (XF loaders): SiLU on the hardware exponential (v_exp_f32, ~1 ulp of exp2) -- the accurate
+// expf / erff paths of act_apply cost the GEMM loaders dozens of VGPRs and scratch; none / ReLU / SiLU are what the producers of
+// a pointwise conv's input use (torchvision MBConv / FusedMBConv)
+__device__ __forceinline__ float xf_act(float u, int act) {
+    const float s = u * __builtin_amdgcn_rcpf(1.f + __expf(-u));       // v_exp_f32 + v_rcp_f32: ~1 ulp each
+    return act == SUHPE_ACT_SILU ? s : (act == SUHPE_ACT_RELU ? fmaxf(u, 0.f) : u);
+}
+
+struct GatherGeom {
+    int N, GH, GW;       // gathered tensor spatial dims
+    int OH, OW;          // GEMM-row enumeration: m = (n, oh, ow)
+    int ldg;             // gathered tensor pixel stride (elements)
+    int Cg;              // channels per group in the gathered tensor (k = tap*Cg + c)
+    int R, S;
+    int stride, pad;
+    int mode;            // 0: gh = oh*stride - pad + r      (forward / wgrad gather of x)
+                         // 1: gh = (oh + pad - r)/stride     (dgrad gather of dy; only exact multiples)
+    int K;               // R*S*Cg
+    int64_t M;           // N*OH*OW
+    // affine form used by the fast paths: coordinate = o*gm + sgn*tap + off
+    //   forward (any stride): gm = stride, sgn = +1, off = -pad ;  dgrad stride 1: gm = 1, sgn = -1, off = +pad
+    int gm, sgn, off;
+    // magic numbers for n / (OH*OW) and rem / OW on dividends < 2^31 (q = umulhi(n, mul) >> shr)
+    unsigned div_hw_mul, div_hw_shr, div_w_mul, div_w_shr;
+    // MODE 3 (dgrad of a strided conv, one launch per output parity class (ph,pw)): rows enumerate the sub-grid
+    // (n, a, b) -> output pixel (a*om+ph, b*om+pw) of a (YH,YW) tensor; taps enumerate only the filter rows/cols
+    // r = r0 + om*th, s = s0 + om*tw that hit this parity (R,S hold the enumerated counts, Sfull the filter width);
+    // gathered coordinate = a - th + off_h, b - tw + off_w.
+    int om, ph, pw, YH, YW, r0, s0, Sfull, off_h, off_w;
+};
+
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned mul, unsigned shr) {
+    return mul ? (__umulhi(n, mul) >> shr) : n;       // mul == 0 encodes divisor 1
+}
+
+struct NtParams {
+    GatherGeom g;
+    const float* x;      // gathered tensor
+    const float* f;      // filter rows [Ng_total][K]
+    const float* bias;   // per output column or null
+    float* y;            // [M][ldy]
+    int Ng;              // output columns per group
+    int ldy;
+    int col_tiles;       // ceil(Ng / BN), set by the launcher
+    int ldf;             // filter row length in elements (== g.K except in MODE 3)
+    int64_t x_bytes, f_bytes;   // extents of the gathered tensor and of the filter matrix (buffer descriptors)
+    const float* scale;  // optional per-channel affine + activation + residual in the epilogue (eval-mode BatchNorm folded into
+    const float* shift;  // the conv): y = act(acc*scale + shift [+ res]) [+ res], res_mode 1 = before / 2 = after the activation
+    const float* residual;
+    int act, res_mode;
+    float* stats;        // optional BatchNorm statistics from the epilogue: records [stat_gx][stat_cout][4] = (S, Q, k, n)
+    float* stats_extra;  // [stat_cout][4]: second record of the one row tile that straddles seg_row (see below), or NULL
+    int64_t seg_row;     // batch segments (two sub-batches normalised separately): rows < seg_row belong to the first; a tile
+                         // that contains the boundary emits its first-segment rows to `stats` and the rest to `stats_extra`
+    int stat_cout;       // channels of the whole output (record pitch)
+    int stat_gx;         // row tiles = ceil(M / BM)
+    // optional transform of the GATHERED operand while it is staged (pointwise GEMMs only, XF instantiations):
+    //   a[m][k] <- act(a[m][k] * a_scale[s][k] + a_shift[s][k]) * a_rowscale[m / a_hw][k]      (s = segment of row m, a_rowscale may be NULL)
+    // i.e. the producer's BatchNorm + activation (+ SqueezeExcitation scale) applied by the consumer's loader: the activated
+    // tensor is never written to or read from HBM (a_scale / a_shift are [segments][K] as suhpe_bn_affine_from_stats writes them)
+    const float* a_scale = nullptr;
+    const float* a_shift = nullptr;
+    const float* a_rowscale = nullptr;
+    int a_act = 0, a_hw = 1;
+    int64_t a_seg_row = 0;
+    unsigned a_div_mul = 0, a_div_shr = 0;
+    // activation epilogues of the pointwise ACT2 instantiations (Linear -> activation chains, TinyViT's Mlp):
+    //   y2 != NULL : y = acc + bias (the pre-activation, kept for the backward) AND y2 = act(y), from one epilogue;
+    //   res_mode 4 : y = acc * act'(residual)  -- an input gradient multiplied by the activation's derivative at the saved pre-activation
+    float* y2 = nullptr;
+    //   res_mode 5 : the conv's INPUT was act(BatchNorm(residual)) in train mode: y = g = acc * act'(residual * scale[s][c] + shift[s][c]), the
+    //                gradient of that BatchNorm's output, AND its backward sums (sum g, sum g xhat), xhat = (residual - bn_mean[s][c]) bn_rstd[s][c],
+    //                per (row tile, channel) as float2 records in `stats`: [plane s][row tile][channel] (s = batch segment of the row, seg_row)
+    const float* bn_mean = nullptr;
+    const float* bn_rstd = nullptr;
+    // residual connection with a per-sample keep scale (timm DropPath / torchvision StochasticDepth 'row') in the epilogue of the plain igemm
+    // tiles: y = (acc + bias) * o_rowscale[row / rows per sample] + residual   (res_mode 3; o_rowscale == NULL: scale 1)
+    const float* o_rowscale = nullptr;
+    unsigned o_div_mul = 0, o_div_shr = 0;
+    // Winograd-domain filter of the conv (suhpe_conv2d_wino_filter), or NULL: the Winograd tile then transforms the filter rows itself
+    const float* fw = nullptr;
+    // start-up stagger (see stagger_wait): workgroups of the first resident generation delay their first barrier by
+    // (hardware wave slot) * stagger quanta so that co-resident workgroups run out of phase
+    int stagger = 0, stagger_first = 0;
+};
+
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+inline void magic_div(unsigned d, unsigned* mul, unsigned* shr) {
+    if (d <= 1) { *mul = 0; *shr = 0; return; }
+    unsigned lg = 0;
+    while ((1ull << lg) < d) ++lg;
+    const unsigned pw = 31 + lg;
+    *mul = (unsigned)(((1ull << pw) + d - 1) / d);
+    *shr = pw - 32;
+}
+
+
+// conv_wino.hip: Winograd F(2x2, 3x3) kernel for 3x3 / stride 1 / pad 1 forward and input-gradient GEMMs
+bool wino_geom_ok(const GatherGeom& g, int Ng);
+bool launch_wino(const NtParams& p, int groups, hipStream_t st);
+int64_t wino_filter_floats(int groups, int NR, int NK);
+// w: the filter as stored, [groups * ng_w][3][3][cg_w]; pass 0: NR = ng_w rows, NK = cg_w channels; pass 1 (input gradient): NR = cg_w, NK = ng_w
+void launch_wino_filter(const float* w, float* fw, int groups, int NR, int NK, int ng_w, int cg_w, int pass, hipStream_t st);
+
+}  // namespace suhpe

@@ -211,6 +211,30 @@ def _autotune(d, pass_id, run):
     _tile_db()[skey] = names[winner]
 
 
+# Winograd F(2x2, 3x3) tile (csrc/conv_wino.hip): when the tile selected for a (descriptor, pass) is the Winograd one, the filter is brought
+# into the Winograd domain first (one small launch: the weights move every step) and the *_wino entry points take it.  The buffer is a
+# per-stream workspace: the conv that reads it is enqueued before the next layer's transform overwrites it.
+def _wino_filter(d, pass_id, w):
+    lib = _lib.load()
+    if not lib.suhpe_conv2d_wino_pinned(ctypes.byref(d), pass_id):
+        return None
+    nbytes = lib.suhpe_conv2d_wino_filter_bytes(ctypes.byref(d), pass_id)
+    fw = workspace("wino_fw%d" % pass_id, nbytes, w.device)
+    call("suhpe_conv2d_wino_filter", ctypes.byref(d), pass_id, ptr(w), ptr(fw))
+    return fw
+
+
+def _autotune_fwd(d, x, w, y):
+    """forward menu of a dense conv; the Winograd tile is timed the way it will run: filter transform + conv on the transformed filter"""
+    def run():
+        fw = _wino_filter(d, 0, w)
+        if fw is not None:
+            call("suhpe_conv2d_fwd_wino", ctypes.byref(d), ptr(x), ptr(w), ptr(fw), None, ptr(y), None, None, 0)
+        else:
+            call("suhpe_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(w), None, ptr(y))
+    _autotune(d, 0, run)
+
+
 def conv2d_fwd(x, w, bias=None, stride=1, pad=0, groups=1):
     _chk(x, "x"); _chk(bias, "bias")
     assert filter_is_physical(w), "filter must be stored [Cout][R][S][Cin/g]"
@@ -221,9 +245,13 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, groups=1):
         _dw_fwd(d, x, w, y)
     else:
         if AUTOTUNE:
-            _autotune(d, 0, lambda: call("suhpe_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(y)))
+            _autotune_fwd(d, x, w, y)
+        fw = _wino_filter(d, 0, w)
         with _Prof(d, 0):
-            call("suhpe_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(y))
+            if fw is not None:
+                call("suhpe_conv2d_fwd_wino", ctypes.byref(d), ptr(x), ptr(w), ptr(fw), ptr(bias), ptr(y), None, None, 0)
+            else:
+                call("suhpe_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(y))
     return y
 
 
@@ -454,20 +482,27 @@ def conv2d_fwd_stats(x, w, stride=1, pad=0, groups=1, seg=None, xf=None):
     if xf is not None:
         return _conv2d_fwd_stats_xf(d, x, w, y, seg, xf)
     if AUTOTUNE:
-        _autotune(d, 0, lambda: call("suhpe_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(w), None, ptr(y)))
+        _autotune_fwd(d, x, w, y)
     tiles = _lib.load().suhpe_conv2d_fwd_stats_tiles(ctypes.byref(d))
+    fw = _wino_filter(d, 0, w)
     if seg is not None and 0 < seg < d.n:
         tile_rows = _lib.load().suhpe_conv2d_fwd_stats_tile_rows(ctypes.byref(d))
         seg_row = seg * d.ho * d.wo
         part = torch.empty(d.cout * (tiles + 1) * 4, dtype=torch.float32, device=x.device)
         extra = part[d.cout * tiles * 4:]
         with _Prof(d, 0):
-            call("suhpe_conv2d_fwd_stats_seg", ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(part), ptr(extra), seg_row)
+            if fw is not None:
+                call("suhpe_conv2d_fwd_wino", ctypes.byref(d), ptr(x), ptr(w), ptr(fw), None, ptr(y), ptr(part), ptr(extra), seg_row)
+            else:
+                call("suhpe_conv2d_fwd_stats_seg", ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(part), ptr(extra), seg_row)
         straddle = seg_row % tile_rows != 0
         return y, part, tiles, (seg_row // tile_rows + int(straddle), extra if straddle else None)
     part = torch.empty(d.cout * tiles * 4, dtype=torch.float32, device=x.device)
     with _Prof(d, 0):
-        call("suhpe_conv2d_fwd_stats", ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(part))
+        if fw is not None:
+            call("suhpe_conv2d_fwd_wino", ctypes.byref(d), ptr(x), ptr(w), ptr(fw), None, ptr(y), ptr(part), None, 0)
+        else:
+            call("suhpe_conv2d_fwd_stats", ctypes.byref(d), ptr(x), ptr(w), ptr(y), ptr(part))
     return y, part, tiles
 
 
@@ -613,6 +648,12 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, groups=1, skip=None):
         _dw_dgrad(d, dy, w, dx)
     else:
         key = (w.data_ptr(), d.cin, d.cout, d.r, d.s, d.groups)
+        known = (not AUTOTUNE) or ((1, d.n, d.h, d.w, d.cin, d.cout, d.r, d.s, d.stride, d.pad, d.groups) in _tuned)
+        fw = _wino_filter(d, 1, w) if known else None
+        if fw is not None:                                   # Winograd tile: the filter transform reads w as stored, no transposed copy
+            with _Prof(d, 1):
+                call("suhpe_conv2d_dgrad_wino", ctypes.byref(d), ptr(dy), None, ptr(fw), ptr(skip), ptr(dx))
+            return dx
         wt = _WT_CACHE.get(key) if _WT_CACHE is not None else None
         if wt is None:
             if _WT_CACHE is not None:
@@ -622,9 +663,19 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, groups=1, skip=None):
                 wt = workspace("wt", w.numel() * 4, dy.device)
             call("suhpe_conv2d_transpose_filter", ctypes.byref(d), ptr(w), ptr(wt))
         if AUTOTUNE:
-            _autotune(d, 1, lambda: call("suhpe_conv2d_dgrad", ctypes.byref(d), ptr(dy), ptr(wt), ptr(dx)))
+            def run():
+                fw_ = _wino_filter(d, 1, w)
+                if fw_ is not None:
+                    call("suhpe_conv2d_dgrad_wino", ctypes.byref(d), ptr(dy), ptr(wt), ptr(fw_), None, ptr(dx))
+                else:
+                    call("suhpe_conv2d_dgrad", ctypes.byref(d), ptr(dy), ptr(wt), ptr(dx))
+            _autotune(d, 1, run)
+        fw = _wino_filter(d, 1, w)
         with _Prof(d, 1):
-            call("suhpe_conv2d_dgrad_add", ctypes.byref(d), ptr(dy), ptr(wt), ptr(skip), ptr(dx))
+            if fw is not None:
+                call("suhpe_conv2d_dgrad_wino", ctypes.byref(d), ptr(dy), ptr(wt), ptr(fw), ptr(skip), ptr(dx))
+            else:
+                call("suhpe_conv2d_dgrad_add", ctypes.byref(d), ptr(dy), ptr(wt), ptr(skip), ptr(dx))
     return dx
 
 
