@@ -25,7 +25,7 @@ for net, b, mu in runs:
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_bench.py"), net, str(b), str(mu), "2", "3"], env=env, capture_output=True, text=True)
     print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-500:], flush=True)
 new = json.load(open(out))["tiles"]
-halo = {k: v for k, v in new.items() if "nt3x3" in v}
-print(f"{len(new)} entries, {len(halo)} won by the halo kernel")
+halo = {k: v for k, v in new.items() if "nt3x3" in v or "wino" in v}
+print(f"{len(new)} entries, {sum('nt3x3' in v for v in halo.values())} won by the halo kernel, {sum('wino' in v for v in halo.values())} by the Winograd kernel")
 for k, v in sorted(halo.items()):
     print(" ", k, v)
