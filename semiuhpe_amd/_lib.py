@@ -14,7 +14,7 @@ import re
 import torch  # imported first on purpose: libsuhpe.so must bind to the HIP runtime torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsuhpe.so")
+LIB_PATH = os.environ.get("SUHPE_LIB") or os.path.join(_HERE, "csrc", "libsuhpe.so")      # SUHPE_LIB: a variant build (semiuhpe_amd.build.build_variant)
 HEADER_PATH = os.path.join(_HERE, "..", "include", "suhpe.h")
 
 

@@ -62,5 +62,18 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_variant(name, source, defines):
+    """libsuhpe_<name>.so = the library with `source` recompiled under extra -D flags (timing experiments: SUHPE_LIB=<path> selects it)"""
+    build(verbose=False)
+    hipcc = _hipcc()
+    objdir = os.path.join(CSRC, "build")
+    obj = os.path.join(objdir, source.replace(".hip", f".{name}.o"))
+    subprocess.check_call([hipcc] + FLAGS + [f"-D{d}" for d in defines] + ["-c", os.path.join(CSRC, source), "-o", obj])
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) if s != source else obj for s in SOURCES]
+    out = os.path.join(CSRC, f"libsuhpe_{name}.so")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"])
+    return out
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)

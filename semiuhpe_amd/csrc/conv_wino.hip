@@ -45,6 +45,11 @@
 #include "conv_params.h"
 #include <cstdlib>
 #include <type_traits>
+// timing experiments (tools/wino_ablate.sh builds variant libraries; any bit set = wrong results):
+//   1 no barrier in the chunk loop, 2 no loads (DMA + patch rows), 4 no transform / LDS stores, 8 no MFMAs, 16 no epilogue
+#ifndef WINO_ABLATE
+#define WINO_ABLATE 0
+#endif
 
 namespace suhpe {
 
@@ -63,25 +68,46 @@ struct WinoGeom {
 
 constexpr int WN_XI = 512;               // floats per transform position of one LDS image: 64 rows x 8 channels
 constexpr int WN_IMG = 16 * WN_XI;       // floats per image (V or U) = 32 KB
-constexpr int WN_SCRATCH = 64 + 4 * 64 * 4;   // statistics epilogue: k[64] + partial sums [4 tile blocks][64 couts][4]
 
 template <int CTRL> __device__ __forceinline__ float quad_dpp(float v) {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 
-// float offset of (row, channel vector v, position xi) inside an LDS image (see the header comment)
-__host__ __device__ __forceinline__ int wino_img_off(int xi, int row, int v) {
-    return xi * WN_XI + ((row ^ (xi >> 2)) << 3) + ((v ^ ((row >> 3) & 1)) << 2);
+// LDS image of one operand chunk: 8 position PAIRS m = xi >> 1, each [64 rows][4 slots of 16 bytes]; slot kg of a row holds channels (2 kg, 2 kg + 1)
+// of position 2 m followed by the same channels of position 2 m + 1, so that ONE ds_read_b128 hands a lane (row = lane & 15, k-group kg = lane >> 4)
+// the operands of four MFMAs (two k-steps of two positions).  Swizzle (i = m >> 1 = the patch row that writes the pair):
+//   slot (row, kg) of pair m sits at row ^ (i & 1), slot kg ^ g(row) ^ (i >> 1), g(row) = (-(row >> 2)) & 3.
+// Reads (ds_read_b128: 16-lane groups {rows 0-3, 12-15 of k-group a, rows 4-11 of k-group a + 1}) then cover the 64 banks exactly once, writes
+// (ds_write_b128: 8-lane groups = one row, 2 channel vectors, 4 patch rows) the 32 banks of their window.  (A first version used ds_read_b64 per
+// position: the compiler fused pairs of them into ds_read2st64_b64, which runs at half the LDS rate and broke the swizzle: 45 % of the LDS cycles
+// were bank conflicts.)
+__host__ __device__ __forceinline__ int wino_slot_off(int m, int row, int kg) {
+    const int i = m >> 1;
+    return m * 1024 + ((row ^ (i & 1)) << 4) + (((kg ^ ((-(row >> 2)) & 3) ^ (i >> 1)) & 3) << 2);
 }
 
-template <bool PRE>
+typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+
+// LDS map (floats): V images [2] at 0, U images [3] at 2 * WN_IMG: 160 KB, all of a CU.  The statistics scratch of an item's epilogue aliases the V image
+// the item's last chunk has just finished with (nothing is in flight to it then).
+constexpr int WN_U0 = 2 * WN_IMG;
+constexpr int WN_LDS_FLOATS = 5 * WN_IMG;
+
 __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const WinoGeom wg) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];       // [buffer][V image | U image], then the statistics scratch
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const GatherGeom& g = p.g;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int grp = blockIdx.z;
-    const BufRsrc xr = make_rsrc(p.x + (int64_t)grp * g.Cg, p.x_bytes - (int64_t)grp * g.Cg * 4);
-    const BufRsrc fr = make_rsrc(p.f + (int64_t)grp * p.Ng * p.ldf, p.f_bytes - (int64_t)grp * p.Ng * p.ldf * 4);
+    // buffer descriptor of the gathered tensor as four scalars (the patch-row loads are inline asm: see issue_loads)
+    u32x4w xrs;
+    {
+        const uint64_t addr = reinterpret_cast<uint64_t>(p.x + (int64_t)grp * g.Cg);
+        const int64_t nb = p.x_bytes - (int64_t)grp * g.Cg * 4;
+        xrs.x = __builtin_amdgcn_readfirstlane((uint32_t)addr);
+        xrs.y = __builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32) & 0xffffu);
+        xrs.z = __builtin_amdgcn_readfirstlane((uint32_t)(nb > 0x7fffffff ? 0x7fffffff : nb));
+        xrs.w = 0x00020000u;
+    }
 
     // ---- work items of this workgroup: item = blockIdx.x + k * gridDim.x (gridDim.x is a multiple of 8, so xcd = item & 7 is fixed);
     // an XCD takes one contiguous run of tile blocks, the cout blocks of a tile block consecutively (they re-read the same pixels from L2)
@@ -95,20 +121,25 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
     const int si = t & 3, sv = (t >> 2) & 1, stl = t >> 3;
     const float sxv = si == 1 ? 1.f : -1.f;                    // V's vertical pass: out_i = own + sxv * quad_perm[2,2,1,1](own)
     //   i = 0: H0 - H2, 1: H1 + H2, 2: H2 - H1, 3: H3 - H1 (= -(H1 - H3): row 3 negated)
-    const float ua = si == 0 ? 1.f : (si == 3 ? 0.f : 0.5f), ub = si == 1 ? 0.5f : (si == 2 ? -0.5f : 0.f), uc = si == 3 ? -1.f : (si == 0 ? 0.f : 0.5f);
-    const int wbase = wino_img_off(si * 4, stl, sv);            // + jx * WN_XI
+    int woff[2][2];                                             // [pair p of this patch row: m = 2 i + p][half h: k-group 2 v + h]
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) woff[pp][hh] = wino_slot_off(2 * si + pp, stl, 2 * sv + hh);
 
-    // loader cursor (one chunk ahead of the MFMAs) and the item under the MFMAs
-    int l_item = blockIdx.x, l_chunk = 0;
-    unsigned voff[4], uoff[3];
-    const float* ufw = nullptr;                                 // pre-transformed filter image of (l_item's cout block, chunk 0) + this thread's slice
-    int l_tile0 = 0, l_n0 = 0, l_row_tile = 0;
-    auto setup_item = [&]() __attribute__((always_inline)) {
-        const int jx = l_item >> 3;
-        const int col_tile = jx % p.col_tiles;
-        l_row_tile = rt_first + jx / p.col_tiles;
-        l_tile0 = l_row_tile * 64; l_n0 = col_tile * 64;
-        const int T = l_tile0 + stl;
+    // ---- loader cursors over the flat stream of (item, chunk) pairs.  Channels come in SUPER-CHUNKS of 16: a thread loads 32 contiguous bytes of each of
+    // its four pixels (channels 16 s + 8 v .. + 7) once and stages one half per chunk, so chunk c = 2 s + h holds channels 16 s + 8 v + 4 h + e at its
+    // in-chunk position 4 v + e (the filter transform writes U in the same order).  With 8-channel loads every chunk pulled a whole 128-byte line per
+    // pixel through L2 -> L1 for 32 bytes of it, and the chunk loop was bound by that traffic (1.75 us of staging per chunk beside 1.86 us of MFMAs,
+    // tools/wino_ablate.sh); items have an even number of chunks, so a super-chunk never straddles two items.
+    int lu_item = blockIdx.x, lu_chunk = 0, lu_ub = 0;          // U cursor: next chunk to copy, into U image lu_ub (0..2)
+    int lv_item = blockIdx.x, lv_sc = 0;                        // V cursor: next super-chunk to load
+    unsigned voff[4];
+    const float* ufw = nullptr;                                 // Winograd-domain filter image of (lu_item's cout block, chunk 0) + this thread's slice
+    auto setup_v = [&]() __attribute__((always_inline)) {
+        const int jx = lv_item >> 3;
+        const int tile0 = (rt_first + jx / p.col_tiles) * 64;
+        const int T = tile0 + stl;
         const bool tv = T < wg.MT;
         const unsigned Tn = (unsigned)(tv ? T : 0);
         const unsigned n = fast_div(Tn, wg.div_tpi_mul, wg.div_tpi_shr);
@@ -119,104 +150,86 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const bool ok = rowok && (unsigned)(ix0 + c) < (unsigned)g.GW;
-            voff[c] = ok ? ((unsigned)(((int)n * g.GH + iy) * g.GW + ix0 + c) * (unsigned)g.ldg + 4u * sv) * 4u : kOob;
+            voff[c] = ok ? ((unsigned)(((int)n * g.GH + iy) * g.GW + ix0 + c) * (unsigned)g.ldg + 8u * sv) * 4u : kOob;
         }
-        if constexpr (PRE) {
-            ufw = p.fw + (int64_t)grp * wg.fw_group_stride + (int64_t)col_tile * wg.nchunks * WN_IMG + wave * 1024 + lane * 4;
-        } else {
-            const int co = l_n0 + stl;
-            const bool uok = co < p.Ng && si < 3;
-            const int r = wg.flip ? 2 - si : si;
+    };
+    auto setup_u = [&]() __attribute__((always_inline)) {
+        const int col_tile = (lu_item >> 3) % p.col_tiles;
+        ufw = p.fw + (int64_t)grp * wg.fw_group_stride + (int64_t)col_tile * wg.nchunks * WN_IMG + wave * 1024 + lane * 4;
+    };
+    // Every vector-memory operation of the chunk loop is inline asm and every wait is written by hand.  Behind the builtins the compiler (1) cannot tell
+    // an LDS-DMA's destination image from the fragment reads that follow and parks an s_waitcnt vmcnt(0) in front of the MFMAs, and (2) counts only the
+    // loads it knows when it waits for a register load, so beside DMAs it drains the whole queue.  (Loads return in issue order; the waits below count
+    // what may still be in flight behind the operation they need.)
+    floatx4w raw[4][2];                                          // [pixel of the patch row][half of the 8 channels]
+    auto issue_v = [&]() __attribute__((always_inline)) {        // the V cursor's super-chunk: 8 loads
+        const unsigned cb = (unsigned)lv_sc * 64u;
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const int tap = r * 3 + (wg.flip ? 2 - s : s);
-                uoff[s] = uok ? ((unsigned)co * (unsigned)p.ldf + (unsigned)(tap * g.Cg) + 4u * sv) * 4u : kOob;
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const bool cok = lv_sc * 16 + 8 * sv + 4 * hh < g.Cg;
+                const unsigned off = cok ? voff[c] + cb + 16u * hh : kOob;
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(raw[c][hh]) : "v"(off), "s"(xrs) : "memory");
             }
+        if (++lv_sc == (wg.nchunks >> 1)) {
+            lv_sc = 0;
+            lv_item += gridDim.x;
+            if (item_valid(lv_item)) setup_v();
         }
     };
-
-    float vreg[4][4], ureg[PRE ? 1 : 3][4];
-    auto issue_loads = [&](int buf) __attribute__((always_inline)) {
-        if constexpr (PRE) {
-            // this wavefront's four 1 KiB pieces of the chunk's U image, global -> LDS (LDS address = M0 + instruction offset + 16 * lane; the
-            // instruction offset also advances the global address).  Inline asm on purpose: behind the builtin the compiler cannot tell the DMA's
-            // LDS destination (the OTHER buffer) from the fragment reads that follow and parks an s_waitcnt vmcnt(0) in front of the MFMAs; this way
-            // the DMA is invisible to its wait counting, and the wait that retires it is the one for the patch rows issued right behind it (loads
-            // return in order), backed by the explicit vmcnt(0) in front of the chunk's barrier.
-            const unsigned lds_dst = __builtin_amdgcn_readfirstlane(
-                (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)(smem + buf * 2 * WN_IMG + WN_IMG + wave * 1024));
-            const float* src = ufw + (int64_t)l_chunk * WN_IMG;
-            unsigned keep;
-            asm volatile(
-                "s_mov_b32 %0, m0\n\t"
-                "s_mov_b32 m0, %2\n\t"
-                "s_nop 0\n\t"
-                "global_load_lds_dwordx4 %1, off\n\t"
-                "global_load_lds_dwordx4 %1, off offset:1024\n\t"
-                "global_load_lds_dwordx4 %1, off offset:2048\n\t"
-                "global_load_lds_dwordx4 %1, off offset:3072\n\t"
-                "s_mov_b32 m0, %0"
-                : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
-        }
-        const bool cok = l_chunk * 8 + 4 * sv < g.Cg;
-        const unsigned cb = (unsigned)l_chunk * 32u;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) buf_load<4>(xr, cok ? voff[c] + cb : kOob, vreg[c]);
-        if constexpr (!PRE) {
-#pragma unroll
-            for (int s = 0; s < 3; ++s) buf_load<4>(fr, cok ? uoff[s] + cb : kOob, ureg[s]);
+    auto issue_u = [&]() __attribute__((always_inline)) {        // the U cursor's chunk: this wavefront's four 1 KiB pieces of the image, global -> LDS
+        // (LDS address = M0 + instruction offset + 16 * lane; the instruction offset also advances the global address)
+        const unsigned lds_dst = __builtin_amdgcn_readfirstlane(
+            (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)(smem + WN_U0 + lu_ub * WN_IMG + wave * 1024));
+        const float* src = ufw + (int64_t)lu_chunk * WN_IMG;
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off\n\t"
+            "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+            "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+            "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+        lu_ub = lu_ub == 2 ? 0 : lu_ub + 1;
+        if (++lu_chunk == wg.nchunks) {
+            lu_chunk = 0;
+            lu_item += gridDim.x;
+            if (item_valid(lu_item)) setup_u();
         }
     };
-    float ov[4][4], ou[PRE ? 1 : 4][4];                          // transformed values of the staged chunk: [jx][channel]
-    auto transform = [&]() __attribute__((always_inline)) {
+    float ov[4][4];                                              // transformed values of the staged chunk: [jx][channel]
+    auto transform = [&](auto half) __attribute__((always_inline)) {
+        constexpr int H = decltype(half)::value;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float h0 = vreg[0][e] - vreg[2][e], h1 = vreg[1][e] + vreg[2][e], h2 = vreg[2][e] - vreg[1][e], h3 = vreg[1][e] - vreg[3][e];
+            const float h0 = raw[0][H][e] - raw[2][H][e], h1 = raw[1][H][e] + raw[2][H][e], h2 = raw[2][H][e] - raw[1][H][e], h3 = raw[1][H][e] - raw[3][H][e];
             ov[0][e] = fmaf(sxv, quad_dpp<0x5A>(h0), h0);
             ov[1][e] = fmaf(sxv, quad_dpp<0x5A>(h1), h1);
             ov[2][e] = fmaf(sxv, quad_dpp<0x5A>(h2), h2);
             ov[3][e] = fmaf(sxv, quad_dpp<0x5A>(h3), h3);
         }
-        if constexpr (!PRE) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float s02 = ureg[0][e] + ureg[2][e];
-                const float hu[4] = {ureg[0][e], 0.5f * (s02 + ureg[1][e]), 0.5f * (s02 - ureg[1][e]), ureg[2][e]};
-#pragma unroll
-                for (int jx = 0; jx < 4; ++jx) {
-                    const float a0 = quad_dpp<0x00>(hu[jx]), a1 = quad_dpp<0x55>(hu[jx]), a2 = quad_dpp<0xAA>(hu[jx]);
-                    ou[jx][e] = fmaf(uc, a2, fmaf(ub, a1, ua * a0));
-                }
-            }
-        }
     };
-    auto write_staged = [&](int buf) __attribute__((always_inline)) {
-        float* Vs = smem + buf * 2 * WN_IMG;
+    auto write_staged = [&](int vb) __attribute__((always_inline)) {
+        float* Vs = smem + vb * WN_IMG;
 #pragma unroll
-        for (int jx = 0; jx < 4; ++jx) {
-            *reinterpret_cast<float4*>(&Vs[wbase + jx * WN_XI]) = make_float4(ov[jx][0], ov[jx][1], ov[jx][2], ov[jx][3]);
-            if constexpr (!PRE) *reinterpret_cast<float4*>(&Vs[WN_IMG + wbase + jx * WN_XI]) = make_float4(ou[jx][0], ou[jx][1], ou[jx][2], ou[jx][3]);
-        }
-    };
-    auto advance_loader = [&]() __attribute__((always_inline)) {
-        if (++l_chunk == wg.nchunks) {
-            l_chunk = 0;
-            l_item += gridDim.x;
-            if (item_valid(l_item)) setup_item();
-        }
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+                *reinterpret_cast<float4*>(&Vs[woff[pp][hh]]) = make_float4(ov[2 * pp][2 * hh], ov[2 * pp][2 * hh + 1], ov[2 * pp + 1][2 * hh], ov[2 * pp + 1][2 * hh + 1]);
     };
 
     // ---- MFMA role: tile block tb (16 tiles), cout half ch (2 blocks of 16); lane = (row j of the block, k-group kg)
     const int tb = wave & 3, ch = wave >> 2, j16 = lane & 15, kg = lane >> 4;
-    int vrd[4], urd[2][4];
-    {
-        const int vpos = (((kg >> 1) ^ ((j16 >> 3) & 1)) << 2) + ((kg & 1) << 1);
+    int vrd[4], urd[2][4];                                      // slot offsets for the four patch rows i (pair m adds m * 1024)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            vrd[i] = (((16 * tb + j16) ^ i) << 3) + vpos;
-            urd[0][i] = (((32 * ch + j16) ^ i) << 3) + vpos;
-            urd[1][i] = (((32 * ch + 16 + j16) ^ i) << 3) + vpos;
-        }
+    for (int i = 0; i < 4; ++i) {
+        vrd[i] = wino_slot_off(2 * i, 16 * tb + j16, kg) - 2 * i * 1024;
+        urd[0][i] = wino_slot_off(2 * i, 32 * ch + j16, kg) - 2 * i * 1024;
+        urd[1][i] = wino_slot_off(2 * i, 32 * ch + 16 + j16, kg) - 2 * i * 1024;
     }
     floatx4w acc[16][2];
     auto zero_acc = [&]() __attribute__((always_inline)) {
@@ -227,37 +240,36 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[xi][bb][e] = 0.f;
     };
-    // the chunk's 64 MFMAs; the staged chunk's transform (registers only) sits behind position 7, under the second half
-    auto mma_chunk = [&](int buf, auto stage_t) __attribute__((always_inline)) {
-        constexpr bool stage = decltype(stage_t)::value;
-        const float* Vs = smem + buf * 2 * WN_IMG;
-        const float* Us = Vs + WN_IMG;
-        float2 vf[2], uf[2][2];
-        auto read_frags = [&](int xi, int set) __attribute__((always_inline)) {
-            vf[set] = *reinterpret_cast<const float2*>(&Vs[xi * WN_XI + vrd[xi >> 2]]);
-            uf[set][0] = *reinterpret_cast<const float2*>(&Us[xi * WN_XI + urd[0][xi >> 2]]);
-            uf[set][1] = *reinterpret_cast<const float2*>(&Us[xi * WN_XI + urd[1][xi >> 2]]);
+    // MFMAs of position pairs [m0, m1) of the chunk in V image vb / U image ub (8 pairs = 64 MFMAs per chunk); the fragments of pair m + 1 are read
+    // from LDS before the MFMAs of pair m issue (two register sets, carried across the calls of one chunk)
+    float4 vf[2], uf[2][2];
+    auto mma_pairs = [&](int vb, int ub, auto m0_t, auto m1_t) __attribute__((always_inline)) {
+        constexpr int M0 = decltype(m0_t)::value, M1 = decltype(m1_t)::value;
+        const float* Vs = smem + vb * WN_IMG;
+        const float* Us = smem + WN_U0 + ub * WN_IMG;
+        auto read_frags = [&](int m, int set) __attribute__((always_inline)) {
+            vf[set] = *reinterpret_cast<const float4*>(&Vs[m * 1024 + vrd[m >> 1]]);
+            uf[set][0] = *reinterpret_cast<const float4*>(&Us[m * 1024 + urd[0][m >> 1]]);
+            uf[set][1] = *reinterpret_cast<const float4*>(&Us[m * 1024 + urd[1][m >> 1]]);
         };
-        read_frags(0, 0);
+        if (M0 == 0) read_frags(0, 0);
 #pragma unroll
-        for (int xi = 0; xi < 16; ++xi) {
-            const int cur = xi & 1;
-            if (xi + 1 < 16) read_frags(xi + 1, cur ^ 1);
-            acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].x, vf[cur].x, acc[xi][0], 0, 0, 0);
-            acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][1].x, vf[cur].x, acc[xi][1], 0, 0, 0);
-            acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].y, vf[cur].y, acc[xi][0], 0, 0, 0);
-            acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][1].y, vf[cur].y, acc[xi][1], 0, 0, 0);
-            if constexpr (stage) {
-                if (xi == 7) {
-                    __builtin_amdgcn_sched_barrier(0);           // the transform (and the wait for its loads) stays behind the first 32 MFMAs
-                    transform();
-                }
-            }
+        for (int m = M0; m < M1; ++m) {
+            const int cur = m & 1;
+            if (m + 1 < 8) read_frags(m + 1, cur ^ 1);
+            acc[2 * m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].x, vf[cur].x, acc[2 * m][0], 0, 0, 0);
+            acc[2 * m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][1].x, vf[cur].x, acc[2 * m][1], 0, 0, 0);
+            acc[2 * m + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].z, vf[cur].z, acc[2 * m + 1][0], 0, 0, 0);
+            acc[2 * m + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][1].z, vf[cur].z, acc[2 * m + 1][1], 0, 0, 0);
+            acc[2 * m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].y, vf[cur].y, acc[2 * m][0], 0, 0, 0);
+            acc[2 * m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][1].y, vf[cur].y, acc[2 * m][1], 0, 0, 0);
+            acc[2 * m + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].w, vf[cur].w, acc[2 * m + 1][0], 0, 0, 0);
+            acc[2 * m + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][1].w, vf[cur].w, acc[2 * m + 1][1], 0, 0, 0);
         }
     };
 
     // ---- epilogue of the item under the MFMAs: output transform in registers, stores, statistics
-    auto epilogue = [&](int tile0, int n0, int row_tile) __attribute__((always_inline)) {
+    auto epilogue = [&](int tile0, int n0, int row_tile, float* scratch) __attribute__((always_inline)) {
         float out[4][2][4];                                      // [pixel (py, px) = (q >> 1, q & 1)][cout block][e]
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb)
@@ -317,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
         // BatchNorm statistics: one (S, Q, k, n) record per (tile block, cout), sums over the block's valid pixels shifted by k = the block's
         // first output; the block that contains the segment boundary emits its first-segment tiles to `stats`, the rest to `stats_extra`
         if (p.stats) {
-            float* kk = smem + 4 * WN_IMG;                       // [64]    (its own region: the image buffers hold the next item's first chunk)
+            float* kk = scratch;                                 // [64]
             float* red = kk + 64;                                // [4 tile blocks][64 couts][4]
             if (tb == 0 && j16 == 0) {
 #pragma unroll
@@ -358,47 +370,71 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
                 rec[grp * p.Ng + n0 + t] = make_float4(s.x, s.y, kk[t], 4.f * (float)n1);
                 if (cut != 0x7fffffff) reinterpret_cast<float4*>(p.stats_extra)[grp * p.Ng + n0 + t] = make_float4(s.z, s.w, kk[t], 4.f * (float)(nvalid - n1));
             }
-            // (the next item's statistics write kk / red only after a later __syncthreads of the chunk loop: no hazard with these reads)
+            __syncthreads();                                     // the scratch is a V image: the chunk loop writes it again one iteration later
         }
     };
 
-    if (!item_valid(l_item)) return;
-    setup_item();
-    int c_tile0 = l_tile0, c_n0 = l_n0, c_row_tile = l_row_tile, c_chunk = 0;
-    issue_loads(0);
-    transform();
+    if (!item_valid(lu_item)) return;
+    setup_v();
+    setup_u();
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I6 = std::integral_constant<int, 6>;
+    using I8 = std::integral_constant<int, 8>;
+    // Prologue: super-chunk 0, chunks 0 and 1 of the stream.  Queue: V x 8, U(0) x 4, U(1) x 4 -> vmcnt(4) leaves U(1) in flight.
+    issue_v();
+    issue_u();
+    issue_u();
+    asm volatile("s_waitcnt vmcnt(4)" : "+v"(raw[0][0]), "+v"(raw[1][0]), "+v"(raw[2][0]), "+v"(raw[3][0]), "+v"(raw[0][1]), "+v"(raw[1][1]), "+v"(raw[2][1]), "+v"(raw[3][1]) :: "memory");
+    transform(I0{});
     write_staged(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    advance_loader();
     zero_acc();
-    int buf = 0;
-    auto finish_chunk = [&]() __attribute__((always_inline)) {
-        if (++c_chunk == wg.nchunks) {
-            epilogue(c_tile0, c_n0, c_row_tile);
+    int c_item = blockIdx.x, c_chunk = 0;                       // item / chunk under the MFMAs
+    int ub = 0;                                                  // U image of chunk k
+    // One pass = chunks k (even) and k + 1 of the stream; S = k / 2 is the super-chunk in `raw` (half 0 already staged as chunk k's V image 0).
+    //   even: DMA U(k+2) | MFMAs of chunk k, transform of raw half 1 under them -> V image 1 | loads of super-chunk S+1 | wait: U(k+1) landed | barrier
+    //   odd : DMA U(k+3) | MFMAs of chunk k+1; behind three quarters of them wait for super-chunk S+1, transform its half 0 -> V image 0 | barrier | epilogue?
+    for (;;) {
+        const bool e2 = item_valid(lu_item);                     // chunk k + 2 exists (the U cursor stands on it), and with it chunk k + 3 and super-chunk S + 1
+        // ---- even chunk
+        if (e2 && !(WINO_ABLATE & 2)) issue_u();
+        if (!(WINO_ABLATE & 8)) mma_pairs(0, ub, I0{}, I2{});
+        if (!(WINO_ABLATE & 4)) { transform(I1{}); write_staged(1); }
+        if (e2 && !(WINO_ABLATE & 2)) issue_v();                 // (the registers are free from here: 1.5 chunks until the data is needed)
+        if (!(WINO_ABLATE & 8)) mma_pairs(0, ub, I2{}, I8{});
+        if (e2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");    // behind U(k+1): U(k+2) x 4, super-chunk S+1 x 8
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(WINO_ABLATE & 1)) __syncthreads();
+        // ---- odd chunk
+        const int ub1 = ub == 2 ? 0 : ub + 1;
+        if (e2 && !(WINO_ABLATE & 2)) issue_u();
+        if (!(WINO_ABLATE & 8)) mma_pairs(1, ub1, I0{}, I6{});
+        if (e2) {
+            // behind super-chunk S+1: U(k+3) x 4 (U(k+2), issued before it, has landed with it)
+            asm volatile("s_waitcnt vmcnt(4)" : "+v"(raw[0][0]), "+v"(raw[1][0]), "+v"(raw[2][0]), "+v"(raw[3][0]), "+v"(raw[0][1]), "+v"(raw[1][1]), "+v"(raw[2][1]), "+v"(raw[3][1]) :: "memory");
+            if (!(WINO_ABLATE & 4)) { transform(I0{}); write_staged(0); }
+        }
+        if (!(WINO_ABLATE & 8)) mma_pairs(1, ub1, I6{}, I8{});
+        if (!(WINO_ABLATE & 1)) __syncthreads();
+        c_chunk += 2;
+        if (c_chunk == wg.nchunks) {
+            const int jx = c_item >> 3;
+            const int row_tile = rt_first + jx / p.col_tiles;
+            // (scratch = V image 1: chunk k+1's, just multiplied; it is written again at the end of the next even chunk, behind the epilogue's last barrier)
+            if (!(WINO_ABLATE & 16)) epilogue(row_tile * 64, (jx % p.col_tiles) * 64, row_tile, smem + WN_IMG);
             zero_acc();
             c_chunk = 0;
-            c_tile0 = l_tile0; c_n0 = l_n0; c_row_tile = l_row_tile;      // (the loader is inside the next item by now)
+            c_item += gridDim.x;
         }
-    };
-    while (item_valid(l_item)) {                                 // the loader has a chunk to stage beside this one's MFMAs
-        issue_loads(buf ^ 1);
-        __builtin_amdgcn_sched_barrier(0);                       // (left alone the scheduler sinks the patch-row loads down to their first use)
-        mma_chunk(buf, std::integral_constant<bool, PRE>{});     // (the self-transforming form keeps its longer transform out of the MFMA block: registers)
-        if constexpr (!PRE) transform();
-        write_staged(buf ^ 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        finish_chunk();
-        advance_loader();
-        buf ^= 1;
+        if (!e2) break;
+        ub = ub1 == 2 ? 0 : ub1 + 1;
     }
-    mma_chunk(buf, std::false_type{});                           // the last chunk of the last item
-    finish_chunk();
 }
 
 // ---- filter transform: U = G g G^T (row 3 negated) of every (output row R, reduction channel k) of a group, written in the LDS image order
-// of the main kernel: fw[group][R / 64][k / 8][image of 16 x 512 floats].  pass 0: g[r][s] = w[(group, R)][r][s][k] (the filter as stored,
+// of the main kernel: fw[group][R / 64][chunk][image of 16 x 512 floats] (chunks of 8 channels in super-chunk order, see below).  pass 0: g[r][s] = w[(group, R)][r][s][k] (the filter as stored,
 // [cout][r][s][cin / groups]); pass 1 (input gradient): R = input channel, k = output channel of the group, g[r][s] = w[(group, k)][2 - r][2 - s][R].
 __global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ fw, int groups, int NR, int NK, int ng_w, int cg_w,
                                                           int pass, int rblocks, int kchunks) {
@@ -426,14 +462,16 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restric
             const float s02 = gq[0][s] + gq[2][s];
             hg[0][s] = gq[0][s]; hg[1][s] = 0.5f * (s02 + gq[1][s]); hg[2][s] = 0.5f * (s02 - gq[1][s]); hg[3][s] = -gq[2][s];
         }
-        float* img = fw + (((int64_t)grp * rblocks + R / 64) * kchunks + k / 8) * WN_IMG;
-        const int row = R & 63, v4 = (k & 7) >> 2, e = k & 3;
+        // channel k -> chunk 2 (k / 16) + ((k / 4) & 1), in-chunk position 4 ((k / 8) & 1) + (k & 3): the order the main kernel's super-chunk loads produce
+        const int chunk = 2 * (k >> 4) + ((k >> 2) & 1), kc = 4 * ((k >> 3) & 1) + (k & 3);
+        float* img = fw + (((int64_t)grp * rblocks + R / 64) * kchunks + chunk) * WN_IMG;
+        const int row = R & 63, kgq = kc >> 1, e = kc & 1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float s02 = hg[i][0] + hg[i][2];
             const float u[4] = {hg[i][0], 0.5f * (s02 + hg[i][1]), 0.5f * (s02 - hg[i][1]), hg[i][2]};
 #pragma unroll
-            for (int jx = 0; jx < 4; ++jx) img[wino_img_off(4 * i + jx, row, v4) + e] = u[jx];
+            for (int jx = 0; jx < 4; ++jx) img[wino_slot_off((4 * i + jx) >> 1, row, kgq) + 2 * (jx & 1) + e] = u[jx];
         }
     }
 }
@@ -449,13 +487,13 @@ bool wino_geom_ok(const GatherGeom& g, int Ng) {
 // epilogue forms the kernel has: bias, skip add, statistics records
 static bool wino_params_ok(const NtParams& p) {
     return wino_geom_ok(p.g, p.Ng) && !p.scale && !p.y2 && !p.a_scale && !p.o_rowscale && (p.res_mode == 0 || p.res_mode == 3) && p.ldy % 4 == 0 &&
-           aligned16(p.y) && aligned16(p.x) && (p.fw ? aligned16(p.fw) : aligned16(p.f)) && (!p.residual || aligned16(p.residual)) && (!p.bias || aligned16(p.bias));
+           p.fw && aligned16(p.y) && aligned16(p.x) && aligned16(p.fw) && (!p.residual || aligned16(p.residual)) && (!p.bias || aligned16(p.bias));
 }
 
-int64_t wino_filter_floats(int groups, int NR, int NK) { return (int64_t)groups * ceil_div(NR, 64) * ceil_div(NK, 8) * WN_IMG; }
+int64_t wino_filter_floats(int groups, int NR, int NK) { return (int64_t)groups * ceil_div(NR, 64) * 2 * ceil_div(NK, 16) * WN_IMG; }
 
 void launch_wino_filter(const float* w, float* fw, int groups, int NR, int NK, int ng_w, int cg_w, int pass, hipStream_t st) {
-    const int rblocks = (int)ceil_div(NR, 64), kchunks = (int)ceil_div(NK, 8);
+    const int rblocks = (int)ceil_div(NR, 64), kchunks = 2 * (int)ceil_div(NK, 16);
     const int64_t total = (int64_t)groups * rblocks * 64 * kchunks * 8;
     hipLaunchKernelGGL(wino_filter_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, w, fw, groups, NR, NK, ng_w, cg_w, pass, rblocks, kchunks);
 }
@@ -470,7 +508,7 @@ bool launch_wino(const NtParams& p_in, int groups, hipStream_t st) {
     magic_div((unsigned)wg.TPI, &wg.div_tpi_mul, &wg.div_tpi_shr);
     magic_div((unsigned)wg.TX, &wg.div_tx_mul, &wg.div_tx_shr);
     wg.MT = g.N * wg.TPI;
-    wg.nchunks = (g.Cg + 7) / 8;
+    wg.nchunks = 2 * ((g.Cg + 15) / 16);               // super-chunks of 16 channels, two chunks each
     wg.flip = g.mode == 0 ? 0 : 1;
     wg.seg_tile = (p.stats && p.seg_row > 0) ? (int)(p.seg_row / 4) : 0;
     wg.row_tiles = (int)ceil_div(wg.MT, 64);
@@ -488,14 +526,9 @@ bool launch_wino(const NtParams& p_in, int groups, hipStream_t st) {
     if (per_group < 8) per_group = 8;
     const int gx = (int)(items8 < per_group ? items8 : per_group);
     const dim3 grid((unsigned)gx, 1, groups), block(512);
-    const size_t lds = ((size_t)4 * WN_IMG + WN_SCRATCH) * sizeof(float);
-    if (p.fw) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_nt_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(wino_nt_kernel<true>, grid, block, lds, st, p, wg);
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_nt_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(wino_nt_kernel<false>, grid, block, lds, st, p, wg);
-    }
+    const size_t lds = (size_t)WN_LDS_FLOATS * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_nt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(wino_nt_kernel, grid, block, lds, st, p, wg);
     return true;
 }
 
