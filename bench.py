@@ -125,11 +125,15 @@ def gpu_leg(args, rank, world, device):
     agent.overlap_teacher, K.WGRAD_OVERLAP = overlap
     if rank == 0:
         recs, K.PROFILE = K.PROFILE, None
+        # FLOP of a launch = the multiply-adds its algorithm executes: 2 M N K for the direct kernels; the Winograd F(2x2, 3x3) kernel spends 16
+        # multiplies per 2x2 output tile and channel pair where the direct sum spends 36, so its launches count 1 / 2.25 of the direct figure
+        # (`direct_equivalent_tflops` = the rate a direct kernel would need to finish in the same time; timed with its filter transform launch)
+        exec_share = lambda nm: (16.0 / 36.0) if nm.startswith("wino") else 1.0
         agg = {}
         for name, flops, nbytes, e0, e1, _shape in recs:
             a = agg.setdefault(name, [0.0, 0.0, 0.0, 0])
             a[0] += e0.elapsed_time(e1) * 1e-3
-            a[1] += flops
+            a[1] += flops * exec_share(name)
             a[2] += nbytes
             a[3] += 1
         total_gemm_s = sum(a[0] for a in agg.values())
@@ -142,8 +146,10 @@ def gpu_leg(args, rank, world, device):
                 "avg_launch_gflop": round(flops / launches / 1e9, 3),
                 "kernel_share_of_step": round(secs / nprof / (serial_ms * 1e-3), 3),
                 "timing": "HIP events around every dense-conv launch, single-stream steps (with event overhead: %.1f ms/step)" % serial_ms,
-                "all_gemm_kernels": {k: {"ms_per_step": round(v[0] / nprof * 1e3, 3), "tflops": round(v[1] / v[0] / 1e12, 2),
-                                         "launches_per_step": v[3] // nprof} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])},
+                "all_gemm_kernels": {k: dict({"ms_per_step": round(v[0] / nprof * 1e3, 3), "tflops": round(v[1] / v[0] / 1e12, 2),
+                                              "launches_per_step": v[3] // nprof},
+                                             **({"direct_equivalent_tflops": round(v[1] / exec_share(k) / v[0] / 1e12, 2)} if exec_share(k) != 1.0 else {}))
+                                     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])},
                 "gemm_ms_per_step": round(total_gemm_s / nprof * 1e3, 2)}
     agent.logs_writer.close()
     return dt, info, roof

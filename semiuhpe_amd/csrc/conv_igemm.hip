@@ -1250,7 +1250,9 @@ static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st
     const bool act2 = p.y2 || p.res_mode >= 4 || p.o_rowscale; // activation / keep-scale epilogues live in igemm_nt_kernel's pointwise form only
     if (tile == NT_G64x64) {
         if (launch_wino(p, groups, st)) return;
-        tile = p.stats ? NT_256x32 : NT_128x64;             // (a form the Winograd kernel lacks: the direct tile with the same statistics-record height)
+        // a form the Winograd kernel lacks (eval-mode folded affine, no Winograd-domain filter handed over): the heuristic's direct tile, or with
+        // statistics the direct tile of the same record height
+        tile = p.stats ? NT_256x32 : choose_nt(p.g.M, p.Ng, vec4, -1, halo_ok(p.g, vec4));
     }
     if (act2 && tile >= NT_R128x16) tile = NT_64x64;
     if (act2 && tile >= NT_W128x128) tile = tile == NT_W128x128 ? NT_128x128 : NT_128x64;

@@ -130,6 +130,7 @@ def _memop(fn):
 # database at exit), so known shapes are pinned without measuring and runs are reproducible.
 # Off by default; bench.py, train.py and the agent switch it on (SUHPE_AUTOTUNE=0 keeps the built-in heuristics).
 AUTOTUNE = False
+_TUNE_VERBOSE = os.environ.get("SUHPE_AUTOTUNE_VERBOSE", "0") != "0"      # print every tile's time while the menu is measured
 _tuned = set()
 _flush = {}
 _TILE_DB = None
@@ -199,6 +200,8 @@ def _autotune(d, pass_id, run):
             ms = min(ms, e0.elapsed_time(e1))
         if ms < best[0]:
             best = (ms, tile)
+        if _TUNE_VERBOSE:
+            print(f"autotune {skey} {names[tile]}: {ms * 1e3:.0f} us", flush=True)
     winner = best[1]
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
@@ -246,8 +249,8 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, groups=1):
     else:
         if AUTOTUNE:
             _autotune_fwd(d, x, w, y)
-        fw = _wino_filter(d, 0, w)
         with _Prof(d, 0):
+            fw = _wino_filter(d, 0, w)
             if fw is not None:
                 call("suhpe_conv2d_fwd_wino", ctypes.byref(d), ptr(x), ptr(w), ptr(fw), ptr(bias), ptr(y), None, None, 0)
             else:
@@ -368,7 +371,7 @@ def conv2d_fwd_affine(x, w, scale, shift, act, residual=None, residual_after_act
     y = torch.empty((d.n, d.ho, d.wo, d.cout), dtype=torch.float32, device=x.device)
     assert residual is None or residual.shape == y.shape
     if AUTOTUNE:
-        _autotune(d, 0, lambda: call("suhpe_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(w), None, ptr(y)))
+        _autotune_fwd(d, x, w, y)
     with _Prof(d, 0):
         call("suhpe_conv2d_fwd_affine", ctypes.byref(d), ptr(x), ptr(w), ptr(scale), ptr(shift), ACT[act], ptr(residual),
              int(residual_after_act), ptr(y))
@@ -484,13 +487,13 @@ def conv2d_fwd_stats(x, w, stride=1, pad=0, groups=1, seg=None, xf=None):
     if AUTOTUNE:
         _autotune_fwd(d, x, w, y)
     tiles = _lib.load().suhpe_conv2d_fwd_stats_tiles(ctypes.byref(d))
-    fw = _wino_filter(d, 0, w)
     if seg is not None and 0 < seg < d.n:
         tile_rows = _lib.load().suhpe_conv2d_fwd_stats_tile_rows(ctypes.byref(d))
         seg_row = seg * d.ho * d.wo
         part = torch.empty(d.cout * (tiles + 1) * 4, dtype=torch.float32, device=x.device)
         extra = part[d.cout * tiles * 4:]
         with _Prof(d, 0):
+            fw = _wino_filter(d, 0, w)
             if fw is not None:
                 call("suhpe_conv2d_fwd_wino", ctypes.byref(d), ptr(x), ptr(w), ptr(fw), None, ptr(y), ptr(part), ptr(extra), seg_row)
             else:
@@ -499,6 +502,7 @@ def conv2d_fwd_stats(x, w, stride=1, pad=0, groups=1, seg=None, xf=None):
         return y, part, tiles, (seg_row // tile_rows + int(straddle), extra if straddle else None)
     part = torch.empty(d.cout * tiles * 4, dtype=torch.float32, device=x.device)
     with _Prof(d, 0):
+        fw = _wino_filter(d, 0, w)
         if fw is not None:
             call("suhpe_conv2d_fwd_wino", ctypes.byref(d), ptr(x), ptr(w), ptr(fw), None, ptr(y), ptr(part), None, 0)
         else:
@@ -541,7 +545,7 @@ def _conv2d_fwd_stats_xf(d, x, w, y, seg, xf):
     scale, shift, rowscale, act, hw, rows_a = xf
     lib = _lib.load()
     if AUTOTUNE:
-        _autotune(d, 0, lambda: call("suhpe_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(w), None, ptr(y)))
+        _autotune_fwd(d, x, w, y)
     tiles = lib.suhpe_conv2d_fwd_stats_tiles(ctypes.byref(d))
     two = seg is not None and 0 < seg < d.n
     seg_row = seg * d.ho * d.wo if two else 0
@@ -649,9 +653,9 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, pad=0, groups=1, skip=None):
     else:
         key = (w.data_ptr(), d.cin, d.cout, d.r, d.s, d.groups)
         known = (not AUTOTUNE) or ((1, d.n, d.h, d.w, d.cin, d.cout, d.r, d.s, d.stride, d.pad, d.groups) in _tuned)
-        fw = _wino_filter(d, 1, w) if known else None
-        if fw is not None:                                   # Winograd tile: the filter transform reads w as stored, no transposed copy
+        if known and _lib.load().suhpe_conv2d_wino_pinned(ctypes.byref(d), 1):      # Winograd tile: the filter transform reads w as stored, no transposed copy
             with _Prof(d, 1):
+                fw = _wino_filter(d, 1, w)
                 call("suhpe_conv2d_dgrad_wino", ctypes.byref(d), ptr(dy), None, ptr(fw), ptr(skip), ptr(dx))
             return dx
         wt = _WT_CACHE.get(key) if _WT_CACHE is not None else None

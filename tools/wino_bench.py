@@ -115,6 +115,10 @@ def run(shapes, check_only=False, big_ref=True):
         print(line, flush=True)
 
 
+if __name__ == "__main__" and os.environ.get("WINO_SHAPES"):       # WINO_SHAPES="cin,cout,groups,hw,n,seg;..."
+    run([tuple(int(v) for v in sh.split(",")) + (sh,) for sh in os.environ["WINO_SHAPES"].split(";")])
+    sys.exit(0)
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "all"
     check_only = "--check-only" in sys.argv
