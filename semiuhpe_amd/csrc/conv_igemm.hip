@@ -1167,8 +1167,10 @@ static const TnTile kTnTiles[] = {
     {64, 128, "igemm_tn_kernel<64,128,32,64,4,4>"},   {64, 64, "igemm_tn_kernel<64,64,32,32,4,4>"},
     {32, 128, "igemm_tn_kernel<32,128,32,32,4,4>"},
     {128, 32, "igemm_tn_kernel<128,32,32,32,4,4>"},   // narrow k' (Cin = 160: five exact column tiles instead of 2.5 of 64)
+    {0, 0, "wino_wgrad_kernel<64,64>"},               // Winograd F(3x3, 2x2) filter gradient (conv_wino.hip): 3x3 / stride 1 / pad 1 convs on even sizes; pinned only
 };
 constexpr int TN_TILES = (int)(sizeof(kTnTiles) / sizeof(kTnTiles[0]));
+constexpr int TN_WINO = TN_TILES - 1;
 
 struct TileKey {
     int v[11];
@@ -1328,10 +1330,10 @@ static bool resident_ok_desc(const suhpe_conv_t* d, int pass, int BM) {
 // wgrad (rows = cout, columns = k'): both extents pad; cost = padded area / measured relative efficiency
 static int choose_tn(int ng, int K, int pinned) {
     if (pinned >= 0 && pinned < TN_TILES) return pinned;
-    static const double eff[TN_TILES] = {0.85, 0.95, 0.95, 1.0, 0.9, 0.9};
+    static const double eff[TN_WINO] = {0.85, 0.95, 0.95, 1.0, 0.9, 0.9};
     int best = 3;
     double best_cost = 1e30;
-    for (int i = 0; i < TN_TILES; ++i) {
+    for (int i = 0; i < TN_WINO; ++i) {
         const TnTile& c = kTnTiles[i];
         const double cost = (double)(ceil_div(ng, c.bm) * c.bm) * (double)(ceil_div(K, c.bn) * c.bn) / eff[i];
         if (cost < best_cost) { best_cost = cost; best = i; }
@@ -1692,11 +1694,17 @@ static int wgrad_splits(const suhpe_conv_t* d, int bm, int bn) {
     return (int)(ceil_div(splits, 8) * 8);                   // multiple of 8: one XCD per split (see igemm_tn_kernel)
 }
 
+// is the filter gradient of this conv on the Winograd kernel? (pinned by suhpe_conv2d_set_tile; never the heuristic's choice)
+static bool wgrad_wino(const suhpe_conv_t* d) {
+    return pinned_tile(d, 2) == TN_WINO && wino_wgrad_geom_ok(d->n, d->h, d->w, d->ho, d->wo, d->cin, d->cout, d->r, d->s, d->stride, d->pad, d->groups);
+}
+
 static void wgrad_tile(const suhpe_conv_t* d, int* bm, int* bn) {
     const int ng = d->cout / d->groups, cg = d->cin / d->groups, K = d->r * d->s * cg;
     const bool va = ng % 4 == 0 && d->cout % 4 == 0, vb = cg % 4 == 0 && d->cin % 4 == 0;
     if (!(va && vb)) { *bm = 64; *bn = 64; return; }       // scalar loaders: generic 64x64 tile
-    const TnTile& t = kTnTiles[choose_tn(ng, K, pinned_tile(d, 2))];
+    const int pin = pinned_tile(d, 2);
+    const TnTile& t = kTnTiles[choose_tn(ng, K, pin == TN_WINO ? -1 : pin)];
     *bm = t.bm;
     *bn = t.bn;
 }
@@ -1719,6 +1727,8 @@ int suhpe_conv2d_set_tile(const suhpe_conv_t* d, int pass, int tile) {
     const bool v4 = ng % 4 == 0 && d->cout % 4 == 0 && cg % 4 == 0 && d->cin % 4 == 0;
     SUHPE_REQUIRE(tile < 0 || (v4 && !(pass != 2 && tile == (int)NT_64x64_S)), "suhpe_conv2d_set_tile: the vector tiles need channel counts that are multiples of 4");
     SUHPE_REQUIRE(pass == 2 || tile < (int)NT_H64x64 || tile >= (int)NT_W128x128 || halo_ok_desc(d, pass), "suhpe_conv2d_set_tile: the halo tiles need a 3x3 / stride 1 / pad 1 conv with evenly chunked channels");
+    SUHPE_REQUIRE(pass != 2 || tile != TN_WINO || wino_wgrad_geom_ok(d->n, d->h, d->w, d->ho, d->wo, d->cin, d->cout, d->r, d->s, d->stride, d->pad, d->groups),
+                  "suhpe_conv2d_set_tile: the Winograd filter-gradient tile needs a 3x3 / stride 1 / pad 1 conv on even output sizes");
     SUHPE_REQUIRE(pass == 2 || tile != (int)NT_G64x64 || wino_ok_desc(d, pass), "suhpe_conv2d_set_tile: the Winograd tile needs a 3x3 / stride 1 / pad 1 conv on even output sizes");
     SUHPE_REQUIRE(pass == 2 || tile < (int)NT_R128x16 || tile == (int)NT_G64x64 || resident_ok_desc(d, pass, tile == (int)NT_R128x16 ? 128 : 64),
                   "suhpe_conv2d_set_tile: the resident tiles need a 1x1 / stride 1 conv whose BM x K block fits the LDS");
@@ -1740,11 +1750,13 @@ const char* suhpe_conv2d_kernel_name(const suhpe_conv_t* d, int pass) {
     }
     const bool va = ng % 4 == 0 && d->cout % 4 == 0, vb = cg % 4 == 0 && d->cin % 4 == 0;
     if (!(va && vb)) return va ? "igemm_tn_kernel<64,64,32,32,4,1>" : (vb ? "igemm_tn_kernel<64,64,32,32,1,4>" : "igemm_tn_kernel<64,64,32,32,1,1>");
-    return kTnTiles[choose_tn(ng, d->r * d->s * cg, pinned_tile(d, 2))].name;
+    if (wgrad_wino(d)) return kTnTiles[TN_WINO].name;
+    { const int pin = pinned_tile(d, 2); return kTnTiles[choose_tn(ng, d->r * d->s * cg, pin == TN_WINO ? -1 : pin)].name; }
 }
 
 int64_t suhpe_conv2d_wgrad_workspace_bytes(const suhpe_conv_t* d) {
     if (!d || d->groups <= 0) return 0;
+    if (wgrad_wino(d)) return wino_wgrad_workspace_floats(d->n, d->h, d->w, d->cin, d->cout, d->groups) * 4;
     int bm, bn;
     wgrad_tile(d, &bm, &bn);
     const int K = d->r * d->s * (d->cin / d->groups);
@@ -1762,6 +1774,12 @@ static int wgrad_partial_impl(const suhpe_conv_t* d, const float* x, const float
         set_error("suhpe_conv2d_wgrad: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)suhpe_conv2d_wgrad_workspace_bytes(d));
         return SUHPE_EWORKSPACE;
     }
+    if (wgrad_wino(d) && !xf && aligned16(x) && aligned16(dy) && aligned16(workspace)) {
+        // Winograd F(3x3, 2x2): the launch leaves ONE complete filter-shaped slab at the start of the workspace (suhpe_conv2d_wgrad_splits = 1)
+        launch_wino_wgrad(x, dy, static_cast<float*>(workspace), d->n, d->h, d->w, d->cin, d->cout, d->groups, as_stream(stream));
+        return check_launch("suhpe_conv2d_wgrad_partial");
+    }
+    SUHPE_REQUIRE(!wgrad_wino(d), "suhpe_conv2d_wgrad: the Winograd filter-gradient tile needs 16-byte aligned operands and no input transform");
     int bm, bn;
     wgrad_tile(d, &bm, &bn);
     const int splits = wgrad_splits(d, bm, bn);
@@ -1833,7 +1851,7 @@ int suhpe_conv2d_wgrad_reduce(const suhpe_conv_t* d, const void* workspace, floa
     SUHPE_REQUIRE(workspace && dw, "suhpe_conv2d_wgrad: null pointer");
     int bm, bn;
     wgrad_tile(d, &bm, &bn);
-    const int splits = wgrad_splits(d, bm, bn);
+    const int splits = wgrad_wino(d) ? 1 : wgrad_splits(d, bm, bn);
     const int64_t count = (int64_t)d->cout * d->r * d->s * (d->cin / d->groups);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(count, 256)), dim3(256), 0, as_stream(stream), static_cast<const float*>(workspace),
                        splits, count, dw, accumulate);
@@ -1842,6 +1860,7 @@ int suhpe_conv2d_wgrad_reduce(const suhpe_conv_t* d, const void* workspace, floa
 
 int suhpe_conv2d_wgrad_splits(const suhpe_conv_t* d) {
     if (!d || d->groups <= 0) return 0;
+    if (wgrad_wino(d)) return 1;
     int bm, bn;
     wgrad_tile(d, &bm, &bn);
     return wgrad_splits(d, bm, bn);

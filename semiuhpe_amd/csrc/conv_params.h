@@ -116,4 +116,9 @@ int64_t wino_filter_floats(int groups, int NR, int NK);
 // w: the filter as stored, [groups * ng_w][3][3][cg_w]; pass 0: NR = ng_w rows, NK = cg_w channels; pass 1 (input gradient): NR = cg_w, NK = ng_w
 void launch_wino_filter(const float* w, float* fw, int groups, int NR, int NK, int ng_w, int cg_w, int pass, hipStream_t st);
 
+// Winograd filter gradient F(3x3, 2x2): workspace = one filter-shaped slab [cout][3][3][cin/groups] (complete after the launch) + the split-K partial sums
+bool wino_wgrad_geom_ok(int n, int h, int w, int ho, int wo, int cin, int cout, int r, int s, int stride, int pad, int groups);
+int64_t wino_wgrad_workspace_floats(int n, int h, int w, int cin, int cout, int groups);
+void launch_wino_wgrad(const float* x, const float* dy, float* workspace, int n, int h, int w, int cin, int cout, int groups, hipStream_t st);
+
 }  // namespace suhpe

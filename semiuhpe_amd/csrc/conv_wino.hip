@@ -476,6 +476,208 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restric
     }
 }
 
+// ================================================================================================================================
+// Filter gradient of the same convolutions by the transposed algorithm, F(3x3, 2x2):
+//   dU_xi[cout][cin] = sum over tiles of dM_xi[tile][cout] * V_xi[tile][cin],   dM = A dY A^T (4x4 from the 2x2 tile of dy), V = B^T d B as above,
+//   dW = G^T dU G   (per (cout, cin): 4x4 -> 3x3, linear, so it is applied once after the sum over tiles)
+// again 16 multiplies per tile and channel pair where the direct sum has 36.  A workgroup (8 wavefronts) owns a 64 cout x 64 cin block of all 16
+// positions over a slab of tiles (split-K: the partial sums go to a workspace, a second small kernel adds the slabs in a fixed order and applies
+// G^T . G, writing one filter-shaped slab that the library's deferred reduction adds to the gradient like any other filter gradient).
+//   stage   chunk = 8 tiles; thread (patch row i = t&3, channel vector v = (t>>2)&15, tile = t>>6 = its wavefront): one row of the tile's 4x4 input
+//           patch (four 16-byte loads: the 16 vectors of a pixel are 256 contiguous bytes) and the tile's 2x2 block of dy (four loads, the same for
+//           the four lanes of a quad); horizontal halves in-thread, vertical halves: V across the quad by DPP, dM per lane from its coefficients;
+//           both images [position][tile][64 channels] (rows 3 / columns 3 negated on both sides: the products do not notice);
+//   MFMA    wavefront w owns positions 2w, 2w+1 for the whole 64 x 64 block: reduction index = tile (4 per v_mfma_f32_16x16x4_f32), a lane's
+//           ds_read_b128 of a tile row hands it four channel sub-blocks at once (channel 4 * (lane & 15) + a <-> sub-block a), 16 MFMAs per pair
+//           of reads, 64 MFMAs per chunk; accumulators 2 x 16 sub-blocks x 4 registers.
+struct WinoWgradParams {
+    const float* x; const float* dy; float* part;      // part: [splits][16][cout_all][Cg]
+    int64_t x_bytes, dy_bytes;
+    int N, H, W;                 // image size (input = output size)
+    int ldx, lddy;               // pixel strides (all channels of all groups)
+    int Cg, Ng;                  // channels per group: input, output
+    int TX, TPI, MT;
+    unsigned div_tpi_mul, div_tpi_shr, div_tx_mul, div_tx_shr;
+    int ci_blocks, co_blocks, splits, tiles_per_split;      // tiles_per_split: multiple of 8
+    int cout_all;
+};
+
+constexpr int WW_IMG = 16 * 8 * 64;      // floats per image (dM or V): 16 positions x 8 tiles x 64 channels = 32 KB
+
+// NB = input-channel sub-blocks of a workgroup's block: 4 (64 input channels: channel 4 (lane & 15) + b <-> sub-block b, one ds_read_b128) or 3 (48 input
+// channels, EfficientNetV2-S's 48 -> 192 expand convs: channel 16 b + (lane & 15), three ds_read_b32 -- no matrix work on 16 padding channels)
+template <int NB>
+__global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];       // [buffer][dM image | V image]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int grp = blockIdx.z;
+    const int b = blockIdx.x;
+    const int split = b % p.splits, cb = b / p.splits;
+    const int ci_blk = cb % p.ci_blocks, co_blk = cb / p.ci_blocks;
+    const int cin0 = ci_blk * 64, cout0 = co_blk * 64;
+    const BufRsrc xr = make_rsrc(p.x + (int64_t)grp * p.Cg, p.x_bytes - (int64_t)grp * p.Cg * 4);
+    const BufRsrc yr = make_rsrc(p.dy + (int64_t)grp * p.Ng, p.dy_bytes - (int64_t)grp * p.Ng * 4);
+    const int si = t & 3, sv = (t >> 2) & 15;
+    const bool civ = cin0 + 4 * sv < p.Cg, cov = cout0 + 4 * sv < p.Ng;
+    const float sxv = si == 1 ? 1.f : -1.f;                    // V's vertical pass (row 3 negated), as in wino_nt_kernel
+    const float c0 = si == 3 ? 0.f : 1.f, c1 = si == 0 ? 0.f : (si == 2 ? -1.f : 1.f);      // dM rows: dy0, dy0 + dy1, dy0 - dy1, +dy1 (row 3 negated)
+    // LDS float offset of this thread's vector inside an image: [position][tile][vector ^ 2 i] (the XOR spreads the four patch rows of a quad, which write
+    // four different position planes at the same offset, over the banks; a read of one position sees a fixed permutation of its 16 vectors)
+    const int wvec = ((sv ^ (2 * si)) << 2) + wave * 64 + (4 * si) * 512;       // + jx * 512
+    const int tile_lo = split * p.tiles_per_split;
+    int tile_hi = tile_lo + p.tiles_per_split;
+    if (tile_hi > p.MT) tile_hi = p.MT;
+    const int nchunks = tile_lo < tile_hi ? (tile_hi - tile_lo + 7) >> 3 : 0;
+
+    float xr_[4][4], dr_[4][4];
+    auto load_chunk = [&](int c) __attribute__((always_inline)) {
+        const int T = tile_lo + c * 8 + wave;                      // (wave-uniform)
+        const bool tv = T < tile_hi;
+        const unsigned Tn = (unsigned)(tv ? T : 0);
+        const unsigned n = fast_div(Tn, p.div_tpi_mul, p.div_tpi_shr);
+        const unsigned rem = Tn - n * (unsigned)p.TPI;
+        const unsigned ty = fast_div(rem, p.div_tx_mul, p.div_tx_shr), tx = rem - ty * (unsigned)p.TX;
+        const int iy = 2 * (int)ty - 1 + si, ix0 = 2 * (int)tx - 1;
+        const bool rowok = tv && civ && (unsigned)iy < (unsigned)p.H;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const bool ok = rowok && (unsigned)(ix0 + c4) < (unsigned)p.W;
+            buf_load<4>(xr, ok ? ((unsigned)(((int)n * p.H + iy) * p.W + ix0 + c4) * (unsigned)p.ldx + (unsigned)(cin0 + 4 * sv)) * 4u : kOob, xr_[c4]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool ok = tv && cov;
+            buf_load<4>(yr, ok ? ((unsigned)(((int)n * p.H + 2 * (int)ty + (q >> 1)) * p.W + 2 * (int)tx + (q & 1)) * (unsigned)p.lddy + (unsigned)(cout0 + 4 * sv)) * 4u : kOob, dr_[q]);
+        }
+    };
+    auto stage_chunk = [&](int buf) __attribute__((always_inline)) {
+        float* Ds = smem + buf * 2 * WW_IMG;
+        float* Vs = Ds + WW_IMG;
+        float ov[4][4], od[4][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float h0 = xr_[0][e] - xr_[2][e], h1 = xr_[1][e] + xr_[2][e], h2 = xr_[2][e] - xr_[1][e], h3 = xr_[3][e] - xr_[1][e];      // (column 3 negated)
+            ov[0][e] = fmaf(sxv, quad_dpp<0x5A>(h0), h0);
+            ov[1][e] = fmaf(sxv, quad_dpp<0x5A>(h1), h1);
+            ov[2][e] = fmaf(sxv, quad_dpp<0x5A>(h2), h2);
+            ov[3][e] = fmaf(sxv, quad_dpp<0x5A>(h3), h3);
+            const float r0 = fmaf(c1, dr_[2][e], c0 * dr_[0][e]), r1 = fmaf(c1, dr_[3][e], c0 * dr_[1][e]);          // this lane's row of A dY: columns 0, 1
+            od[0][e] = r0; od[1][e] = r0 + r1; od[2][e] = r0 - r1; od[3][e] = r1;                                      // (column 3 negated)
+        }
+#pragma unroll
+        for (int jx = 0; jx < 4; ++jx) {
+            *reinterpret_cast<float4*>(&Ds[wvec + jx * 512]) = make_float4(od[jx][0], od[jx][1], od[jx][2], od[jx][3]);
+            *reinterpret_cast<float4*>(&Vs[wvec + jx * 512]) = make_float4(ov[jx][0], ov[jx][1], ov[jx][2], ov[jx][3]);
+        }
+    };
+    // ---- MFMA role: positions 2 wave, 2 wave + 1; lane = (vector idx = lane & 15, tile-in-group kg = lane >> 4)
+    const int idx = lane & 15, kg = lane >> 4;
+    floatx4w acc[2][4][NB];
+#pragma unroll
+    for (int x2 = 0; x2 < 2; ++x2)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[x2][a][bb][e] = 0.f;
+    auto mma_chunk = [&](int buf) __attribute__((always_inline)) {
+        const float* Ds = smem + buf * 2 * WW_IMG;
+        const float* Vs = Ds + WW_IMG;
+#pragma unroll
+        for (int x2 = 0; x2 < 2; ++x2) {
+            const int xi = 2 * wave + x2;
+            const int rd = xi * 512 + ((idx ^ (2 * (xi >> 2))) << 2) + kg * 64;
+#pragma unroll
+            for (int s4 = 0; s4 < 2; ++s4) {
+                const float4 af = *reinterpret_cast<const float4*>(&Ds[rd + s4 * 256]);
+                const float av[4] = {af.x, af.y, af.z, af.w};
+                float bv[NB];
+                if constexpr (NB == 4) {
+                    const float4 bf = *reinterpret_cast<const float4*>(&Vs[rd + s4 * 256]);
+                    bv[0] = bf.x; bv[1] = bf.y; bv[2] = bf.z; bv[3] = bf.w;
+                } else {
+#pragma unroll
+                    for (int bb = 0; bb < NB; ++bb) {              // channel 16 bb + idx: vector 4 bb + (idx >> 2) (at its swizzled place), element idx & 3
+                        const int vecp = (4 * bb + (idx >> 2)) ^ (2 * (xi >> 2));
+                        bv[bb] = Vs[xi * 512 + (vecp << 2) + (idx & 3) + kg * 64 + s4 * 256];
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int bb = 0; bb < NB; ++bb) acc[x2][a][bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[bb], acc[x2][a][bb], 0, 0, 0);
+            }
+        }
+    };
+    if (nchunks > 0) {
+        load_chunk(0);
+        stage_chunk(0);
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            if (c + 1 < nchunks) load_chunk(c + 1);
+            __builtin_amdgcn_sched_barrier(0);                   // (left alone the scheduler sinks the loads down to their first use)
+            mma_chunk(c & 1);
+            if (c + 1 < nchunks) stage_chunk((c + 1) & 1);
+            __syncthreads();
+        }
+    }
+    // ---- partial sums: part[split][position][cout][cin]; lane holds cout = cout0 + 16 (lane >> 4) + 4 e + a, cins = cin0 + 4 (lane & 15) + {0..3} (sub-block bb)
+    float* part = p.part + (int64_t)split * 16 * p.cout_all * p.Cg;
+#pragma unroll
+    for (int x2 = 0; x2 < 2; ++x2) {
+        const int xi = 2 * wave + x2;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = cout0 + 16 * kg + 4 * e + a;
+                if (co >= p.Ng) continue;
+                float* dst = &part[((int64_t)xi * p.cout_all + grp * p.Ng + co) * p.Cg];
+                if constexpr (NB == 4) {
+                    const int ci = cin0 + 4 * idx;
+                    if (ci < p.Cg) *reinterpret_cast<float4*>(&dst[ci]) = make_float4(acc[x2][a][0][e], acc[x2][a][1][e], acc[x2][a][2][e], acc[x2][a][3][e]);
+                } else {
+#pragma unroll
+                    for (int bb = 0; bb < NB; ++bb) {
+                        const int ci = cin0 + 16 * bb + idx;
+                        if (ci < p.Cg) dst[ci] = acc[x2][a][bb][e];
+                    }
+                }
+            }
+    }
+}
+
+// sum of the slabs (fixed order) and dW = G^T dU G per (cout, cin), written as ONE filter-shaped slab [cout][3][3][Cg]
+__global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __restrict__ part, float* __restrict__ slab, int splits, int cout_all, int Cg) {
+    const int64_t total = (int64_t)cout_all * Cg;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float u[16];
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) u[xi] = 0.f;
+        for (int s = 0; s < splits; ++s)
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) u[xi] += part[((int64_t)s * 16 + xi) * total + i];
+        float hcol[3][4];                                        // G^T U: rows (1, .5, .5, 0), (0, .5, -.5, 0), (0, .5, .5, 1)
+#pragma unroll
+        for (int jx = 0; jx < 4; ++jx) {
+            const float u0 = u[jx], u1 = u[4 + jx], u2 = u[8 + jx], u3 = u[12 + jx];
+            hcol[0][jx] = u0 + 0.5f * (u1 + u2);
+            hcol[1][jx] = 0.5f * (u1 - u2);
+            hcol[2][jx] = 0.5f * (u1 + u2) + u3;
+        }
+        const int co = (int)(i / Cg), ci = (int)(i - (int64_t)co * Cg);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float g0 = hcol[r][0] + 0.5f * (hcol[r][1] + hcol[r][2]);
+            const float g1 = 0.5f * (hcol[r][1] - hcol[r][2]);
+            const float g2 = 0.5f * (hcol[r][1] + hcol[r][2]) + hcol[r][3];
+            float* dst = slab + ((int64_t)co * 9 + r * 3) * Cg + ci;
+            dst[0] = g0; dst[Cg] = g1; dst[2 * Cg] = g2;
+        }
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------------------
 static const bool kWinoEnabled = !(getenv("SUHPE_WINOGRAD") && atoi(getenv("SUHPE_WINOGRAD")) == 0);   // SUHPE_WINOGRAD=0: the tile is never eligible
 
@@ -530,6 +732,53 @@ bool launch_wino(const NtParams& p_in, int groups, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_nt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(wino_nt_kernel, grid, block, lds, st, p, wg);
     return true;
+}
+
+// ---- filter gradient
+bool wino_wgrad_geom_ok(int n, int h, int w, int ho, int wo, int cin, int cout, int r, int sfilt, int stride, int pad, int groups) {
+    return kWinoEnabled && r == 3 && sfilt == 3 && stride == 1 && pad == 1 && ho == h && wo == w && h % 2 == 0 && w % 2 == 0 && groups > 0 && cin % groups == 0 &&
+           cout % groups == 0 && (cin / groups) % 4 == 0 && (cout / groups) % 4 == 0 && cin % 4 == 0 && cout % 4 == 0 && (int64_t)n * h * w < (1LL << 31);
+}
+static int wino_wgrad_splits(int n, int h, int w, int cin, int cout, int groups) {
+    const int cg = cin / groups, ng = cout / groups;
+    const int64_t blocks = ceil_div(cg, 64) * ceil_div(ng, 64) * groups;
+    const int64_t MT = (int64_t)n * (h / 2) * (w / 2);
+    int64_t splits = 256 / blocks;                            // ONE generation of workgroups (a workgroup per CU: 128 KB of LDS); never a 257th
+    const int64_t max_by_k = ceil_div(MT, 64);                // at least 8 chunks per slab
+    if (splits > max_by_k) splits = max_by_k;
+    if (splits < 1) splits = 1;
+    return (int)splits;
+}
+int64_t wino_wgrad_workspace_floats(int n, int h, int w, int cin, int cout, int groups) {
+    const int cg = cin / groups;
+    return (int64_t)cout * 9 * cg + (int64_t)wino_wgrad_splits(n, h, w, cin, cout, groups) * 16 * cout * cg;
+}
+// x (n,h,w,cin), dy (n,h,w,cout) -> workspace: [filter-shaped slab | partial sums]; the slab is complete when the second kernel has run
+void launch_wino_wgrad(const float* x, const float* dy, float* workspace, int n, int h, int w, int cin, int cout, int groups, hipStream_t st) {
+    WinoWgradParams p;
+    memset(&p, 0, sizeof(p));
+    const int cg = cin / groups, ng = cout / groups;
+    p.x = x; p.dy = dy; p.part = workspace + (int64_t)cout * 9 * cg;
+    p.x_bytes = (int64_t)n * h * w * cin * 4; p.dy_bytes = (int64_t)n * h * w * cout * 4;
+    p.N = n; p.H = h; p.W = w; p.ldx = cin; p.lddy = cout; p.Cg = cg; p.Ng = ng;
+    p.TX = w / 2; p.TPI = (h / 2) * p.TX; p.MT = n * p.TPI;
+    magic_div((unsigned)p.TPI, &p.div_tpi_mul, &p.div_tpi_shr);
+    magic_div((unsigned)p.TX, &p.div_tx_mul, &p.div_tx_shr);
+    p.ci_blocks = (int)ceil_div(cg, 64); p.co_blocks = (int)ceil_div(ng, 64);
+    p.splits = wino_wgrad_splits(n, h, w, cin, cout, groups);
+    p.tiles_per_split = (int)(ceil_div(ceil_div(p.MT, p.splits), 8) * 8);
+    p.cout_all = cout;
+    const dim3 grid((unsigned)(p.ci_blocks * p.co_blocks * p.splits), 1, groups), block(512);
+    const size_t lds = (size_t)4 * WW_IMG * sizeof(float);
+    if (cg % 64 == 48 && p.ci_blocks == 1) {                     // (one block of 48 input channels)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wgrad_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(wino_wgrad_kernel<3>, grid, block, lds, st, p);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wgrad_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(wino_wgrad_kernel<4>, grid, block, lds, st, p);
+    }
+    const int64_t total = (int64_t)cout * cg;
+    hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, p.part, workspace, p.splits, cout, cg);
 }
 
 }  // namespace suhpe

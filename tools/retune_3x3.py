@@ -12,7 +12,7 @@ db = json.load(open(src))
 keep = {}
 for k, v in db["tiles"].items():
     p = k.split(",")          # pass,n,h,w,cin,cout,r,s,stride,pad,groups
-    if p[0] in ("0", "1") and p[6] == "3" and p[7] == "3" and p[8] == "1" and p[9] == "1":
+    if p[0] in ("0", "1", "2") and p[6] == "3" and p[7] == "3" and p[8] == "1" and p[9] == "1":
         continue
     keep[k] = v
 print(f"dropped {len(db['tiles']) - len(keep)} of {len(db['tiles'])} entries")

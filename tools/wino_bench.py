@@ -87,6 +87,30 @@ def run(shapes, check_only=False, big_ref=True):
             if not check_only:
                 res[tag]["t"] = (timeit(lambda: K.conv2d_fwd(x, w, None, 1, 1, g)), timeit(lambda: K.conv2d_dgrad(dy, w, x.shape, 1, 1, g, skip=skip)),
                                  timeit(lambda: K.conv2d_fwd_stats(x, w, 1, 1, g, seg=seg)))
+        # filter gradient: Winograd F(3x3, 2x2) tile against the direct tile (float64 reference on the CPU for the small shapes)
+        tn_names = [lib.suhpe_conv2d_tile_name(2, i).decode() for i in range(lib.suhpe_conv2d_tile_count(2))]
+        pin(d, 2, -1)
+        dw_a = K.conv2d_wgrad(x, dy, w.shape, 1, 1, g)
+        pin(d, 2, tn_names.index("wino_wgrad_kernel<64,64>"))
+        dw_b = K.conv2d_wgrad(x, dy, w.shape, 1, 1, g)
+        wg_rel = (dw_a - dw_b).abs().max().item() / dw_a.abs().max().item()
+        wg64 = ""
+        if n * hw * hw * cin * cout <= 4e8:
+            xx = x.cpu().double().permute(0, 3, 1, 2).requires_grad_(False)
+            wref = torch.zeros(cout, cin // g, 3, 3, dtype=torch.float64, requires_grad=True)
+            F.conv2d(xx, wref, None, 1, 1, 1, g).backward(dy.cpu().double().permute(0, 3, 1, 2))
+            ref = wref.grad.cuda()
+            la, lb = K.from_filter_layout(dw_a) if hasattr(K, "from_filter_layout") else dw_a, K.from_filter_layout(dw_b) if hasattr(K, "from_filter_layout") else dw_b
+            wg64 = f" (vs fp64: direct {(la.double() - ref).abs().max().item() / ref.abs().max().item():.1e} wino {(lb.double() - ref).abs().max().item() / ref.abs().max().item():.1e})"
+        t_wg = ""
+        if not check_only:
+            tb_ = timeit(lambda: K.conv2d_wgrad(x, dy, w.shape, 1, 1, g))
+            best = 1e9
+            for c in range(len(tn_names) - 1):
+                if lib.suhpe_conv2d_set_tile(ctypes.byref(d), 2, c) == 0:
+                    best = min(best, timeit(lambda: K.conv2d_wgrad(x, dy, w.shape, 1, 1, g), 3))
+            t_wg = f" wgrad {best*1e6:.0f} -> {tb_*1e6:.0f} us ({fl/best/1e12:.0f} -> {fl/tb_/1e12:.0f} TF eff)"
+        pin(d, 2, -1)
         # the self-transforming form of the kernel (no Winograd-domain filter handed over): plain entry points with the tile pinned
         from semiuhpe_amd._lib import call, ptr
         y_self = torch.empty_like(res["wino"]["y"])
@@ -107,7 +131,7 @@ def run(shapes, check_only=False, big_ref=True):
                       ((b["rstd1"].double() - (yall.var(0, unbiased=False) + 1e-3).rsqrt()) * (yall.var(0, unbiased=False) + 1e-3).sqrt()).abs().max().item())
         line = (f"{label:11s} {cin}->{cout} g{g} {hw}x{hw} n{n}: rel err vs fp64 fwd direct {a['err'][0]:.1e} wino {b['err'][0]:.1e} | dgrad+skip direct {a['err'][1]:.1e} "
                 f"wino {b['err'][1]:.1e} | wino-direct max {((a['y'] - b['y']).abs().max().item() / ymax):.1e} stats_y==y {torch.equal(b['ys'], b['y'])} "
-                f"stats err seg {st_err:.1e} one {st1_err:.1e} self-vs-pre {self_err:.1e}")
+                f"stats err seg {st_err:.1e} one {st1_err:.1e} self-vs-pre {self_err:.1e} | wgrad wino-direct {wg_rel:.1e}{wg64}{t_wg}")
         if not check_only:
             ta, tb = a["t"], b["t"]
             line += (f" | fwd {ta[0]*1e6:.0f} -> {tb[0]*1e6:.0f} us ({fl/ta[0]/1e12:.0f} -> {fl/tb[0]/1e12:.0f} TF eff), dgrad {ta[1]*1e6:.0f} -> {tb[1]*1e6:.0f} us "
