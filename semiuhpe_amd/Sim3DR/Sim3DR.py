@@ -2,6 +2,8 @@
 suhpe_rasterize (csrc/raster.hip) on the current HIP device.  numpy arrays in and out, as the reference's callers expect
 (src/renderer.py, Sim3DR/lighting.py); the arrays cross to the device for the call.  No CPU path: without libsuhpe.so or a GPU the
 calls raise (semiuhpe_amd._lib)."""
+import hashlib
+
 import numpy as np
 import torch
 
@@ -14,7 +16,8 @@ _adjacency = {}
 def _vertex_triangles(triangles, nver):
     """vertex -> triangles in CSR form, each vertex's triangles in increasing index (the order _get_normal accumulates them in,
     rasterize_kernel.cpp:191-201); cached per mesh (the demo renders one fixed mesh)"""
-    key = (triangles.ctypes.data, triangles.shape[0], nver, int(triangles[0, 0]), int(triangles[-1, -1]))
+    # keyed on the CONTENT: `triangles` may be a temporary of get_normal (its address is reused by the next mesh of the same shape)
+    key = (hashlib.blake2b(triangles.tobytes(), digest_size=16).digest(), triangles.shape[0], nver)
     hit = _adjacency.get(key)
     if hit is None:
         flat = triangles.reshape(-1).astype(np.int64)

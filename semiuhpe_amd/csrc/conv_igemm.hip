@@ -1195,9 +1195,10 @@ static int pinned_tile(const suhpe_conv_t* d, int pass) {
 }
 
 static const bool kHaloDefault = !(getenv("SUHPE_HALO") && atoi(getenv("SUHPE_HALO")) == 0);   // SUHPE_HALO=0: heuristics never pick the halo kernel
-static NtTile choose_nt(int64_t M, int ng, bool vec4, int pinned, bool halo = false) {
+static NtTile choose_nt(int64_t M, int ng, bool vec4, int pinned, bool halo = false, bool wino = false) {
     if (!vec4) return NT_64x64_S;
     if (pinned >= 1 && pinned < (int)NT_TILES) return (NtTile)pinned;
+    if (wino && wino_preferred()) return NT_G64x64;
     if (halo && kHaloDefault && M >= 8192) return ng <= 32 ? NT_H128x32 : ((ng % 128 == 0 || ng > 256) ? NT_H128x128 : NT_H128x64);
     if (M < 2048) return ng > 32 ? NT_64x64 : NT_128x32;     // small row counts (Linear, SE): more, smaller tiles
     if (ng <= 32) return NT_256x32;                           // narrow outputs are operand-bandwidth bound anyway
@@ -1248,7 +1249,7 @@ static NtTile effective_nt(NtTile tile, bool plain, bool halo = false, bool resi
 }
 
 static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st, int pinned) {
-    NtTile tile = choose_nt(p.g.M, p.Ng, vec4, pinned, halo_ok(p.g, vec4));
+    NtTile tile = choose_nt(p.g.M, p.Ng, vec4, pinned, halo_ok(p.g, vec4), wino_geom_ok(p.g, p.Ng));
     const bool act2 = p.y2 || p.res_mode >= 4 || p.o_rowscale; // activation / keep-scale epilogues live in igemm_nt_kernel's pointwise form only
     if (tile == NT_G64x64) {
         if (launch_wino(p, groups, st)) return;
@@ -1483,14 +1484,14 @@ int suhpe_conv2d_fwd_stats_tiles(const suhpe_conv_t* d) {
     if (stem_ok(d) && pinned_tile(d, 0) < 0) return (int)ceil_div((int64_t)d->n * d->ho * d->wo, kStemRows);
     const int cg = d->cin / d->groups, ng = d->cout / d->groups;
     const int64_t M = (int64_t)d->n * d->ho * d->wo;
-    return (int)ceil_div(M, nt_tile_bm(choose_nt(M, ng, cg % 4 == 0 && d->cin % 4 == 0, pinned_tile(d, 0), halo_ok_desc(d, 0))));
+    return (int)ceil_div(M, nt_tile_bm(choose_nt(M, ng, cg % 4 == 0 && d->cin % 4 == 0, pinned_tile(d, 0), halo_ok_desc(d, 0), wino_ok_desc(d, 0))));
 }
 
 int suhpe_conv2d_fwd_stats_tile_rows(const suhpe_conv_t* d) {
     if (!d || d->groups <= 0) return 0;
     if (stem_ok(d) && pinned_tile(d, 0) < 0) return kStemRows;
     const int cg = d->cin / d->groups, ng = d->cout / d->groups;
-    return nt_tile_bm(choose_nt((int64_t)d->n * d->ho * d->wo, ng, cg % 4 == 0 && d->cin % 4 == 0, pinned_tile(d, 0), halo_ok_desc(d, 0)));
+    return nt_tile_bm(choose_nt((int64_t)d->n * d->ho * d->wo, ng, cg % 4 == 0 && d->cin % 4 == 0, pinned_tile(d, 0), halo_ok_desc(d, 0), wino_ok_desc(d, 0)));
 }
 
 static int conv2d_fwd_stats_impl(const suhpe_conv_t* d, const float* x, const float* w, float* y, float* stats, float* stats_extra,
@@ -1529,7 +1530,7 @@ int suhpe_conv2d_wino_pinned(const suhpe_conv_t* d, int pass) {
     if (!d || d->groups <= 0 || pass < 0 || pass > 1 || !wino_ok_desc(d, pass)) return 0;
     const int cg = d->cin / d->groups, ng = d->cout / d->groups;
     const int64_t M = (int64_t)d->n * d->ho * d->wo;
-    const NtTile tile = pass == 0 ? choose_nt(M, ng, true, pinned_tile(d, 0), halo_ok_desc(d, 0)) : choose_nt(M, cg, true, pinned_tile(d, 1), halo_ok_desc(d, 1));
+    const NtTile tile = pass == 0 ? choose_nt(M, ng, true, pinned_tile(d, 0), halo_ok_desc(d, 0), true) : choose_nt(M, cg, true, pinned_tile(d, 1), halo_ok_desc(d, 1), true);
     return tile == NT_G64x64 ? 1 : 0;
 }
 
@@ -1696,7 +1697,8 @@ static int wgrad_splits(const suhpe_conv_t* d, int bm, int bn) {
 
 // is the filter gradient of this conv on the Winograd kernel? (pinned by suhpe_conv2d_set_tile; never the heuristic's choice)
 static bool wgrad_wino(const suhpe_conv_t* d) {
-    return pinned_tile(d, 2) == TN_WINO && wino_wgrad_geom_ok(d->n, d->h, d->w, d->ho, d->wo, d->cin, d->cout, d->r, d->s, d->stride, d->pad, d->groups);
+    const int pin = pinned_tile(d, 2);
+    return (pin == TN_WINO || (pin < 0 && wino_preferred())) && wino_wgrad_geom_ok(d->n, d->h, d->w, d->ho, d->wo, d->cin, d->cout, d->r, d->s, d->stride, d->pad, d->groups);
 }
 
 static void wgrad_tile(const suhpe_conv_t* d, int* bm, int* bn) {
@@ -1743,10 +1745,10 @@ const char* suhpe_conv2d_kernel_name(const suhpe_conv_t* d, int pass) {
     const int ng = d->cout / d->groups, cg = d->cin / d->groups;
     const bool plain = d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0;
     if (pass == 0 && stem_ok(d) && pinned_tile(d, 0) < 0) return d->cout == 24 ? "rgb_conv3x3_kernel<24>" : (d->cout == 48 ? "rgb_conv3x3_kernel<48>" : "rgb_conv3x3_kernel<64>");
-    if (pass == 0) return kNtNames[effective_nt(choose_nt((int64_t)d->n * d->ho * d->wo, ng, cg % 4 == 0 && d->cin % 4 == 0, pinned_tile(d, 0), halo_ok_desc(d, 0)), plain, halo_ok_desc(d, 0), resident_ok_desc(d, 0, 128), resident_ok_desc(d, 0, 64), wino_ok_desc(d, 0))];
+    if (pass == 0) return kNtNames[effective_nt(choose_nt((int64_t)d->n * d->ho * d->wo, ng, cg % 4 == 0 && d->cin % 4 == 0, pinned_tile(d, 0), halo_ok_desc(d, 0), wino_ok_desc(d, 0)), plain, halo_ok_desc(d, 0), resident_ok_desc(d, 0, 128), resident_ok_desc(d, 0, 64), wino_ok_desc(d, 0))];
     if (pass == 1) {
         const int st = d->stride;
-        return kNtNames[effective_nt(choose_nt((int64_t)d->n * ((d->h + st - 1) / st) * ((d->w + st - 1) / st), cg, ng % 4 == 0 && d->cout % 4 == 0, pinned_tile(d, 1), halo_ok_desc(d, 1)), plain, halo_ok_desc(d, 1), resident_ok_desc(d, 1, 128), resident_ok_desc(d, 1, 64), wino_ok_desc(d, 1))];
+        return kNtNames[effective_nt(choose_nt((int64_t)d->n * ((d->h + st - 1) / st) * ((d->w + st - 1) / st), cg, ng % 4 == 0 && d->cout % 4 == 0, pinned_tile(d, 1), halo_ok_desc(d, 1), wino_ok_desc(d, 1)), plain, halo_ok_desc(d, 1), resident_ok_desc(d, 1, 128), resident_ok_desc(d, 1, 64), wino_ok_desc(d, 1))];
     }
     const bool va = ng % 4 == 0 && d->cout % 4 == 0, vb = cg % 4 == 0 && d->cin % 4 == 0;
     if (!(va && vb)) return va ? "igemm_tn_kernel<64,64,32,32,4,1>" : (vb ? "igemm_tn_kernel<64,64,32,32,1,4>" : "igemm_tn_kernel<64,64,32,32,1,1>");

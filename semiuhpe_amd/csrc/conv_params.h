@@ -111,6 +111,7 @@ inline void magic_div(unsigned d, unsigned* mul, unsigned* shr) {
 
 // conv_wino.hip: Winograd F(2x2, 3x3) kernel for 3x3 / stride 1 / pad 1 forward and input-gradient GEMMs
 bool wino_geom_ok(const GatherGeom& g, int Ng);
+bool wino_preferred();          // SUHPE_WINOGRAD=2: unpinned eligible shapes run the Winograd tiles
 bool launch_wino(const NtParams& p, int groups, hipStream_t st);
 int64_t wino_filter_floats(int groups, int NR, int NK);
 // w: the filter as stored, [groups * ng_w][3][3][cg_w]; pass 0: NR = ng_w rows, NK = cg_w channels; pass 1 (input gradient): NR = cg_w, NK = ng_w

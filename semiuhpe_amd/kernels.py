@@ -178,6 +178,13 @@ def _autotune(d, pass_id, run):
     known = _tile_db().get(skey)
     if known in names and lib.suhpe_conv2d_set_tile(ctypes.byref(d), pass_id, names.index(known)) == 0:
         return
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # More than one rank: shapes outside the database keep the library's heuristic tile.  Measuring here would let the replicas pin different
+        # winners (different split-K partitions, Winograd vs direct rounding: the replicas would stop holding the same bits), and agreeing on rank 0's
+        # winner needs a collective at a point that the ranks do not reach together -- the autotuner fires the first time a rank sees a shape, and
+        # validation deals a ragged number of batches to the ranks (a lone rank would wait in the broadcast while the others are in their gather).
+        return
     dev = torch.cuda.current_device()
     # this shape really has to be measured: drain the device first, so the trials do not share the GPU with the teacher pass /
     # filter-gradient GEMMs still running on the side streams (the host is inside this function: nothing new is enqueued)
@@ -203,13 +210,6 @@ def _autotune(d, pass_id, run):
         if _TUNE_VERBOSE:
             print(f"autotune {skey} {names[tile]}: {ms * 1e3:.0f} us", flush=True)
     winner = best[1]
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        # every rank timed the menu (they reach a new shape at the same point of the step), rank 0's winner is the one all pin: the
-        # replicas then run the same kernels (same speed, and the same split-K partition of the filter gradients)
-        t = torch.tensor([winner], dtype=torch.int32, device="cuda")
-        dist.broadcast(t, 0)
-        winner = int(t.item())
     lib.suhpe_conv2d_set_tile(ctypes.byref(d), pass_id, winner)
     _tile_db()[skey] = names[winner]
 
@@ -1233,6 +1233,9 @@ _counters = {}
 _host_offsets = {}
 
 
+_reseed_hooks = []
+
+
 def rng_counter(device, seed=None):
     """Device-resident (seed, offset) pair of the counter-based mask generator; the running position is kept on the
     host (one launch per draw)."""
@@ -1241,6 +1244,8 @@ def rng_counter(device, seed=None):
         s = int(seed if seed is not None else torch.initial_seed()) & ((1 << 63) - 1)
         _counters[key] = torch.tensor([s, 0], dtype=torch.int64).to(key)
         _host_offsets[key] = 0
+        for hook in _reseed_hooks:                           # masks drawn ahead under the old seed / position are dropped (layers.prefetch_masks)
+            hook()
     return _counters[key]
 
 

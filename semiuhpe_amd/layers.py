@@ -35,6 +35,14 @@ def set_mask_hook(fn):
 _mask_queue = None
 
 
+def _drop_mask_queue():
+    global _mask_queue
+    _mask_queue = None
+
+
+K._reseed_hooks.append(_drop_mask_queue)        # a reseeded generator must not hand out masks drawn from the old seed
+
+
 def prefetch_masks(requests, device):
     """requests: [(kind, shape, keep)] in the order the forward pass will draw them"""
     global _mask_queue

@@ -26,9 +26,10 @@ V2_S = [
 ]
 LAST_CHANNEL = 1280
 BN_EPS = 1e-3           # torchvision: partial(nn.BatchNorm2d, eps=1e-03) for the V2 family
-# Folding the expand conv's BatchNorm + SiLU into the depthwise loaders removes two passes over the largest activation but
-# makes the depthwise kernels recompute the SiLU 1.5x (forward) to 3x (filter gradient) per element: measured 84.1 vs 79.7
-# ms/step on C2, so it is off; the kernels and their tests stay (memory-saving mode: the expanded tensor is never stored).
+# Folding the expand conv's BatchNorm + SiLU into the depthwise loaders removes two passes over the largest activation.  ON by default since
+# round 3: the image-tile depthwise kernels apply the transform once per element while they fill LDS (57.1 -> 56.4 ms/step on C2); with the
+# sliding-window kernels of round 2 the SiLU was recomputed 1.5x (forward) to 3x (filter gradient) per element and the fold lost (84.1 vs
+# 79.7 ms/step), which is why SUHPE_FUSE_EXPAND_DW=0 still exists.
 FUSE_EXPAND_BN_INTO_DW = os.environ.get("SUHPE_FUSE_EXPAND_DW", "1") != "0"
 BN_SUMS_FROM_PROJECT = os.environ.get("SUHPE_BN_SUMS_PROJECT", "1") != "0"     # FusedMBConv: expand BatchNorm's backward sums from the project conv's dgrad epilogue
 FUSE_EXPAND_NO_TAPE = os.environ.get("SUHPE_FUSE_EXPAND_NO_TAPE", "1") != "0"      # the same fold in train-mode forwards that keep no tape (teacher pass)
@@ -222,9 +223,9 @@ class MBConv(_ResidualBlock):
     # Its BatchNorm still gets exact statistics (from the expand conv's epilogue) and the standard backward (from the raw
     # output and the gradient the depthwise dgrad returns).  Train mode, inside the fused depthwise-SE section only.
     def _expand_folded(self, no_tape=False):
-        """no_tape: a forward without a backward (the teacher pass): there the fold costs one SiLU recompute in the depthwise forward
-        loader and saves the whole BatchNorm pass over the expanded tensor (FUSE_EXPAND_NO_TAPE); with a tape the filter gradient
-        would recompute the activation three times per element, which costs more than the pass (FUSE_EXPAND_BN_INTO_DW, off)."""
+        """no_tape: a forward without a backward (the teacher pass, FUSE_EXPAND_NO_TAPE); with a tape the fold is on too since round 3
+        (FUSE_EXPAND_BN_INTO_DW, default ON): the image-tile depthwise kernels apply BatchNorm + SiLU once per element while they fill LDS, so
+        the filter gradient no longer pays a threefold recompute (that was the sliding-window kernels of round 2, where the fold lost)."""
         from .. import layers as L
         if not ((FUSE_EXPAND_BN_INTO_DW or (no_tape and FUSE_EXPAND_NO_TAPE)) and self.has_expand and self._dw_se_fused() and not L.SYNC_BN):
             return False

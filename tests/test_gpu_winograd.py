@@ -1,0 +1,157 @@
+"""Winograd F(2x2, 3x3) / F(3x3, 2x2) kernels (csrc/conv_wino.hip) behind the 3x3 / stride 1 convolutions of torchvision's FusedMBConv
+(reference src/networks.py:303) and of RepVGGBlock.rbr_dense (src/repvgg.py:28-32,67-76):
+
+  * kernel level: forward (+ bias), input gradient (+ skip add), filter gradient (+ accumulate) and the BatchNorm statistics epilogue (one and
+    two batch segments, the boundary inside a 64-tile block) against float64 torch references, on shapes that exercise ragged tile blocks,
+    groups, partial channel chunks and output-channel padding.  Tolerance 2e-5 of the tensor's max (the suite's fp32 bar; measured ~3e-7:
+    the Winograd sums are CLOSER to float64 than the direct kernels', fewer accumulation steps per output);
+  * network level: the parity suite runs on the heuristic tiles, which never pick a Winograd tile; the bench runs on the tile database, which
+    pins them for most 3x3 shapes.  SUHPE_WINOGRAD=2 makes the heuristics take the Winograd tiles wherever the geometry allows, and the
+    network-level parity tests of the two backbones that have such convs are re-run that way in a child process.
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def K():
+    from semiuhpe_amd import kernels
+    return kernels
+
+
+def rel(x, ref):
+    x = x.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    return float((x - ref).abs().max() / max(1.0, float(ref.abs().max())))
+
+
+def _pin(K, d, names_by_pass, wino=True):
+    from semiuhpe_amd import _lib
+    lib = _lib.load()
+    for pid, name in ((0, "wino_nt_kernel<64,64>"), (1, "wino_nt_kernel<64,64>"), (2, "wino_wgrad_kernel<64,64>")):
+        rc = lib.suhpe_conv2d_set_tile(ctypes.byref(d), pid, names_by_pass[pid].index(name) if wino else -1)
+        assert rc == 0, (pid, rc)
+
+
+def _names():
+    from semiuhpe_amd import _lib
+    lib = _lib.load()
+    lib.suhpe_conv2d_tile_name.restype = ctypes.c_char_p
+    return {pid: [lib.suhpe_conv2d_tile_name(pid, i).decode() for i in range(lib.suhpe_conv2d_tile_count(pid))] for pid in (0, 1, 2)}
+
+
+# n, cin, cout, groups, h, w, samples of the first batch segment
+SHAPES = [
+    (3, 8, 12, 1, 6, 6, 1),          # one ragged tile block, one chunk pair, 12 of 64 output channels
+    (5, 20, 36, 1, 10, 10, 2),       # partial super-chunk (20 of 32 channels), segment boundary inside a block
+    (7, 16, 16, 2, 4, 4, 3),         # groups: 8 channels per group
+    (4, 48, 192, 1, 28, 28, 1),      # EfficientNetV2-S stage 2 (48 input channels: the 3-sub-block filter-gradient form), three cout blocks
+    (6, 64, 256, 1, 14, 14, 2),      # stage 3: 294 tiles = 4.6 blocks, boundary at tile 98
+    (2, 24, 24, 1, 16, 16, 1),       # stage 1 widths
+    (3, 128, 128, 2, 12, 10, 1),     # RepVGG grouped block, non-square image
+    (2, 256, 128, 1, 8, 8, 1),       # long reduction (16 super-chunks), two items per workgroup stream
+]
+
+
+@pytest.mark.parametrize("cfg", SHAPES, ids=str)
+def test_winograd_kernels_match_float64(K, cfg):
+    n, cin, cout, g, h, w, seg = cfg
+    gen = torch.Generator().manual_seed(abs(hash(cfg)) % 1000)
+    x = torch.randn(n, cin, h, w, generator=gen)
+    wt = torch.randn(cout, cin // g, 3, 3, generator=gen) / (3 * (cin // g) ** 0.5)
+    bias = torch.randn(cout, generator=gen)
+    xd, wd = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    y_ref = F.conv2d(xd, wd, None, 1, 1, 1, g)
+    dy = torch.randn(y_ref.shape, generator=gen)
+    y_ref.backward(dy.double())
+    skip = torch.randn(n, h, w, cin, generator=gen)
+    xg, dyg = x.permute(0, 2, 3, 1).contiguous().cuda(), dy.permute(0, 2, 3, 1).contiguous().cuda()
+    wg = K.to_filter_layout(wt.cuda())
+    d = K.conv_desc(xg.shape, wg.shape, 1, 1, g)
+    names = _names()
+    from semiuhpe_amd import _lib
+    lib = _lib.load()
+    lib.suhpe_conv2d_kernel_name.restype = ctypes.c_char_p
+    _pin(K, d, names, True)
+    try:
+        assert lib.suhpe_conv2d_wino_pinned(ctypes.byref(d), 0) == 1 and lib.suhpe_conv2d_wino_pinned(ctypes.byref(d), 1) == 1
+        assert lib.suhpe_conv2d_kernel_name(ctypes.byref(d), 2).decode() == "wino_wgrad_kernel<64,64>"
+        nhwc = lambda t: t.permute(0, 2, 3, 1)
+        y = K.conv2d_fwd(xg, wg, None, 1, 1, g)
+        assert rel(y, nhwc(y_ref)) < 2e-5
+        yb = K.conv2d_fwd(xg, wg, bias.cuda(), 1, 1, g)
+        assert rel(yb, nhwc(y_ref) + bias.double()) < 2e-5
+        dx = K.conv2d_dgrad(dyg, wg, xg.shape, 1, 1, g)
+        assert rel(dx, nhwc(xd.grad)) < 2e-5
+        dxs = K.conv2d_dgrad(dyg, wg, xg.shape, 1, 1, g, skip=skip.cuda())
+        assert rel(dxs, nhwc(xd.grad) + skip.double()) < 2e-5
+        dw = K.conv2d_wgrad(xg, dyg, wg.shape, 1, 1, g)
+        assert rel(dw, wd.grad) < 2e-5
+        dw2 = K.conv2d_wgrad(xg, dyg, wg.shape, 1, 1, g, out=dw.clone(), accumulate=True)
+        assert rel(dw2, 2 * wd.grad) < 2e-5
+        # statistics epilogue: one segment, then two (same tensors as the plain forward, bit for bit)
+        ys, part, tiles = K.conv2d_fwd_stats(xg, wg, 1, 1, g)
+        assert torch.equal(ys, y)
+        mean, rstd = K.bn_stats_from_partials(part, tiles, n * h * w, cout, 1e-3, 0.1)
+        flat = y_ref.detach().permute(0, 2, 3, 1).reshape(-1, cout)
+        assert rel(mean, flat.mean(0)) < 2e-5
+        assert float(((rstd.cpu().double() - (flat.var(0, unbiased=False) + 1e-3).rsqrt()) * (flat.var(0, unbiased=False) + 1e-3).sqrt()).abs().max()) < 2e-5
+        ys2, part2, tiles2, (first, extra) = K.conv2d_fwd_stats(xg, wg, 1, 1, g, seg=seg)
+        assert torch.equal(ys2, y)
+        m2, r2 = K.bn_stats_from_partials_seg(part2, tiles2, first, extra, n * h * w, seg * h * w, cout, 1e-3, 0.1)
+        for s_, rows in ((0, y_ref.detach()[:seg]), (1, y_ref.detach()[seg:])):
+            fl = rows.permute(0, 2, 3, 1).reshape(-1, cout)
+            assert rel(m2[s_], fl.mean(0)) < 2e-5, s_
+            assert float(((r2[s_].cpu().double() - (fl.var(0, unbiased=False) + 1e-3).rsqrt()) * (fl.var(0, unbiased=False) + 1e-3).sqrt()).abs().max()) < 2e-5, s_
+    finally:
+        _pin(K, d, names, False)
+
+
+def test_winograd_tile_is_refused_where_it_cannot_run(K):
+    """stride 2, 1x1, odd image sizes: suhpe_conv2d_set_tile refuses the Winograd tiles; an eval-mode (folded affine) forward with the tile pinned
+    runs a direct tile and gives the direct result"""
+    from semiuhpe_amd import _lib
+    lib = _lib.load()
+    names = _names()
+    for xs, ws, stride, pad in (((2, 8, 8, 16), (16, 16, 3, 3), 2, 1), ((2, 8, 8, 16), (16, 16, 1, 1), 1, 0), ((2, 7, 7, 16), (16, 16, 3, 3), 1, 1)):
+        d = K.conv_desc(xs, ws, stride, pad, 1)
+        assert lib.suhpe_conv2d_set_tile(ctypes.byref(d), 0, names[0].index("wino_nt_kernel<64,64>")) != 0
+        assert lib.suhpe_conv2d_set_tile(ctypes.byref(d), 2, names[2].index("wino_wgrad_kernel<64,64>")) != 0
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 8, 8, 16, generator=gen).cuda()
+    wg = K.to_filter_layout((torch.randn(24, 16, 3, 3, generator=gen) * 0.1).cuda())
+    scale, shift = torch.rand(24, generator=gen).cuda() + 0.5, torch.randn(24, generator=gen).cuda()
+    d = K.conv_desc(x.shape, wg.shape, 1, 1, 1)
+    ref = K.conv2d_fwd_affine(x, wg, scale, shift, "silu", stride=1, pad=1)
+    assert lib.suhpe_conv2d_set_tile(ctypes.byref(d), 0, names[0].index("wino_nt_kernel<64,64>")) == 0
+    try:
+        out = K.conv2d_fwd_affine(x, wg, scale, shift, "silu", stride=1, pad=1)
+    finally:
+        lib.suhpe_conv2d_set_tile(ctypes.byref(d), 0, -1)
+    assert rel(out, ref) < 3e-6
+
+
+def test_network_parity_suite_on_the_winograd_tiles():
+    """second pass of the network-level parity tests with every eligible 3x3 conv on the Winograd kernels (forward, input gradient, filter gradient)"""
+    env = dict(os.environ, SUHPE_WINOGRAD="2", SUHPE_AUTOTUNE="0")
+    tests = ["tests/test_gpu_effnet.py", "tests/test_gpu_agent_repvgg.py", "tests/test_gpu_resnet.py",
+             "tests/test_gpu_backbones.py::test_repvgg_b1g2_vs_reference", "tests/test_gpu_backbones.py::test_repvgg_block_vs_reference",
+             "tests/test_gpu_segments.py"]
+    # (node ids that do not exist are dropped: the list names the suites, not a contract with their test names)
+    listing = subprocess.run([sys.executable, "-m", "pytest", "--collect-only", "-q", "-m", "gpu"] + [t.split("::")[0] for t in tests], cwd=ROOT, env=env,
+                             capture_output=True, text=True, timeout=600).stdout
+    keep = [t for t in tests if "::" not in t or t in listing]
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + keep, cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=1500)
+    tail = r.stdout[-3000:] + r.stderr[-1500:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout, tail

@@ -5,8 +5,17 @@
 # SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES / 4 (share of the time a SIMD's matrix pipe was busy; 1.000 on tools/micro/mfma_peak),
 # SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES, SQ_LDS_BANK_CONFLICT.
 R=$(pwd); cd /tmp && export TMPDIR=/tmp PYTHONPATH=$R
+# menu indices resolved BY NAME (the menu grows: fixed numbers went stale once)
+TILES=$(python3 - <<'PY'
+import ctypes
+from semiuhpe_amd import _lib
+lib = _lib.load(); lib.suhpe_conv2d_tile_name.restype = ctypes.c_char_p
+names = [lib.suhpe_conv2d_tile_name(0, i).decode() for i in range(lib.suhpe_conv2d_tile_count(0))]
+print(" ".join(str(names.index(n)) for n in ("igemm_nt_kernel<64,64,32,32,4>", "igemm_nt_kernel<128,64,32,32,4>", "gemm_nt_resident<128,2,16>", "gemm_nt_resident<64,2,8>", "gemm_nt_resident<64,2,16>")))
+PY
+)
 for shape in "31360 960 160" "31360 160 960" "7840 1536 256" "31360 960 2048"; do
-  for tile in 1 4 16 17 18; do   # igemm 64x64, 128x64; resident 128x16, 64x8, 64x16 (menu indices: suhpe_conv2d_tile_name)
+  for tile in $TILES; do
     rm -rf /tmp/pm; timeout 180 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d /tmp/pm -- python3 $R/tools/gemm_pmc.py $shape 0 $tile > /dev/null 2>&1
     python3 - "$shape" $tile <<'PY'
 import csv,glob,sys
