@@ -1208,7 +1208,7 @@ static NtTile choose_nt(int64_t M, int ng, bool vec4, int pinned, bool halo = fa
 }
 
 // (row-tile height = rows per BatchNorm statistics record; the resident tiles emit one record per 64-row unit)
-static int nt_tile_bm(NtTile t) { return t == NT_G64x64 ? 256 : (t == NT_64x64_S || t == NT_64x64 || t == NT_P64x64 || t == NT_H64x64 || t >= NT_R128x16) ? 64 : (t == NT_256x32 ? 256 : 128); }    // (the Winograd tile's record = 64 tiles of 2x2 pixels)
+static int nt_tile_bm(NtTile t) { return (t == NT_G64x64 || t == NT_64x64_S || t == NT_64x64 || t == NT_P64x64 || t == NT_H64x64 || t >= NT_R128x16) ? 64 : (t == NT_256x32 ? 256 : 128); }    // (the Winograd tile's record = the 16 tiles of 2x2 pixels of one wavefront)
 // the halo kernel runs 3x3 / stride 1 / pad 1 forward and input-gradient GEMMs whose channel counts chunk evenly
 static bool halo_ok(const GatherGeom& g, bool vec4) { return vec4 && halo_capable(g, 128) && halo_capable(g, 64); }
 
@@ -1255,7 +1255,7 @@ static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st
         if (launch_wino(p, groups, st)) return;
         // a form the Winograd kernel lacks (eval-mode folded affine, no Winograd-domain filter handed over): the heuristic's direct tile, or with
         // statistics the direct tile of the same record height
-        tile = p.stats ? NT_256x32 : choose_nt(p.g.M, p.Ng, vec4, -1, halo_ok(p.g, vec4));
+        tile = p.stats ? NT_64x64 : choose_nt(p.g.M, p.Ng, vec4, -1, halo_ok(p.g, vec4));
     }
     if (act2 && tile >= NT_R128x16) tile = NT_64x64;
     if (act2 && tile >= NT_W128x128) tile = tile == NT_W128x128 ? NT_128x128 : NT_128x64;

@@ -46,7 +46,8 @@
 #include <cstdlib>
 #include <type_traits>
 // timing experiments (tools/wino_ablate.sh builds variant libraries; any bit set = wrong results):
-//   1 no barrier in the chunk loop, 2 no loads (DMA + patch rows), 4 no transform / LDS stores, 8 no MFMAs, 16 no epilogue
+//   1 no barrier in the chunk loop, 2 no loads (DMA + patch rows), 4 no transform / LDS stores, 8 no MFMAs, 16 no epilogue, 32 no output stores,
+//   64 no statistics
 #ifndef WINO_ABLATE
 #define WINO_ABLATE 0
 #endif
@@ -88,8 +89,7 @@ __host__ __device__ __forceinline__ int wino_slot_off(int m, int row, int kg) {
 
 typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
 
-// LDS map (floats): V images [2] at 0, U images [3] at 2 * WN_IMG: 160 KB, all of a CU.  The statistics scratch of an item's epilogue aliases the V image
-// the item's last chunk has just finished with (nothing is in flight to it then).
+// LDS map (floats): V images [2] at 0, U images [3] at 2 * WN_IMG: 160 KB, all of a CU.
 constexpr int WN_U0 = 2 * WN_IMG;
 constexpr int WN_LDS_FLOATS = 5 * WN_IMG;
 
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
     };
 
     // ---- epilogue of the item under the MFMAs: output transform in registers, stores, statistics
-    auto epilogue = [&](int tile0, int n0, int row_tile, float* scratch) __attribute__((always_inline)) {
+    auto epilogue = [&](int tile0, int n0, int row_tile) __attribute__((always_inline)) {
         float out[4][2][4];                                      // [pixel (py, px) = (q >> 1, q & 1)][cout block][e]
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb)
@@ -315,6 +315,7 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb) {
                 if (!(tvalid && colb[bb] < p.Ng)) continue;
+                if ((WINO_ABLATE & 32) && out[0][bb][0] != 12345.678f) continue;      // (timing experiment: the output transform stays, the stores go)
                 float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (p.bias) bv = *reinterpret_cast<const float4*>(&p.bias[grp * p.Ng + colb[bb]]);
 #pragma unroll
@@ -326,51 +327,46 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
                 }
             }
         }
-        // BatchNorm statistics: one (S, Q, k, n) record per (tile block, cout), sums over the block's valid pixels shifted by k = the block's
-        // first output; the block that contains the segment boundary emits its first-segment tiles to `stats`, the rest to `stats_extra`
-        if (p.stats) {
-            float* kk = scratch;                                 // [64]
-            float* red = kk + 64;                                // [4 tile blocks][64 couts][4]
-            if (tb == 0 && j16 == 0) {
-#pragma unroll
-                for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) kk[32 * ch + 16 * bb + 4 * kg + e] = out[0][bb][e];
-            }
-            __syncthreads();
-            const int cut = wg.seg_tile > tile0 && wg.seg_tile < tile0 + 64 && p.stats_extra ? wg.seg_tile : 0x7fffffff;    // first tile of the second part
+        // BatchNorm statistics: one (S, Q, k, n) record per (16-tile block of a wavefront = 64 output pixels, cout): sums over the block's valid pixels
+        // shifted by k = the block's first output.  Everything stays inside the wavefront -- k by a 16-lane broadcast, the sums over the 16 tiles by
+        // DPP row rotations, the record written by the row's first lane -- no LDS, no barrier (the first version went through LDS with three barriers
+        // and 128 ds_bpermute shuffles per item: 60-85 us of a 480 us launch, tools/wino_ablate.sh).  The block that contains the segment boundary
+        // emits its first-segment tiles to `stats`, the rest to `stats_extra`.
+        if (p.stats && !(WINO_ABLATE & 64)) {
+            const int blk0 = tile0 + 16 * tb;                    // first tile of this wavefront's block
+            const int cut = wg.seg_tile > blk0 && wg.seg_tile < blk0 + 16 && p.stats_extra ? wg.seg_tile : 0x7fffffff;    // first tile of the second part
             const bool first = tvalid && Tj < cut, second = tvalid && Tj >= cut;
+            int nvalid = wg.MT - blk0;
+            nvalid = nvalid < 0 ? 0 : (nvalid > 16 ? 16 : nvalid);
+            const int n1 = cut == 0x7fffffff ? nvalid : cut - blk0;
+            float4* rec = reinterpret_cast<float4*>(p.stats) + ((int64_t)row_tile * 4 + tb) * p.stat_cout + grp * p.Ng;
+            float4* rec2 = reinterpret_cast<float4*>(p.stats_extra) + grp * p.Ng;
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float k = kk[32 * ch + 16 * bb + 4 * kg + e];
+                    // lane 0 of each 16-lane row -> the row (ds_swizzle, bit mode: lane' = lane & 0x10 inside each half of the wavefront)
+                    const float k = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(out[0][bb][e]), 0x0010));
                     float a = 0.f, qq = 0.f;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { const float v = out[q][bb][e] - k; a += v; qq += v * v; }
                     float a1 = first ? a : 0.f, q1 = first ? qq : 0.f, a2 = second ? a : 0.f, q2 = second ? qq : 0.f;
-#pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) {
-                        a1 += __shfl_xor(a1, o, 64); q1 += __shfl_xor(q1, o, 64);
-                        if (cut != 0x7fffffff) { a2 += __shfl_xor(a2, o, 64); q2 += __shfl_xor(q2, o, 64); }
+                    a1 += quad_dpp<0x128>(a1); q1 += quad_dpp<0x128>(q1);       // row_ror:8, 4, 2, 1: every lane of the row ends with the row's sum
+                    a1 += quad_dpp<0x124>(a1); q1 += quad_dpp<0x124>(q1);
+                    a1 += quad_dpp<0x122>(a1); q1 += quad_dpp<0x122>(q1);
+                    a1 += quad_dpp<0x121>(a1); q1 += quad_dpp<0x121>(q1);
+                    if (cut != 0x7fffffff) {
+                        a2 += quad_dpp<0x128>(a2); q2 += quad_dpp<0x128>(q2);
+                        a2 += quad_dpp<0x124>(a2); q2 += quad_dpp<0x124>(q2);
+                        a2 += quad_dpp<0x122>(a2); q2 += quad_dpp<0x122>(q2);
+                        a2 += quad_dpp<0x121>(a2); q2 += quad_dpp<0x121>(q2);
                     }
-                    if (j16 == 0) *reinterpret_cast<float4*>(&red[(tb * 64 + 32 * ch + 16 * bb + 4 * kg + e) * 4]) = make_float4(a1, q1, a2, q2);
+                    const int co = colb[bb] + e;
+                    if (j16 == 0 && co < p.Ng && nvalid > 0) {            // (a block beyond the last tile has no record)
+                        rec[co] = make_float4(a1, q1, k, 4.f * (float)n1);
+                        if (cut != 0x7fffffff) rec2[co] = make_float4(a2, q2, k, 4.f * (float)(nvalid - n1));
+                    }
                 }
-            __syncthreads();
-            if (t < 64 && n0 + t < p.Ng) {
-                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const float4 r4 = *reinterpret_cast<const float4*>(&red[(w * 64 + t) * 4]);
-                    s.x += r4.x; s.y += r4.y; s.z += r4.z; s.w += r4.w;
-                }
-                const int nvalid = wg.MT - tile0 < 64 ? wg.MT - tile0 : 64;
-                const int n1 = cut == 0x7fffffff ? nvalid : cut - tile0;
-                float4* rec = reinterpret_cast<float4*>(p.stats) + (int64_t)row_tile * p.stat_cout;
-                rec[grp * p.Ng + n0 + t] = make_float4(s.x, s.y, kk[t], 4.f * (float)n1);
-                if (cut != 0x7fffffff) reinterpret_cast<float4*>(p.stats_extra)[grp * p.Ng + n0 + t] = make_float4(s.z, s.w, kk[t], 4.f * (float)(nvalid - n1));
-            }
-            __syncthreads();                                     // the scratch is a V image: the chunk loop writes it again one iteration later
         }
     };
 
@@ -422,8 +418,7 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
         if (c_chunk == wg.nchunks) {
             const int jx = c_item >> 3;
             const int row_tile = rt_first + jx / p.col_tiles;
-            // (scratch = V image 1: chunk k+1's, just multiplied; it is written again at the end of the next even chunk, behind the epilogue's last barrier)
-            if (!(WINO_ABLATE & 16)) epilogue(row_tile * 64, (jx % p.col_tiles) * 64, row_tile, smem + WN_IMG);
+            if (!(WINO_ABLATE & 16)) epilogue(row_tile * 64, (jx % p.col_tiles) * 64, row_tile);
             zero_acc();
             c_chunk = 0;
             c_item += gridDim.x;

@@ -13,7 +13,7 @@ for cin, cout, g, hw, n in ((48, 192, 1, 56, 160), (64, 256, 1, 28, 160), (512, 
     w = K.to_filter_layout(torch.randn(cout, cin // g, 3, 3, device="cuda") * 0.05)
     d = K.conv_desc(x.shape, w.shape, 1, 1, g)
     assert lib.suhpe_conv2d_set_tile(ctypes.byref(d), 0, names.index("wino_nt_kernel<64,64>")) == 0
-    fn = lambda: K.conv2d_fwd(x, w, None, 1, 1, g)
+    fn = (lambda: K.conv2d_fwd_stats(x, w, 1, 1, g, seg=32)) if os.environ.get("WINO_STATS") else (lambda: K.conv2d_fwd(x, w, None, 1, 1, g))
     fn(); torch.cuda.synchronize()
     best = 1e9
     for _ in range(5):
