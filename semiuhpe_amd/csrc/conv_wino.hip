@@ -93,6 +93,8 @@ typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
 constexpr int WN_U0 = 2 * WN_IMG;
 constexpr int WN_LDS_FLOATS = 5 * WN_IMG;
 
+// HALF: at most 48 output channels in all (one cout block per item whose upper half ch = 1 holds a single 16-channel block)
+template <bool HALF>
 __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const WinoGeom wg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const GatherGeom& g = p.g;
@@ -243,6 +245,10 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
     // MFMAs of position pairs [m0, m1) of the chunk in V image vb / U image ub (8 pairs = 64 MFMAs per chunk); the fragments of pair m + 1 are read
     // from LDS before the MFMAs of pair m issue (two register sets, carried across the calls of one chunk)
     float4 vf[2], uf[2][2];
+    // second_block: this wavefront's second cout block exists (48 output channels -- the input gradient of EfficientNetV2-S's 48 -> 192 convs -- leave
+    // the cout half ch = 1 with one block: its wavefronts skip the padding block's MFMAs, and since wavefronts w and w + 4 share a SIMD every SIMD
+    // then carries 96 MFMAs per chunk instead of 128)
+    const bool second_block = !HALF || ch == 0;
     auto mma_pairs = [&](int vb, int ub, auto m0_t, auto m1_t) __attribute__((always_inline)) {
         constexpr int M0 = decltype(m0_t)::value, M1 = decltype(m1_t)::value;
         const float* Vs = smem + vb * WN_IMG;
@@ -257,14 +263,21 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
         for (int m = M0; m < M1; ++m) {
             const int cur = m & 1;
             if (m + 1 < 8) read_frags(m + 1, cur ^ 1);
-            acc[2 * m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].x, vf[cur].x, acc[2 * m][0], 0, 0, 0);
-            acc[2 * m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][1].x, vf[cur].x, acc[2 * m][1], 0, 0, 0);
-            acc[2 * m + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].z, vf[cur].z, acc[2 * m + 1][0], 0, 0, 0);
-            acc[2 * m + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][1].z, vf[cur].z, acc[2 * m + 1][1], 0, 0, 0);
-            acc[2 * m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].y, vf[cur].y, acc[2 * m][0], 0, 0, 0);
-            acc[2 * m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][1].y, vf[cur].y, acc[2 * m][1], 0, 0, 0);
-            acc[2 * m + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].w, vf[cur].w, acc[2 * m + 1][0], 0, 0, 0);
-            acc[2 * m + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][1].w, vf[cur].w, acc[2 * m + 1][1], 0, 0, 0);
+            if (second_block) {
+                acc[2 * m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].x, vf[cur].x, acc[2 * m][0], 0, 0, 0);
+                acc[2 * m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][1].x, vf[cur].x, acc[2 * m][1], 0, 0, 0);
+                acc[2 * m + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].z, vf[cur].z, acc[2 * m + 1][0], 0, 0, 0);
+                acc[2 * m + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][1].z, vf[cur].z, acc[2 * m + 1][1], 0, 0, 0);
+                acc[2 * m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].y, vf[cur].y, acc[2 * m][0], 0, 0, 0);
+                acc[2 * m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][1].y, vf[cur].y, acc[2 * m][1], 0, 0, 0);
+                acc[2 * m + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].w, vf[cur].w, acc[2 * m + 1][0], 0, 0, 0);
+                acc[2 * m + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][1].w, vf[cur].w, acc[2 * m + 1][1], 0, 0, 0);
+            } else {
+                acc[2 * m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].x, vf[cur].x, acc[2 * m][0], 0, 0, 0);
+                acc[2 * m + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].z, vf[cur].z, acc[2 * m + 1][0], 0, 0, 0);
+                acc[2 * m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].y, vf[cur].y, acc[2 * m][0], 0, 0, 0);
+                acc[2 * m + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].w, vf[cur].w, acc[2 * m + 1][0], 0, 0, 0);
+            }
         }
     };
 
@@ -388,6 +401,7 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
     __syncthreads();
     zero_acc();
     int c_item = blockIdx.x, c_chunk = 0;                       // item / chunk under the MFMAs
+
     int ub = 0;                                                  // U image of chunk k
     // One pass = chunks k (even) and k + 1 of the stream; S = k / 2 is the super-chunk in `raw` (half 0 already staged as chunk k's V image 0).
     //   even: DMA U(k+2) | MFMAs of chunk k, transform of raw half 1 under them -> V image 1 | loads of super-chunk S+1 | wait: U(k+1) landed | barrier
@@ -728,8 +742,13 @@ bool launch_wino(const NtParams& p_in, int groups, hipStream_t st) {
     const int gx = (int)(items8 < per_group ? items8 : per_group);
     const dim3 grid((unsigned)gx, 1, groups), block(512);
     const size_t lds = (size_t)WN_LDS_FLOATS * sizeof(float);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_nt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(wino_nt_kernel, grid, block, lds, st, p, wg);
+    if (p.Ng > 32 && p.Ng <= 48) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_nt_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(wino_nt_kernel<true>, grid, block, lds, st, p, wg);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_nt_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(wino_nt_kernel<false>, grid, block, lds, st, p, wg);
+    }
     return true;
 }
 
