@@ -146,7 +146,8 @@ def test_network_parity_suite_on_the_winograd_tiles():
     env = dict(os.environ, SUHPE_WINOGRAD="2", SUHPE_AUTOTUNE="0")
     tests = ["tests/test_gpu_effnet.py", "tests/test_gpu_agent_repvgg.py", "tests/test_gpu_resnet.py",
              "tests/test_gpu_backbones.py::test_repvgg_block_vs_reference",
-             "tests/test_gpu_segments.py::test_segmented_conv_statistics_match_per_segment_sums"]
+             "tests/test_gpu_segments.py::test_segmented_conv_statistics_match_per_segment_sums",
+             "tests/test_gpu_train_eval.py::test_train_then_eval"]       # train.py (both stages, validation, threshold scan, checkpoints) + eval.py
     # (node ids that do not exist are dropped: the list names the suites, not a contract with their test names)
     listing = subprocess.run([sys.executable, "-m", "pytest", "--collect-only", "-q", "-m", "gpu"] + [t.split("::")[0] for t in tests], cwd=ROOT, env=env,
                              capture_output=True, text=True, timeout=600).stdout
