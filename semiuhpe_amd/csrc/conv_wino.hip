@@ -51,6 +51,9 @@
 #ifndef WINO_ABLATE
 #define WINO_ABLATE 0
 #endif
+#ifndef WINO_STAGGER
+#define WINO_STAGGER 0     // 1: wavefronts 4-7 stage the next chunk half a chunk later than 0-3 (measured: +1.5 % on 6-chunk items, -0.8 % on 64-chunk items: off)
+#endif
 
 namespace suhpe {
 
@@ -403,29 +406,42 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
     int c_item = blockIdx.x, c_chunk = 0;                       // item / chunk under the MFMAs
 
     int ub = 0;                                                  // U image of chunk k
+    const bool late = WINO_STAGGER && wave >= 4;                 // (see the stagger note in the loop)
     // One pass = chunks k (even) and k + 1 of the stream; S = k / 2 is the super-chunk in `raw` (half 0 already staged as chunk k's V image 0).
     //   even: DMA U(k+2) | MFMAs of chunk k, transform of raw half 1 under them -> V image 1 | loads of super-chunk S+1 | wait: U(k+1) landed | barrier
     //   odd : DMA U(k+3) | MFMAs of chunk k+1; behind three quarters of them wait for super-chunk S+1, transform its half 0 -> V image 0 | barrier | epilogue?
     for (;;) {
         const bool e2 = item_valid(lu_item);                     // chunk k + 2 exists (the U cursor stands on it), and with it chunk k + 3 and super-chunk S + 1
+        // (WINO_STAGGER: the two wavefronts of a SIMD, w and w + 4, run the same program between the same barriers; with the switch on wavefronts 4-7 stage
+        // the next chunk behind the third quarter of their MFMAs instead of the first, so that one computes while the other stages.  Measured neutral.)
         // ---- even chunk
         if (e2 && !(WINO_ABLATE & 2)) issue_u();
+        auto stage_even = [&]() __attribute__((always_inline)) {
+            if (!(WINO_ABLATE & 4)) { transform(I1{}); write_staged(1); }
+            if (e2 && !(WINO_ABLATE & 2)) issue_v();             // (the registers are free from here: at least a chunk until the data is needed)
+        };
         if (!(WINO_ABLATE & 8)) mma_pairs(0, ub, I0{}, I2{});
-        if (!(WINO_ABLATE & 4)) { transform(I1{}); write_staged(1); }
-        if (e2 && !(WINO_ABLATE & 2)) issue_v();                 // (the registers are free from here: 1.5 chunks until the data is needed)
-        if (!(WINO_ABLATE & 8)) mma_pairs(0, ub, I2{}, I8{});
+        if (!late) stage_even();
+        if (!(WINO_ABLATE & 8)) mma_pairs(0, ub, I2{}, I6{});
+        if (late) stage_even();
+        if (!(WINO_ABLATE & 8)) mma_pairs(0, ub, I6{}, I8{});
         if (e2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");    // behind U(k+1): U(k+2) x 4, super-chunk S+1 x 8
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(WINO_ABLATE & 1)) __syncthreads();
         // ---- odd chunk
         const int ub1 = ub == 2 ? 0 : ub + 1;
         if (e2 && !(WINO_ABLATE & 2)) issue_u();
-        if (!(WINO_ABLATE & 8)) mma_pairs(1, ub1, I0{}, I6{});
-        if (e2) {
-            // behind super-chunk S+1: U(k+3) x 4 (U(k+2), issued before it, has landed with it)
-            asm volatile("s_waitcnt vmcnt(4)" : "+v"(raw[0][0]), "+v"(raw[1][0]), "+v"(raw[2][0]), "+v"(raw[3][0]), "+v"(raw[0][1]), "+v"(raw[1][1]), "+v"(raw[2][1]), "+v"(raw[3][1]) :: "memory");
-            if (!(WINO_ABLATE & 4)) { transform(I0{}); write_staged(0); }
-        }
+        auto stage_odd = [&]() __attribute__((always_inline)) {
+            if (e2) {
+                // behind super-chunk S+1: U(k+3) x 4 (U(k+2), issued before it, has landed with it)
+                asm volatile("s_waitcnt vmcnt(4)" : "+v"(raw[0][0]), "+v"(raw[1][0]), "+v"(raw[2][0]), "+v"(raw[3][0]), "+v"(raw[0][1]), "+v"(raw[1][1]), "+v"(raw[2][1]), "+v"(raw[3][1]) :: "memory");
+                if (!(WINO_ABLATE & 4)) { transform(I0{}); write_staged(0); }
+            }
+        };
+        if (!(WINO_ABLATE & 8)) mma_pairs(1, ub1, I0{}, I2{});
+        if (!late) stage_odd();
+        if (!(WINO_ABLATE & 8)) mma_pairs(1, ub1, I2{}, I6{});
+        if (late) stage_odd();
         if (!(WINO_ABLATE & 8)) mma_pairs(1, ub1, I6{}, I8{});
         if (!(WINO_ABLATE & 1)) __syncthreads();
         c_chunk += 2;
