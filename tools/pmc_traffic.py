@@ -29,7 +29,13 @@ def normalize(name):
     if m:
         return m.group(1) + ">"
     m = re.match(r"(gemm_nt_resident<\d+,\d+,\d+),(true|false)>", name)
-    return m.group(1) + ">" if m else name
+    if m:
+        return m.group(1) + ">"
+    if re.match(r"wino_nt_kernel<(true|false)>", name):          # both instantiations (<true>: at most 48 output channels) are the menu's one tile
+        return "wino_nt_kernel<64,64>"
+    if re.match(r"wino_wgrad_kernel<\d+>", name):
+        return "wino_wgrad_kernel<64,64>"
+    return name
 
 
 def collect(d, counter):
