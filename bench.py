@@ -151,6 +151,11 @@ def gpu_leg(args, rank, world, device):
                                              **({"direct_equivalent_tflops": round(v[1] / exec_share(k) / v[0] / 1e12, 2)} if exec_share(k) != 1.0 else {}))
                                      for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])},
                 "gemm_ms_per_step": round(total_gemm_s / nprof * 1e3, 2)}
+        if exec_share(name) != 1.0:
+            roof["direct_equivalent_tflops"] = round(tf / exec_share(name), 2)
+            roof["note"] = ("Winograd F(2x2,3x3): `achieved` counts the multiply-adds the algorithm executes (16 per 2x2 tile and channel pair; the direct sum "
+                            "has 36), so `frac` is the share of the fp32-MFMA peak the kernel keeps busy; `direct_equivalent_tflops` = SURVEY 8d's 2*M*N*K per "
+                            "launch / time, the rate a direct kernel would need (its ratio to the peak exceeds 1); launches timed with their filter-transform launch")
     agent.logs_writer.close()
     return dt, info, roof
 
