@@ -15,33 +15,32 @@
 // so per transform position xi = (i, jx) of the 4x4 grid there is one GEMM  M_xi[cout][tile] = sum_c U_xi[cout][c] V_xi[tile][c]
 // over the input channels, 16 of them sharing their rows and columns.  (Row i = 3 of both U and V is stored NEGATED -- the product
 // does not notice and V's vertical pass becomes one multiply-add per value.)  One launch does everything: a PERSISTENT workgroup
-// (8 wavefronts, one per CU: 2 x (32 + 32) KB of LDS) walks work items = 64 tiles (2x2 output patches in (n, ty, tx) order = 256 output
-// pixels) x 64 output channels, and inside an item the input channels in chunks of 8:
+// (8 wavefronts, one per CU: all 160 KB of LDS = 2 V images + 3 U images of 32 KB) walks work items = 64 tiles (2x2 output patches in
+// (n, ty, tx) order = 256 output pixels) x 64 output channels, and inside an item the input channels in chunks of 8:
 //
-//   stage   thread (patch row i = t&3, channel vector v = (t>>2)&1, tile = t>>3) holds one row of a 4x4 input patch (four 16-byte
-//           descriptor loads, zero outside the image): the horizontal half of B^T d B is in-thread, the vertical half runs across
-//           the four lanes of a quad with a DPP quad_perm operand -- no LDS pass for the raw pixels, every lane the same work -- and
-//           the 16 values go to the LDS image V[xi][tile][8 ch] (16-byte stores).  The filter side comes pre-transformed
-//           (suhpe_conv2d_wino_filter: one small launch per layer and step, the weights move every step) in exactly the LDS image
-//           order, so a chunk's U image is one contiguous 32 KB block copied global -> LDS by LDS-DMA (global_load_lds_dwordx4:
-//           no registers, no VALU, no ds_write).  Without a pre-transformed filter (plain suhpe_conv2d_fwd / _dgrad with the tile
-//           pinned) the same threads load a filter row each and run G g G^T the same way (three quad broadcasts per value);
+//   stage   thread (patch row i = t&3, channel vector v = (t>>2)&1, tile = t>>3) holds one row of a 4x4 input patch -- per SUPER-chunk of
+//           16 channels two 16-byte descriptor loads per pixel (32 contiguous bytes; zero outside the image), one half staged per chunk --:
+//           the horizontal half of B^T d B is in-thread, the vertical half runs across the four lanes of a quad with a DPP quad_perm
+//           operand -- no LDS pass for the raw pixels, every lane the same work -- and the 16 values go to the LDS image of the chunk
+//           (16-byte stores).  The filter side comes pre-transformed (suhpe_conv2d_wino_filter: one small launch per layer and weight
+//           update) in exactly the LDS image order, so a chunk's U image is one contiguous 32 KB block copied global -> LDS by LDS-DMA
+//           (global_load_lds_dwordx4: no registers, no VALU, no ds_write), two chunks ahead;
 //   MFMA    wavefront (tile block tb = w&3, cout half ch = w>>2) owns 16 tiles x 32 couts for ALL 16 positions: 32 accumulators of
-//           v_mfma_f32_16x16x4_f32 (A = U rows, B = V rows; one ds_read_b64 hands a lane two k-steps), 64 MFMAs per chunk, so the
-//           output transform A^T M A happens in registers: a lane ends up with the 2x2 pixels of one tile x 4 consecutive couts
-//           and stores them as 16-byte vectors;
-//   the two LDS buffers alternate per chunk with ONE barrier per chunk; the next chunk's loads (DMA + patch rows) are issued right
-//   after the barrier and land under the MFMAs, its transform sits in the second half of the MFMA block, and the stream of chunks runs
-//   ACROSS item boundaries: the first chunk of the next item is staged while the current item's last chunk is multiplied, so an
-//   item's prologue costs nothing and only its epilogue (output transform + stores) interrupts the matrix pipe.
+//           v_mfma_f32_16x16x4_f32 (A = U rows, B = V rows; one ds_read_b128 hands a lane two k-steps of two positions), 64 MFMAs per
+//           chunk, so the output transform A^T M A happens in registers: a lane ends up with the 2x2 pixels of one tile x 4 consecutive
+//           couts and stores them as 16-byte vectors;
+//   the chunks of ALL items of a workgroup form one stream: V images alternate, U images rotate through three, ONE barrier per chunk;
+//   every memory operation of the loop is inline asm with hand-counted waits (see issue_v / issue_u); the first chunks of the next item
+//   are staged while the current item's last chunks are multiplied, so an item's prologue costs nothing and only its epilogue (output
+//   transform + stores + statistics, all from registers) interrupts the matrix pipe.
 //
-// LDS images are unpadded; bank conflicts are avoided by two XORs of the address: row r of position xi sits at row r ^ (xi >> 2), and
-// the two channel vectors of rows 8-15 (mod 16) are swapped.  Reads (ds_read_b64, 32-lane groups: 16 rows x 2 channel pairs) then
-// cover all 64 banks once, writes (ds_write_b128, 8-lane groups: one row index, 2 vectors, 4 positions) all 32.
+// LDS images are unpadded; bank conflicts are avoided by XOR swizzles of the slot address (wino_slot_off): reads (ds_read_b128) cover all
+// 64 banks once per lane group, writes (ds_write_b128, 8-lane groups: one row, 2 channel vectors, 4 patch rows) all 32.
 //
-// Epilogues: bias, skip-connection add (res_mode 3), BatchNorm statistics records per 64-tile block (256 rows per record, the same
-// (S, Q, k, n) format and segment rule as igemm_nt_kernel's).  No folded-affine (eval) form: eval passes keep the direct kernels, so the
-// eval-mode parity figures are untouched.
+// Epilogues: bias, skip-connection add (res_mode 3), BatchNorm statistics records per wavefront block of 16 tiles (64 rows per record, the
+// same (S, Q, k, n) format and segment rule as igemm_nt_kernel's).  No folded-affine (eval) form: eval passes keep the direct kernels, so
+// the eval-mode parity figures are untouched; no self-transforming form either: without a Winograd-domain filter (plain suhpe_conv2d_fwd
+// with the tile pinned) the dispatch runs a direct tile.
 #include "conv_params.h"
 #include <cstdlib>
 #include <type_traits>
