@@ -4,6 +4,8 @@ max-pool kernels against torch.
 
 Tolerances as for the other backbones: eval rotation matrices 1e-4 absolute, outputs 2e-4 relative, gradients 2e-3 of each
 tensor's max; max-pool forward and backward bit-exact (a selection and a fixed-order sum of at most four terms)."""
+import os
+
 import pytest
 import torch
 
@@ -100,7 +102,8 @@ def test_train_forward_backward_and_running_stats(models):
         scale = max(1e-6, float(t.abs().max()))
         noise = float((g_ref[n].grad.double() - t).abs().max()) / scale
         err = float((g_hip[n].grad.detach().cpu().double() - t).abs().max()) / scale
-        assert err <= max(2e-3, 6.0 * noise), (n, err, noise)
+        # (SUHPE_TEST_NOISE_FACTOR: the Winograd second pass of tests/test_gpu_winograd.py allows 9 x -- the quantity is chaotic, see there)
+        assert err <= max(2e-3, float(os.environ.get("SUHPE_TEST_NOISE_FACTOR", "6.0")) * noise), (n, err, noise)
     for (n, b_ref), (_, b) in zip(ref.named_buffers(), hip.named_buffers()):
         if b_ref.dtype == torch.float32:
             # running statistics 50 train-mode layers deep: the fp32 CPU oracle's own reduction order (its thread count) moves them by ~1e-4
