@@ -46,6 +46,24 @@ def test_train_then_eval(tmp_path):
     assert os.path.exists(os.path.join(str(tmp_path), "exps", "MAE_300WLP_AFLW2000_effinetv2_AFLW2000.json"))
 
 
+def test_two_rank_training_with_autotune_and_a_ragged_validation_deal(tmp_path):
+    """with the autotuner ON, two ranks and an odd number of validation batches (one rank meets a batch shape the other never sees) the job
+    must finish: the autotuner enters no collective, so the ranks' collectives stay paired (gloo rehearsal of the two-rank flow on one GPU)."""
+    env = dict(os.environ, SUHPE_SYNTH_SIZE="64", SUHPE_SYNTH_BATCHES="3", SUHPE_AUTOTUNE="1", SUHPE_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29561",
+           os.path.join(ROOT, "train.py"), "--config", os.path.join(ROOT, "settings", "300WLP_AFLW2000.yml"), "--network", "effinetv2", "--synthetic",
+           "--exp_root", str(tmp_path), "--batch_size", "8", "--ulb_batch_ratio", "2", "--stage1_iteration", "2", "--max_iteration", "6",
+           "--log_frequency", "2", "--val_frequency", "2", "--save_frequency", "6", "--dynamic_thres", "--cutout_aug", "--cutmix_aug", "--rotate_aug",
+           "--left_ratio", "0.75"]
+    r = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    runs = glob.glob(os.path.join(str(tmp_path), "300WLP_AFLW2000", "*", "*"))
+    assert len(runs) == 1 and os.path.exists(os.path.join(runs[0], "best.pth"))
+    log = open(glob.glob(os.path.join(runs[0], "txt_*.log"))[0]).read()
+    assert "test/err_mean:" in log and "train_SSL/unsuper_loss:" in log
+
+
 def test_checkpoint_roundtrip_is_exact(tmp_path):
     from types import SimpleNamespace
 

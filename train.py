@@ -59,7 +59,7 @@ def validate(agent, test_loader, s1, eval_ema, tag):
 
 
 def main():
-    rank, world = init_from_env("nccl")
+    rank, world = init_from_env(os.environ.get("SUHPE_DIST_BACKEND", "nccl"))      # (gloo: the multi-rank flow rehearsed on one GPU, tests)
     config = get_config("train")
     train_loader, ulb_train_loader, test_loader = build_loaders(config, rank, world)
     ssl = config.stage1_iteration < config.max_iteration
