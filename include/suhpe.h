@@ -113,8 +113,9 @@ int suhpe_conv2d_fwd_stats_seg(const suhpe_conv_t* d, const float* x, const floa
                                int64_t seg_row, suhpe_stream_t stream);
 /* Tile menu of the GEMM kernels.  pass: 0 forward, 1 input gradient, 2 filter gradient.  A caller that has timed the
  * menu on a shape pins the winner with suhpe_conv2d_set_tile (tile = -1 unpins: back to the built-in heuristic); the
- * pin is process-wide and keyed by the whole descriptor.  Results of pass 0 / 1 do not depend on the tile; pass 2
- * changes the split-K partition (summation order) with it. */
+ * pin is process-wide and keyed by the whole descriptor.  Results of pass 0 / 1 do not depend on the tile among the direct
+ * kernels (the Winograd tile below computes the same sums through a different factorisation: equal to fp32 rounding, not
+ * bit-equal); pass 2 changes the split-K partition (summation order) with it. */
 int suhpe_conv2d_tile_count(int pass);
 /* start-up stagger of the GEMM workgroups (0 = off): see stagger_wait in csrc/conv_igemm.hip */
 int suhpe_conv2d_set_stagger(int quanta, int first_gen);

@@ -35,3 +35,37 @@ def test_ops_fail_loudly_without_gpu():
     from semiuhpe_amd import kernels
     with pytest.raises(RuntimeError, match="no CPU"):
         kernels.fisher_entropy(torch.zeros(4, 9))
+
+
+def test_winograd_tile_selection_is_host_logic():
+    """the Winograd tiles are menu entries: which geometries may pin them, what the transformed filter and the filter-gradient workspace
+    take, and that the pin is what suhpe_conv2d_wino_pinned reports -- all decided on the host, no GPU needed"""
+    from semiuhpe_amd import _lib
+    lib = _lib.load()
+    lib.suhpe_conv2d_wino_filter_bytes.restype = ctypes.c_int64
+    lib.suhpe_conv2d_wgrad_workspace_bytes.restype = ctypes.c_int64
+    names = {p: [lib.suhpe_conv2d_tile_name(p, i).decode() for i in range(lib.suhpe_conv2d_tile_count(p))] for p in (0, 1, 2)}
+    assert names[0] == names[1]
+    nt, tn = names[0].index("wino_nt_kernel<64,64>"), names[2].index("wino_wgrad_kernel<64,64>")
+    ok = _lib.ConvDesc(32, 28, 28, 128, 28, 28, 128, 3, 3, 1, 1, 1)            # 3x3, stride 1, pad 1
+    for bad in (_lib.ConvDesc(32, 28, 28, 128, 14, 14, 128, 3, 3, 2, 1, 1),    # stride 2
+                _lib.ConvDesc(32, 28, 28, 128, 28, 28, 128, 1, 1, 1, 0, 1),    # pointwise
+                _lib.ConvDesc(32, 28, 28, 3, 28, 28, 24, 3, 3, 1, 1, 1)):      # 3 input channels: not a multiple of 4
+        for p, t in ((0, nt), (2, tn)):
+            assert lib.suhpe_conv2d_set_tile(ctypes.byref(bad), p, t) == -1, (p, bad.cin, bad.stride)
+            assert lib.suhpe_conv2d_wino_pinned(ctypes.byref(bad), p) == 0
+    try:
+        for p in (0, 1):
+            assert lib.suhpe_conv2d_set_tile(ctypes.byref(ok), p, nt) == 0
+            assert lib.suhpe_conv2d_wino_pinned(ctypes.byref(ok), p) == 1
+            # 16 positions x (channels rounded to super-chunks of 16) x 64-wide cout blocks, fp32
+            assert lib.suhpe_conv2d_wino_filter_bytes(ctypes.byref(ok), p) == 16 * 128 * 128 * 4
+        assert lib.suhpe_conv2d_set_tile(ctypes.byref(ok), 2, tn) == 0
+        splits = lib.suhpe_conv2d_wgrad_splits(ctypes.byref(ok))
+        blocks = (128 // 64) * (128 // 64)
+        assert 1 <= splits <= 256 // blocks                                    # one generation of workgroups on 256 CUs
+        assert lib.suhpe_conv2d_wgrad_workspace_bytes(ctypes.byref(ok)) >= splits * 16 * 128 * 128 * 4
+    finally:
+        for p in (0, 1, 2):
+            assert lib.suhpe_conv2d_set_tile(ctypes.byref(ok), p, -1) == 0
+    assert lib.suhpe_conv2d_wino_pinned(ctypes.byref(ok), 0) in (0, 1)          # back to the heuristic (SUHPE_WINOGRAD decides)
