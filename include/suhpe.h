@@ -341,6 +341,13 @@ int suhpe_bn_stats_from_partials_seg(const float* part, int tiles, int first_rec
                                      int64_t rows_a, int c, float eps, float momentum, float* mean, float* rstd,
                                      float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                      suhpe_stream_t stream);
+/* suhpe_bn_stats_from_partials (first_records == tiles, rows_a == rows, boundary NULL, mean / rstd [c]) or _seg (otherwise) for LONG record
+ * lists: the finalizers above reduce a channel's records on ceil(c / 8) workgroups, which takes 20-60 us for the 4 000-16 000 records of a
+ * 24..192-channel layer at 112 x 112 / 56 x 56; this form first adds runs of records on workgroups all over the chip (fp64 pairs written
+ * over each run's first record: `part` is CONSUMED) and finishes from <= 32 pairs per channel and segment.  Same statistics to fp64 rounding. */
+int suhpe_bn_stats_from_partials_consume(float* part, int tiles, int first_records, const float* boundary, int64_t rows, int64_t rows_a, int c,
+                                         float eps, float momentum, float* mean, float* rstd, float* running_mean, float* running_var,
+                                         int64_t* num_batches_tracked, suhpe_stream_t stream);
 /* post = 0: act(BN(x) + residual); post = 1: residual + rowscale[sample] * act(BN(x)) */
 int suhpe_bn_act_fwd_seg(const float* x, int64_t rows, int64_t rows_a, int c, const float* mean, const float* rstd,
                          const float* gamma, const float* beta, int act, const float* residual, int post,

@@ -274,6 +274,79 @@ __global__ __launch_bounds__(kFinThreads) void bn_stats_finalize2(const float* _
     bn_stats_finish(part + (int64_t)gx_a * c * 4, gx_b, c, rows_b, eps, momentum, mean + c, rstd + c, running_mean, running_var, extra_b);
 }
 
+// ---- long record lists (the 112 x 112 and 56 x 56 layers of a 160-image batch leave 4 000 - 16 000 records per channel): the finalizers above
+// run ceil(c / 8) workgroups, so a 24-channel layer reduced 6 MB of records on THREE compute units (62 us; rocprofv3 kernel trace of the C2 step).
+// bn_records_fold spreads the same reduction over the chip: workgroup (channel group, run) adds the records of one run, re-centred on zero in fp64
+// as bn_stats_finish does, and leaves (sum x, sum x^2) as two doubles IN the run's first record (16 bytes either way; the run's other records are
+// not read again, and no other workgroup reads this run).  bn_stats_finalize_folded then adds <= kFoldRuns pairs per channel and segment.
+constexpr int kFoldRuns = 32;
+struct FoldSeg { int first, count, run; };               // records [first, first + count) in runs of `run`
+__global__ __launch_bounds__(kFinThreads) void bn_records_fold(float* __restrict__ part, FoldSeg sa, FoldSeg sb, int runs_a, int c) {
+    const bool second = (int)blockIdx.y >= runs_a;
+    const FoldSeg sg = second ? sb : sa;
+    const int f = second ? blockIdx.y - runs_a : blockIdx.y;
+    const int lo = sg.first + f * sg.run, hi = min(sg.first + sg.count, lo + sg.run);
+    const int chl = threadIdx.x & (kFinCh - 1), sub = threadIdx.x / kFinCh;
+    const int ch = blockIdx.x * kFinCh + chl;
+    double a = 0.0, b = 0.0;
+    if (ch < c) {
+        const float4* pr = reinterpret_cast<const float4*>(part) + ch;
+#pragma unroll 4
+        for (int i = lo + sub; i < hi; i += kFinSub) {
+            const float4 v = pr[(int64_t)i * c];
+            const double S = v.x, Q = v.y, k = v.z, n = v.w;
+            a += S + n * k;
+            b += Q + 2.0 * k * S + n * k * k;
+        }
+    }
+    if (!fin_reduce(&a, &b, ch, c)) return;              // (behind its barrier: every read of the run has been made)
+    reinterpret_cast<double2*>(part)[(int64_t)lo * c + ch] = make_double2(a, b);
+}
+__device__ __forceinline__ void bn_stats_finish_folded(const float* __restrict__ part, FoldSeg sg, int c, int64_t rows, float eps, float momentum,
+                                                       float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
+                                                       float* __restrict__ running_var, const float* __restrict__ extra) {
+    const int chl = threadIdx.x & (kFinCh - 1), sub = threadIdx.x / kFinCh;
+    const int ch = blockIdx.x * kFinCh + chl;
+    const int runs = (sg.count + sg.run - 1) / sg.run;
+    double a = 0.0, b = 0.0;
+    if (ch < c) {
+        if (sub < runs) {
+            const double2 v = reinterpret_cast<const double2*>(part)[(int64_t)(sg.first + sub * sg.run) * c + ch];
+            a = v.x;
+            b = v.y;
+        }
+        if (extra && sub == kFinSub - 1) {               // the boundary record of a conv epilogue (never a folded one)
+            const float4 v = reinterpret_cast<const float4*>(extra)[ch];
+            const double S = v.x, Q = v.y, k = v.z, n = v.w;
+            a += S + n * k;
+            b += Q + 2.0 * k * S + n * k * k;
+        }
+    }
+    if (!fin_reduce(&a, &b, ch, c)) return;
+    const double m = a / (double)rows;
+    double var = b / (double)rows - m * m;               // fp64 sums of values of O(1): bn_stats_finish's extra centring buys nothing here
+    if (var < 0.0) var = 0.0;
+    mean[ch] = (float)m;
+    rstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unb = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
+        running_mean[ch] = (float)((1.0 - momentum) * (double)running_mean[ch] + momentum * m);
+        running_var[ch] = (float)((1.0 - momentum) * (double)running_var[ch] + momentum * unb);
+    }
+}
+__global__ __launch_bounds__(kFinThreads) void bn_stats_finalize_folded(const float* __restrict__ part, FoldSeg sa, FoldSeg sb, int c, int64_t rows_a,
+                                                                        int64_t rows_b, float eps, float momentum, float* __restrict__ mean,
+                                                                        float* __restrict__ rstd, float* __restrict__ running_mean,
+                                                                        float* __restrict__ running_var, int64_t* __restrict__ nbt,
+                                                                        const float* __restrict__ extra_b) {
+    const bool two = rows_b > 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += two ? 2 : 1;
+    bn_stats_finish_folded(part, sa, c, rows_a, eps, momentum, mean, rstd, running_mean, running_var, nullptr);
+    if (!two) return;
+    __syncthreads();
+    bn_stats_finish_folded(part, sb, c, rows_b, eps, momentum, mean + c, rstd + c, running_mean, running_var, extra_b);
+}
+
 __global__ void bn_eval_stats_kernel(const float* __restrict__ rm, const float* __restrict__ rv, int c, float eps,
                                      float* __restrict__ mean, float* __restrict__ rstd) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1879,6 +1952,29 @@ int suhpe_bn_stats_from_partials_seg(const float* part, int tiles, int first_rec
     LAUNCH(bn_stats_finalize2, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, first_records, tiles - first_records, c, rows_a,
            rows - rows_a, eps, momentum, mean, rstd, running_mean, running_var, nbt, boundary);
     return check_launch("suhpe_bn_stats_from_partials_seg");
+}
+
+// the two entry points above for LONG record lists, spread over the chip (bn_records_fold); the records are overwritten
+int suhpe_bn_stats_from_partials_consume(float* part, int tiles, int first_records, const float* boundary, int64_t rows, int64_t rows_a, int c,
+                                         float eps, float momentum, float* mean, float* rstd, float* running_mean, float* running_var,
+                                         int64_t* nbt, suhpe_stream_t stream) {
+    const bool two = rows_a < rows;
+    SUHPE_REQUIRE(part && mean && rstd && c > 0 && rows > 0 && rows_a > 0 && rows_a <= rows && tiles > 0 && first_records > 0 && first_records <= tiles,
+                  "suhpe_bn_stats_from_partials_consume: bad arguments");
+    SUHPE_REQUIRE(two ? (first_records < tiles || boundary) : (first_records == tiles && !boundary),
+                  "suhpe_bn_stats_from_partials_consume: one segment takes every record and no boundary record; two need records or a boundary record for the second");
+    auto seg_of = [](int first, int count) {
+        FoldSeg s{first, count, 1};
+        s.run = count > 0 ? (count + kFoldRuns - 1) / kFoldRuns : 1;
+        return s;
+    };
+    const FoldSeg sa = seg_of(0, first_records), sb = seg_of(first_records, tiles - first_records);
+    const int runs_a = (sa.count + sa.run - 1) / sa.run, runs_b = sb.count > 0 ? (sb.count + sb.run - 1) / sb.run : 0;
+    static_assert(kFoldRuns <= kFinSub - 1, "one pair per reducing thread, the last one takes the boundary record");
+    LAUNCH(bn_records_fold, dim3((c + kFinCh - 1) / kFinCh, runs_a + runs_b), dim3(kFinThreads), stream, part, sa, sb, runs_a, c);
+    LAUNCH(bn_stats_finalize_folded, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, sa, sb, c, rows_a, rows - rows_a, eps, momentum,
+           mean, rstd, running_mean, running_var, nbt, boundary);
+    return check_launch("suhpe_bn_stats_from_partials_consume");
 }
 
 int suhpe_bn_act_fwd_seg(const float* x, int64_t rows, int64_t rows_a, int c, const float* mean, const float* rstd, const float* gamma,

@@ -1287,3 +1287,53 @@ def test_linear_closes_residual_connection_in_epilogue(K, n, tokens, cin, cout, 
     if rs is not None:
         yd = yd * rs.double().cpu()[:, None, None]
     assert rel(y.view(n, tokens, cout), yd + skip.double().cpu()) < 2e-5
+
+
+@pytest.mark.parametrize("c,tiles,first,boundary", [(24, 4000, 4000, None), (24, 4000, 801, True), (40, 37, 12, True), (192, 3100, 620, False),
+                                                   (8, 65, 65, True), (12, 1, 1, True), (16, 2500, 2500, None)], ids=str)
+def test_bn_statistics_from_long_record_lists(K, c, tiles, first, boundary):
+    """suhpe_bn_stats_from_partials_consume (runs of records folded all over the chip, then <= 32 fp64 pairs per channel and segment) gives the
+    statistics and running-stat updates of the one-launch finalizers and of float64, for one and two segments, with and without the boundary
+    record, for run lengths that do and do not divide the record counts.  boundary None = the one-segment form."""
+    from semiuhpe_amd import kernels as KK
+    g = torch.Generator().manual_seed(c * 1000 + tiles)
+    rows_per = 16
+    x = torch.randn(tiles + 1, rows_per, c, generator=g) * (0.5 + torch.rand(c, generator=g)) + 3.0 * torch.randn(c, generator=g)
+    k = x[:, 0, :]
+    d = x - k[:, None, :]
+    rec = torch.stack([d.sum(1), (d * d).sum(1), k, torch.full_like(k, float(rows_per))], dim=-1).contiguous()       # [tile][c][4]
+    part = rec[:tiles].cuda()
+    extra = rec[tiles].contiguous().cuda() if boundary else None
+    two = boundary is not None
+    rows_a = first * rows_per if two else tiles * rows_per
+    rows = tiles * rows_per + (rows_per if boundary else 0)
+    xa = x[:first].reshape(-1, c).double() if two else x[:tiles].reshape(-1, c).double()
+    xb = torch.cat([x[first:tiles].reshape(-1, c), x[tiles].reshape(-1, c) if boundary else x[:0].reshape(-1, c)]).double() if two else None
+    eps, mom = 1e-3, 0.1
+
+    def fresh():
+        return (torch.full((c,), 0.25, device="cuda"), torch.full((c,), 1.5, device="cuda"), torch.zeros((), dtype=torch.int64, device="cuda"))
+
+    def run(fold_min):
+        old, KK._FOLD_MIN_RECORDS = KK._FOLD_MIN_RECORDS, fold_min
+        try:
+            rm, rv, nb = fresh()
+            p = part.clone()
+            if two:
+                m, r = K.bn_stats_from_partials_seg(p, tiles, first, extra, rows, rows_a, c, eps, mom, rm, rv, nb)
+            else:
+                m, r = K.bn_stats_from_partials(p, tiles, rows, c, eps, mom, rm, rv, nb)
+            torch.cuda.synchronize()
+            return m.cpu(), r.cpu(), rm.cpu(), rv.cpu(), int(nb), p
+        finally:
+            KK._FOLD_MIN_RECORDS = old
+    plain, folded = run(1 << 30), run(1)
+    assert torch.equal(plain[5], part) and (tiles < 2 or not torch.equal(folded[5], part))          # only the folding form consumes its records
+    for a, b in zip(plain[:4], folded[:4]):
+        assert rel(b, a) < 1e-6
+    assert plain[4] == folded[4] == (2 if two else 1)
+    segs = [xa, xb] if two else [xa]
+    for i, xs in enumerate(segs):
+        m = folded[0][i] if two else folded[0]
+        r = folded[1][i] if two else folded[1]
+        assert rel(m, xs.mean(0)) < 1e-5 and rel(r, (xs.var(0, unbiased=False) + eps).rsqrt()) < 2e-5
