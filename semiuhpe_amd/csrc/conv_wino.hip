@@ -673,33 +673,71 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParam
 }
 
 // sum of the slabs (fixed order) and dW = G^T dU G per (cout, cin), written as ONE filter-shaped slab [cout][3][3][Cg]
-__global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __restrict__ part, float* __restrict__ slab, int splits, int cout_all, int Cg) {
-    const int64_t total = (int64_t)cout_all * Cg;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        float u[16];
+// G^T U G of one (cout, cin) pair's sixteen sums -> the nine filter taps of `slab`
+__device__ __forceinline__ void wino_wgrad_store_taps(const float (&u)[16], float* __restrict__ slab, int64_t i, int Cg) {
+    float hcol[3][4];                                            // G^T U: rows (1, .5, .5, 0), (0, .5, -.5, 0), (0, .5, .5, 1)
 #pragma unroll
-        for (int xi = 0; xi < 16; ++xi) u[xi] = 0.f;
-        for (int s = 0; s < splits; ++s)
+    for (int jx = 0; jx < 4; ++jx) {
+        const float u0 = u[jx], u1 = u[4 + jx], u2 = u[8 + jx], u3 = u[12 + jx];
+        hcol[0][jx] = u0 + 0.5f * (u1 + u2);
+        hcol[1][jx] = 0.5f * (u1 - u2);
+        hcol[2][jx] = 0.5f * (u1 + u2) + u3;
+    }
+    const int co = (int)(i / Cg), ci = (int)(i - (int64_t)co * Cg);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float g0 = hcol[r][0] + 0.5f * (hcol[r][1] + hcol[r][2]);
+        const float g1 = 0.5f * (hcol[r][1] - hcol[r][2]);
+        const float g2 = 0.5f * (hcol[r][1] + hcol[r][2]) + hcol[r][3];
+        float* dst = slab + ((int64_t)co * 9 + r * 3) * Cg + ci;
+        dst[0] = g0; dst[Cg] = g1; dst[2 * Cg] = g2;
+    }
+}
+// Sum of the split-K slabs + output transform.  SL = 1: a thread adds all the slabs of its (cout, cin) pair -- fine when cout x cin fills the chip and
+// the splits are few (RepVGG's wide layers: 4 splits).  EfficientNetV2-S's 48 -> 192 and 64 -> 256 layers are the opposite: 12 k - 16 k pairs and 64 - 85
+// splits, so that form ran 36 - 64 workgroups each walking a chain of 64 - 85 dependent rounds of 16 loads (225 us for 67 MB, kernel trace of the C2
+// step).  SL = 16: sixteen wavefronts per 64 pairs take every sixteenth slab each and meet in LDS (fixed order: the result does not depend on timing).
+template <int SL>
+__global__ __launch_bounds__(SL == 1 ? 256 : 64 * SL) void wino_wgrad_finish_kernel(const float* __restrict__ part, float* __restrict__ slab, int splits, int cout_all, int Cg) {
+    const int64_t total = (int64_t)cout_all * Cg;
+    if (SL == 1) {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+            float u[16];
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) u[xi] = 0.f;
+            for (int s = 0; s < splits; ++s)
+#pragma unroll
+                for (int xi = 0; xi < 16; ++xi) u[xi] += part[((int64_t)s * 16 + xi) * total + i];
+            wino_wgrad_store_taps(u, slab, i, Cg);
+        }
+        return;
+    }
+    __shared__ float red[SL > 1 ? SL * 16 * 64 : 1];             // [split lane][position][pair]
+    const int il = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + il;
+    const bool ok = i < total;
+    float u[16];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) u[xi] = 0.f;
+    if (ok)
+        for (int s = sl; s < splits; s += SL)
 #pragma unroll
             for (int xi = 0; xi < 16; ++xi) u[xi] += part[((int64_t)s * 16 + xi) * total + i];
-        float hcol[3][4];                                        // G^T U: rows (1, .5, .5, 0), (0, .5, -.5, 0), (0, .5, .5, 1)
 #pragma unroll
-        for (int jx = 0; jx < 4; ++jx) {
-            const float u0 = u[jx], u1 = u[4 + jx], u2 = u[8 + jx], u3 = u[12 + jx];
-            hcol[0][jx] = u0 + 0.5f * (u1 + u2);
-            hcol[1][jx] = 0.5f * (u1 - u2);
-            hcol[2][jx] = 0.5f * (u1 + u2) + u3;
-        }
-        const int co = (int)(i / Cg), ci = (int)(i - (int64_t)co * Cg);
+    for (int xi = 0; xi < 16; ++xi) red[(sl * 16 + xi) * 64 + il] = u[xi];
+    __syncthreads();
+    // wavefront sl adds position sl over the split lanes and leaves it in lane 0's plane; the first wavefront then holds all sixteen
+    static_assert(SL == 1 || SL == 16, "one wavefront per Winograd position in the second round");
+    float t = 0.f;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const float g0 = hcol[r][0] + 0.5f * (hcol[r][1] + hcol[r][2]);
-            const float g1 = 0.5f * (hcol[r][1] - hcol[r][2]);
-            const float g2 = 0.5f * (hcol[r][1] + hcol[r][2]) + hcol[r][3];
-            float* dst = slab + ((int64_t)co * 9 + r * 3) * Cg + ci;
-            dst[0] = g0; dst[Cg] = g1; dst[2 * Cg] = g2;
-        }
-    }
+    for (int k = 0; k < SL; ++k) t += red[(k * 16 + sl) * 64 + il];
+    __syncthreads();
+    red[sl * 64 + il] = t;
+    __syncthreads();
+    if (sl != 0 || !ok) return;
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) u[xi] = red[xi * 64 + il];
+    wino_wgrad_store_taps(u, slab, i, Cg);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
@@ -811,7 +849,10 @@ void launch_wino_wgrad(const float* x, const float* dy, float* workspace, int n,
         hipLaunchKernelGGL(wino_wgrad_kernel<4>, grid, block, lds, st, p);
     }
     const int64_t total = (int64_t)cout * cg;
-    hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, p.part, workspace, p.splits, cout, cg);
+    if (p.splits >= 16 && total <= 64 * 1024)                    // many slabs over few pairs: sixteen wavefronts share a pair's chain
+        hipLaunchKernelGGL(wino_wgrad_finish_kernel<16>, dim3((unsigned)ceil_div(total, 64)), dim3(1024), 0, st, p.part, workspace, p.splits, cout, cg);
+    else
+        hipLaunchKernelGGL(wino_wgrad_finish_kernel<1>, dim3(grid_for(total, 256)), dim3(256), 0, st, p.part, workspace, p.splits, cout, cg);
 }
 
 }  // namespace suhpe

@@ -50,7 +50,8 @@ def test_winograd_tile_selection_is_host_logic():
     ok = _lib.ConvDesc(32, 28, 28, 128, 28, 28, 128, 3, 3, 1, 1, 1)            # 3x3, stride 1, pad 1
     for bad in (_lib.ConvDesc(32, 28, 28, 128, 14, 14, 128, 3, 3, 2, 1, 1),    # stride 2
                 _lib.ConvDesc(32, 28, 28, 128, 28, 28, 128, 1, 1, 1, 0, 1),    # pointwise
-                _lib.ConvDesc(32, 28, 28, 3, 28, 28, 24, 3, 3, 1, 1, 1)):      # 3 input channels: not a multiple of 4
+                _lib.ConvDesc(32, 28, 28, 3, 28, 28, 24, 3, 3, 1, 1, 1),       # 3 input channels: not a multiple of 4
+                _lib.ConvDesc(32, 7, 7, 512, 7, 7, 512, 3, 3, 1, 1, 1)):       # odd image size (2 x 2 output tiles need even heights and widths)
         for p, t in ((0, nt), (2, tn)):
             assert lib.suhpe_conv2d_set_tile(ctypes.byref(bad), p, t) == -1, (p, bad.cin, bad.stride)
             assert lib.suhpe_conv2d_wino_pinned(ctypes.byref(bad), p) == 0

@@ -60,8 +60,7 @@ SHAPES = [
     (3, 128, 128, 2, 12, 10, 1),     # RepVGG grouped block, non-square image
     (2, 256, 128, 1, 8, 8, 1),       # long reduction (16 super-chunks), two items per workgroup stream
     (8, 256, 256, 1, 10, 10, 3),     # ResNet-50 layer3 conv2 at 160-pixel inputs: 200 tiles, four filter-gradient slabs, 4 x 4 channel blocks
-    (3, 32, 40, 1, 7, 5, 1),         # odd height and width (ResNet-50 layer4 runs 3x3 / stride 1 at 7 x 7): the last tile row / column is half outside
-    (2, 16, 64, 1, 1, 9, 1),         # one image row: every tile has its lower half outside
+    (2, 16, 64, 1, 2, 18, 1),        # one row of tiles per image (odd heights / widths -- ResNet-50's layer4 at 7 x 7 -- are refused: tests/test_cabi.py)
 ]
 
 
