@@ -96,7 +96,9 @@ constexpr int WN_U0 = 2 * WN_IMG;
 constexpr int WN_LDS_FLOATS = 5 * WN_IMG;
 
 // HALF: at most 48 output channels in all (one cout block per item whose upper half ch = 1 holds a single 16-channel block)
-template <bool HALF>
+//   NARROW: at most 32 output channels in all (EfficientNetV2-S's 24 -> 24 stage): each wavefront holds ONE 16-channel block (cout 16 ch + j), half the
+//   MFMAs and accumulators, so a chunk is as short as its staging allows
+template <int MODE>
 __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const WinoGeom wg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const GatherGeom& g = p.g;
@@ -227,20 +229,22 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
     };
 
     // ---- MFMA role: tile block tb (16 tiles), cout half ch (2 blocks of 16); lane = (row j of the block, k-group kg)
+    constexpr bool HALF = MODE == 1, NARROW = MODE == 2;
+    constexpr int NBLK = NARROW ? 1 : 2;                        // cout blocks of a wavefront
     const int tb = wave & 3, ch = wave >> 2, j16 = lane & 15, kg = lane >> 4;
     int vrd[4], urd[2][4];                                      // slot offsets for the four patch rows i (pair m adds m * 1024)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         vrd[i] = wino_slot_off(2 * i, 16 * tb + j16, kg) - 2 * i * 1024;
-        urd[0][i] = wino_slot_off(2 * i, 32 * ch + j16, kg) - 2 * i * 1024;
+        urd[0][i] = wino_slot_off(2 * i, (NARROW ? 16 : 32) * ch + j16, kg) - 2 * i * 1024;
         urd[1][i] = wino_slot_off(2 * i, 32 * ch + 16 + j16, kg) - 2 * i * 1024;
     }
-    floatx4w acc[16][2];
+    floatx4w acc[16][NBLK];
     auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi)
 #pragma unroll
-            for (int bb = 0; bb < 2; ++bb)
+            for (int bb = 0; bb < NBLK; ++bb)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[xi][bb][e] = 0.f;
     };
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
     // second_block: this wavefront's second cout block exists (48 output channels -- the input gradient of EfficientNetV2-S's 48 -> 192 convs -- leave
     // the cout half ch = 1 with one block: its wavefronts skip the padding block's MFMAs, and since wavefronts w and w + 4 share a SIMD every SIMD
     // then carries 96 MFMAs per chunk instead of 128)
-    const bool second_block = !HALF || ch == 0;
+    const bool second_block = !NARROW && (!HALF || ch == 0);
     auto mma_pairs = [&](int vb, int ub, auto m0_t, auto m1_t) __attribute__((always_inline)) {
         constexpr int M0 = decltype(m0_t)::value, M1 = decltype(m1_t)::value;
         const float* Vs = smem + vb * WN_IMG;
@@ -258,14 +262,14 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
         auto read_frags = [&](int m, int set) __attribute__((always_inline)) {
             vf[set] = *reinterpret_cast<const float4*>(&Vs[m * 1024 + vrd[m >> 1]]);
             uf[set][0] = *reinterpret_cast<const float4*>(&Us[m * 1024 + urd[0][m >> 1]]);
-            uf[set][1] = *reinterpret_cast<const float4*>(&Us[m * 1024 + urd[1][m >> 1]]);
+            if (!NARROW) uf[set][1] = *reinterpret_cast<const float4*>(&Us[m * 1024 + urd[1][m >> 1]]);
         };
         if (M0 == 0) read_frags(0, 0);
 #pragma unroll
         for (int m = M0; m < M1; ++m) {
             const int cur = m & 1;
             if (m + 1 < 8) read_frags(m + 1, cur ^ 1);
-            if (second_block) {
+            if constexpr (!NARROW) if (second_block) {
                 acc[2 * m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].x, vf[cur].x, acc[2 * m][0], 0, 0, 0);
                 acc[2 * m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][1].x, vf[cur].x, acc[2 * m][1], 0, 0, 0);
                 acc[2 * m + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].z, vf[cur].z, acc[2 * m + 1][0], 0, 0, 0);
@@ -274,12 +278,12 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
                 acc[2 * m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][1].y, vf[cur].y, acc[2 * m][1], 0, 0, 0);
                 acc[2 * m + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].w, vf[cur].w, acc[2 * m + 1][0], 0, 0, 0);
                 acc[2 * m + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][1].w, vf[cur].w, acc[2 * m + 1][1], 0, 0, 0);
-            } else {
-                acc[2 * m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].x, vf[cur].x, acc[2 * m][0], 0, 0, 0);
-                acc[2 * m + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].z, vf[cur].z, acc[2 * m + 1][0], 0, 0, 0);
-                acc[2 * m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].y, vf[cur].y, acc[2 * m][0], 0, 0, 0);
-                acc[2 * m + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].w, vf[cur].w, acc[2 * m + 1][0], 0, 0, 0);
+                continue;
             }
+            acc[2 * m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].x, vf[cur].x, acc[2 * m][0], 0, 0, 0);
+            acc[2 * m + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].z, vf[cur].z, acc[2 * m + 1][0], 0, 0, 0);
+            acc[2 * m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].y, vf[cur].y, acc[2 * m][0], 0, 0, 0);
+            acc[2 * m + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[cur][0].w, vf[cur].w, acc[2 * m + 1][0], 0, 0, 0);
         }
     };
 
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
     auto epilogue = [&](int tile0, int n0, int row_tile) __attribute__((always_inline)) {
         float out[4][2][4];                                      // [pixel (py, px) = (q >> 1, q & 1)][cout block][e]
 #pragma unroll
-        for (int bb = 0; bb < 2; ++bb)
+        for (int bb = 0; bb < NBLK; ++bb)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float t0[4], t1[4];
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
             const unsigned ty = fast_div(rem, wg.div_tx_mul, wg.div_tx_shr), tx = rem - ty * (unsigned)wg.TX;
             pix0 = ((int64_t)n * g.OH + 2 * ty) * g.OW + 2 * tx;
         }
-        const int colb[2] = {n0 + 32 * ch + 4 * kg, n0 + 32 * ch + 16 + 4 * kg};
+        const int colb[2] = {n0 + (NARROW ? 16 : 32) * ch + 4 * kg, n0 + 32 * ch + 16 + 4 * kg};
         float* __restrict__ y = p.y + (int64_t)grp * p.Ng;
         {
             float rv[4][2][4];
@@ -320,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int bb = 0; bb < 2; ++bb) {
+                    for (int bb = 0; bb < NBLK; ++bb) {
                         const int64_t pix = pix0 + (q >> 1) * g.OW + (q & 1);
                         const bool ok = tvalid && colb[bb] < p.Ng;
                         const float4 r4 = ok ? *reinterpret_cast<const float4*>(&p.residual[pix * p.ldy + grp * p.Ng + colb[bb]]) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
                     }
             }
 #pragma unroll
-            for (int bb = 0; bb < 2; ++bb) {
+            for (int bb = 0; bb < NBLK; ++bb) {
                 if (!(tvalid && colb[bb] < p.Ng)) continue;
                 if ((WINO_ABLATE & 32) && out[0][bb][0] != 12345.678f) continue;      // (timing experiment: the output transform stays, the stores go)
                 float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
             float4* rec = reinterpret_cast<float4*>(p.stats) + ((int64_t)row_tile * 4 + tb) * p.stat_cout + grp * p.Ng;
             float4* rec2 = reinterpret_cast<float4*>(p.stats_extra) + grp * p.Ng;
 #pragma unroll
-            for (int bb = 0; bb < 2; ++bb)
+            for (int bb = 0; bb < NBLK; ++bb)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     // lane 0 of each 16-lane row -> the row (ds_swizzle, bit mode: lane' = lane & 0x10 inside each half of the wavefront)
@@ -795,12 +799,15 @@ bool launch_wino(const NtParams& p_in, int groups, hipStream_t st) {
     const int gx = (int)(items8 < per_group ? items8 : per_group);
     const dim3 grid((unsigned)gx, 1, groups), block(512);
     const size_t lds = (size_t)WN_LDS_FLOATS * sizeof(float);
-    if (p.Ng > 32 && p.Ng <= 48) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_nt_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(wino_nt_kernel<true>, grid, block, lds, st, p, wg);
+    if (p.Ng <= 32) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_nt_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(wino_nt_kernel<2>, grid, block, lds, st, p, wg);
+    } else if (p.Ng <= 48) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_nt_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(wino_nt_kernel<1>, grid, block, lds, st, p, wg);
     } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_nt_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(wino_nt_kernel<false>, grid, block, lds, st, p, wg);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_nt_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(wino_nt_kernel<0>, grid, block, lds, st, p, wg);
     }
     return true;
 }

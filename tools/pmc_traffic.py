@@ -31,7 +31,7 @@ def normalize(name):
     m = re.match(r"(gemm_nt_resident<\d+,\d+,\d+),(true|false)>", name)
     if m:
         return m.group(1) + ">"
-    if re.match(r"wino_nt_kernel<(true|false)>", name):          # both instantiations (<true>: at most 48 output channels) are the menu's one tile
+    if re.match(r"wino_nt_kernel<(true|false|[012])>", name):          # both instantiations (<true>: at most 48 output channels) are the menu's one tile
         return "wino_nt_kernel<64,64>"
     if re.match(r"wino_wgrad_kernel<\d+>", name):
         return "wino_wgrad_kernel<64,64>"
