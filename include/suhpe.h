@@ -140,6 +140,10 @@ int64_t suhpe_conv2d_wino_filter_bytes(const suhpe_conv_t* d, int pass);
 int suhpe_conv2d_wino_filter(const suhpe_conv_t* d, int pass, const float* w, float* fw, suhpe_stream_t stream);
 int suhpe_conv2d_fwd_wino(const suhpe_conv_t* d, const float* x, const float* w, const float* fw, const float* bias, float* y, float* stats,
                           float* stats_extra, int64_t seg_row, suhpe_stream_t stream);
+/* suhpe_conv2d_fwd_affine (eval-mode conv -> BatchNorm -> activation [-> + skip], RepVGG's re-parameterised blocks) with the same rule:
+ * fw from suhpe_conv2d_wino_filter(d, 0, ...) or NULL */
+int suhpe_conv2d_fwd_affine_wino(const suhpe_conv_t* d, const float* x, const float* w, const float* fw, const float* scale, const float* shift, int act,
+                                 const float* residual, int residual_after_act, float* y, suhpe_stream_t stream);
 int suhpe_conv2d_dgrad_wino(const suhpe_conv_t* d, const float* dy, const float* wt, const float* fw, const float* skip, float* dx,
                             suhpe_stream_t stream);
 /* Pointwise conv whose INPUT is act(BN(x)) [* per-sample scale] of a tensor x that was never normalised in memory: the loader of

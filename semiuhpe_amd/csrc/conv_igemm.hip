@@ -1569,6 +1569,25 @@ int suhpe_conv2d_fwd_wino(const suhpe_conv_t* d, const float* x, const float* w,
     return check_launch("suhpe_conv2d_fwd_wino");
 }
 
+int suhpe_conv2d_fwd_affine_wino(const suhpe_conv_t* d, const float* x, const float* w, const float* fw, const float* scale, const float* shift, int act,
+                                 const float* residual, int residual_after_act, float* y, suhpe_stream_t stream) {
+    int rc = check_desc(d, "suhpe_conv2d_fwd_affine_wino");
+    if (rc) return rc;
+    SUHPE_REQUIRE(x && w && y && scale && shift, "suhpe_conv2d_fwd_affine_wino: null pointer");
+    SUHPE_REQUIRE(act >= SUHPE_ACT_NONE && act <= SUHPE_ACT_SIGMOID, "suhpe_conv2d_fwd_affine_wino: unknown activation %d", act);
+    NtParams p;
+    const int cg = d->cin / d->groups;
+    p.g = make_geom(d->n, d->h, d->w, d->ho, d->wo, d->cin, cg, d->r, d->s, d->stride, d->pad, 0);
+    p.x = x; p.f = w; p.bias = nullptr; p.y = y; p.Ng = d->cout / d->groups; p.ldy = d->cout; p.ldf = p.g.K;
+    p.x_bytes = (int64_t)d->n * d->h * d->w * d->cin * 4; p.f_bytes = (int64_t)d->cout * p.g.K * 4;
+    p.stats = nullptr; p.stats_extra = nullptr; p.seg_row = 0; p.stat_gx = 0; p.stat_cout = 0;
+    p.scale = scale; p.shift = shift; p.residual = residual; p.act = act; p.res_mode = residual ? (residual_after_act ? 2 : 1) : 0;
+    p.fw = fw;
+    const bool vec4 = (cg % 4 == 0) && (d->cin % 4 == 0) && aligned16(x) && aligned16(w);
+    dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 0));
+    return check_launch("suhpe_conv2d_fwd_affine_wino");
+}
+
 int suhpe_conv2d_dgrad_wino(const suhpe_conv_t* d, const float* dy, const float* wt, const float* fw, const float* skip, float* dx,
                             suhpe_stream_t stream) {
     int rc = check_desc(d, "suhpe_conv2d_dgrad_wino");

@@ -229,7 +229,8 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
     };
 
     // ---- MFMA role: tile block tb (16 tiles), cout half ch (2 blocks of 16); lane = (row j of the block, k-group kg)
-    constexpr bool HALF = MODE == 1, NARROW = MODE == 2;
+    constexpr bool HALF = (MODE & 3) == 1, NARROW = (MODE & 3) == 2;
+    constexpr bool AFFINE = (MODE & 4) != 0;                    // eval-mode epilogue: y = act(acc * scale + shift [+ res]) [+ res] (no bias, no statistics)
     constexpr int NBLK = NARROW ? 1 : 2;                        // cout blocks of a wavefront
     const int tb = wave & 3, ch = wave >> 2, j16 = lane & 15, kg = lane >> 4;
     int vrd[4], urd[2][4];                                      // slot offsets for the four patch rows i (pair m adds m * 1024)
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
         float* __restrict__ y = p.y + (int64_t)grp * p.Ng;
         {
             float rv[4][2][4];
-            if (p.res_mode == 3) {                               // the skip operand, every load ahead of the stores (it may alias y for the compiler)
+            if (AFFINE ? p.res_mode != 0 : p.res_mode == 3) {    // the skip operand, every load ahead of the stores (it may alias y for the compiler)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -335,6 +336,26 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
             for (int bb = 0; bb < NBLK; ++bb) {
                 if (!(tvalid && colb[bb] < p.Ng)) continue;
                 if ((WINO_ABLATE & 32) && out[0][bb][0] != 12345.678f) continue;      // (timing experiment: the output transform stays, the stores go)
+                if constexpr (AFFINE) {
+                    const float4 sc = *reinterpret_cast<const float4*>(&p.scale[grp * p.Ng + colb[bb]]);
+                    const float4 sh = *reinterpret_cast<const float4*>(&p.shift[grp * p.Ng + colb[bb]]);
+                    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int64_t pix = pix0 + (q >> 1) * g.OW + (q & 1);
+                        float o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = fmaf(out[q][bb][e], scv[e], shv[e]);
+                            if (p.res_mode == 1) v += rv[q][bb][e];
+                            v = act_apply(v, p.act);
+                            if (p.res_mode == 2) v += rv[q][bb][e];
+                            o[e] = v;
+                        }
+                        *reinterpret_cast<float4*>(&y[pix * p.ldy + colb[bb]]) = make_float4(o[0], o[1], o[2], o[3]);
+                    }
+                    continue;
+                }
                 float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (p.bias) bv = *reinterpret_cast<const float4*>(&p.bias[grp * p.Ng + colb[bb]]);
 #pragma unroll
@@ -351,7 +372,7 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
         // DPP row rotations, the record written by the row's first lane -- no LDS, no barrier (the first version went through LDS with three barriers
         // and 128 ds_bpermute shuffles per item: 60-85 us of a 480 us launch, tools/wino_ablate.sh).  The block that contains the segment boundary
         // emits its first-segment tiles to `stats`, the rest to `stats_extra`.
-        if (p.stats && !(WINO_ABLATE & 64)) {
+        if (!AFFINE && p.stats && !(WINO_ABLATE & 64)) {
             const int blk0 = tile0 + 16 * tb;                    // first tile of this wavefront's block
             const int cut = wg.seg_tile > blk0 && wg.seg_tile < blk0 + 16 && p.stats_extra ? wg.seg_tile : 0x7fffffff;    // first tile of the second part
             const bool first = tvalid && Tj < cut, second = tvalid && Tj >= cut;
@@ -756,9 +777,12 @@ bool wino_geom_ok(const GatherGeom& g, int Ng) {
     return kWinoEnabled && g.om == 1 && g.R == 3 && g.S == 3 && g.stride == 1 && g.pad == 1 && g.GH == g.OH && g.GW == g.OW && g.OH % 2 == 0 && g.OW % 2 == 0 &&
            g.M < (1LL << 31) && g.Cg % 4 == 0 && Ng % 4 == 0 && g.ldg % 4 == 0;
 }
-// epilogue forms the kernel has: bias, skip add, statistics records
+// epilogue forms the kernel has: bias, skip add, statistics records; or (AFFINE instantiations) the folded eval-mode BatchNorm + activation + skip
 static bool wino_params_ok(const NtParams& p) {
-    return wino_geom_ok(p.g, p.Ng) && !p.scale && !p.y2 && !p.a_scale && !p.o_rowscale && (p.res_mode == 0 || p.res_mode == 3) && p.ldy % 4 == 0 &&
+    const bool affine = p.scale != nullptr;                      // eval-mode form: scale AND shift, activation, skip before / after it; no bias, no statistics
+    const bool epi_ok = affine ? (p.shift && !p.bias && !p.stats && p.res_mode >= 0 && p.res_mode <= 2 && aligned16(p.scale) && aligned16(p.shift))
+                               : (p.res_mode == 0 || p.res_mode == 3);
+    return wino_geom_ok(p.g, p.Ng) && epi_ok && !p.y2 && !p.a_scale && !p.o_rowscale && p.ldy % 4 == 0 &&
            p.fw && aligned16(p.y) && aligned16(p.x) && aligned16(p.fw) && (!p.residual || aligned16(p.residual)) && (!p.bias || aligned16(p.bias));
 }
 
@@ -799,15 +823,16 @@ bool launch_wino(const NtParams& p_in, int groups, hipStream_t st) {
     const int gx = (int)(items8 < per_group ? items8 : per_group);
     const dim3 grid((unsigned)gx, 1, groups), block(512);
     const size_t lds = (size_t)WN_LDS_FLOATS * sizeof(float);
-    if (p.Ng <= 32) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_nt_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(wino_nt_kernel<2>, grid, block, lds, st, p, wg);
-    } else if (p.Ng <= 48) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_nt_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(wino_nt_kernel<1>, grid, block, lds, st, p, wg);
+    auto go = [&](auto mode) {
+        constexpr int M = decltype(mode)::value;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_nt_kernel<M>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(wino_nt_kernel<M>, grid, block, lds, st, p, wg);
+    };
+    const int form = p.Ng <= 32 ? 2 : (p.Ng <= 48 ? 1 : 0);
+    if (p.scale) {
+        if (form == 2) go(std::integral_constant<int, 6>()); else if (form == 1) go(std::integral_constant<int, 5>()); else go(std::integral_constant<int, 4>());
     } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_nt_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(wino_nt_kernel<0>, grid, block, lds, st, p, wg);
+        if (form == 2) go(std::integral_constant<int, 2>()); else if (form == 1) go(std::integral_constant<int, 1>()); else go(std::integral_constant<int, 0>());
     }
     return true;
 }

@@ -373,8 +373,13 @@ def conv2d_fwd_affine(x, w, scale, shift, act, residual=None, residual_after_act
     if AUTOTUNE:
         _autotune_fwd(d, x, w, y)
     with _Prof(d, 0):
-        call("suhpe_conv2d_fwd_affine", ctypes.byref(d), ptr(x), ptr(w), ptr(scale), ptr(shift), ACT[act], ptr(residual),
-             int(residual_after_act), ptr(y))
+        fw = _wino_filter(d, 0, w)
+        if fw is not None:
+            call("suhpe_conv2d_fwd_affine_wino", ctypes.byref(d), ptr(x), ptr(w), ptr(fw), ptr(scale), ptr(shift), ACT[act], ptr(residual),
+                 int(residual_after_act), ptr(y))
+        else:
+            call("suhpe_conv2d_fwd_affine", ctypes.byref(d), ptr(x), ptr(w), ptr(scale), ptr(shift), ACT[act], ptr(residual),
+                 int(residual_after_act), ptr(y))
     return y
 
 

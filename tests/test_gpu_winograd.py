@@ -119,8 +119,7 @@ def test_winograd_kernels_match_float64(K, cfg):
 
 
 def test_winograd_tile_is_refused_where_it_cannot_run(K):
-    """stride 2, 1x1, odd image sizes: suhpe_conv2d_set_tile refuses the Winograd tiles; an eval-mode (folded affine) forward with the tile pinned
-    runs a direct tile and gives the direct result"""
+    """stride 2, 1x1, odd image sizes: suhpe_conv2d_set_tile refuses the Winograd tiles"""
     from semiuhpe_amd import _lib
     lib = _lib.load()
     names = _names()
@@ -128,18 +127,43 @@ def test_winograd_tile_is_refused_where_it_cannot_run(K):
         d = K.conv_desc(xs, ws, stride, pad, 1)
         assert lib.suhpe_conv2d_set_tile(ctypes.byref(d), 0, names[0].index("wino_nt_kernel<64,64>")) != 0
         assert lib.suhpe_conv2d_set_tile(ctypes.byref(d), 2, names[2].index("wino_wgrad_kernel<64,64>")) != 0
-    gen = torch.Generator().manual_seed(5)
-    x = torch.randn(3, 8, 8, 16, generator=gen).cuda()
-    wg = K.to_filter_layout((torch.randn(24, 16, 3, 3, generator=gen) * 0.1).cuda())
-    scale, shift = torch.rand(24, generator=gen).cuda() + 0.5, torch.randn(24, generator=gen).cuda()
-    d = K.conv_desc(x.shape, wg.shape, 1, 1, 1)
-    ref = K.conv2d_fwd_affine(x, wg, scale, shift, "silu", stride=1, pad=1)
+
+
+@pytest.mark.parametrize("cfg", [(3, 16, 24, 1, 8, 8), (2, 32, 48, 1, 12, 10), (5, 48, 192, 1, 14, 14), (4, 128, 128, 2, 6, 6), (3, 64, 80, 1, 28, 28)], ids=str)
+@pytest.mark.parametrize("act,res", [("silu", 0), ("relu", 1), ("none", 2), ("silu", 2), ("relu", 0)])
+def test_winograd_eval_epilogue_matches_float64(K, cfg, act, res):
+    """eval-mode conv -> folded BatchNorm -> activation (-> skip before / after it) on the Winograd kernel (suhpe_conv2d_fwd_affine_wino: the FusedMBConv
+    blocks of an EfficientNetV2-S in eval(), RepVGG's re-parameterised blocks): against float64, and against the direct tile of the same call, for the
+    one-block (<= 32 output channels), three-block (<= 48) and full forms of the kernel"""
+    from semiuhpe_amd import _lib
+    lib = _lib.load()
+    names = _names()
+    n, cin, cout, g, h, w = cfg
+    gen = torch.Generator().manual_seed(cin * 7 + cout + res)
+    x = torch.randn(n, cin, h, w, generator=gen)
+    wt = torch.randn(cout, cin // g, 3, 3, generator=gen) / (3 * (cin // g) ** 0.5)
+    scale, shift = torch.rand(cout, generator=gen) + 0.5, torch.randn(cout, generator=gen)
+    skip = torch.randn(n, cout, h, w, generator=gen)
+    z = F.conv2d(x.double(), wt.double(), None, 1, 1, 1, g) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    if res == 1:
+        z = z + skip.double()
+    z = {"silu": F.silu, "relu": F.relu, "none": lambda t: t}[act](z)
+    if res == 2:
+        z = z + skip.double()
+    ref = z.permute(0, 2, 3, 1)
+    xg = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wg = K.to_filter_layout(wt.cuda())
+    sk = skip.permute(0, 2, 3, 1).contiguous().cuda() if res else None
+    d = K.conv_desc(xg.shape, wg.shape, 1, 1, g)
+    direct = K.conv2d_fwd_affine(xg, wg, scale.cuda(), shift.cuda(), act, sk, res == 2, stride=1, pad=1, groups=g)
     assert lib.suhpe_conv2d_set_tile(ctypes.byref(d), 0, names[0].index("wino_nt_kernel<64,64>")) == 0
     try:
-        out = K.conv2d_fwd_affine(x, wg, scale, shift, "silu", stride=1, pad=1)
+        assert lib.suhpe_conv2d_wino_pinned(ctypes.byref(d), 0) == 1
+        out = K.conv2d_fwd_affine(xg, wg, scale.cuda(), shift.cuda(), act, sk, res == 2, stride=1, pad=1, groups=g)
     finally:
         lib.suhpe_conv2d_set_tile(ctypes.byref(d), 0, -1)
-    assert rel(out, ref) < 3e-6
+    assert rel(direct, ref) < 2e-5 and rel(out, ref) < 2e-5
+    assert not torch.equal(out, direct)                     # (the Winograd kernel did run: another factorisation, other roundings)
 
 
 def test_network_parity_suite_on_the_winograd_tiles():
