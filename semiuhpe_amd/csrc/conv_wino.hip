@@ -555,6 +555,9 @@ constexpr int WW_IMG = 16 * 8 * 64;      // floats per image (dM or V): 16 posit
 
 // NB = input-channel sub-blocks of a workgroup's block: 4 (64 input channels: channel 4 (lane & 15) + b <-> sub-block b, one ds_read_b128) or 3 (48 input
 // channels, EfficientNetV2-S's 48 -> 192 expand convs: channel 16 b + (lane & 15), three ds_read_b32 -- no matrix work on 16 padding channels)
+#ifndef WW_STAGE_AT
+#define WW_STAGE_AT 3          // MFMA quarters of a chunk in front of the next chunk's staging (4 = staging behind all of them)
+#endif
 template <int NB>
 __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];       // [buffer][dM image | V image]
@@ -630,15 +633,18 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParam
             for (int bb = 0; bb < NB; ++bb)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[x2][a][bb][e] = 0.f;
-    auto mma_chunk = [&](int buf) __attribute__((always_inline)) {
+    // quarters [q0, q1) of a chunk's MFMAs: quarter = (position x2, k-step pair s4)
+    auto mma_chunk = [&](int buf, auto q0_t, auto q1_t) __attribute__((always_inline)) {
+        constexpr int Q0 = decltype(q0_t)::value, Q1 = decltype(q1_t)::value;
         const float* Ds = smem + buf * 2 * WW_IMG;
         const float* Vs = Ds + WW_IMG;
 #pragma unroll
-        for (int x2 = 0; x2 < 2; ++x2) {
+        for (int qq = Q0; qq < Q1; ++qq) {
+            const int x2 = qq >> 1;
             const int xi = 2 * wave + x2;
             const int rd = xi * 512 + ((idx ^ (2 * (xi >> 2))) << 2) + kg * 64;
-#pragma unroll
-            for (int s4 = 0; s4 < 2; ++s4) {
+            {
+                const int s4 = qq & 1;
                 const float4 af = *reinterpret_cast<const float4*>(&Ds[rd + s4 * 256]);
                 const float av[4] = {af.x, af.y, af.z, af.w};
                 float bv[NB];
@@ -660,14 +666,22 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParam
         }
     };
     if (nchunks > 0) {
+        using Q0 = std::integral_constant<int, 0>;
+        using Q3 = std::integral_constant<int, WW_STAGE_AT>;
+        using Q4 = std::integral_constant<int, 4>;
         load_chunk(0);
         stage_chunk(0);
         __syncthreads();
         for (int c = 0; c < nchunks; ++c) {
             if (c + 1 < nchunks) load_chunk(c + 1);
             __builtin_amdgcn_sched_barrier(0);                   // (left alone the scheduler sinks the loads down to their first use)
-            mma_chunk(c & 1);
+            // The next chunk is staged (transforms + LDS stores: VALU) between this chunk's MFMA quarters, not behind them: the two wavefronts of a SIMD
+            // run the same program between two barriers, so a VALU block at the end is a stretch in which neither of them feeds the matrix pipe
+            mma_chunk(c & 1, Q0(), Q3());
+            __builtin_amdgcn_sched_barrier(0);
             if (c + 1 < nchunks) stage_chunk((c + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_chunk(c & 1, Q3(), Q4());
             __syncthreads();
         }
     }
