@@ -60,6 +60,7 @@ SHAPES = [
     (3, 128, 128, 2, 12, 10, 1),     # RepVGG grouped block, non-square image
     (2, 256, 128, 1, 8, 8, 1),       # long reduction (16 super-chunks), two items per workgroup stream
     (8, 256, 256, 1, 10, 10, 3),     # ResNet-50 layer3 conv2 at 160-pixel inputs: 200 tiles, four filter-gradient slabs, 4 x 4 channel blocks
+    (16, 16, 16, 1, 32, 32, 5),      # many tiles, one channel block: 64 split-K slabs of the filter gradient (the sixteen-wavefront finish kernel)
     (2, 16, 64, 1, 2, 18, 1),        # one row of tiles per image (odd heights / widths -- ResNet-50's layer4 at 7 x 7 -- are refused: tests/test_cabi.py)
 ]
 
