@@ -70,3 +70,23 @@ def test_winograd_tile_selection_is_host_logic():
         for p in (0, 1, 2):
             assert lib.suhpe_conv2d_set_tile(ctypes.byref(ok), p, -1) == 0
     assert lib.suhpe_conv2d_wino_pinned(ctypes.byref(ok), 0) in (0, 1)          # back to the heuristic (SUHPE_WINOGRAD decides)
+
+
+def test_consuming_finalizer_rejects_inconsistent_segments():
+    """suhpe_bn_stats_from_partials_consume: one segment takes every record and no boundary record; two segments need records or a boundary record
+    for the second one (host-side validation, nothing is launched)"""
+    from semiuhpe_amd import _lib
+    lib = _lib.load()
+    f = lib.suhpe_bn_stats_from_partials_consume
+    buf = ctypes.c_void_p(16)                                 # never dereferenced: every call below fails validation
+    args = dict(eps=ctypes.c_float(1e-3), mom=ctypes.c_float(0.1))
+
+    def call(tiles, first, boundary, rows, rows_a, c=8):
+        return f(buf, tiles, first, boundary, ctypes.c_int64(rows), ctypes.c_int64(rows_a), c, args["eps"], args["mom"], buf, buf, None, None, None, None)
+    assert call(10, 10, None, 640, 320) == -1                 # two segments, no record and no boundary record for the second
+    assert b"consume" in lib.suhpe_last_error()
+    assert call(10, 4, None, 640, 640) == -1                  # one segment must take every record
+    assert call(10, 10, buf, 640, 640) == -1                  # ... and has no boundary record
+    assert call(10, 11, None, 640, 320) == -1                 # more first-segment records than records
+    assert call(0, 0, None, 640, 640) == -1
+    assert call(10, 10, None, 640, 0) == -1
