@@ -13,9 +13,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("net,steps", [("effinetv2", 6), ("repvgg", 4)])
-def test_two_runs_end_on_identical_weights(net, steps):
-    env = dict(os.environ, SUHPE_AUTOTUNE="0", SUHPE_WINOGRAD="2", DET_B="8", DET_SIZE="128")
+@pytest.mark.parametrize("net,steps,size", [("effinetv2", 6, 128), ("repvgg", 4, 128), ("tinyvit", 3, 224)])
+def test_two_runs_end_on_identical_weights(net, steps, size):
+    env = dict(os.environ, SUHPE_AUTOTUNE="0", SUHPE_WINOGRAD="2", DET_B="8", DET_SIZE=str(size))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "debug", "determinism_soak.py"), net, str(steps)], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
