@@ -187,3 +187,37 @@ def test_network_parity_suite_on_the_winograd_tiles():
     tail = r.stdout[-3000:] + r.stderr[-1500:]
     assert r.returncode == 0, tail
     assert " passed" in r.stdout, tail
+
+
+def test_winograd_results_do_not_depend_on_memory_latency(K):
+    """The chunk loops of the Winograd kernels wait for their loads with hand-counted s_waitcnt vmcnt(N): a count that is one too high returns stale
+    registers or reads an LDS image before its DMA has landed -- but only when the load is slow.  Here a second stream keeps HBM saturated (large copies)
+    while forward, input gradient and filter gradient run repeatedly on bench-sized shapes: every result must be bit-identical to the quiet run."""
+    from semiuhpe_amd import _lib
+    lib = _lib.load()
+    names = _names()
+    gen = torch.Generator().manual_seed(11)
+    for n, cin, cout, hw in ((64, 48, 192, 56), (96, 64, 256, 28), (64, 512, 512, 14)):
+        x = torch.randn(n, hw, hw, cin, generator=gen).cuda()
+        dy = torch.randn(n, hw, hw, cout, generator=gen).cuda()
+        wg = K.to_filter_layout((torch.randn(cout, cin, 3, 3, generator=gen) / (3 * cin ** 0.5)).cuda())
+        d = K.conv_desc(x.shape, wg.shape, 1, 1, 1)
+        _pin(K, d, names, True)
+        try:
+            quiet = (K.conv2d_fwd(x, wg, None, 1, 1, 1), K.conv2d_dgrad(dy, wg, x.shape, 1, 1, 1), K.conv2d_wgrad(x, dy, wg.shape, 1, 1, 1),
+                     K.conv2d_fwd_stats(x, wg, 1, 1, 1)[1].clone())
+            torch.cuda.synchronize()
+            noise = torch.cuda.Stream()
+            big = torch.empty(1 << 28, dtype=torch.float32, device="cuda")           # 1 GiB: every copy below misses the caches
+            with torch.cuda.stream(noise):
+                for _ in range(60):
+                    big[: 1 << 27].copy_(big[1 << 27:], non_blocking=True)
+            for it in range(12):
+                assert torch.equal(K.conv2d_fwd(x, wg, None, 1, 1, 1), quiet[0]), ("fwd", n, cin, it)
+                assert torch.equal(K.conv2d_dgrad(dy, wg, x.shape, 1, 1, 1), quiet[1]), ("dgrad", n, cin, it)
+                assert torch.equal(K.conv2d_wgrad(x, dy, wg.shape, 1, 1, 1), quiet[2]), ("wgrad", n, cin, it)
+                assert torch.equal(K.conv2d_fwd_stats(x, wg, 1, 1, 1)[1], quiet[3]), ("stats records", n, cin, it)
+            torch.cuda.synchronize()
+            del big
+        finally:
+            _pin(K, d, names, False)
