@@ -1,0 +1,130 @@
+"""Out-of-bounds writes of the round-4 kernels, through the C ABI with caller-owned buffers: every output (and every scratch buffer) sits between two guard
+bands filled with a sentinel; after the launch the bands must be untouched and the payload fully written where the contract says so.  Ragged geometry is
+where such bugs live: tile counts that are no multiple of a 64-tile item (or of a wavefront's 16-tile block), channel counts that are no multiple of a
+64- / 32- / 16-channel block, groups, a batch segment that cuts a block.  (PyTorch's allocator rounds sizes up and packs tensors: a stray store usually
+lands in a neighbour and no parity test of THIS op sees it.)"""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GUARD = 4096                  # floats on each side
+SENT = -7.25e33
+
+
+class Guarded:
+    def __init__(self, floats):
+        self.n = int(floats)
+        self.buf = torch.full((self.n + 2 * GUARD,), SENT, dtype=torch.float32, device="cuda")
+
+    @property
+    def ptr(self):
+        return ctypes.c_void_p(self.buf.data_ptr() + 4 * GUARD)
+
+    @property
+    def payload(self):
+        return self.buf[GUARD:GUARD + self.n]
+
+    def check(self, what, fully_written=True):
+        torch.cuda.synchronize()
+        assert bool((self.buf[:GUARD] == SENT).all()), f"{what}: store below the buffer"
+        assert bool((self.buf[GUARD + self.n:] == SENT).all()), f"{what}: store beyond the buffer"
+        if fully_written:
+            assert not bool((self.payload == SENT).any()), f"{what}: part of the output was never written"
+
+
+def _lib_and_names():
+    from semiuhpe_amd import _lib
+    lib = _lib.load()
+    lib.suhpe_conv2d_tile_name.restype = ctypes.c_char_p
+    lib.suhpe_conv2d_wino_filter_bytes.restype = ctypes.c_int64
+    lib.suhpe_conv2d_wgrad_workspace_bytes.restype = ctypes.c_int64
+    names = {p: [lib.suhpe_conv2d_tile_name(p, i).decode() for i in range(lib.suhpe_conv2d_tile_count(p))] for p in (0, 1, 2)}
+    return _lib, lib, names
+
+
+# n, cin, cout, groups, h, w, images of the first batch segment
+CASES = [(3, 8, 12, 1, 6, 6, 1), (5, 20, 36, 1, 10, 10, 2), (7, 16, 16, 2, 4, 4, 3), (2, 24, 24, 1, 18, 14, 1), (3, 48, 72, 1, 14, 22, 1),
+         (5, 64, 200, 1, 6, 10, 2), (2, 136, 44, 1, 8, 8, 1), (9, 32, 32, 4, 2, 2, 4)]
+
+
+@pytest.mark.parametrize("cfg", CASES, ids=str)
+def test_winograd_entry_points_stay_inside_their_buffers(cfg):
+    _lib, lib, names = _lib_and_names()
+    from semiuhpe_amd import kernels as K
+    n, cin, cout, g, h, w, seg = cfg
+    gen = torch.Generator().manual_seed(sum(cfg))
+    x = torch.randn(n, h, w, cin, generator=gen).cuda()
+    dy = torch.randn(n, h, w, cout, generator=gen).cuda()
+    wt = K.to_filter_layout((torch.randn(cout, cin // g, 3, 3, generator=gen) * 0.1).cuda())
+    d = K.conv_desc(x.shape, wt.shape, 1, 1, g)
+    dref = ctypes.byref(d)
+    for pid, nm in ((0, "wino_nt_kernel<64,64>"), (1, "wino_nt_kernel<64,64>"), (2, "wino_wgrad_kernel<64,64>")):
+        assert lib.suhpe_conv2d_set_tile(dref, pid, names[pid].index(nm)) == 0
+    try:
+        P = lambda t: ctypes.c_void_p(t.data_ptr())
+        # transformed filters (forward / input gradient)
+        fw = [Guarded(lib.suhpe_conv2d_wino_filter_bytes(dref, p) // 4) for p in (0, 1)]
+        for p in (0, 1):
+            _lib.call("suhpe_conv2d_wino_filter", dref, p, P(wt), fw[p].ptr)
+            fw[p].check(f"wino_filter pass {p}")
+        # forward + statistics records of two segments (the boundary record only exists when the segment cuts a 16-tile block)
+        tiles = lib.suhpe_conv2d_fwd_stats_tiles(dref)
+        y, st, ex = Guarded(n * h * w * cout), Guarded(cout * tiles * 4), Guarded(cout * 4)
+        _lib.call("suhpe_conv2d_fwd_wino", dref, P(x), P(wt), fw[0].ptr, None, y.ptr, st.ptr, ex.ptr, ctypes.c_int64(seg * h * w))
+        y.check("fwd_wino y")
+        st.check("fwd_wino stats")
+        ex.check("fwd_wino boundary record", fully_written=False)
+        # eval-mode epilogue
+        sc, sh = torch.rand(cout, generator=gen).cuda() + 0.5, torch.randn(cout, generator=gen).cuda()
+        ya = Guarded(n * h * w * cout)
+        _lib.call("suhpe_conv2d_fwd_affine_wino", dref, P(x), P(wt), fw[0].ptr, P(sc), P(sh), 3, y.ptr, 1, ya.ptr)
+        ya.check("fwd_affine_wino y")
+        # input gradient + skip (no transposed filter)
+        dx = Guarded(n * h * w * cin)
+        _lib.call("suhpe_conv2d_dgrad_wino", dref, P(dy), None, fw[1].ptr, P(x), dx.ptr)
+        dx.check("dgrad_wino dx")
+        # filter gradient: split-K slabs + finish kernel in the caller's workspace, then the reduction into dw
+        wsb = lib.suhpe_conv2d_wgrad_workspace_bytes(dref)
+        ws, dw = Guarded(wsb // 4), Guarded(wt.numel())
+        _lib.call("suhpe_conv2d_wgrad", dref, P(x), P(dy), dw.ptr, 0, ws.ptr, ctypes.c_int64(wsb))
+        ws.check("wgrad workspace", fully_written=False)
+        dw.check("wgrad dw")
+        # results against the direct tiles (the guard bands did not change what the kernels compute)
+        for pid in (0, 1, 2):
+            lib.suhpe_conv2d_set_tile(dref, pid, -1)
+        ref_y = K.conv2d_fwd(x, wt, None, 1, 1, g)
+        ref_dx = K.conv2d_dgrad(dy, wt, x.shape, 1, 1, g, skip=x)
+        ref_dw = K.conv2d_wgrad(x, dy, wt.shape, 1, 1, g)
+        rel = lambda a, b: float((a.double() - b.double().reshape(a.shape)).abs().max() / max(1.0, float(b.abs().max())))
+        assert rel(y.payload, ref_y) < 2e-5 and rel(dx.payload, ref_dx) < 2e-5
+        assert rel(dw.payload, ref_dw.permute(0, 2, 3, 1)) < 2e-5          # (filters are stored [cout][r][s][cin / groups])
+    finally:
+        for pid in (0, 1, 2):
+            lib.suhpe_conv2d_set_tile(dref, pid, -1)
+
+
+@pytest.mark.parametrize("c,tiles,first,boundary", [(24, 4000, 801, True), (12, 65, 65, True), (40, 37, 12, False), (192, 3100, 3100, None)], ids=str)
+def test_consuming_finalizer_stays_inside_its_buffers(c, tiles, first, boundary):
+    _lib, lib, _ = _lib_and_names()
+    gen = torch.Generator().manual_seed(c + tiles)
+    rec = Guarded(tiles * c * 4)
+    rec.payload.copy_(torch.randn(tiles * c * 4, generator=gen).cuda())
+    rec.payload.view(tiles, c, 4)[:, :, 3] = 16.0
+    two = boundary is not None
+    extra = torch.randn(c, 4, generator=gen).cuda() if boundary else None
+    if extra is not None:
+        extra[:, 3] = 16.0
+    rows = 16 * (tiles + (1 if boundary else 0))
+    rows_a = 16 * first if two else rows
+    mean, rstd, rm, rv = Guarded((2 if two else 1) * c), Guarded((2 if two else 1) * c), Guarded(c), Guarded(c)
+    rm.payload.fill_(0.0)
+    rv.payload.fill_(1.0)
+    nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+    _lib.call("suhpe_bn_stats_from_partials_consume", rec.ptr, tiles, first if two else tiles, ctypes.c_void_p(extra.data_ptr()) if boundary else None,
+              ctypes.c_int64(rows), ctypes.c_int64(rows_a), c, ctypes.c_float(1e-3), ctypes.c_float(0.1), mean.ptr, rstd.ptr, rm.ptr, rv.ptr,
+              ctypes.c_void_p(nbt.data_ptr()))
+    for gbuf, what in ((rec, "records"), (mean, "mean"), (rstd, "rstd"), (rm, "running_mean"), (rv, "running_var")):
+        gbuf.check(what)
+    assert int(nbt) == (2 if two else 1)
