@@ -128,3 +128,59 @@ def test_consuming_finalizer_stays_inside_its_buffers(c, tiles, first, boundary)
     for gbuf, what in ((rec, "records"), (mean, "mean"), (rstd, "rstd"), (rm, "running_mean"), (rv, "running_var")):
         gbuf.check(what)
     assert int(nbt) == (2 if two else 1)
+
+
+# n, cin, cout, k, stride, pad, groups, h, w: row counts off every tile height, channel counts off every tile width, strides, groups
+MENU_CASES = [(3, 20, 36, 1, 1, 0, 1, 9, 7), (2, 40, 24, 3, 1, 1, 1, 9, 11), (5, 16, 72, 3, 2, 1, 1, 13, 9), (2, 64, 48, 3, 1, 1, 2, 6, 10),
+              (37, 256, 132, 1, 1, 0, 1, 3, 3), (1, 8, 520, 1, 1, 0, 1, 5, 5)]
+
+
+@pytest.mark.parametrize("cfg", MENU_CASES, ids=str)
+def test_every_gemm_tile_stays_inside_its_buffers(cfg):
+    """every entry of the three tile menus that accepts the geometry (direct, halo, 48-column, persistent, resident, Winograd), forward / input gradient /
+    filter gradient, outputs and the split-K workspace between guard bands"""
+    _lib, lib, names = _lib_and_names()
+    from semiuhpe_amd import kernels as K
+    n, cin, cout, k, stride, pad, g, h, w = cfg
+    gen = torch.Generator().manual_seed(sum(cfg))
+    x = torch.randn(n, h, w, cin, generator=gen).cuda()
+    wt = K.to_filter_layout((torch.randn(cout, cin // g, k, k, generator=gen) * 0.1).cuda())
+    d = K.conv_desc(x.shape, wt.shape, stride, pad, g)
+    dref = ctypes.byref(d)
+    dy = torch.randn(n, d.ho, d.wo, cout, generator=gen).cuda()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    ref_y = K.conv2d_fwd(x, wt, None, stride, pad, g)
+    ref_dx = K.conv2d_dgrad(dy, wt, x.shape, stride, pad, g)
+    ref_dw = K.conv2d_wgrad(x, dy, wt.shape, stride, pad, g)
+    wT = torch.empty_like(wt)
+    _lib.call("suhpe_conv2d_transpose_filter", dref, P(wt), P(wT))
+    rel = lambda a, b: float((a.double() - b.double().reshape(a.shape)).abs().max() / max(1.0, float(b.abs().max())))
+    ran = 0
+    try:
+        for pid in (0, 1, 2):
+            for idx, name in enumerate(names[pid]):
+                if lib.suhpe_conv2d_set_tile(dref, pid, idx) != 0:
+                    continue                                    # this tile does not take the geometry
+                ran += 1
+                if pid == 0:
+                    y = Guarded(ref_y.numel())
+                    _lib.call("suhpe_conv2d_fwd", dref, P(x), P(wt), None, y.ptr)
+                    y.check(f"fwd {name}")
+                    assert rel(y.payload, ref_y) < 2e-5, name
+                elif pid == 1:
+                    dx = Guarded(x.numel())
+                    _lib.call("suhpe_conv2d_dgrad", dref, P(dy), P(wT), dx.ptr)
+                    dx.check(f"dgrad {name}")
+                    assert rel(dx.payload, ref_dx) < 2e-5, name
+                else:
+                    wsb = lib.suhpe_conv2d_wgrad_workspace_bytes(dref)
+                    ws, dw = Guarded(max(1, wsb // 4)), Guarded(wt.numel())
+                    _lib.call("suhpe_conv2d_wgrad", dref, P(x), P(dy), dw.ptr, 0, ws.ptr, ctypes.c_int64(wsb))
+                    ws.check(f"wgrad workspace {name}", fully_written=False)
+                    dw.check(f"wgrad {name}")
+                    assert rel(dw.payload, ref_dw.permute(0, 2, 3, 1)) < 2e-5, name
+                lib.suhpe_conv2d_set_tile(dref, pid, -1)
+    finally:
+        for pid in (0, 1, 2):
+            lib.suhpe_conv2d_set_tile(dref, pid, -1)
+    assert ran >= 12
