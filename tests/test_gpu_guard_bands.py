@@ -184,3 +184,96 @@ def test_every_gemm_tile_stays_inside_its_buffers(cfg):
         for pid in (0, 1, 2):
             lib.suhpe_conv2d_set_tile(dref, pid, -1)
     assert ran >= 12
+
+
+# n, c, h, w, stride: the image-tile kernels (14 x 14, 7 x 7), the sliding-window kernels, odd sizes, stride 2, few channels
+DW_CASES = [(5, 24, 14, 14, 1), (9, 40, 7, 7, 1), (3, 16, 28, 28, 1), (2, 8, 56, 56, 1), (3, 12, 15, 9, 1), (4, 20, 14, 14, 2), (2, 36, 13, 13, 2), (33, 4, 7, 7, 1)]
+
+
+@pytest.mark.parametrize("cfg", DW_CASES, ids=str)
+def test_depthwise_kernels_stay_inside_their_buffers(cfg):
+    """depthwise 3x3: forward, forward + statistics records (two segments), forward with the producer's BatchNorm + SiLU in the loader, input gradient,
+    filter gradient (+ its workspace)"""
+    _lib, lib, _ = _lib_and_names()
+    from semiuhpe_amd import kernels as K
+    lib.suhpe_dwconv_wgrad_workspace_bytes.restype = ctypes.c_int64
+    n, c, h, w, stride = cfg
+    gen = torch.Generator().manual_seed(sum(cfg))
+    x = torch.randn(n, h, w, c, generator=gen).cuda()
+    wt = (torch.randn(c, 1, 3, 3, generator=gen) * 0.3).cuda()
+    d = K.conv_desc(x.shape, wt.shape, stride, 1, c)
+    dref = ctypes.byref(d)
+    dy = torch.randn(n, d.ho, d.wo, c, generator=gen).cuda()
+    mean, rstd = torch.randn(2, c, generator=gen).cuda(), (torch.rand(2, c, generator=gen) + 0.5).cuda()
+    gamma, beta = torch.randn(c, generator=gen).cuda(), torch.randn(c, generator=gen).cuda()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    ysz = n * d.ho * d.wo * c
+    y = Guarded(ysz)
+    _lib.call("suhpe_dwconv_fwd", dref, P(x), P(wt), y.ptr)
+    y.check("dwconv_fwd")
+    blocks = lib.suhpe_dwconv_fwd_stats_blocks(dref)
+    seg = max(1, n // 3)
+    if blocks > 0:
+        y2, st = Guarded(ysz), Guarded(2 * blocks * c * 4)
+        _lib.call("suhpe_dwconv_fwd_stats", dref, P(x), P(wt), y2.ptr, st.ptr, seg)
+        y2.check("dwconv_fwd_stats y")
+        st.check("dwconv_fwd_stats records")
+        assert float((y2.payload - y.payload).abs().max()) < 1e-5          # (another kernel instance: other summation order)
+        y3, st3 = Guarded(ysz), Guarded(2 * blocks * c * 4)
+        _lib.call("suhpe_dwconv_bnact_fwd", dref, P(x), P(mean), P(rstd), P(gamma), P(beta), 3, seg, P(wt), y3.ptr, st3.ptr)
+        y3.check("dwconv_bnact_fwd y")
+        st3.check("dwconv_bnact_fwd records")
+    dx = Guarded(x.numel())
+    _lib.call("suhpe_dwconv_dgrad", dref, P(dy), P(wt), dx.ptr)
+    dx.check("dwconv_dgrad")
+    wsb = lib.suhpe_dwconv_wgrad_workspace_bytes(dref)
+    ws, dw = Guarded(max(1, wsb // 4)), Guarded(wt.numel())
+    _lib.call("suhpe_dwconv_wgrad", dref, P(x), P(dy), dw.ptr, 0, ws.ptr, ctypes.c_int64(wsb))
+    ws.check("dwconv_wgrad workspace", fully_written=False)
+    dw.check("dwconv_wgrad")
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double().cpu(), wt.double().cpu(), None, stride, 1, 1, c).permute(0, 2, 3, 1)
+    assert float((y.payload.cpu().double() - ref.reshape(-1)).abs().max()) < 1e-4
+
+
+# rows, c, hw (rows per sample): channel counts off the 4-wide vectors and the 64-column blocks, row counts off every block height
+BN_CASES = [(37 * 9, 24, 9), (5 * 49, 10, 49), (3 * 196, 132, 196), (1000, 7, 1), (64 * 16, 520, 16), (2 * 3136, 48, 3136)]
+
+
+@pytest.mark.parametrize("cfg", BN_CASES, ids=str)
+def test_batchnorm_kernels_stay_inside_their_buffers(cfg):
+    """train-mode BatchNorm: statistics (one and two segments) with their workspace, normalise + SiLU (+ skip), backward with its workspace"""
+    _lib, lib, _ = _lib_and_names()
+    lib.suhpe_bn_workspace_bytes.restype = ctypes.c_int64
+    rows, c, hw = cfg
+    gen = torch.Generator().manual_seed(rows + c)
+    x = torch.randn(rows, c, generator=gen).cuda()
+    dy = torch.randn(rows, c, generator=gen).cuda()
+    gamma, beta = torch.randn(c, generator=gen).cuda(), torch.randn(c, generator=gen).cuda()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    wsf = lib.suhpe_bn_workspace_bytes(c) // 4
+    nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+    ws, mean, rstd, rm, rv = Guarded(wsf), Guarded(c), Guarded(c), Guarded(c), Guarded(c)
+    rm.payload.zero_(); rv.payload.fill_(1.0)
+    _lib.call("suhpe_bn_stats", P(x), ctypes.c_int64(rows), c, ctypes.c_float(1e-3), ctypes.c_float(0.1), mean.ptr, rstd.ptr, rm.ptr, rv.ptr, P(nbt), ws.ptr)
+    ws.check("bn_stats workspace", fully_written=False)
+    for gb, what in ((mean, "mean"), (rstd, "rstd"), (rm, "running_mean"), (rv, "running_var")):
+        gb.check("bn_stats " + what)
+    assert float((mean.payload.cpu().double() - x.double().cpu().mean(0)).abs().max()) < 1e-5
+    y = Guarded(rows * c)
+    _lib.call("suhpe_bn_act_fwd", P(x), ctypes.c_int64(rows), c, mean.ptr, rstd.ptr, P(gamma), P(beta), 3, P(dy), y.ptr)
+    y.check("bn_act_fwd")
+    ws2, dx, dg, db = Guarded(wsf), Guarded(rows * c), Guarded(c), Guarded(c)
+    _lib.call("suhpe_bn_act_bwd", P(x), P(dy), None, ctypes.c_int64(rows), c, mean.ptr, rstd.ptr, P(gamma), P(beta), 3, 1, dx.ptr, dg.ptr, db.ptr, 0, ws2.ptr)
+    ws2.check("bn_act_bwd workspace", fully_written=False)
+    for gb, what in ((dx, "dx"), (dg, "dgamma"), (db, "dbeta")):
+        gb.check("bn_act_bwd " + what)
+    if rows // hw >= 2:                                             # two batch segments (whole samples each)
+        rows_a = (rows // hw // 2) * hw
+        ws3, m2, r2 = Guarded(wsf), Guarded(2 * c), Guarded(2 * c)
+        _lib.call("suhpe_bn_stats_seg", P(x), ctypes.c_int64(rows), ctypes.c_int64(rows_a), c, ctypes.c_float(1e-3), ctypes.c_float(0.1), m2.ptr, r2.ptr,
+                  rm.ptr, rv.ptr, P(nbt), ws3.ptr)
+        ws3.check("bn_stats_seg workspace", fully_written=False)
+        m2.check("bn_stats_seg mean"); r2.check("bn_stats_seg rstd")
+        y2 = Guarded(rows * c)
+        _lib.call("suhpe_bn_act_fwd_seg", P(x), ctypes.c_int64(rows), ctypes.c_int64(rows_a), c, m2.ptr, r2.ptr, P(gamma), P(beta), 3, None, 0, None, hw, y2.ptr)
+        y2.check("bn_act_fwd_seg")
