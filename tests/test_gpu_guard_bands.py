@@ -277,3 +277,50 @@ def test_batchnorm_kernels_stay_inside_their_buffers(cfg):
         y2 = Guarded(rows * c)
         _lib.call("suhpe_bn_act_fwd_seg", P(x), ctypes.c_int64(rows), ctypes.c_int64(rows_a), c, m2.ptr, r2.ptr, P(gamma), P(beta), 3, None, 0, None, hw, y2.ptr)
         y2.check("bn_act_fwd_seg")
+
+
+# B, H, W, window, heads: TinyViT's windows (7 x 7 on 7 / 14 / 28-wide maps, 14 x 14 on the 14-wide map)
+ATTN_CASES = [(3, 14, 14, 7, 2), (2, 28, 28, 7, 3), (5, 7, 7, 7, 1), (2, 14, 14, 14, 4), (1, 28, 14, 7, 18)]
+
+
+@pytest.mark.parametrize("cfg", ATTN_CASES, ids=str)
+def test_window_attention_stays_inside_its_buffers(cfg):
+    """windowed attention forward (output, saved probabilities, bias workspace) and backward (dqkv, score-gradient workspace, bias-table gradient)"""
+    _lib, lib, _ = _lib_and_names()
+    from semiuhpe_amd.src.tiny_vit import attention_bias_index
+    for f in ("suhpe_window_attn_fwd_workspace_bytes", "suhpe_window_attn_probs_elems", "suhpe_window_attn_dbias_workspace_bytes"):
+        getattr(lib, f).restype = ctypes.c_int64
+    B, H, W, ws, heads = cfg
+    dh, N = 32, ws * ws
+    gen = torch.Generator().manual_seed(sum(cfg))
+    idx, noff = attention_bias_index(ws)
+    bias_idx = idx.to(torch.int32).cuda().contiguous()
+    qkv = torch.randn(B * H * W, heads * 3 * dh, generator=gen).cuda()
+    table = torch.randn(heads, noff, generator=gen).cuda()
+    dout = torch.randn(B * H * W, heads * dh, generator=gen).cuda()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    pe = lib.suhpe_window_attn_probs_elems(B, H, W, ws, heads)
+    out, probs, wsf = Guarded(B * H * W * heads * dh), Guarded(pe), Guarded(lib.suhpe_window_attn_fwd_workspace_bytes(ws, heads) // 4)
+    _lib.call("suhpe_window_attn_fwd", P(qkv), P(table), P(bias_idx), B, H, W, ws, heads, dh, noff, ctypes.c_float(dh ** -0.5), out.ptr, probs.ptr, wsf.ptr)
+    out.check("attn_fwd out")
+    probs.check("attn_fwd probs")
+    wsf.check("attn_fwd workspace", fully_written=False)
+    dqkv, dS = Guarded(qkv.numel()), Guarded(pe)
+    _lib.call("suhpe_window_attn_bwd", P(qkv), probs.ptr, P(dout), P(bias_idx), B, H, W, ws, heads, dh, noff, ctypes.c_float(dh ** -0.5), dqkv.ptr, None, dS.ptr)
+    dqkv.check("attn_bwd dqkv")
+    dS.check("attn_bwd score gradient")
+    # inverse of bias_idx in CSR form, then the reproducible bias-table gradient
+    flat = idx.reshape(-1)
+    order = torch.argsort(flat, stable=True)
+    inv_list = order.to(torch.int32).cuda().contiguous()
+    inv_ptr = torch.zeros(noff + 1, dtype=torch.int32)
+    inv_ptr[1:] = torch.cumsum(torch.bincount(flat, minlength=noff), 0).to(torch.int32)
+    inv_ptr = inv_ptr.cuda()
+    dtab, wsd = Guarded(heads * noff), Guarded(max(1, lib.suhpe_window_attn_dbias_workspace_bytes(ws, heads) // 4))
+    dtab.payload.zero_()
+    _lib.call("suhpe_window_attn_dbias", dS.ptr, P(inv_ptr), P(inv_list), B, H, W, ws, heads, noff, dtab.ptr, wsd.ptr)
+    dtab.check("attn_dbias table")
+    wsd.check("attn_dbias workspace", fully_written=False)
+    # the probabilities of a window are a softmax: rows sum to one
+    pr = probs.payload.view(-1, N, N)
+    assert float((pr.sum(-1) - 1.0).abs().max()) < 1e-4
