@@ -324,3 +324,67 @@ def test_window_attention_stays_inside_its_buffers(cfg):
     # the probabilities of a window are a softmax: rows sum to one
     pr = probs.payload.view(-1, N, N)
     assert float((pr.sum(-1) - 1.0).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("rows,c", [(784 * 3, 192), (49 * 5 + 3, 576), (1000, 100), (37, 384)], ids=str)
+def test_layernorm_stays_inside_its_buffers(rows, c):
+    _lib, lib, _ = _lib_and_names()
+    lib.suhpe_bn_workspace_bytes.restype = ctypes.c_int64
+    gen = torch.Generator().manual_seed(rows + c)
+    x, dy = torch.randn(rows, c, generator=gen).cuda(), torch.randn(rows, c, generator=gen).cuda()
+    gamma, beta = torch.randn(c, generator=gen).cuda(), torch.randn(c, generator=gen).cuda()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    y, mean, rstd = Guarded(rows * c), Guarded(rows), Guarded(rows)
+    _lib.call("suhpe_layernorm_fwd", P(x), ctypes.c_int64(rows), c, ctypes.c_float(1e-5), P(gamma), P(beta), y.ptr, mean.ptr, rstd.ptr)
+    for gb, what in ((y, "y"), (mean, "mean"), (rstd, "rstd")):
+        gb.check("layernorm_fwd " + what)
+    ref = torch.nn.functional.layer_norm(x.double().cpu(), (c,), gamma.double().cpu(), beta.double().cpu(), 1e-5)
+    assert float((y.payload.cpu().double() - ref.reshape(-1)).abs().max()) < 1e-4
+    ws, dx, dg, db = Guarded(lib.suhpe_bn_workspace_bytes(c) // 4), Guarded(rows * c), Guarded(c), Guarded(c)
+    _lib.call("suhpe_layernorm_bwd_skip", P(x), P(dy), ctypes.c_int64(rows), c, mean.ptr, rstd.ptr, P(gamma), P(x), dx.ptr, dg.ptr, db.ptr, 0, ws.ptr)
+    ws.check("layernorm_bwd workspace", fully_written=False)
+    for gb, what in ((dx, "dx"), (dg, "dgamma"), (db, "dbeta")):
+        gb.check("layernorm_bwd " + what)
+
+
+@pytest.mark.parametrize("n,c,csq,hw", [(7, 96, 8, 49), (33, 512, 32, 196), (5, 1536, 64, 49), (160, 960, 40, 4)], ids=str)
+def test_squeeze_excitation_section_stays_inside_its_buffers(n, c, csq, hw):
+    """depthwise BatchNorm -> SiLU -> squeeze, excitation MLP (forward / backward with its workspace), scale pass, backward reduce / combine / apply"""
+    _lib, lib, _ = _lib_and_names()
+    gen = torch.Generator().manual_seed(n + c)
+    rows = n * hw
+    x, dout = torch.randn(rows, c, generator=gen).cuda(), torch.randn(rows, c, generator=gen).cuda()
+    mean, rstd = torch.randn(c, generator=gen).cuda() * 0.1, (torch.rand(c, generator=gen) + 0.5).cuda()
+    gamma, beta = torch.randn(c, generator=gen).cuda(), torch.randn(c, generator=gen).cuda()
+    w1, b1 = (torch.randn(csq, c, generator=gen) * 0.05).cuda(), torch.randn(csq, generator=gen).cuda()
+    w2, b2 = (torch.randn(c, csq, generator=gen) * 0.05).cuda(), torch.randn(c, generator=gen).cuda()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    pool = Guarded(n * c)
+    _lib.call("suhpe_bn_act_pool_fwd", P(x), ctypes.c_int64(rows), ctypes.c_int64(0), c, hw, P(mean), P(rstd), P(gamma), P(beta), 3, None, pool.ptr)
+    pool.check("bn_act_pool_fwd (squeeze alone)")
+    a1, s = Guarded(n * csq), Guarded(n * c)
+    _lib.call("suhpe_se_mlp_fwd", pool.ptr, P(w1), P(b1), P(w2), P(b2), n, c, csq, a1.ptr, s.ptr)
+    a1.check("se_mlp_fwd a1"); s.check("se_mlp_fwd s")
+    y = Guarded(rows * c)
+    _lib.call("suhpe_bn_act_scale_fwd", P(x), ctypes.c_int64(rows), ctypes.c_int64(0), c, hw, P(mean), P(rstd), P(gamma), P(beta), 3, s.ptr, y.ptr)
+    y.check("bn_act_scale_fwd")
+    sums = Guarded(5 * n * c)
+    _lib.call("suhpe_se_bn_bwd_reduce", P(x), P(dout), ctypes.c_int64(rows), ctypes.c_int64(0), c, hw, P(mean), P(rstd), P(gamma), P(beta), 3, sums.ptr)
+    sums.check("se_bn_bwd_reduce sums")
+    ws, dp = Guarded(n * (c + 2 * csq)), Guarded(n * c)
+    dws = [Guarded(t.numel()) for t in (w1, b1, w2, b2)]
+    for g_ in dws:
+        g_.payload.zero_()
+    _lib.call("suhpe_se_mlp_bwd", sums.ptr, s.ptr, a1.ptr, pool.ptr, P(w1), P(w2), n, c, csq, dp.ptr, dws[0].ptr, dws[1].ptr, dws[2].ptr, dws[3].ptr, ws.ptr)
+    ws.check("se_mlp_bwd workspace", fully_written=False)
+    dp.check("se_mlp_bwd dp")
+    for g_, what in zip(dws, ("dw1", "db1", "dw2", "db2")):
+        g_.check("se_mlp_bwd " + what)
+    chan, dg, db = Guarded(4 * c), Guarded(c), Guarded(c)
+    _lib.call("suhpe_se_bn_bwd_combine", sums.ptr, s.ptr, dp.ptr, n, 0, c, hw, chan.ptr, dg.ptr, db.ptr, 0)
+    chan.check("se_bn_bwd_combine chan", fully_written=False)
+    dg.check("se_bn_bwd_combine dgamma"); db.check("se_bn_bwd_combine dbeta")
+    dyo = Guarded(rows * c)
+    _lib.call("suhpe_se_bn_bwd_apply", P(x), P(dout), ctypes.c_int64(rows), ctypes.c_int64(0), c, hw, P(mean), P(rstd), P(gamma), P(beta), 3, s.ptr, dp.ptr, chan.ptr,
+              1, dyo.ptr)
+    dyo.check("se_bn_bwd_apply")
