@@ -130,10 +130,13 @@ int suhpe_conv2d_set_tile(const suhpe_conv_t* d, int pass, int tile);
  *                                            its transposed / 180-degree rotated form for pass 1 (input gradient: no transposed copy needed),
  *                                            in the kernel's LDS image order; redo after every weight update
  *   suhpe_conv2d_fwd_wino                    suhpe_conv2d_fwd / _fwd_stats / _fwd_stats_seg in one: bias may be NULL; stats NULL = no records;
- *                                            stats_extra / seg_row as suhpe_conv2d_fwd_stats_seg.  fw NULL = the tile transforms the filter rows
- *                                            itself (slower); on a (d, pass) whose tile is not the Winograd one, fw is ignored and w is used
- *   suhpe_conv2d_dgrad_wino                  suhpe_conv2d_dgrad_add with the same rule; wt (the transposed filter) may be NULL when fw is given
- *                                            and suhpe_conv2d_wino_pinned(d, 1) holds
+ *                                            stats_extra / seg_row as suhpe_conv2d_fwd_stats_seg.  fw NULL = the launch falls back to a DIRECT tile
+ *                                            on w (direct-kernel rounding, no Winograd arithmetic: the kernel never transforms filters itself);
+ *                                            on a (d, pass) whose tile is not the Winograd one, fw is ignored and w is used
+ *   suhpe_conv2d_dgrad_wino                  suhpe_conv2d_dgrad_add with the same rule; wt (the transposed filter) may be NULL ONLY when fw is given
+ *                                            and suhpe_conv2d_wino_pinned(d, 1) holds -- any other call with wt NULL returns SUHPE_EINVAL
+ * Eval-mode passes on database-pinned shapes run the AFFINE instantiations of the same kernel (suhpe_conv2d_fwd_affine_wino), i.e. on
+ * Winograd rounding as well.
  * Results differ from the direct tiles by rounding (measured: closer to float64 than the direct sum).  SUHPE_WINOGRAD=0 disables the tile. */
 int suhpe_conv2d_wino_pinned(const suhpe_conv_t* d, int pass);
 int64_t suhpe_conv2d_wino_filter_bytes(const suhpe_conv_t* d, int pass);

@@ -38,9 +38,11 @@
 // 64 banks once per lane group, writes (ds_write_b128, 8-lane groups: one row, 2 channel vectors, 4 patch rows) all 32.
 //
 // Epilogues: bias, skip-connection add (res_mode 3), BatchNorm statistics records per wavefront block of 16 tiles (64 rows per record, the
-// same (S, Q, k, n) format and segment rule as igemm_nt_kernel's).  No folded-affine (eval) form: eval passes keep the direct kernels, so
-// the eval-mode parity figures are untouched; no self-transforming form either: without a Winograd-domain filter (plain suhpe_conv2d_fwd
-// with the tile pinned) the dispatch runs a direct tile.
+// same (S, Q, k, n) format and segment rule as igemm_nt_kernel's).  MODE bit 2 (instantiations 4-6, `AFFINE`) is the eval-mode form: folded
+// BatchNorm scale / shift + activation + skip add in the output-transform epilogue, no statistics (suhpe_conv2d_fwd_affine_wino), so eval passes
+// on database-pinned shapes run on Winograd rounding too (parity re-measured: tests/test_gpu_winograd.py, bench.py mae_parity).  There is no
+// self-transforming form: without a Winograd-domain filter (fw NULL, or plain suhpe_conv2d_fwd with the tile pinned) the dispatch runs a
+// direct tile.
 #include "conv_params.h"
 #include <cstdlib>
 #include <type_traits>
@@ -72,6 +74,15 @@ struct WinoGeom {
 constexpr int WN_XI = 512;               // floats per transform position of one LDS image: 64 rows x 8 channels
 constexpr int WN_IMG = 16 * WN_XI;       // floats per image (V or U) = 32 KB
 
+// A 16-byte store hipcc does not see.  The compiler waits (s_waitcnt vmcnt(0)) before it reuses the data registers of a store IT issued, and inside the
+// persistent chunk loop every such wait also drains the hand-managed prefetch queue: the round-4 epilogue sat through eight of them per item (one per
+// statistics record round).  The hardware reads a store's data registers right after issue: two wait states (s_nop 1) cover it.
+__device__ __forceinline__ void store4_unseen(float* ptr, float a, float b, float c, float d) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 v = {a, b, c, d};
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(ptr), "v"(v) : "memory");
+}
+
 template <int CTRL> __device__ __forceinline__ float quad_dpp(float v) {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, false));
 }
@@ -102,7 +113,16 @@ template <int MODE>
 __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const WinoGeom wg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const GatherGeom& g = p.g;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // The wavefront index is uniform (a scalar register); the lane index is RE-MADE where the rarely run parts need it (setup_v, the epilogue) by two
+    // v_mbcnt instructions instead of being kept in a register across the chunk loop: every register kept alive there is one the 48-output form spills,
+    // and a spill reload anywhere in the loop makes the compiler drain the vector-memory queue (prefetches included) at the head of every pass.
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    auto lane_now = [&]() __attribute__((always_inline)) {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    };
+    const int lane = lane_now(), t = wave * 64 + lane;
     const int grp = blockIdx.z;
     // buffer descriptor of the gathered tensor as four scalars (the patch-row loads are inline asm: see issue_loads)
     u32x4w xrs;
@@ -141,8 +161,9 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
     int lu_item = blockIdx.x, lu_chunk = 0, lu_ub = 0;          // U cursor: next chunk to copy, into U image lu_ub (0..2)
     int lv_item = blockIdx.x, lv_sc = 0;                        // V cursor: next super-chunk to load
     unsigned voff[4];
-    const float* ufw = nullptr;                                 // Winograd-domain filter image of (lu_item's cout block, chunk 0) + this thread's slice
+    const float* ufw = nullptr;                                 // Winograd-domain filter image of (lu_item's cout block, chunk 0)
     auto setup_v = [&]() __attribute__((always_inline)) {
+        const int t = wave * 64 + lane_now(), si = t & 3, sv = (t >> 2) & 1, stl = t >> 3;      // (re-made, see above)
         const int jx = lv_item >> 3;
         const int tile0 = (rt_first + jx / p.col_tiles) * 64;
         const int T = tile0 + stl;
@@ -161,8 +182,9 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
     };
     auto setup_u = [&]() __attribute__((always_inline)) {
         const int col_tile = (lu_item >> 3) % p.col_tiles;
-        ufw = p.fw + (int64_t)grp * wg.fw_group_stride + (int64_t)col_tile * wg.nchunks * WN_IMG + wave * 1024 + lane * 4;
+        ufw = p.fw + (int64_t)grp * wg.fw_group_stride + (int64_t)col_tile * wg.nchunks * WN_IMG;      // (workgroup-uniform: lives in scalar registers)
     };
+    const unsigned u_lane_off = (unsigned)(wave * 1024 + lane * 4) * 4u;      // this thread's 16 bytes of each 1 KiB piece of a U image
     // Every vector-memory operation of the chunk loop is inline asm and every wait is written by hand.  Behind the builtins the compiler (1) cannot tell
     // an LDS-DMA's destination image from the fragment reads that follow and parks an s_waitcnt vmcnt(0) in front of the MFMAs, and (2) counts only the
     // loads it knows when it waits for a register load, so beside DMAs it drains the whole queue.  (Loads return in issue order; the waits below count
@@ -188,18 +210,19 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
         // (LDS address = M0 + instruction offset + 16 * lane; the instruction offset also advances the global address)
         const unsigned lds_dst = __builtin_amdgcn_readfirstlane(
             (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)(smem + WN_U0 + lu_ub * WN_IMG + wave * 1024));
+        // scalar base + one 32-bit lane offset (a 64-bit per-lane address costs two more registers, and the 48-output form spilled exactly such pairs)
         const float* src = ufw + (int64_t)lu_chunk * WN_IMG;
         unsigned keep;
         asm volatile(
             "s_mov_b32 %0, m0\n\t"
             "s_mov_b32 m0, %2\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, off\n\t"
-            "global_load_lds_dwordx4 %1, off offset:1024\n\t"
-            "global_load_lds_dwordx4 %1, off offset:2048\n\t"
-            "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+            "s_nop 2\n\t"                                       // 5 wait states in all: the scalar base may come straight from a v_readlane (an SGPR the compiler parked in a VGPR)
+            "global_load_lds_dwordx4 %1, %3\n\t"
+            "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+            "global_load_lds_dwordx4 %1, %3 offset:2048\n\t"
+            "global_load_lds_dwordx4 %1, %3 offset:3072\n\t"
             "s_mov_b32 m0, %0"
-            : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+            : "=&s"(keep) : "v"(u_lane_off), "s"(lds_dst), "s"(src) : "memory");
         lu_ub = lu_ub == 2 ? 0 : lu_ub + 1;
         if (++lu_chunk == wg.nchunks) {
             lu_chunk = 0;
@@ -233,13 +256,12 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
     constexpr bool AFFINE = (MODE & 4) != 0;                    // eval-mode epilogue: y = act(acc * scale + shift [+ res]) [+ res] (no bias, no statistics)
     constexpr int NBLK = NARROW ? 1 : 2;                        // cout blocks of a wavefront
     const int tb = wave & 3, ch = wave >> 2, j16 = lane & 15, kg = lane >> 4;
-    int vrd[4], urd[2][4];                                      // slot offsets for the four patch rows i (pair m adds m * 1024)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        vrd[i] = wino_slot_off(2 * i, 16 * tb + j16, kg) - 2 * i * 1024;
-        urd[0][i] = wino_slot_off(2 * i, (NARROW ? 16 : 32) * ch + j16, kg) - 2 * i * 1024;
-        urd[1][i] = wino_slot_off(2 * i, 32 * ch + 16 + j16, kg) - 2 * i * 1024;
-    }
+    // slot offsets of this lane's fragment rows for patch row i = 0 (pair m adds m * 1024).  The swizzle of wino_slot_off only XORs bit 4 with i & 1 and
+    // bits 2-3 with i >> 1, so the other three patch rows are one v_xor with a constant away (vrd(i)) and the second cout block (row + 16: same swizzle)
+    // sits 256 floats behind the first: 2 registers instead of 12 -- the 48-output form spilled with the table, and its reloads put s_waitcnt vmcnt(0)
+    // between the prefetches of the chunk loop.
+    const int vrd0 = wino_slot_off(0, 16 * tb + j16, kg), urd0 = wino_slot_off(0, (NARROW ? 16 : 32) * ch + j16, kg);
+    auto swz = [](int base, int i) __attribute__((always_inline)) { return base ^ (((i & 1) << 4) | ((i >> 1) << 2)); };
     floatx4w acc[16][NBLK];
     auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -261,9 +283,9 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
         const float* Vs = smem + vb * WN_IMG;
         const float* Us = smem + WN_U0 + ub * WN_IMG;
         auto read_frags = [&](int m, int set) __attribute__((always_inline)) {
-            vf[set] = *reinterpret_cast<const float4*>(&Vs[m * 1024 + vrd[m >> 1]]);
-            uf[set][0] = *reinterpret_cast<const float4*>(&Us[m * 1024 + urd[0][m >> 1]]);
-            if (!NARROW) uf[set][1] = *reinterpret_cast<const float4*>(&Us[m * 1024 + urd[1][m >> 1]]);
+            vf[set] = *reinterpret_cast<const float4*>(&Vs[m * 1024 + swz(vrd0, m >> 1)]);
+            uf[set][0] = *reinterpret_cast<const float4*>(&Us[m * 1024 + swz(urd0, m >> 1)]);
+            if (!NARROW) uf[set][1] = *reinterpret_cast<const float4*>(&Us[m * 1024 + 256 + swz(urd0, m >> 1)]);
         };
         if (M0 == 0) read_frags(0, 0);
 #pragma unroll
@@ -289,24 +311,15 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
     };
 
     // ---- epilogue of the item under the MFMAs: output transform in registers, stores, statistics
-    auto epilogue = [&](int tile0, int n0, int row_tile) __attribute__((always_inline)) {
-        float out[4][2][4];                                      // [pixel (py, px) = (q >> 1, q & 1)][cout block][e]
-#pragma unroll
-        for (int bb = 0; bb < NBLK; ++bb)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t0[4], t1[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float m0 = acc[4 * i][bb][e], m1 = acc[4 * i + 1][bb][e], m2 = acc[4 * i + 2][bb][e], m3 = acc[4 * i + 3][bb][e];
-                    t0[i] = m0 + m1 + m2;
-                    t1[i] = m1 - m2 - m3;
-                }
-                out[0][bb][e] = t0[0] + t0[1] + t0[2];
-                out[1][bb][e] = t1[0] + t1[1] + t1[2];
-                out[2][bb][e] = t0[1] - t0[2] - t0[3];
-                out[3][bb][e] = t1[1] - t1[2] - t1[3];
-            }
+    // LOADS: the launch has epilogue operands (skip tensor, bias, or the eval-mode scale / shift).  Two compile-time copies of the epilogue behind one
+    // uniform branch, and in the copy WITH operands every load is an unseen asm load from an always-valid address (a dummy when the operand is absent or
+    // the lane out of range), waited for ONCE by hand and selected afterwards.  Why: any load or store hipcc itself issues inside the persistent loop puts
+    // its s_waitcnt vmcnt(0) there -- at the use, at the join of a divergent branch, or (a use under another run-time test than its load) carried around
+    // the back edge to the head of EVERY pass, right behind the U image's DMA issue, where the round-4 build waited out the whole DMA latency before the
+    // first MFMA of every second chunk -- and each of them drains the hand-managed prefetch queue (tools/debug/wino_waits.py lists them: none now).
+    auto epilogue = [&](int tile0, int n0, int row_tile, auto loads_t) __attribute__((always_inline)) {
+        constexpr bool LOADS = decltype(loads_t)::value;
+        const int lane = lane_now(), j16 = lane & 15, kg = lane >> 4;      // (re-made, see the top of the kernel)
         const int Tj = tile0 + 16 * tb + j16;
         const bool tvalid = Tj < wg.MT;
         int64_t pix0;
@@ -319,77 +332,122 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
         }
         const int colb[2] = {n0 + (NARROW ? 16 : 32) * ch + 4 * kg, n0 + 32 * ch + 16 + 4 * kg};
         float* __restrict__ y = p.y + (int64_t)grp * p.Ng;
-        {
-            float rv[4][2][4];
-            if (AFFINE ? p.res_mode != 0 : p.res_mode == 3) {    // the skip operand, every load ahead of the stores (it may alias y for the compiler)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int bb = 0; bb < NBLK; ++bb) {
-                        const int64_t pix = pix0 + (q >> 1) * g.OW + (q & 1);
-                        const bool ok = tvalid && colb[bb] < p.Ng;
-                        const float4 r4 = ok ? *reinterpret_cast<const float4*>(&p.residual[pix * p.ldy + grp * p.Ng + colb[bb]]) : make_float4(0.f, 0.f, 0.f, 0.f);
-                        rv[q][bb][0] = r4.x; rv[q][bb][1] = r4.y; rv[q][bb][2] = r4.z; rv[q][bb][3] = r4.w;
-                    }
-            }
+        const bool has_res = AFFINE ? p.res_mode != 0 : p.res_mode == 3;
+        floatx4w rvq[LOADS ? 4 : 1][2], opa[2], opb[2];          // skip values [pixel][block]; bias or scale; shift
+        if constexpr (LOADS) {
+            const float* dummy = p.y;                            // (16-byte aligned, always mapped; what it holds is never used)
+            auto ld4 = [&](const float* ptr, floatx4w& dst) __attribute__((always_inline)) {
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+            };
 #pragma unroll
             for (int bb = 0; bb < NBLK; ++bb) {
-                if (!(tvalid && colb[bb] < p.Ng)) continue;
-                if ((WINO_ABLATE & 32) && out[0][bb][0] != 12345.678f) continue;      // (timing experiment: the output transform stays, the stores go)
-                if constexpr (AFFINE) {
-                    const float4 sc = *reinterpret_cast<const float4*>(&p.scale[grp * p.Ng + colb[bb]]);
-                    const float4 sh = *reinterpret_cast<const float4*>(&p.shift[grp * p.Ng + colb[bb]]);
-                    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int64_t pix = pix0 + (q >> 1) * g.OW + (q & 1);
-                        float o[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float v = fmaf(out[q][bb][e], scv[e], shv[e]);
-                            if (p.res_mode == 1) v += rv[q][bb][e];
-                            v = act_apply(v, p.act);
-                            if (p.res_mode == 2) v += rv[q][bb][e];
-                            o[e] = v;
-                        }
-                        *reinterpret_cast<float4*>(&y[pix * p.ldy + colb[bb]]) = make_float4(o[0], o[1], o[2], o[3]);
-                    }
-                    continue;
-                }
-                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.bias) bv = *reinterpret_cast<const float4*>(&p.bias[grp * p.Ng + colb[bb]]);
+                const bool col_ok = colb[bb] < p.Ng;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int64_t pix = pix0 + (q >> 1) * g.OW + (q & 1);
-                    float4 o = make_float4(out[q][bb][0] + bv.x, out[q][bb][1] + bv.y, out[q][bb][2] + bv.z, out[q][bb][3] + bv.w);
-                    if (p.res_mode == 3) { o.x += rv[q][bb][0]; o.y += rv[q][bb][1]; o.z += rv[q][bb][2]; o.w += rv[q][bb][3]; }
-                    *reinterpret_cast<float4*>(&y[pix * p.ldy + colb[bb]]) = o;
+                    ld4(has_res && tvalid && col_ok ? &p.residual[pix * p.ldy + grp * p.Ng + colb[bb]] : dummy, rvq[q][bb]);
+                }
+                if constexpr (AFFINE) {
+                    ld4(col_ok ? &p.scale[grp * p.Ng + colb[bb]] : dummy, opa[bb]);
+                    ld4(col_ok ? &p.shift[grp * p.Ng + colb[bb]] : dummy, opb[bb]);
+                } else {
+                    ld4(p.bias && col_ok ? &p.bias[grp * p.Ng + colb[bb]] : dummy, opa[bb]);
                 }
             }
         }
-        // BatchNorm statistics: one (S, Q, k, n) record per (16-tile block of a wavefront = 64 output pixels, cout): sums over the block's valid pixels
-        // shifted by k = the block's first output.  Everything stays inside the wavefront -- k by a 16-lane broadcast, the sums over the 16 tiles by
-        // DPP row rotations, the record written by the row's first lane -- no LDS, no barrier (the first version went through LDS with three barriers
-        // and 128 ds_bpermute shuffles per item: 60-85 us of a 480 us launch, tools/wino_ablate.sh).  The block that contains the segment boundary
-        // emits its first-segment tiles to `stats`, the rest to `stats_extra`.
-        if (!AFFINE && p.stats && !(WINO_ABLATE & 64)) {
-            const int blk0 = tile0 + 16 * tb;                    // first tile of this wavefront's block
-            const int cut = wg.seg_tile > blk0 && wg.seg_tile < blk0 + 16 && p.stats_extra ? wg.seg_tile : 0x7fffffff;    // first tile of the second part
-            const bool first = tvalid && Tj < cut, second = tvalid && Tj >= cut;
-            int nvalid = wg.MT - blk0;
-            nvalid = nvalid < 0 ? 0 : (nvalid > 16 ? 16 : nvalid);
-            const int n1 = cut == 0x7fffffff ? nvalid : cut - blk0;
-            float4* rec = reinterpret_cast<float4*>(p.stats) + ((int64_t)row_tile * 4 + tb) * p.stat_cout + grp * p.Ng;
-            float4* rec2 = reinterpret_cast<float4*>(p.stats_extra) + grp * p.Ng;
+        // statistics bookkeeping of this wavefront's 16-tile block (see below)
+        const int blk0 = tile0 + 16 * tb;                        // first tile of the block
+        const int cut = wg.seg_tile > blk0 && wg.seg_tile < blk0 + 16 && p.stats_extra ? wg.seg_tile : 0x7fffffff;    // first tile of the second part
+        const bool first = tvalid && Tj < cut, second = tvalid && Tj >= cut;
+        int nvalid = wg.MT - blk0;
+        nvalid = nvalid < 0 ? 0 : (nvalid > 16 ? 16 : nvalid);
+        const int n1 = cut == 0x7fffffff ? nvalid : cut - blk0;
+        // One cout block at a time -- output transform A^T M A in registers, stores, statistics -- so that only 16 transformed values are live beside the
+        // accumulators and the next item's prefetched patch rows (both blocks at once spilled in the 48-output form, and a spill reload inside this loop
+        // makes the compiler drain the whole vector-memory queue, prefetches included, at the head of every pass).
 #pragma unroll
-            for (int bb = 0; bb < NBLK; ++bb)
+        for (int bb = 0; bb < NBLK; ++bb) {
+            float out[4][4];                                     // [pixel (py, px) = (q >> 1, q & 1)][e]
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t0[4], t1[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float m0 = acc[4 * i][bb][e], m1 = acc[4 * i + 1][bb][e], m2 = acc[4 * i + 2][bb][e], m3 = acc[4 * i + 3][bb][e];
+                    t0[i] = m0 + m1 + m2;
+                    t1[i] = m1 - m2 - m3;
+                }
+                out[0][e] = t0[0] + t0[1] + t0[2];
+                out[1][e] = t1[0] + t1[1] + t1[2];
+                out[2][e] = t0[1] - t0[2] - t0[3];
+                out[3][e] = t1[1] - t1[2] - t1[3];
+            }
+            const bool col_ok = colb[bb] < p.Ng;
+            const bool store_ok = tvalid && col_ok && !((WINO_ABLATE & 32) && out[0][0] != 12345.678f);      // (timing experiment: the transform stays, the stores go)
+            if constexpr (LOADS) {
+                if (bb == 0) {                                   // the one wait of the epilogue: every operand of both blocks (issued before block 0's transform)
+                    if constexpr (NBLK == 2) {
+                        if constexpr (AFFINE)
+                            asm volatile("s_waitcnt vmcnt(0) ; covers-loads" : "+v"(rvq[0][0]), "+v"(rvq[1][0]), "+v"(rvq[2][0]), "+v"(rvq[3][0]), "+v"(rvq[0][1]), "+v"(rvq[1][1]), "+v"(rvq[2][1]),
+                                         "+v"(rvq[3][1]), "+v"(opa[0]), "+v"(opa[1]), "+v"(opb[0]), "+v"(opb[1]) :: "memory");
+                        else
+                            asm volatile("s_waitcnt vmcnt(0) ; covers-loads" : "+v"(rvq[0][0]), "+v"(rvq[1][0]), "+v"(rvq[2][0]), "+v"(rvq[3][0]), "+v"(rvq[0][1]), "+v"(rvq[1][1]), "+v"(rvq[2][1]),
+                                         "+v"(rvq[3][1]), "+v"(opa[0]), "+v"(opa[1]) :: "memory");
+                    } else {
+                        if constexpr (AFFINE)
+                            asm volatile("s_waitcnt vmcnt(0) ; covers-loads" : "+v"(rvq[0][0]), "+v"(rvq[1][0]), "+v"(rvq[2][0]), "+v"(rvq[3][0]), "+v"(opa[0]), "+v"(opb[0]) :: "memory");
+                        else
+                            asm volatile("s_waitcnt vmcnt(0) ; covers-loads" : "+v"(rvq[0][0]), "+v"(rvq[1][0]), "+v"(rvq[2][0]), "+v"(rvq[3][0]), "+v"(opa[0]) :: "memory");
+                    }
+                }
+            }
+            float o[4][4];
+            if constexpr (AFFINE) {
+                const bool r1 = p.res_mode == 1 && tvalid && col_ok, r2 = p.res_mode == 2 && tvalid && col_ok;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = fmaf(out[q][e], col_ok ? opa[bb][e] : 0.f, col_ok ? opb[bb][e] : 0.f);
+                        v += r1 ? rvq[q][bb][e] : 0.f;
+                        v = act_apply(v, p.act);
+                        v += r2 ? rvq[q][bb][e] : 0.f;
+                        o[q][e] = v;
+                    }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o[q][e] = out[q][e];
+                        if constexpr (LOADS) {
+                            o[q][e] += p.bias && col_ok ? opa[bb][e] : 0.f;
+                            o[q][e] += has_res && tvalid && col_ok ? rvq[q][bb][e] : 0.f;
+                        }
+                    }
+            }
+            if (store_ok) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t pix = pix0 + (q >> 1) * g.OW + (q & 1);
+                    store4_unseen(&y[pix * p.ldy + colb[bb]], o[q][0], o[q][1], o[q][2], o[q][3]);
+                }
+            }
+            // BatchNorm statistics: one (S, Q, k, n) record per (16-tile block of a wavefront = 64 output pixels, cout): sums over the block's valid pixels
+            // shifted by k = the block's first output.  Everything stays inside the wavefront -- k by a 16-lane broadcast, the sums over the 16 tiles by
+            // DPP row rotations, the record written by the row's first lane -- no LDS, no barrier (the first version went through LDS with three barriers
+            // and 128 ds_bpermute shuffles per item: 60-85 us of a 480 us launch, tools/wino_ablate.sh).  The block that contains the segment boundary
+            // emits its first-segment tiles to `stats`, the rest to `stats_extra`.
+            if (!AFFINE && p.stats && !(WINO_ABLATE & 64)) {
+                float4* rec = reinterpret_cast<float4*>(p.stats) + ((int64_t)row_tile * 4 + tb) * p.stat_cout + grp * p.Ng;
+                float4* rec2 = reinterpret_cast<float4*>(p.stats_extra) + grp * p.Ng;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     // lane 0 of each 16-lane row -> the row (ds_swizzle, bit mode: lane' = lane & 0x10 inside each half of the wavefront)
-                    const float k = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(out[0][bb][e]), 0x0010));
+                    const float k = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(out[0][e]), 0x0010));
                     float a = 0.f, qq = 0.f;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { const float v = out[q][bb][e] - k; a += v; qq += v * v; }
+                    for (int q = 0; q < 4; ++q) { const float v = out[q][e] - k; a += v; qq += v * v; }
                     float a1 = first ? a : 0.f, q1 = first ? qq : 0.f, a2 = second ? a : 0.f, q2 = second ? qq : 0.f;
                     a1 += quad_dpp<0x128>(a1); q1 += quad_dpp<0x128>(q1);       // row_ror:8, 4, 2, 1: every lane of the row ends with the row's sum
                     a1 += quad_dpp<0x124>(a1); q1 += quad_dpp<0x124>(q1);
@@ -403,10 +461,11 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
                     }
                     const int co = colb[bb] + e;
                     if (j16 == 0 && co < p.Ng && nvalid > 0) {            // (a block beyond the last tile has no record)
-                        rec[co] = make_float4(a1, q1, k, 4.f * (float)n1);
-                        if (cut != 0x7fffffff) rec2[co] = make_float4(a2, q2, k, 4.f * (float)(nvalid - n1));
+                        store4_unseen(reinterpret_cast<float*>(rec + co), a1, q1, k, 4.f * (float)n1);
+                        if (cut != 0x7fffffff) store4_unseen(reinterpret_cast<float*>(rec2 + co), a2, q2, k, 4.f * (float)(nvalid - n1));
                     }
                 }
+            }
         }
     };
 
@@ -422,7 +481,7 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
     issue_v();
     issue_u();
     issue_u();
-    asm volatile("s_waitcnt vmcnt(4)" : "+v"(raw[0][0]), "+v"(raw[1][0]), "+v"(raw[2][0]), "+v"(raw[3][0]), "+v"(raw[0][1]), "+v"(raw[1][1]), "+v"(raw[2][1]), "+v"(raw[3][1]) :: "memory");
+    asm volatile("s_waitcnt vmcnt(4) ; covers-loads" : "+v"(raw[0][0]), "+v"(raw[1][0]), "+v"(raw[2][0]), "+v"(raw[3][0]), "+v"(raw[0][1]), "+v"(raw[1][1]), "+v"(raw[2][1]), "+v"(raw[3][1]) :: "memory");
     transform(I0{});
     write_staged(0);
     __syncthreads();
@@ -458,7 +517,7 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
         auto stage_odd = [&]() __attribute__((always_inline)) {
             if (e2) {
                 // behind super-chunk S+1: U(k+3) x 4 (U(k+2), issued before it, has landed with it)
-                asm volatile("s_waitcnt vmcnt(4)" : "+v"(raw[0][0]), "+v"(raw[1][0]), "+v"(raw[2][0]), "+v"(raw[3][0]), "+v"(raw[0][1]), "+v"(raw[1][1]), "+v"(raw[2][1]), "+v"(raw[3][1]) :: "memory");
+                asm volatile("s_waitcnt vmcnt(4) ; covers-loads" : "+v"(raw[0][0]), "+v"(raw[1][0]), "+v"(raw[2][0]), "+v"(raw[3][0]), "+v"(raw[0][1]), "+v"(raw[1][1]), "+v"(raw[2][1]), "+v"(raw[3][1]) :: "memory");
                 if (!(WINO_ABLATE & 4)) { transform(I0{}); write_staged(0); }
             }
         };
@@ -472,7 +531,10 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
         if (c_chunk == wg.nchunks) {
             const int jx = c_item >> 3;
             const int row_tile = rt_first + jx / p.col_tiles;
-            if (!(WINO_ABLATE & 16)) epilogue(row_tile * 64, (jx % p.col_tiles) * 64, row_tile);
+            if (!(WINO_ABLATE & 16)) {
+                if (AFFINE || p.res_mode == 3 || p.bias) epilogue(row_tile * 64, (jx % p.col_tiles) * 64, row_tile, std::true_type{});
+                else epilogue(row_tile * 64, (jx % p.col_tiles) * 64, row_tile, std::false_type{});
+            }
             zero_acc();
             c_chunk = 0;
             c_item += gridDim.x;
@@ -789,14 +851,15 @@ bool wino_preferred() { return kWinoMode == 2; }
 // geometry: 3x3 / stride 1 / pad 1 forward (mode 0) or input gradient (mode 1) on even output sizes, 16-byte channel vectors on both sides
 bool wino_geom_ok(const GatherGeom& g, int Ng) {
     return kWinoEnabled && g.om == 1 && g.R == 3 && g.S == 3 && g.stride == 1 && g.pad == 1 && g.GH == g.OH && g.GW == g.OW && g.OH % 2 == 0 && g.OW % 2 == 0 &&
-           g.M < (1LL << 31) && g.Cg % 4 == 0 && Ng % 4 == 0 && g.ldg % 4 == 0;
+           g.M < (1LL << 31) && g.Cg % 4 == 0 && Ng % 4 == 0 && g.ldg % 4 == 0 &&
+           g.M * (int64_t)g.ldg * 4 < (1LL << 31);      // 32-bit byte offsets against a descriptor of < 2 GiB: larger inputs take the direct tiles
 }
 // epilogue forms the kernel has: bias, skip add, statistics records; or (AFFINE instantiations) the folded eval-mode BatchNorm + activation + skip
 static bool wino_params_ok(const NtParams& p) {
     const bool affine = p.scale != nullptr;                      // eval-mode form: scale AND shift, activation, skip before / after it; no bias, no statistics
     const bool epi_ok = affine ? (p.shift && !p.bias && !p.stats && p.res_mode >= 0 && p.res_mode <= 2 && aligned16(p.scale) && aligned16(p.shift))
                                : (p.res_mode == 0 || p.res_mode == 3);
-    return wino_geom_ok(p.g, p.Ng) && epi_ok && !p.y2 && !p.a_scale && !p.o_rowscale && p.ldy % 4 == 0 &&
+    return wino_geom_ok(p.g, p.Ng) && epi_ok && !p.y2 && !p.a_scale && !p.o_rowscale && p.ldy % 4 == 0 && p.g.M * (int64_t)p.ldy * 4 < (1LL << 31) &&
            p.fw && aligned16(p.y) && aligned16(p.x) && aligned16(p.fw) && (!p.residual || aligned16(p.residual)) && (!p.bias || aligned16(p.bias));
 }
 
@@ -854,7 +917,8 @@ bool launch_wino(const NtParams& p_in, int groups, hipStream_t st) {
 // ---- filter gradient
 bool wino_wgrad_geom_ok(int n, int h, int w, int ho, int wo, int cin, int cout, int r, int sfilt, int stride, int pad, int groups) {
     return kWinoEnabled && r == 3 && sfilt == 3 && stride == 1 && pad == 1 && ho == h && wo == w && h % 2 == 0 && w % 2 == 0 && groups > 0 && cin % groups == 0 &&
-           cout % groups == 0 && (cin / groups) % 4 == 0 && (cout / groups) % 4 == 0 && cin % 4 == 0 && cout % 4 == 0 && (int64_t)n * h * w < (1LL << 31);
+           cout % groups == 0 && (cin / groups) % 4 == 0 && (cout / groups) % 4 == 0 && cin % 4 == 0 && cout % 4 == 0 && (int64_t)n * h * w < (1LL << 31) &&
+           (int64_t)n * h * w * cin * 4 < (1LL << 31) && (int64_t)n * h * w * cout * 4 < (1LL << 31);      // x and dy extents: 32-bit byte offsets
 }
 static int wino_wgrad_splits(int n, int h, int w, int cin, int cout, int groups) {
     const int cg = cin / groups, ng = cout / groups;

@@ -573,10 +573,13 @@ _FOLD_MIN_RECORDS = int(os.environ.get("SUHPE_BN_FOLD_MIN", "3072"))
 
 
 @_memop
-def bn_stats_from_partials(part, tiles, rows, c, eps, momentum, running_mean=None, running_var=None, nbt=None):
+def bn_stats_from_partials(part, tiles, rows, c, eps, momentum, running_mean=None, running_var=None, nbt=None, consume=True):
+    """train-mode statistics from a conv epilogue's (S, Q, k, n) records.  consume=True (what the layers pass: the records are scratch):
+    from SUHPE_BN_FOLD_MIN records per channel on, `part` is OVERWRITTEN (fp64 pairs over each run's first record) by the two-launch
+    folding finalizer; below the threshold, or with consume=False, `part` is left intact and the one-launch finalizer runs."""
     mean = torch.empty(c, dtype=torch.float32, device=part.device)
     rstd = torch.empty(c, dtype=torch.float32, device=part.device)
-    if tiles >= _FOLD_MIN_RECORDS:                      # long record lists are reduced all over the chip first (the records are consumed)
+    if consume and tiles >= _FOLD_MIN_RECORDS:          # long record lists are reduced all over the chip first (the records are consumed)
         call("suhpe_bn_stats_from_partials_consume", ptr(part), int(tiles), int(tiles), None, int(rows), int(rows), c, float(eps), float(momentum),
              ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var), ptr(nbt))
         return mean, rstd
@@ -919,9 +922,10 @@ def bn_stats_seg(x, rows_a, c, eps, momentum, running_mean=None, running_var=Non
 
 @_memop
 def bn_stats_from_partials_seg(part, tiles, first_records, boundary, rows, rows_a, c, eps, momentum, running_mean=None, running_var=None,
-                               nbt=None):
+                               nbt=None, consume=True):
+    """two-segment form of bn_stats_from_partials; same `consume` contract (`part` is overwritten from SUHPE_BN_FOLD_MIN records on)"""
     stats = torch.empty((2, 2, c), dtype=torch.float32, device=part.device)
-    if tiles >= _FOLD_MIN_RECORDS:
+    if consume and tiles >= _FOLD_MIN_RECORDS:
         call("suhpe_bn_stats_from_partials_consume", ptr(part), int(tiles), int(first_records), ptr(boundary), int(rows), int(rows_a), c, float(eps),
              float(momentum), ptr(stats[0]), ptr(stats[1]), ptr(running_mean), ptr(running_var), ptr(nbt))
         return stats[0], stats[1]

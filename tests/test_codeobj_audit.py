@@ -1,0 +1,39 @@
+"""Build-time audit of the hand-pipelined Winograd kernel (correctness of the asm loads rested on one compiler's register allocation).
+Compiles csrc/conv_wino.hip for gfx950 here (hipcc cross-compiles without a GPU) and requires, for every wino_nt_kernel instantiation:
+  * no scratch: ScratchSize 0, no VGPR spills (a spill reload inside the persistent loop also makes hipcc drain the prefetch queue every pass);
+  * no s_waitcnt vmcnt(..) written by the compiler anywhere in the kernel (every vector-memory operation is inline asm with a hand-counted wait);
+  * no compiler instruction touching the destination registers of an unseen (asm) register load before the hand wait that covers it.
+A hipcc upgrade that changes any of this fails loudly instead of racing silently."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_winograd_kernels_have_no_scratch_no_compiler_waits_and_untouched_load_registers():
+    src = os.path.join(ROOT, "semiuhpe_amd", "csrc", "conv_wino.hip")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", os.devnull],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    cur, seen = None, {}
+    for line in r.stderr.split("\n"):
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1)
+        m = re.search(r"(ScratchSize \[bytes/lane\]|VGPRs Spill|SGPRs Spill): (\d+)", line)
+        if m and cur and "wino_" in cur:
+            seen.setdefault(cur, {})[m.group(1)] = int(m.group(2))
+    nt = [k for k in seen if "wino_nt_kernel" in k]
+    assert len(nt) == 6, sorted(seen)
+    for k, v in seen.items():
+        assert v.get("ScratchSize [bytes/lane]") == 0 and v.get("VGPRs Spill") == 0, (k, v)
+    # the wait / register audit (tools/debug/wino_waits.py exits non-zero and prints what it found)
+    a = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "debug", "wino_waits.py")], capture_output=True, text=True, timeout=600)
+    assert a.returncode == 0, a.stdout[-3000:] + a.stderr[-1000:]
+    assert "registers of unseen loads touched before their wait: none" in a.stdout

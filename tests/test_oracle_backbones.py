@@ -123,6 +123,28 @@ def test_efficientnet_v2_s_sanity_counts():
     assert abs(macs / 1e9 - 2.849) < 0.02
 
 
+def test_efficientnet_v2_s_state_dict_keys_and_shapes_match_the_committed_fixture():
+    """The one extra architecture pin available offline: tests/golden/effnetv2s_state_dict.json lists every state-dict key and
+    tensor shape of torchvision's efficientnet_v2_s under the reference's head, generated by tools/make_golden_effnet_keys.py from the module
+    tree WITHOUT instantiating either implementation (and checked there against torchvision's published 21,458,488 parameters).  The oracle
+    module and the HIP model must expose exactly these entries, in module-tree order -- what makes a released `*-effinetv2-*.pth` load."""
+    import hashlib
+    import json
+    from semiuhpe_amd.src.efficientnet_v2 import EfficientNetV2S
+    doc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "effnetv2s_state_dict.json")))
+    assert hashlib.sha256(json.dumps(doc["entries"]).encode()).hexdigest() == doc["sha256"]
+    want = {k: tuple(s) for k, s in doc["entries"]}
+    assert len(want) == 796 and doc["backbone_params"] == 20177488 and doc["params_with_reference_head"] == 20901465
+    for name, mod in (("oracle", ON.EfficientNetV2S()), ("hip", EfficientNetV2S())):
+        sd = mod.state_dict()
+        assert set(sd) == set(want), (name, sorted(set(sd) ^ set(want))[:8])
+        bad = [k for k in sd if tuple(sd[k].shape) != want[k]]
+        assert not bad, (name, bad[:8])
+    # same order on both sides (torch.load(strict=True) does not need it; optimizer state indexed by position does)
+    assert list(ON.EfficientNetV2S().state_dict().keys()) == list(EfficientNetV2S().state_dict().keys())
+    assert "features.6.14.block.2.fc2.bias" in want and want["features.2.0.block.0.0.weight"] == (96, 24, 3, 3) and want["features.7.0.weight"] == (1280, 256, 1, 1)
+
+
 def test_resnet50_oracle_matches_the_published_size_and_the_module_tree_of_the_hip_model():
     """ResNet-50 (torchvision architecture restated, parity unpinned): 25,557,032 parameters with the 1000-class fc, and the same
     state-dict keys and shapes on both sides (released checkpoints load into either)."""

@@ -18,12 +18,22 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c3_serial -o s -- p
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5_serial -o s -- python3 $R/tools/step_bench.py tinyvit 32 128 2 6 > $OUT/c5_serial.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $R/tools/step_bench.py effinetv2 32 128 1 2 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $R/tools/step_bench.py effinetv2 32 128 1 2 > $OUT/pmc_write.log 2>&1
+if [ "${PMC_OTHERS:-1}" = "1" ]; then      # the same two passes for C3 and C5 (bench.py's other_configs.*.hbm_traffic_ratio)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_repvgg -- python3 $R/tools/step_bench.py repvgg 64 256 1 2 > $OUT/pmc_fetch_repvgg.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_repvgg -- python3 $R/tools/step_bench.py repvgg 64 256 1 2 > $OUT/pmc_write_repvgg.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_tinyvit -- python3 $R/tools/step_bench.py tinyvit 32 128 1 2 > $OUT/pmc_fetch_tinyvit.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_tinyvit -- python3 $R/tools/step_bench.py tinyvit 32 128 1 2 > $OUT/pmc_write_tinyvit.log 2>&1
+fi
 unset SUHPE_OVERLAP SUHPE_WGRAD_OVERLAP
 cd $R
-python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json > $OUT/pmc_traffic.log 2>&1
+python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json "effinetv2 32+128" > $OUT/pmc_traffic.log 2>&1
+if [ "${PMC_OTHERS:-1}" = "1" ]; then
+python3 tools/pmc_traffic.py $OUT/pmc_fetch_repvgg $OUT/pmc_write_repvgg $OUT/pmc_traffic_repvgg.json "repvgg 64+256" >> $OUT/pmc_traffic.log 2>&1
+python3 tools/pmc_traffic.py $OUT/pmc_fetch_tinyvit $OUT/pmc_write_tinyvit $OUT/pmc_traffic_tinyvit.json "tinyvit 32+128" >> $OUT/pmc_traffic.log 2>&1
+fi
 python3 tools/timeline.py $(ls $OUT/c2_streams/*kernel_trace.csv | head -1) 3 > $OUT/c2_streams_timeline.txt 2>&1
 # keep the merge small: the raw traces stay on the box, the summaries travel
 for d in c2_serial c3_serial c5_serial; do cp $OUT/$d/*kernel_stats.csv $OUT/${d}_kernel_stats.csv 2>/dev/null; done
 mkdir -p $OUT/pmc && cp $OUT/pmc_fetch/*/*counter_collection.csv $OUT/pmc/fetch_size_counter_collection.csv 2>/dev/null; cp $OUT/pmc_write/*/*counter_collection.csv $OUT/pmc/write_size_counter_collection.csv 2>/dev/null
-rm -rf $OUT/c2_serial $OUT/c2_streams $OUT/c3_serial $OUT/c5_serial $OUT/pmc_fetch $OUT/pmc_write
+rm -rf $OUT/c2_serial $OUT/c2_streams $OUT/c3_serial $OUT/c5_serial $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_fetch_repvgg $OUT/pmc_write_repvgg $OUT/pmc_fetch_tinyvit $OUT/pmc_write_tinyvit
 ls -la $OUT
