@@ -89,6 +89,14 @@ def gpu_leg(args, rank, world, device):
     info = dict(mask_ratio=float(fu["mask_ratio"]), loss_all=float(out["loss_all"]), conf_thres=float(cfg.conf_thres),
                 hbm_gib={"peak_allocated": round(torch.cuda.max_memory_allocated() * gib, 2), "reserved": round(torch.cuda.memory_reserved() * gib, 2)})
     if world > 1:
+        # what the step pays for the gradient exchange: mean time per timed step the compute stream waited for the communication stream at the end of the
+        # backward (BucketedAllReduce.finish); everything else of the all-reduce ran under the backward.  With it the line explains its own scaling.
+        bk = getattr(agent, "_buckets", None)
+        ex = bk.exposed_ms(last=args.steps) if bk is not None else None
+        info["allreduce_exposed_ms"] = round(ex, 3) if ex is not None else None
+        info["grad_buckets"] = (len(bk.bounds) - 1) if bk is not None else 1
+        info["transport"] = "suhpe_comm (library-owned RCCL communicator; torch.distributed on gloo as host channel)" if os.environ.get("SUHPE_COMM") == "native" \
+            else f"torch.distributed/{dist.get_backend()}"
         # data-parallel replicas must hold the same bits after the timed steps: every rank's student / teacher parameters and
         # BatchNorm buffers as (sum, sum of squares) in float64, gathered and compared (outside the timed region)
         fbs = [fb.data for fb in agent.optimizer.flat_buffers] + [agent._ema_flat.data] + ([agent._bn_flat_all.data] if agent._bn_flat_all is not None else [])
@@ -435,6 +443,14 @@ def main():
             with contextlib.redirect_stdout(sys.stderr):
                 out["cpu_baseline"] = cpu_leg()
             out["mae_parity"] = out["cpu_baseline"].pop("mae_parity", None)
+            # the 20-step drift of the two training trajectories at the BASELINE batch is CPU-bound (about 7 minutes of oracle steps): measured once per
+            # round on the GPU box (`python tools/mae_parity.py trend profiles/drift_trend.json`) and quoted here with the kernel-source digest it ran on
+            tpath = os.path.join(ROOT, "profiles", "drift_trend.json")
+            if isinstance(out["mae_parity"], dict) and os.path.exists(tpath):
+                with open(tpath) as fh:
+                    tdoc = json.load(fh)
+                out["mae_parity"]["own_trajectory_trend"] = {"source": "profiles/drift_trend.json", "same_kernel_sources": tdoc.get("csrc_digest") == csrc_digest(),
+                                                             "protocol": tdoc.get("protocol"), "rows": tdoc.get("rows")}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

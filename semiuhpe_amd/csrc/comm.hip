@@ -5,6 +5,7 @@
 // caller is a PyTorch process), so libsuhpe.so loads -- and every other entry point works -- on a box without it.
 #include "common.h"
 #include <dlfcn.h>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -30,10 +31,15 @@ static Rccl& rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (r.handle) break;
-        }
+        // SUHPE_RCCL_LIB: another build of the collective library (any shared object that exports the seven nccl* entry points used below);
+        // tests/test_comm_abi_two_ranks.py points it at a host-memory transport to drive this ABI with two ranks on a box without GPUs
+        const char* override_path = getenv("SUHPE_RCCL_LIB");
+        if (override_path && *override_path) r.handle = dlopen(override_path, RTLD_NOW | RTLD_GLOBAL);
+        if (!r.handle)
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (r.handle) break;
+            }
         if (!r.handle) return;
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.handle, "ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.handle, "ncclCommInitRank"));

@@ -20,6 +20,12 @@ def world():
     return 0, 1
 
 
+def native_mode():
+    """SUHPE_COMM=native: every DEVICE collective of the job goes through suhpe_comm_* (ONE library-owned RCCL communicator, so one order of
+    collectives), and torch.distributed is brought up on gloo -- a host channel for the rendezvous, the unique id and Python objects only."""
+    return os.environ.get("SUHPE_COMM", "") == "native"
+
+
 def init_from_env(backend="nccl"):
     """torchrun-style env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) -> process group."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
@@ -27,6 +33,11 @@ def init_from_env(backend="nccl"):
         return world()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     kw = {}
+    if native_mode() and backend == "nccl":
+        # no second GPU communicator beside the library's: torch.distributed keeps the host side (store, object broadcasts, host barriers)
+        backend = "gloo"
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
     if backend == "nccl":
         local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local)
@@ -69,12 +80,32 @@ class NativeComm:
         if rc != 0:
             raise RuntimeError(self._libmod.last_error())
 
-    @staticmethod
-    def _chk(t):
-        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), "suhpe_comm_*: contiguous float32 device tensors"
+    # SUHPE_COMM_HOST_BUFFERS=1 (tests only, together with SUHPE_RCCL_LIB = the host-memory transport of tests/host_build): host tensors are accepted
+    HOST_OK = os.environ.get("SUHPE_COMM_HOST_BUFFERS", "0") == "1"
+
+    @classmethod
+    def _chk(cls, t):
+        assert (t.is_cuda or cls.HOST_OK) and t.dtype == torch.float32 and t.is_contiguous(), "suhpe_comm_*: contiguous float32 device tensors"
 
     def _stream(self, t):
-        return self._ct.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+        return self._ct.c_void_p(torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0)
+
+    def barrier(self, device):
+        """all ranks have enqueued everything before this point on the current stream (a one-element SUM all-reduce; the host does not wait)"""
+        t = torch.zeros(1, dtype=torch.float32, device=device)
+        return self.allreduce_(t)
+
+    def gather_varlen(self, t):
+        """1-D float32 tensors of different lengths from all ranks, concatenated in rank order on every rank (two all-gathers: lengths, padded data)"""
+        self._chk(t)
+        n = torch.tensor([float(t.numel())], dtype=torch.float32, device=t.device)      # (exact below 2^24 elements per rank)
+        assert t.numel() < (1 << 24)
+        sizes = [int(v) for v in self.allgather(n).reshape(-1).tolist()]
+        mx = max(max(sizes), 1)
+        pad = torch.zeros(mx, dtype=torch.float32, device=t.device)
+        pad[:t.numel()] = t
+        parts = self.allgather(pad)
+        return torch.cat([parts[r, :sizes[r]] for r in range(self.world)])
 
     def allreduce_(self, t, average=False):
         self._chk(t)
@@ -104,16 +135,29 @@ _NATIVE = None
 
 def native():
     """the process-wide NativeComm when SUHPE_COMM=native and more than one rank runs (created on first use), else None.
-    EXPERIMENTAL: a second RCCL communicator beside torch.distributed's (which keeps gather_varlen, the object gathers and barriers): collectives
-    on the two communicators are not ordered against each other, and the mode has only run with one rank -- keep the default on multi-GPU jobs."""
+    In this mode the library's communicator is the ONLY one that touches the GPUs (init_from_env brings torch.distributed up on gloo), so the
+    order of device collectives is the order this process enqueues them -- gradient buckets, BatchNorm-buffer average, broadcasts, the entropy
+    gather and barriers alike.  Two-rank coverage without GPUs: tests/test_comm_abi_two_ranks.py (host-memory transport behind the same C ABI);
+    on RCCL itself the mode has run with one rank only (no multi-GPU box in the pool): the default transport stays torch.distributed."""
     global _NATIVE
-    if _NATIVE is None and os.environ.get("SUHPE_COMM", "") == "native" and world()[1] > 1 and torch.cuda.is_available():
+    if _NATIVE is None and native_mode() and world()[1] > 1 and (torch.cuda.is_available() or NativeComm.HOST_OK):
         _NATIVE = NativeComm()
     return _NATIVE
 
 
 def _native_for(t):
-    return native() if (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()) else None
+    return native() if ((t.is_cuda or NativeComm.HOST_OK) and t.dtype == torch.float32 and t.is_contiguous()) else None
+
+
+def barrier(device=None):
+    """device-side barrier in native mode (no torch GPU communicator exists there), torch.distributed's otherwise"""
+    if world()[1] > 1:
+        nc = native()
+        if nc is not None and device is not None:
+            nc.barrier(device)
+            if torch.device(device).type == "cuda":
+                torch.cuda.current_stream(device).synchronize()
+        dist.barrier()
 
 
 def allreduce_sum_(t):
@@ -153,6 +197,11 @@ def gather_varlen(t):
     rank, ws = world()
     if ws == 1:
         return t
+    nc = _native_for(t) if t.dim() == 1 else None
+    if nc is not None:
+        return nc.gather_varlen(t)
+    if native_mode() and t.is_cuda:
+        return gather_varlen(t.cpu()).to(t.device)      # (other dtypes: over the host channel -- no torch GPU communicator in native mode)
     n = torch.tensor([t.numel()], dtype=torch.long, device=t.device)
     sizes = [torch.zeros_like(n) for _ in range(ws)]
     dist.all_gather(sizes, n)
@@ -236,6 +285,8 @@ class BucketedAllReduce:
         self.ready = ready                      # callback(k) before bucket k is sent (flush deferred work)
         self.streams = streams                  # callable -> compute streams the collective has to wait for (CUDA only)
         self.comm = None
+        self.exposed = []                       # (event before, event after) of the main stream's wait for the communication stream, per step
+        self.exposed_host_s = 0.0               # host tensors (gloo tests): seconds spent in the handles' wait()
         self.begin()
 
     def begin(self):
@@ -281,9 +332,29 @@ class BucketedAllReduce:
             with torch.cuda.stream(self.comm):
                 for h in self.handles:
                     h.wait()
-            torch.cuda.current_stream(self.flat.device).wait_stream(self.comm)
+            # what the step pays for the exchange: the time the compute stream sits in this wait (everything else ran under the backward)
+            cur = torch.cuda.current_stream(self.flat.device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
+            cur.wait_stream(self.comm)
+            e1.record(cur)
+            self.exposed.append((e0, e1))
+            if len(self.exposed) > 64:
+                del self.exposed[:-64]
         else:
+            import time
+            t0 = time.perf_counter()
             for h in self.handles:
                 h.wait()
+            self.exposed_host_s += time.perf_counter() - t0
         self.handles = []
         self.active = False
+
+
+    def exposed_ms(self, last=None):
+        """mean milliseconds per step the compute stream waited for the gradient exchange in finish() (device runs: the last `last` steps, after a
+        synchronize by the caller), i.e. the part of the all-reduce the backward did not hide"""
+        ev = self.exposed[-last:] if last else self.exposed
+        if not ev:
+            return None
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev)

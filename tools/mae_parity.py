@@ -83,15 +83,11 @@ def _hip_eval(agent, cfg, batches, eval_ema=False):
     return np.concatenate(Rs), mae
 
 
-def run(n_images=EVAL_IMAGES, warm_steps=3, train_batch=(8, 16), size=224, network="effinetv2", threads=None, verbose=False, conditioned=True):
+def _make_pair(network, size, conditioned):
+    """the oracle agent and the HIP agent on the same seeded, conditioned initial state (see the comments inside)"""
     from oracle import networks as ON
     from oracle.agent import OracleAgent, synthetic_batches
-    from parity_utils import MaskTape
-    from semiuhpe_amd import layers as L
     from semiuhpe_amd.src.agent import SSLAgent
-    if threads:
-        torch.set_num_threads(threads)
-    t_start = time.perf_counter()
     torch.manual_seed(0)
     make = {"effinetv2": ON.EfficientNetV2S, "repvgg": ON.RepVggNet, "tinyvit": ON.TinyViT21M}[network]
     ref = make()
@@ -128,21 +124,70 @@ def run(n_images=EVAL_IMAGES, warm_steps=3, train_batch=(8, 16), size=224, netwo
     agent = SSLAgent(cfg_h)
     agent.net.load_state_dict(sd0)
     agent.ema_net.load_state_dict(sd0)
+    return oracle, agent, cfg_h
+
+
+def _train_step_both(oracle, agent, step, B, muB, size):
+    """one SSL step on both paths: same inputs, the oracle's Bernoulli draws replayed to the HIP agent"""
+    from oracle import networks as ON
+    from oracle.agent import synthetic_batches
+    from parity_utils import MaskTape
+    from semiuhpe_amd import layers as L
+    data, ulb = synthetic_batches(B, muB, size=size, seed=step)
+    tape = MaskTape(900 + step)
+    ON.set_mask_hook(tape.record)
+    torch.manual_seed(50 + step)
+    oracle.iteration = step
+    oracle.train_func({k: v.clone() for k, v in data.items()}, {k: v.clone() for k, v in ulb.items()})
+    ON.set_mask_hook(None)
+    L.set_mask_hook(tape.replay_merged)
+    torch.manual_seed(50 + step)
+    agent.clock.iteration = step
+    agent.train_func({k: v.cuda() for k, v in data.items()}, {k: v.cuda() for k, v in ulb.items()})
+    L.set_mask_hook(None)
+    assert tape.done(), "the two paths drew different numbers of Bernoulli masks"
+
+
+def drift_trend(steps=20, at=(1, 2, 3, 5, 8, 12, 16, 20), train_batch=(32, 128), n_images=256, size=224, network="effinetv2", threads=None):
+    """How two fp32 training trajectories drift apart (the 3.3e-4 of `own_trajectory` was a point, this is the trend): both paths train
+    `steps` SSL steps at the BASELINE batch from the same initial state, each on ITS OWN weights; after the steps in `at` both evaluate the first
+    `n_images` images of the 8d evaluation set: max |R_hip - R_cpu| and |delta MAE| per listed step.  CPU-bound (about 20 s per oracle step on 32
+    threads): run once per round on the GPU box -- `python tools/mae_parity.py trend` writes profiles/<tag>_drift_trend.json, which bench.py's
+    `mae_parity.own_trajectory_trend` quotes together with the digest of the kernel sources it was measured on."""
+    if threads:
+        torch.set_num_threads(threads)
+    t0 = time.perf_counter()
+    oracle, agent, cfg_h = _make_pair(network, size, True)
+    batches = eval_batches(n_images, EVAL_BATCH, size)
+    B, muB = train_batch
+    rows = []
+    for step in range(steps):
+        _train_step_both(oracle, agent, step, B, muB, size)
+        if step + 1 in at:
+            R_cpu, err_cpu = _oracle_eval(oracle, batches)
+            R_own, mae_own = _hip_eval(agent, cfg_h, batches)
+            mae_cpu = _mae(err_cpu)
+            # parameter distance of the two students (relative L2 over the flat buffer)
+            po = torch.cat([q.detach().reshape(-1) for q in oracle.net.parameters()])
+            ph = torch.cat([q.detach().reshape(-1).cpu() for q in agent.net.parameters()])
+            rows.append({"step": step + 1, "max_abs_dR": float(np.abs(R_own - R_cpu).max()), "mean_abs_dR": float(np.abs(R_own - R_cpu).mean()),
+                         "d_mae_deg": {k: round(abs(mae_own[k] - mae_cpu[k]), 6) for k in mae_cpu},
+                         "param_rel_l2": float((po - ph).norm() / po.norm()), "elapsed_s": round(time.perf_counter() - t0, 1)})
+            print(rows[-1], flush=True)
+    agent.logs_writer.close()
+    return {"protocol": f"{steps} SSL steps B={B}+muB={muB} on both paths from the same conditioned init ({network}), each on its own weights; after steps {list(at)} "
+                        f"both evaluate {n_images} images of the 8d set (seed {EVAL_SEED}, batch {EVAL_BATCH})",
+            "rows": rows, "bars": {"max_abs_dR (identical weights only)": 1e-4, "d_mae_deg": 0.05}}
+
+
+def run(n_images=EVAL_IMAGES, warm_steps=3, train_batch=(8, 16), size=224, network="effinetv2", threads=None, verbose=False, conditioned=True):
+    if threads:
+        torch.set_num_threads(threads)
+    t_start = time.perf_counter()
+    oracle, agent, cfg_h = _make_pair(network, size, conditioned)
     B, muB = train_batch
     for step in range(warm_steps):
-        data, ulb = synthetic_batches(B, muB, size=size, seed=step)
-        tape = MaskTape(900 + step)
-        ON.set_mask_hook(tape.record)
-        torch.manual_seed(50 + step)
-        oracle.iteration = step
-        oracle.train_func({k: v.clone() for k, v in data.items()}, {k: v.clone() for k, v in ulb.items()})
-        ON.set_mask_hook(None)
-        L.set_mask_hook(tape.replay_merged)
-        torch.manual_seed(50 + step)
-        agent.clock.iteration = step
-        agent.train_func({k: v.cuda() for k, v in data.items()}, {k: v.cuda() for k, v in ulb.items()})
-        L.set_mask_hook(None)
-        assert tape.done(), "the two paths drew different numbers of Bernoulli masks"
+        _train_step_both(oracle, agent, step, B, muB, size)
     t_train = time.perf_counter()
 
     batches = eval_batches(n_images, EVAL_BATCH, size)
@@ -188,6 +233,15 @@ def run(n_images=EVAL_IMAGES, warm_steps=3, train_batch=(8, 16), size=224, netwo
 
 if __name__ == "__main__":
     import json
+    if len(sys.argv) > 1 and sys.argv[1] == "trend":      # python tools/mae_parity.py trend <out.json> [steps]
+        sys.path.insert(0, ROOT)
+        import bench
+        steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+        at = tuple(a for a in (1, 2, 3, 5, 8, 12, 16, 20, 30, 40) if a <= steps)
+        doc = drift_trend(steps=steps, at=at, threads=32)
+        doc["csrc_digest"] = bench.csrc_digest()
+        json.dump(doc, open(sys.argv[2], "w"), indent=1)
+        raise SystemExit(0)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else EVAL_IMAGES
     net = sys.argv[2] if len(sys.argv) > 2 else "effinetv2"
     print(json.dumps(run(n_images=n, network=net)))
