@@ -1099,6 +1099,7 @@ static int nt_mode(const GatherGeom& g) {
 }
 
 #include "conv_resident.inl"
+#include "conv_dma.inl"
 
 static int g_stagger = 0, g_stagger_first = 0;     // experiment knob (suhpe_conv2d_set_stagger)
 static thread_local bool g_nt_unsupported = false;  // set when a dispatch reached a (tile, form) that has no instantiation
@@ -1150,6 +1151,7 @@ enum NtTile { NT_64x64_S = 0, NT_64x64, NT_128x32, NT_128x128, NT_128x64, NT_256
               NT_W128x128, NT_W128x64,       // four wavefronts with 64x64 / 64x32 accumulators each: half the LDS fragment reads per MFMA
               NT_R128x16, NT_R64x8, NT_R64x16,   // operand-resident pointwise kernel (conv_resident.inl): 128 / 64 resident rows, 16 / 8 / 16 wavefronts
               NT_G64x64,                     // Winograd F(2x2, 3x3) kernel (conv_wino.inl): 64 tiles (256 output pixels) x 64 output channels
+              NT_D128x128,                   // both operands by LDS-DMA through a four-slab ring, persistent 128 x 128 tiles (conv_dma.inl): plain pointwise GEMMs, K % 32 == 0
               NT_TILES };
 static const char* kNtNames[] = {"igemm_nt_kernel<64,64,32,32,1>", "igemm_nt_kernel<64,64,32,32,4>", "igemm_nt_kernel<128,32,32,32,4>",
                                  "igemm_nt_kernel<128,128,64,32,4>", "igemm_nt_kernel<128,64,32,32,4>", "igemm_nt_kernel<256,32,64,32,4>",
@@ -1159,7 +1161,7 @@ static const char* kNtNames[] = {"igemm_nt_kernel<64,64,32,32,1>", "igemm_nt_ker
                                  "igemm_nt3x3_kernel<128,128,64,32>", "igemm_nt3x3_n48_kernel<128,48>",
                                  "igemm_nt_kernel<128,128,64,64,4>", "igemm_nt_kernel<128,64,64,32,4>",
                                  "gemm_nt_resident<128,2,16>", "gemm_nt_resident<64,2,8>", "gemm_nt_resident<64,2,16>",
-                                 "wino_nt_kernel<64,64>"};
+                                 "wino_nt_kernel<64,64>", "gemm_nt_dma<128,128>"};
 
 struct TnTile { int bm, bn; const char* name; };
 static const TnTile kTnTiles[] = {
@@ -1236,7 +1238,8 @@ static void launch_persistent(const NtParams& p_in, int groups, hipStream_t st) 
 }
 
 // a pinned persistent tile on a shape that is not a plain GEMM runs the igemm tile of the same size
-static NtTile effective_nt(NtTile tile, bool plain, bool halo = false, bool resident128 = false, bool resident64 = false, bool wino = false) {
+static NtTile effective_nt(NtTile tile, bool plain, bool halo = false, bool resident128 = false, bool resident64 = false, bool wino = false, bool dma = false) {
+    if (tile == NT_D128x128) return dma ? tile : NT_64x64;     // (same statistics-record height: 64 rows)
     if (tile == NT_G64x64) return wino ? tile : NT_128x64;
     if (tile >= NT_R128x16) return ((tile == NT_R128x16 && resident128) || (tile != NT_R128x16 && resident64)) ? tile : NT_64x64;   // (same record height)
     if (tile >= NT_W128x128) return tile;
@@ -1256,6 +1259,10 @@ static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st
         // a form the Winograd kernel lacks (eval-mode folded affine, no Winograd-domain filter handed over): the heuristic's direct tile, or with
         // statistics the direct tile of the same record height
         tile = p.stats ? NT_64x64 : choose_nt(p.g.M, p.Ng, vec4, -1, halo_ok(p.g, vec4));
+    }
+    if (tile == NT_D128x128) {
+        if (!act2 && dma_ok(p, groups, vec4)) { launch_dma(p, st); return; }
+        tile = NT_64x64;                                    // an epilogue / operand form the DMA kernel lacks: the direct tile of the same record height
     }
     if (act2 && tile >= NT_R128x16) tile = NT_64x64;
     if (act2 && tile >= NT_W128x128) tile = tile == NT_W128x128 ? NT_128x128 : NT_128x64;
@@ -1751,8 +1758,9 @@ int suhpe_conv2d_set_tile(const suhpe_conv_t* d, int pass, int tile) {
     SUHPE_REQUIRE(pass != 2 || tile != TN_WINO || wino_wgrad_geom_ok(d->n, d->h, d->w, d->ho, d->wo, d->cin, d->cout, d->r, d->s, d->stride, d->pad, d->groups),
                   "suhpe_conv2d_set_tile: the Winograd filter-gradient tile needs a 3x3 / stride 1 / pad 1 conv on even output sizes");
     SUHPE_REQUIRE(pass == 2 || tile != (int)NT_G64x64 || wino_ok_desc(d, pass), "suhpe_conv2d_set_tile: the Winograd tile needs a 3x3 / stride 1 / pad 1 conv on even output sizes");
-    SUHPE_REQUIRE(pass == 2 || tile < (int)NT_R128x16 || tile == (int)NT_G64x64 || resident_ok_desc(d, pass, tile == (int)NT_R128x16 ? 128 : 64),
+    SUHPE_REQUIRE(pass == 2 || tile < (int)NT_R128x16 || tile == (int)NT_G64x64 || tile == (int)NT_D128x128 || resident_ok_desc(d, pass, tile == (int)NT_R128x16 ? 128 : 64),
                   "suhpe_conv2d_set_tile: the resident tiles need a 1x1 / stride 1 conv whose BM x K block fits the LDS");
+    SUHPE_REQUIRE(pass == 2 || tile != (int)NT_D128x128 || dma_ok_desc(d, pass), "suhpe_conv2d_set_tile: the LDS-DMA tile needs a 1x1 / stride 1 conv, one group, reduction a multiple of 32");
     std::lock_guard<std::mutex> lock(tile_mutex());
     if (tile < 0) tile_table().erase(tile_key(d, pass));
     else tile_table()[tile_key(d, pass)] = tile;
@@ -1764,10 +1772,10 @@ const char* suhpe_conv2d_kernel_name(const suhpe_conv_t* d, int pass) {
     const int ng = d->cout / d->groups, cg = d->cin / d->groups;
     const bool plain = d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0;
     if (pass == 0 && stem_ok(d) && pinned_tile(d, 0) < 0) return d->cout == 24 ? "rgb_conv3x3_kernel<24>" : (d->cout == 48 ? "rgb_conv3x3_kernel<48>" : "rgb_conv3x3_kernel<64>");
-    if (pass == 0) return kNtNames[effective_nt(choose_nt((int64_t)d->n * d->ho * d->wo, ng, cg % 4 == 0 && d->cin % 4 == 0, pinned_tile(d, 0), halo_ok_desc(d, 0), wino_ok_desc(d, 0)), plain, halo_ok_desc(d, 0), resident_ok_desc(d, 0, 128), resident_ok_desc(d, 0, 64), wino_ok_desc(d, 0))];
+    if (pass == 0) return kNtNames[effective_nt(choose_nt((int64_t)d->n * d->ho * d->wo, ng, cg % 4 == 0 && d->cin % 4 == 0, pinned_tile(d, 0), halo_ok_desc(d, 0), wino_ok_desc(d, 0)), plain, halo_ok_desc(d, 0), resident_ok_desc(d, 0, 128), resident_ok_desc(d, 0, 64), wino_ok_desc(d, 0), dma_ok_desc(d, 0))];
     if (pass == 1) {
         const int st = d->stride;
-        return kNtNames[effective_nt(choose_nt((int64_t)d->n * ((d->h + st - 1) / st) * ((d->w + st - 1) / st), cg, ng % 4 == 0 && d->cout % 4 == 0, pinned_tile(d, 1), halo_ok_desc(d, 1), wino_ok_desc(d, 1)), plain, halo_ok_desc(d, 1), resident_ok_desc(d, 1, 128), resident_ok_desc(d, 1, 64), wino_ok_desc(d, 1))];
+        return kNtNames[effective_nt(choose_nt((int64_t)d->n * ((d->h + st - 1) / st) * ((d->w + st - 1) / st), cg, ng % 4 == 0 && d->cout % 4 == 0, pinned_tile(d, 1), halo_ok_desc(d, 1), wino_ok_desc(d, 1)), plain, halo_ok_desc(d, 1), resident_ok_desc(d, 1, 128), resident_ok_desc(d, 1, 64), wino_ok_desc(d, 1), dma_ok_desc(d, 1))];
     }
     const bool va = ng % 4 == 0 && d->cout % 4 == 0, vb = cg % 4 == 0 && d->cin % 4 == 0;
     if (!(va && vb)) return va ? "igemm_tn_kernel<64,64,32,32,4,1>" : (vb ? "igemm_tn_kernel<64,64,32,32,1,4>" : "igemm_tn_kernel<64,64,32,32,1,1>");

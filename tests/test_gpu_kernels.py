@@ -953,6 +953,100 @@ def test_resident_pointwise_kernel(K, cfg):
             lib.suhpe_conv2d_set_tile(ctypes.byref(d), pid, -1)
 
 
+DMA_SHAPES = [
+    # (n, cin, cout, h, w, seg): plain 1x1 / stride 1 convs with K % 32 == 0 as gemm_nt_dma sees them
+    (40, 160, 960, 14, 14, 8),         # the C2 expand shape at a quarter of the batch: N = 960 = 7.5 column tiles, M = 7840 = 61.25 row tiles (XCD padding tiles skipped)
+    (160, 256, 1536, 7, 7, 32),        # the 7 x 7 expand shape, boundary inside a 64-row unit (32 * 49 = 1568 = 24.5 units)
+    (7, 32, 36, 5, 5, 2),              # ONE k-slab per tile (a tile ends at every slab: the store-count side of the waits), N < one stripe, M = 175
+    (24, 64, 200, 14, 14, None),       # two slabs per tile, ragged columns (200 = 1.56 column tiles)
+    (2, 96, 640, 3, 3, 1),             # fewer tiles than workgroups (M = 18)
+    (300, 128, 512, 14, 14, 60),       # long streams: 9 tiles per workgroup
+]
+
+
+@pytest.mark.parametrize("cfg", DMA_SHAPES, ids=str)
+def test_lds_dma_pointwise_kernel(K, cfg):
+    """gemm_nt_dma (conv_dma.inl, round 5): forward and input gradient are bit-equal to the igemm tile (same k order per output element), its
+    per-unit BatchNorm statistics records (one or two batch segments, a unit that straddles the boundary) finish to the statistics of the igemm
+    tile's records and of a float64 reference; forms it lacks (bias, skip add, folded eval epilogue) fall back to a direct tile and stay bit-equal;
+    repeated launches give the same bits (a race in the hand-counted waits would show here)."""
+    import ctypes
+    from semiuhpe_amd import _lib
+    lib = _lib.load()
+    lib.suhpe_conv2d_tile_name.restype = ctypes.c_char_p
+    lib.suhpe_conv2d_kernel_name.restype = ctypes.c_char_p
+    n, cin, cout, h, w, seg = cfg
+    g = torch.Generator().manual_seed(47)
+    x = (torch.randn(n, h, w, cin, generator=g) + 0.2).cuda()
+    wg = K.to_filter_layout((torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5).cuda())
+    bias = torch.randn(cout, generator=g).cuda()
+    dy = torch.randn(n, h, w, cout, generator=g).cuda()
+    skip = torch.randn(n, h, w, cin, generator=g).cuda()
+    scale, shift = (torch.rand(cout, generator=g) + 0.5).cuda(), torch.randn(cout, generator=g).cuda()
+    res = torch.randn(n, h, w, cout, generator=g).cuda()
+    d = K.conv_desc(x.shape, wg.shape, 1, 0, 1)
+    names = [lib.suhpe_conv2d_tile_name(0, t) for t in range(lib.suhpe_conv2d_tile_count(0))]
+    dma = names.index(b"gemm_nt_dma<128,128>")
+    igemm = names.index(b"igemm_nt_kernel<64,64,32,32,4>")
+    rows = n * h * w
+
+    def run_all():
+        out = [K.conv2d_fwd(x, wg, None, 1, 0, 1), K.conv2d_dgrad(dy, wg, x.shape, 1, 0, 1),
+               K.conv2d_fwd(x, wg, bias, 1, 0, 1), K.conv2d_dgrad(dy, wg, x.shape, 1, 0, 1, skip=skip),
+               K.conv2d_fwd_affine(x, wg, scale, shift, "silu", res, True, 1, 0, 1)]
+        if seg is None:
+            y, part, nt = K.conv2d_fwd_stats(x, wg, 1, 0, 1)
+            st = K.bn_stats_from_partials(part, nt, rows, cout, 1e-3, 0.1, consume=False)
+        else:
+            y, part, nt, (first, extra) = K.conv2d_fwd_stats(x, wg, 1, 0, 1, seg=seg)
+            st = K.bn_stats_from_partials_seg(part, nt, first, extra, rows, seg * h * w, cout, 1e-3, 0.1, consume=False)
+        return out + [y], st
+
+    try:
+        for pid in (0, 1):
+            assert lib.suhpe_conv2d_set_tile(ctypes.byref(d), pid, igemm) == 0
+        ref, st_ref = run_all()
+        ok = [lib.suhpe_conv2d_set_tile(ctypes.byref(d), pid, dma) == 0 for pid in (0, 1)]
+        assert ok[0] == (cin % 32 == 0) and ok[1] == (cout % 32 == 0), ok
+        for pid in (0, 1):
+            if not ok[pid]:
+                lib.suhpe_conv2d_set_tile(ctypes.byref(d), pid, igemm)
+        assert (b"gemm_nt_dma" in lib.suhpe_conv2d_kernel_name(ctypes.byref(d), 0)) == ok[0]
+        for rep in range(3):
+            out, st = run_all()
+            for i, (a, b) in enumerate(zip(out, ref)):
+                assert torch.equal(a, b), (rep, i)
+            for a, b in zip(st, st_ref):
+                assert rel(a, b.cpu()) < 2e-6
+        yd = ref[0].double().cpu().reshape(rows, cout)
+        if seg is None:
+            assert rel(st[0], yd.mean(0)) < 2e-5 and rel(st[1], (yd.var(0, unbiased=False) + 1e-3).rsqrt()) < 2e-5
+        else:
+            ra = seg * h * w
+            for i, part_rows in enumerate((yd[:ra], yd[ra:])):
+                assert rel(st[0][i], part_rows.mean(0)) < 2e-5 and rel(st[1][i], (part_rows.var(0, unbiased=False) + 1e-3).rsqrt()) < 2e-5
+    finally:
+        for pid in (0, 1):
+            lib.suhpe_conv2d_set_tile(ctypes.byref(d), pid, -1)
+
+
+def test_lds_dma_tile_is_refused_where_it_cannot_run(K):
+    """the LDS-DMA tile needs a plain 1x1 / stride 1 conv, one group, reduction a multiple of 32: set_tile refuses everything else"""
+    import ctypes
+    from semiuhpe_amd import _lib
+    lib = _lib.load()
+    lib.suhpe_conv2d_tile_name.restype = ctypes.c_char_p
+    dma = [lib.suhpe_conv2d_tile_name(0, t) for t in range(lib.suhpe_conv2d_tile_count(0))].index(b"gemm_nt_dma<128,128>")
+    for shape, wshape, stride, pad, groups, want in (((4, 8, 8, 64), (96, 64, 1, 1), 1, 0, 1, (0, 0)), ((4, 8, 8, 40), (96, 40, 1, 1), 1, 0, 1, (-1, 0)),
+                                                      ((4, 8, 8, 64), (96, 32, 1, 1), 1, 0, 2, (-1, -1)), ((4, 8, 8, 64), (96, 64, 3, 3), 1, 1, 1, (-1, -1)),
+                                                      ((4, 8, 8, 64), (100, 64, 1, 1), 1, 0, 1, (0, -1))):
+        d = K.conv_desc(shape, wshape, stride, pad, groups)
+        got = tuple(lib.suhpe_conv2d_set_tile(ctypes.byref(d), pid, dma) for pid in (0, 1))
+        for pid in (0, 1):
+            lib.suhpe_conv2d_set_tile(ctypes.byref(d), pid, -1)
+        assert got == want, (shape, wshape, groups, got)
+
+
 @pytest.mark.parametrize("n,h,c,seg,act", [(160, 14, 512, 32, "silu"), (160, 7, 1536, None, "silu"), (160, 28, 256, 8, "relu"), (80, 14, 960, 5, "silu")])
 def test_depthwise_dgrad_reduces_producer_batchnorm_sums(K, n, h, c, seg, act):
     """suhpe_dwconv_dgrad_bnsums: the depthwise input gradient is bit-equal to suhpe_dwconv_dgrad's, and the BatchNorm backward built from

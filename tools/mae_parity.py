@@ -127,8 +127,8 @@ def _make_pair(network, size, conditioned):
     return oracle, agent, cfg_h
 
 
-def _train_step_both(oracle, agent, step, B, muB, size):
-    """one SSL step on both paths: same inputs, the oracle's Bernoulli draws replayed to the HIP agent"""
+def _train_step_both(oracle, agent, step, B, muB, size, control=None):
+    """one SSL step on both paths: same inputs, the oracle's Bernoulli draws replayed to the HIP agent (and to `control`, a second oracle agent)"""
     from oracle import networks as ON
     from oracle.agent import synthetic_batches
     from parity_utils import MaskTape
@@ -146,9 +146,16 @@ def _train_step_both(oracle, agent, step, B, muB, size):
     agent.train_func({k: v.cuda() for k, v in data.items()}, {k: v.cuda() for k, v in ulb.items()})
     L.set_mask_hook(None)
     assert tape.done(), "the two paths drew different numbers of Bernoulli masks"
+    if control is not None:
+        ON.set_mask_hook(tape.replay)
+        torch.manual_seed(50 + step)
+        control.iteration = step
+        control.train_func({k: v.clone() for k, v in data.items()}, {k: v.clone() for k, v in ulb.items()})
+        ON.set_mask_hook(None)
+        assert tape.cursor == len(tape.masks)
 
 
-def drift_trend(steps=20, at=(1, 2, 3, 5, 8, 12, 16, 20), train_batch=(32, 128), n_images=256, size=224, network="effinetv2", threads=None):
+def drift_trend(steps=20, at=(1, 2, 3, 5, 8, 12, 16, 20), train_batch=(32, 128), n_images=256, size=224, network="effinetv2", threads=None, with_control=True):
     """How two fp32 training trajectories drift apart (the 3.3e-4 of `own_trajectory` was a point, this is the trend): both paths train
     `steps` SSL steps at the BASELINE batch from the same initial state, each on ITS OWN weights; after the steps in `at` both evaluate the first
     `n_images` images of the 8d evaluation set: max |R_hip - R_cpu| and |delta MAE| per listed step.  CPU-bound (about 20 s per oracle step on 32
@@ -158,11 +165,24 @@ def drift_trend(steps=20, at=(1, 2, 3, 5, 8, 12, 16, 20), train_batch=(32, 128),
         torch.set_num_threads(threads)
     t0 = time.perf_counter()
     oracle, agent, cfg_h = _make_pair(network, size, True)
+    # CONTROL: the oracle against ITSELF from an initial state that differs by one unit in the last place of every weight (random direction) --
+    # how fast this training problem pulls ANY two fp32 computations apart; the HIP path's distance from the oracle is to be read against it
+    control = None
+    if with_control:
+        from oracle.agent import OracleAgent
+        import copy
+        control = copy.deepcopy(oracle)
+        g = torch.Generator().manual_seed(99)
+        with torch.no_grad():
+            for net in (control.net, control.ema_net):
+                for q in net.parameters():
+                    up = torch.rand(q.shape, generator=g) < 0.5
+                    q.copy_(torch.where(up, torch.nextafter(q, torch.full_like(q, float("inf"))), torch.nextafter(q, torch.full_like(q, float("-inf")))))
     batches = eval_batches(n_images, EVAL_BATCH, size)
     B, muB = train_batch
     rows = []
     for step in range(steps):
-        _train_step_both(oracle, agent, step, B, muB, size)
+        _train_step_both(oracle, agent, step, B, muB, size, control=control)
         if step + 1 in at:
             R_cpu, err_cpu = _oracle_eval(oracle, batches)
             R_own, mae_own = _hip_eval(agent, cfg_h, batches)
@@ -173,11 +193,20 @@ def drift_trend(steps=20, at=(1, 2, 3, 5, 8, 12, 16, 20), train_batch=(32, 128),
             rows.append({"step": step + 1, "max_abs_dR": float(np.abs(R_own - R_cpu).max()), "mean_abs_dR": float(np.abs(R_own - R_cpu).mean()),
                          "d_mae_deg": {k: round(abs(mae_own[k] - mae_cpu[k]), 6) for k in mae_cpu},
                          "param_rel_l2": float((po - ph).norm() / po.norm()), "elapsed_s": round(time.perf_counter() - t0, 1)})
+            if control is not None:
+                R_c, err_c = _oracle_eval(control, batches)
+                mae_c = _mae(err_c)
+                pc = torch.cat([q.detach().reshape(-1) for q in control.net.parameters()])
+                rows[-1]["control_oracle_vs_oracle_1ulp"] = {"max_abs_dR": float(np.abs(R_c - R_cpu).max()), "mean_abs_dR": float(np.abs(R_c - R_cpu).mean()),
+                                                            "d_mae_deg": {k: round(abs(mae_c[k] - mae_cpu[k]), 6) for k in mae_cpu},
+                                                            "param_rel_l2": float((po - pc).norm() / po.norm())}
             print(rows[-1], flush=True)
     agent.logs_writer.close()
     return {"protocol": f"{steps} SSL steps B={B}+muB={muB} on both paths from the same conditioned init ({network}), each on its own weights; after steps {list(at)} "
                         f"both evaluate {n_images} images of the 8d set (seed {EVAL_SEED}, batch {EVAL_BATCH})",
-            "rows": rows, "bars": {"max_abs_dR (identical weights only)": 1e-4, "d_mae_deg": 0.05}}
+            "rows": rows, "bars": {"max_abs_dR (identical weights only)": 1e-4, "d_mae_deg": 0.05},
+            "control": "control_oracle_vs_oracle_1ulp = the CPU oracle against a copy of itself whose initial weights differ by one unit in the last place: the rate at "
+                       "which this training problem (random-init network, N(0,1) images, Adam lr 1e-4) separates any two fp32 computations"}
 
 
 def run(n_images=EVAL_IMAGES, warm_steps=3, train_batch=(8, 16), size=224, network="effinetv2", threads=None, verbose=False, conditioned=True):
