@@ -1152,6 +1152,7 @@ enum NtTile { NT_64x64_S = 0, NT_64x64, NT_128x32, NT_128x128, NT_128x64, NT_256
               NT_R128x16, NT_R64x8, NT_R64x16,   // operand-resident pointwise kernel (conv_resident.inl): 128 / 64 resident rows, 16 / 8 / 16 wavefronts
               NT_G64x64,                     // Winograd F(2x2, 3x3) kernel (conv_wino.inl): 64 tiles (256 output pixels) x 64 output channels
               NT_D128x128,                   // both operands by LDS-DMA through a four-slab ring, persistent 128 x 128 tiles (conv_dma.inl): plain pointwise GEMMs, K % 32 == 0
+              NT_D256x64,                    // the same pipeline as 256 x 64 tiles for outputs of at most 64 channels, with the XF = 1 loader transform on the fragments
               NT_TILES };
 static const char* kNtNames[] = {"igemm_nt_kernel<64,64,32,32,1>", "igemm_nt_kernel<64,64,32,32,4>", "igemm_nt_kernel<128,32,32,32,4>",
                                  "igemm_nt_kernel<128,128,64,32,4>", "igemm_nt_kernel<128,64,32,32,4>", "igemm_nt_kernel<256,32,64,32,4>",
@@ -1161,7 +1162,7 @@ static const char* kNtNames[] = {"igemm_nt_kernel<64,64,32,32,1>", "igemm_nt_ker
                                  "igemm_nt3x3_kernel<128,128,64,32>", "igemm_nt3x3_n48_kernel<128,48>",
                                  "igemm_nt_kernel<128,128,64,64,4>", "igemm_nt_kernel<128,64,64,32,4>",
                                  "gemm_nt_resident<128,2,16>", "gemm_nt_resident<64,2,8>", "gemm_nt_resident<64,2,16>",
-                                 "wino_nt_kernel<64,64>", "gemm_nt_dma<128,128>"};
+                                 "wino_nt_kernel<64,64>", "gemm_nt_dma<128,128>", "gemm_nt_dma<256,64>"};
 
 struct TnTile { int bm, bn; const char* name; };
 static const TnTile kTnTiles[] = {
@@ -1210,7 +1211,7 @@ static NtTile choose_nt(int64_t M, int ng, bool vec4, int pinned, bool halo = fa
 }
 
 // (row-tile height = rows per BatchNorm statistics record; the resident tiles emit one record per 64-row unit)
-static int nt_tile_bm(NtTile t) { return (t == NT_G64x64 || t == NT_64x64_S || t == NT_64x64 || t == NT_P64x64 || t == NT_H64x64 || t >= NT_R128x16) ? 64 : (t == NT_256x32 ? 256 : 128); }    // (the Winograd tile's record = the 16 tiles of 2x2 pixels of one wavefront)
+static int nt_tile_bm(NtTile t) { if (t == NT_D256x64) return 32; return (t == NT_G64x64 || t == NT_64x64_S || t == NT_64x64 || t == NT_P64x64 || t == NT_H64x64 || t >= NT_R128x16) ? 64 : (t == NT_256x32 ? 256 : 128); }    // (the Winograd tile's record = the 16 tiles of 2x2 pixels of one wavefront)
 // the halo kernel runs 3x3 / stride 1 / pad 1 forward and input-gradient GEMMs whose channel counts chunk evenly
 static bool halo_ok(const GatherGeom& g, bool vec4) { return vec4 && halo_capable(g, 128) && halo_capable(g, 64); }
 
@@ -1240,6 +1241,7 @@ static void launch_persistent(const NtParams& p_in, int groups, hipStream_t st) 
 // a pinned persistent tile on a shape that is not a plain GEMM runs the igemm tile of the same size
 static NtTile effective_nt(NtTile tile, bool plain, bool halo = false, bool resident128 = false, bool resident64 = false, bool wino = false, bool dma = false) {
     if (tile == NT_D128x128) return dma ? tile : NT_64x64;     // (same statistics-record height: 64 rows)
+    if (tile == NT_D256x64) return tile;                        // (checked when it was pinned: dma_ok_desc; no other tile writes 32-row records)
     if (tile == NT_G64x64) return wino ? tile : NT_128x64;
     if (tile >= NT_R128x16) return ((tile == NT_R128x16 && resident128) || (tile != NT_R128x16 && resident64)) ? tile : NT_64x64;   // (same record height)
     if (tile >= NT_W128x128) return tile;
@@ -1261,8 +1263,14 @@ static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st
         tile = p.stats ? NT_64x64 : choose_nt(p.g.M, p.Ng, vec4, -1, halo_ok(p.g, vec4));
     }
     if (tile == NT_D128x128) {
-        if (!act2 && dma_ok(p, groups, vec4)) { launch_dma(p, st); return; }
+        if (!act2 && dma_ok(p, groups, vec4, false)) { launch_dma(p, st); return; }
         tile = NT_64x64;                                    // an epilogue / operand form the DMA kernel lacks: the direct tile of the same record height
+    }
+    if (tile == NT_D256x64) {
+        if (!act2 && dma_ok(p, groups, vec4, true)) { launch_dma_narrow(p, st); return; }
+        // no other tile writes 32-row statistics records: with statistics asked for, a form this kernel lacks is an error, never a silent mismatch
+        if (p.stats) { g_nt_unsupported = true; return; }
+        tile = NT_64x64;
     }
     if (act2 && tile >= NT_R128x16) tile = NT_64x64;
     if (act2 && tile >= NT_W128x128) tile = tile == NT_W128x128 ? NT_128x128 : NT_128x64;
@@ -1518,7 +1526,9 @@ static int conv2d_fwd_stats_impl(const suhpe_conv_t* d, const float* x, const fl
     p.stats = stats; p.stats_extra = stats_extra; p.seg_row = seg_row; p.stat_gx = suhpe_conv2d_fwd_stats_tiles(d); p.stat_cout = d->cout; p.scale = p.shift = p.residual = nullptr; p.act = 0; p.res_mode = 0;
     const bool vec4 = (cg % 4 == 0) && (d->cin % 4 == 0);
     SUHPE_REQUIRE(!vec4 || (aligned16(x) && aligned16(w)), "suhpe_conv2d_fwd_stats: x / w must be 16-byte aligned");
+    g_nt_unsupported = false;
     dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 0));
+    if (g_nt_unsupported) { set_error("suhpe_conv2d_fwd_stats: the pinned tile cannot run this call (operand alignment / size): unpin it"); return SUHPE_EINVAL; }
     return check_launch("suhpe_conv2d_fwd_stats");
 }
 
@@ -1758,9 +1768,10 @@ int suhpe_conv2d_set_tile(const suhpe_conv_t* d, int pass, int tile) {
     SUHPE_REQUIRE(pass != 2 || tile != TN_WINO || wino_wgrad_geom_ok(d->n, d->h, d->w, d->ho, d->wo, d->cin, d->cout, d->r, d->s, d->stride, d->pad, d->groups),
                   "suhpe_conv2d_set_tile: the Winograd filter-gradient tile needs a 3x3 / stride 1 / pad 1 conv on even output sizes");
     SUHPE_REQUIRE(pass == 2 || tile != (int)NT_G64x64 || wino_ok_desc(d, pass), "suhpe_conv2d_set_tile: the Winograd tile needs a 3x3 / stride 1 / pad 1 conv on even output sizes");
-    SUHPE_REQUIRE(pass == 2 || tile < (int)NT_R128x16 || tile == (int)NT_G64x64 || tile == (int)NT_D128x128 || resident_ok_desc(d, pass, tile == (int)NT_R128x16 ? 128 : 64),
+    SUHPE_REQUIRE(pass == 2 || tile < (int)NT_R128x16 || tile == (int)NT_G64x64 || tile == (int)NT_D128x128 || tile == (int)NT_D256x64 || resident_ok_desc(d, pass, tile == (int)NT_R128x16 ? 128 : 64),
                   "suhpe_conv2d_set_tile: the resident tiles need a 1x1 / stride 1 conv whose BM x K block fits the LDS");
     SUHPE_REQUIRE(pass == 2 || tile != (int)NT_D128x128 || dma_ok_desc(d, pass), "suhpe_conv2d_set_tile: the LDS-DMA tile needs a 1x1 / stride 1 conv, one group, reduction a multiple of 32");
+    SUHPE_REQUIRE(pass == 2 || tile != (int)NT_D256x64 || dma_ok_desc(d, pass, true), "suhpe_conv2d_set_tile: the narrow LDS-DMA tile needs a 1x1 / stride 1 conv, one group, reduction a multiple of 32, at most 64 outputs");
     std::lock_guard<std::mutex> lock(tile_mutex());
     if (tile < 0) tile_table().erase(tile_key(d, pass));
     else tile_table()[tile_key(d, pass)] = tile;

@@ -198,7 +198,10 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
             for (int hh = 0; hh < 2; ++hh) {
                 const bool cok = lv_sc * 16 + 8 * sv + 4 * hh < g.Cg;
                 const unsigned off = cok ? voff[c] + cb + 16u * hh : kOob;
-                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(raw[c][hh]) : "v"(off), "s"(xrs) : "memory");
+                // (s_nop 4: five wait states between a vector instruction that may have just written the descriptor's scalar registers -- the compiler
+                //  parks scalars in vector registers under pressure and brings them back with v_readlane -- and the load that reads them; hipcc pads
+                //  that hazard only for instructions it can see)
+                asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(raw[c][hh]) : "v"(off), "s"(xrs) : "memory");
             }
         if (++lv_sc == (wg.nchunks >> 1)) {
             lv_sc = 0;

@@ -1030,6 +1030,87 @@ def test_lds_dma_pointwise_kernel(K, cfg):
             lib.suhpe_conv2d_set_tile(ctypes.byref(d), pid, -1)
 
 
+NARROW_SHAPES = [
+    # (n, cin, cout, h, w, seg, act): FusedMBConv project convs as the narrow LDS-DMA tile sees them (outputs of at most 64 channels)
+    (20, 192, 48, 28, 28, 4, "silu"),      # the C2 stage-2 shape at an eighth of the rows: N = 48 (16 dropped columns), boundary at a 32-row unit edge
+    (9, 256, 64, 14, 14, 2, "silu"),       # N = 64 exactly, boundary inside a unit (2 * 196 = 392 = 12.25 units) and inside a 256-row tile
+    (5, 96, 48, 10, 10, None, "relu"),     # three slabs, ReLU, one segment, M = 500 (a last partial tile)
+    (3, 32, 12, 6, 6, 1, "none"),          # ONE slab per tile, identity activation, 12 outputs
+    (130, 64, 24, 14, 14, 26, "silu"),     # long streams (100 row tiles), two slabs per tile
+]
+
+
+@pytest.mark.parametrize("cfg", NARROW_SHAPES, ids=str)
+def test_lds_dma_narrow_kernel_with_loader_transform(K, cfg):
+    """gemm_nt_dma<256,64> (conv_dma.inl): forward with the producer's BatchNorm + activation applied to the MFMA fragments (XF = 1) equals the igemm
+    tile's XF form (the same fmaf + activation per element; the k order is the same: bit-equal or within fp32 rounding of the transcendental), its
+    32-row statistics records finish to the igemm tile's statistics, the plain form and the input gradient (N = cin <= 64) are bit-equal, repeated
+    launches give the same bits, and against float64 the result is as close as the igemm tile's."""
+    import ctypes
+    from semiuhpe_amd import _lib
+    lib = _lib.load()
+    lib.suhpe_conv2d_tile_name.restype = ctypes.c_char_p
+    n, cin, cout, h, w, seg, act = cfg
+    g = torch.Generator().manual_seed(53)
+    x = (torch.randn(n, h, w, cin, generator=g) * 1.3 + 0.2).cuda()
+    wg = K.to_filter_layout((torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5).cuda())
+    dy = torch.randn(n, h, w, cout, generator=g).cuda()
+    nseg = 2 if seg else 1
+    scale, shift = (torch.rand(nseg, cin, generator=g) + 0.5).cuda(), (torch.randn(nseg, cin, generator=g) * 0.3).cuda()
+    d = K.conv_desc(x.shape, wg.shape, 1, 0, 1)
+    names = [lib.suhpe_conv2d_tile_name(0, t) for t in range(lib.suhpe_conv2d_tile_count(0))]
+    narrow, igemm = names.index(b"gemm_nt_dma<256,64>"), names.index(b"igemm_nt_kernel<64,64,32,32,4>")
+    rows, hw = n * h * w, h * w
+    rows_a = seg * hw if seg else 0
+    xf = (scale, shift, None, act, hw, rows_a)
+
+    def run_all():
+        if seg is None:
+            y, part, nt = K.conv2d_fwd_stats(x, wg, 1, 0, 1, xf=xf)
+            st = K.bn_stats_from_partials(part, nt, rows, cout, 1e-3, 0.1, consume=False)
+            y0, part0, nt0 = K.conv2d_fwd_stats(x, wg, 1, 0, 1)
+            st0 = K.bn_stats_from_partials(part0, nt0, rows, cout, 1e-3, 0.1, consume=False)
+        else:
+            y, part, nt, (first, extra) = K.conv2d_fwd_stats(x, wg, 1, 0, 1, seg=seg, xf=xf)
+            st = K.bn_stats_from_partials_seg(part, nt, first, extra, rows, rows_a, cout, 1e-3, 0.1, consume=False)
+            y0, part0, nt0, (first0, extra0) = K.conv2d_fwd_stats(x, wg, 1, 0, 1, seg=seg)
+            st0 = K.bn_stats_from_partials_seg(part0, nt0, first0, extra0, rows, rows_a, cout, 1e-3, 0.1, consume=False)
+        return [y, y0, K.conv2d_fwd(x, wg, None, 1, 0, 1)], [st, st0]
+
+    try:
+        assert lib.suhpe_conv2d_set_tile(ctypes.byref(d), 0, igemm) == 0
+        ref, st_ref = run_all()
+        assert lib.suhpe_conv2d_set_tile(ctypes.byref(d), 0, narrow) == 0
+        assert lib.suhpe_conv2d_fwd_stats_tile_rows(ctypes.byref(d)) == 32
+        for rep in range(3):
+            out, st = run_all()
+            assert rel(out[0], ref[0].cpu()) < 2e-6, rep                     # XF form (hardware exp / rcp: allow the last bit of the activation)
+            assert torch.equal(out[1], ref[1]) and torch.equal(out[2], ref[2]), rep
+            for a, b in zip(st, st_ref):
+                for u, v in zip(a, b):
+                    assert rel(u, v.cpu()) < 5e-6
+            if rep:
+                assert torch.equal(out[0], first_out)                        # run-to-run bit-identical
+            first_out = out[0]
+        # float64 reference of the transformed GEMM
+        xs = x.double().cpu().reshape(rows, cin)
+        seg_of = (torch.arange(rows) >= rows_a).long() if seg else torch.zeros(rows, dtype=torch.long)
+        u = xs * scale.double().cpu()[seg_of] + shift.double().cpu()[seg_of]
+        a64 = u * torch.sigmoid(u) if act == "silu" else (u.clamp(min=0) if act == "relu" else u)
+        y64 = a64 @ wg.double().cpu().reshape(cout, cin).T
+        e_new, e_old = rel(out[0].reshape(rows, cout), y64), rel(ref[0].reshape(rows, cout), y64)
+        assert e_new < 2e-5 and e_new < 2 * e_old + 1e-6, (e_new, e_old)
+        # input gradient through the narrow tile where N = cin <= 64
+        if cin <= 64 and cout % 32 == 0:
+            lib.suhpe_conv2d_set_tile(ctypes.byref(d), 1, igemm)
+            dref = K.conv2d_dgrad(dy, wg, x.shape, 1, 0, 1)
+            assert lib.suhpe_conv2d_set_tile(ctypes.byref(d), 1, narrow) == 0
+            assert torch.equal(K.conv2d_dgrad(dy, wg, x.shape, 1, 0, 1), dref)
+    finally:
+        for pid in (0, 1):
+            lib.suhpe_conv2d_set_tile(ctypes.byref(d), pid, -1)
+
+
 def test_lds_dma_tile_is_refused_where_it_cannot_run(K):
     """the LDS-DMA tile needs a plain 1x1 / stride 1 conv, one group, reduction a multiple of 32: set_tile refuses everything else"""
     import ctypes
