@@ -46,7 +46,8 @@ struct DmaCfg {
     static_assert(NW == 8 && PIECES % NW == 0 && STAGES >= 3 && STAGES <= 4, "eight wavefronts, whole pieces per wavefront");
 };
 
-// XF: 0 = none, 1 = the gathered operand is act(x * a_scale[s][k] + a_shift[s][k]) of the stored tensor (WAVES_N == 1 only)
+// XF: 0 = none; 1 = the gathered operand is act(x * a_scale[s][k] + a_shift[s][k]) of the stored tensor, act = p.a_act; 2 = the same with act = SiLU
+// at compile time (WAVES_N == 1 only)
 template <int TM, int TN, int WAVES_M, int WAVES_N, int STAGES, bool STATS, int XF>
 __global__ __launch_bounds__(512) void gemm_nt_dma(const NtParams p, int total_vb, int nk) {
     using C = DmaCfg<TM, TN, WAVES_M, WAVES_N, STAGES>;
@@ -157,27 +158,40 @@ __global__ __launch_bounds__(512) void gemm_nt_dma(const NtParams p, int total_v
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[set][j] = *reinterpret_cast<const float4*>(&S[b_rd[j] ^ (kg << 3)]);
     };
-    // the producer's BatchNorm + activation on fragment set `set` = k-group kg of slab kt of the tile under the MFMAs (xf_seg: 0 / 1 = every row of the
-    // tile in that segment, 2 = the tile straddles the boundary: per-row choice)
-    int xf_seg = 0;
-    bool xf_row1[XF ? TM : 1];
+    // the producer's BatchNorm + activation on fragment set `set` = k-group kg of slab kt of the tile under the MFMAs.  Branch-free: a lane reads the
+    // scale / shift vectors of ITS row's batch segment (xf_row[i] = float offset of that segment's block in the table), so the tile that straddles the
+    // boundary needs no other code, and the whole k-group -- eight MFMAs of the previous fragments, this transform, the next fragment reads -- is ONE
+    // scheduling region: interleave() below pins an MFMA / vector-ALU pattern on it.  (Left to itself hipcc keeps the MFMAs of a k-group together
+    // and the transform behind them; the two wavefronts of a SIMD run in phase, so for that long neither fed the matrix pipe: the transform cost
+    // 192 -> 48 @ 56^2 40 us on top of 146.)  XF == 2: the activation is SiLU at compile time (no selects).
+    int xf_row[XF ? TM : 1];
     auto transform = [&](int kt, int kg, int set) __attribute__((always_inline)) {
         if constexpr (XF != 0) {
             const int k0 = kt * 32 + kg * 8 + h * 4;
-            const float* t0 = xf_tab + (xf_seg == 1 ? 2 * g.K : 0) + k0;
-            const float4 sc0 = *reinterpret_cast<const float4*>(t0), sh0 = *reinterpret_cast<const float4*>(t0 + g.K);
-            float4 sc1 = sc0, sh1 = sh0;
-            if (xf_seg == 2) {                                   // (workgroup-uniform: at most one tile per launch)
-                sc1 = *reinterpret_cast<const float4*>(xf_tab + 2 * g.K + k0);
-                sh1 = *reinterpret_cast<const float4*>(xf_tab + 3 * g.K + k0);
-            }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const bool q = xf_seg == 2 && xf_row1[i];
-                af[set][i].x = xf_act(af[set][i].x * (q ? sc1.x : sc0.x) + (q ? sh1.x : sh0.x), p.a_act);
-                af[set][i].y = xf_act(af[set][i].y * (q ? sc1.y : sc0.y) + (q ? sh1.y : sh0.y), p.a_act);
-                af[set][i].z = xf_act(af[set][i].z * (q ? sc1.z : sc0.z) + (q ? sh1.z : sh0.z), p.a_act);
-                af[set][i].w = xf_act(af[set][i].w * (q ? sc1.w : sc0.w) + (q ? sh1.w : sh0.w), p.a_act);
+                const float* t0 = xf_tab + xf_row[i] + k0;
+                const float4 sc = *reinterpret_cast<const float4*>(t0), sh = *reinterpret_cast<const float4*>(t0 + g.K);
+                auto act1 = [&](float a, float c, float d) __attribute__((always_inline)) {
+                    const float u = a * c + d;
+                    if constexpr (XF == 2) return u * __builtin_amdgcn_rcpf(1.f + __expf(-u));
+                    else return xf_act(u, p.a_act);
+                };
+                af[set][i].x = act1(af[set][i].x, sc.x, sh.x);
+                af[set][i].y = act1(af[set][i].y, sc.y, sh.y);
+                af[set][i].z = act1(af[set][i].z, sc.z, sh.z);
+                af[set][i].w = act1(af[set][i].w, sc.w, sh.w);
+            }
+        }
+    };
+    // one MFMA, then a handful of vector-ALU instructions, eight times: the transform of the next fragments rides in the issue slots between this
+    // k-group's MFMAs (a 64-cycle fp32 MFMA leaves its wavefront ~48 cycles of vector issue)
+    auto interleave = [&]() __attribute__((always_inline)) {
+        if constexpr (XF != 0) {
+#pragma unroll
+            for (int r = 0; r < 4 * TM * TN; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, XF == 2 ? 4 : 6, 0);      // vector ALU (the transcendentals count among them)
             }
         }
     };
@@ -185,9 +199,8 @@ __global__ __launch_bounds__(512) void gemm_nt_dma(const NtParams p, int total_v
         if constexpr (XF != 0) {
             int m0, n0, rt;
             tile_of(vb, &m0, &n0, &rt);
-            xf_seg = p.a_seg_row > 0 ? (m0 + BM <= p.a_seg_row ? 0 : (m0 >= p.a_seg_row ? 1 : 2)) : 0;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) xf_row1[i] = m0 + (wm * TM + i) * 32 + r32 >= p.a_seg_row;
+            for (int i = 0; i < TM; ++i) xf_row[i] = (p.a_seg_row > 0 && m0 + (wm * TM + i) * 32 + r32 >= p.a_seg_row) ? 2 * (int)g.K : 0;
         }
     };
     floatx16 acc[TM][TN];
@@ -334,9 +347,11 @@ __global__ __launch_bounds__(512) void gemm_nt_dma(const NtParams p, int total_v
         read_frags(c_stage, 1, 1);
         mma(0);
         transform(c_kt, 1, 1);
+        interleave();
         read_frags(c_stage, 2, 0);
         mma(1);
         transform(c_kt, 2, 0);
+        interleave();
         if constexpr (!EARLY) {
             if (gs + 1 < n_slabs) {
                 if (issued - (gs + 2) == STAGES - 3) {
@@ -352,6 +367,7 @@ __global__ __launch_bounds__(512) void gemm_nt_dma(const NtParams p, int total_v
         read_frags(c_stage, 3, 1);
         mma(0);
         transform(c_kt, 3, 1);
+        interleave();
         if constexpr (!EARLY) { if (gs + 1 < n_slabs) read_frags(n_stage, 0, 0); }
         mma(1);
         ended <<= 1;
@@ -410,7 +426,11 @@ static void launch_dma_cfg(const NtParams& p_in, hipStream_t st) {
     };
     if constexpr (WAVES_N == 1) {
         if (p.a_scale) {
-            if (p.stats) go(gemm_nt_dma<TM, TN, WAVES_M, WAVES_N, STAGES, true, 1>); else go(gemm_nt_dma<TM, TN, WAVES_M, WAVES_N, STAGES, false, 1>);
+            if (p.a_act == SUHPE_ACT_SILU) {
+                if (p.stats) go(gemm_nt_dma<TM, TN, WAVES_M, WAVES_N, STAGES, true, 2>); else go(gemm_nt_dma<TM, TN, WAVES_M, WAVES_N, STAGES, false, 2>);
+            } else {
+                if (p.stats) go(gemm_nt_dma<TM, TN, WAVES_M, WAVES_N, STAGES, true, 1>); else go(gemm_nt_dma<TM, TN, WAVES_M, WAVES_N, STAGES, false, 1>);
+            }
             return;
         }
     }
