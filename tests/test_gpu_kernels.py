@@ -103,13 +103,15 @@ def test_tile_menu_every_pinned_tile_matches(K, cfg):
                 wino = b"wino" in lib.suhpe_conv2d_tile_name(pid, tile)
                 halo = b"nt3x3" in lib.suhpe_conv2d_tile_name(pid, tile) or (wino and pid < 2)      # (Winograd: other arithmetic, rounding-level differences)
                 resident = b"resident" in lib.suhpe_conv2d_tile_name(pid, tile)
+                dma = b"gemm_nt_dma" in lib.suhpe_conv2d_tile_name(pid, tile)
                 if lib.suhpe_conv2d_set_tile(ctypes.byref(d), pid, tile) != 0:
                     # the scalar-loader tile is refused for vector shapes, the halo / Winograd tiles for anything but 3x3 / stride 1 / pad 1,
-                    # the resident tiles for anything but 1x1 / stride 1
-                    assert (pid < 2 and (tile == 0 or halo or resident)) or wino
+                    # the resident and LDS-DMA tiles for anything but 1x1 / stride 1 (the DMA tiles also for reductions that are not multiples of 32,
+                    # the narrow one for more than 64 outputs)
+                    assert (pid < 2 and (tile == 0 or halo or resident or dma)) or wino
                     continue
                 assert not wino or (k == 3 and stride == 1)
-                assert not resident or k == 1
+                assert not (resident or dma) or k == 1
                 if halo:            # channel-chunk-major reduction order: same sums, different rounding
                     out = K.conv2d_fwd(x, wg, None, stride, pad, groups) if pid == 0 else K.conv2d_dgrad(dy, wg, x.shape, stride, pad, groups)
                     assert rel(out, (y0 if pid == 0 else dx0).cpu()) < 3e-6, tile

@@ -11,10 +11,12 @@ import ctypes
 from semiuhpe_amd import _lib
 lib = _lib.load(); lib.suhpe_conv2d_tile_name.restype = ctypes.c_char_p
 names = [lib.suhpe_conv2d_tile_name(0, i).decode() for i in range(lib.suhpe_conv2d_tile_count(0))]
-print(" ".join(str(names.index(n)) for n in ("igemm_nt_kernel<64,64,32,32,4>", "igemm_nt_kernel<128,64,32,32,4>", "gemm_nt_resident<128,2,16>", "gemm_nt_resident<64,2,8>", "gemm_nt_resident<64,2,16>")))
+print(" ".join(str(names.index(n)) for n in ("igemm_nt_kernel<64,64,32,32,4>", "igemm_nt_kernel<128,64,32,32,4>", "gemm_nt_resident<128,2,16>", "gemm_nt_resident<64,2,8>", "gemm_nt_dma<128,128>", "gemm_nt_dma<256,64>")))
 PY
 )
-for shape in "31360 960 160" "31360 160 960" "7840 1536 256" "31360 960 2048"; do
+# shapes "M N K": the two VERDICT r4 names (160 -> 960 @ 14^2, 256 -> 1536 @ 7^2), 128 -> 512, a narrow-output stream, a long reduction
+SHAPE_LIST=("31360 960 160" "7840 1536 256" "31360 512 128" "501760 64 192" "31360 960 2048")
+for shape in "${SHAPE_LIST[@]}"; do
   for tile in $TILES; do
     rm -rf /tmp/pm; timeout 180 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d /tmp/pm -- python3 $R/tools/gemm_pmc.py $shape 0 $tile > /dev/null 2>&1
     python3 - "$shape" $tile <<'PY'
