@@ -56,11 +56,19 @@ while i < len(lines):
                         out.extend(wrap(f"*{name}:* {val}", "- ", "  "))
             out.append("")
         i = j; continue
+    if not l.strip() or l.startswith("#"):
+        out.append(l); i += 1; continue
     m = re.match(r"^(\s*)([*\-] |\d+\. )?(.*)$", l)
     indent, bullet, text = m.group(1), m.group(2) or "", m.group(3)
-    if len(l) <= W or l.startswith("#"):
-        out.append(l); i += 1; continue
+    # the paragraph / list item continues over the following lines until a blank line, a heading, a table row, a code fence or the next list item
+    j = i + 1
+    while j < len(lines):
+        n = lines[j]
+        if not n.strip() or n.startswith("#") or n.lstrip().startswith("|") or n.strip().startswith("```") or re.match(r"^\s*([*\-] |\d+\. )", n):
+            break
+        text += " " + n.strip()
+        j += 1
     out.extend(wrap(text, indent + bullet, indent + " " * len(bullet)))
-    i += 1
+    i = j
 open(path, "w").write("\n".join(out))
 print(len(out), "lines, longest", max(len(x) for x in out))
