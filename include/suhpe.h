@@ -499,6 +499,25 @@ int suhpe_window_attn_bwd(const float* qkv, const float* probs, const float* dou
                           int H, int W, int ws, int heads, int dh, int noff, float scale, float* dqkv,
                           float* dbias_table, void* workspace, suhpe_stream_t stream);
 
+/* The recomputing form of the same attention (round 5; what the training step runs): the forward keeps TWO floats per query row -- the row max
+ * of the scaled, biased scores and the reciprocal of the row's exp sum -- instead of the N x N probabilities, and the backward recomputes the
+ * probabilities from q k^T and those two (bit-identical to the forward's) and takes delta_i = sum_j P_ij dP_ij as dO_i . O_i from the forward's
+ * output.  Same operands and results as suhpe_window_attn_fwd / _bwd (src/tiny_vit.py:262-286 and its autograd backward); ws*ws <= 196.
+ *   rowstats: (windows*heads, NP, 2) floats, NP = 64 for ws*ws <= 64 else 224: suhpe_window_attn_rowstats_elems(); NULL for inference.
+ *   workspace / bias_workspace: suhpe_window_attn_rs_workspace_bytes(ws, heads) bytes (two tile-ordered expansions of the bias table, rebuilt
+ *     by a small first launch of either call: the two calls need not share it).
+ *   fwd_out: the forward's `out`.  dS_workspace: suhpe_window_attn_probs_elems floats, left holding dS for suhpe_window_attn_dbias.
+ *   dbias_table: as in suhpe_window_attn_bwd (NULL + suhpe_window_attn_dbias = the reproducible form). */
+int64_t suhpe_window_attn_rs_workspace_bytes(int ws, int heads);
+int64_t suhpe_window_attn_rowstats_elems(int B, int H, int W, int ws, int heads);
+int suhpe_window_attn_fwd_rs(const float* qkv, const float* bias_table, const int32_t* bias_idx, int B, int H, int W,
+                             int ws, int heads, int dh, int noff, float scale, float* out, float* rowstats,
+                             void* workspace, suhpe_stream_t stream);
+int suhpe_window_attn_bwd_rs(const float* qkv, const float* fwd_out, const float* rowstats, const float* dout,
+                             const float* bias_table, const int32_t* bias_idx, int B, int H, int W, int ws, int heads,
+                             int dh, int noff, float scale, float* dqkv, float* dbias_table, void* dS_workspace,
+                             void* bias_workspace, suhpe_stream_t stream);
+
 /* Bias-table gradient of tiny_vit.Attention (attention_biases[:, attention_bias_idxs], src/tiny_vit.py:237-260) without atomics:
  * dbias_table[h][o] += sum over windows and over the (i, j) with bias_idx[i][j] == o of dS, in a fixed order.  inv_ptr (noff + 1) /
  * inv_list (N*N) is the inverse of bias_idx in CSR form (pairs i*N + j grouped by offset, ascending).  dS: suhpe_window_attn_bwd's

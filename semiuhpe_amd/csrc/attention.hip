@@ -532,6 +532,305 @@ __global__ __launch_bounds__(NP == 64 ? 128 : 512, 2) void window_attn_bwd_mfma(
     }
 }
 
+// ---- Round 5: the recomputing form.  The forward keeps two floats per query row (the row max of the scaled, biased scores and the reciprocal of
+// the row's exp sum) instead of the N x N probabilities; the backward recomputes every probability tile from Q K^T and those two numbers with
+// the forward's own instruction sequence, and takes delta_i = sum_j P_ij dP_ij from the identity delta_i = dO_i . O_i (O = the forward's
+// output, which the proj GEMM keeps for its filter gradient anyway): the 3 x N x N probability reads of the old backward, its delta sweep and the
+// forward's N x N stores (784-byte rows, the bound of the old forward) are gone.
+// No LDS staging between the chained products either: whichever product feeds the next one is computed TRANSPOSED, so that its MFMA C layout
+// (lane r32 = column, register e = row (e&3) + 8(e>>2) + 4h) IS the next product's A operand (lane r32 = row, step kk of the half h = reduction
+// index) once the reduction index of step kk is read as (kk&3) + 8(kk>>2) + 4h -- the other operand comes from LDS one value per lane at exactly
+// that row.  With the query on the lane (forward, backward phase A) the softmax statistics are per-lane scalars: two cross-half shuffles per
+// query block where the old kernels ran 2 x 16 x 5 xor-shuffle steps.
+//   forward / phase A (a wavefront per 32 queries):  S^T = K Q^T, dP^T = V dO^T (A operand: K / V rows of the key tile from LDS, b128; B: the
+//       query block's Q / dO rows in registers)  ->  P^T, dS^T in registers = A operands of O = P V and dQ = dS K (B: V / K from LDS).
+//   phase B (a wavefront per 32 keys):  S = Q K^T, dP = dO V^T (A: Q / dO rows of the query block from LDS; B: the key tile's K / V rows in
+//       registers)  ->  P, dS with the key on the lane = A operands of dV = P^T dO and dK = dS^T Q (B: dO / Q from LDS); dS goes to the scratch
+//       matrix for the bias gradient from here (rows of 32 consecutive keys: coalesced).
+// The additive bias comes from two tile-ordered expansions of the table (one per lane assignment), so that a lane's 16 values of a tile are four
+// coalesced 16-byte loads: tiledA[h][qb][kt][g][lane (r32 = query, half)][4 keys 8g + 4 half ..], tiledB[h][qb][kt][g][lane (r32 = key)][4 queries].
+constexpr float kLog2e = 1.4426950408889634f;
+__device__ __forceinline__ int c_row(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
+
+__global__ __launch_bounds__(256) void window_attn_tiled_bias_kernel(const float* __restrict__ table, const int32_t* __restrict__ bias_idx, int heads,
+                                                                      int N, int QB, int noff, float* __restrict__ tiledA, float* __restrict__ tiledB) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)heads * QB * QB * 1024) return;
+    const int q = (int)(e & 3), lane = (int)((e >> 2) & 63), gq = (int)((e >> 8) & 3);
+    const int tile = (int)(e >> 10), kt = tile % QB, qb = (tile / QB) % QB, hd = tile / (QB * QB);
+    const int r32 = lane & 31, hh = lane >> 5, sub = 8 * gq + 4 * hh + q;
+    {
+        const int i = qb * 32 + r32, j = kt * 32 + sub;
+        tiledA[e] = (i < N && j < N) ? table[hd * noff + bias_idx[i * N + j]] : -3.0e38f;
+    }
+    {
+        const int i = qb * 32 + sub, j = kt * 32 + r32;
+        tiledB[e] = (i < N && j < N) ? table[hd * noff + bias_idx[i * N + j]] : -3.0e38f;
+    }
+}
+
+// tok[t] = row of window token t in the (B*H*W, C) tensors, -1 beyond the window: computed once per workgroup (three integer divisions per
+// token; the first version redid them for every loaded slice and every stored row: a tenth of the kernel's instructions)
+template <int NP>
+__device__ __forceinline__ void attn_token_table(const AttnGeom& g, int win, int* tok) {
+    for (int t = threadIdx.x; t < NP; t += blockDim.x) tok[t] = t < g.N ? (int)token_row(g, win, t) : -1;
+}
+__device__ __forceinline__ unsigned attn_off(int row, int ld, int col) { return row >= 0 ? (unsigned)((row * ld + col) * 4) : kOob; }
+// rows of one 32-float slice per token into LDS, [token][KP]; tokens beyond the window are zero
+template <int NP, int THREADS>
+__device__ __forceinline__ void attn_load_rows(const int* tok, BufRsrc src, int ldsrc, int off, float* dst) {
+    constexpr int IT = NP * (DH / 4) / THREADS;         // 7 (224 tokens, 256 threads) or 4 (64 tokens, 128 threads): exact
+    static_assert(IT * THREADS == NP * (DH / 4), "attn_load_rows: the slices must divide over the threads");
+    // all row numbers, then all loads, then all LDS writes: written as one loop, the compiler kept `tok` (LDS) and `dst` (LDS) ordered against
+    // each other and every slice went load -> wait -> write before the next row number was read
+    int rows[IT];
+    float4 v[IT];
+#pragma unroll
+    for (int k = 0; k < IT; ++k) rows[k] = tok[(threadIdx.x + k * THREADS) >> 3];
+#pragma unroll
+    for (int k = 0; k < IT; ++k) buf_load<4>(src, attn_off(rows[k], ldsrc, off + ((threadIdx.x + k * THREADS) & 7) * 4), &v[k].x);
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+        const int e = threadIdx.x + k * THREADS;
+        *reinterpret_cast<float4*>(&dst[(e >> 3) * KP + (e & 7) * 4]) = v[k];
+    }
+}
+// store the 16 rows (c_row(e, h) of the 32-row block `blk`) x column r32 of a C-layout tile, scaled, to rows tok[] of a (rows, ld) tensor:
+// buffer stores whose offset is pushed out of range beyond the window (no branch per row)
+__device__ __forceinline__ void attn_store_tile(const floatx16& c, float mul, const int* tok, int blk, int h, BufRsrc dst, int ld, int col) {
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const int4 r4 = *reinterpret_cast<const int4*>(&tok[blk * 32 + 8 * gq + 4 * h]);
+        const int rr[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c[4 * gq + q] * mul), dst, attn_off(rr[q], ld, col), 0, 0);
+    }
+}
+// the A / B fragment of one row held in registers: lane (row r32, half h) takes channels 8 kg + 4 h .. + 3 of its row
+__device__ __forceinline__ void attn_row_frag(BufRsrc src, int row, int ld, int col, float4 (&f)[DH / 8]) {
+#pragma unroll
+    for (int kg = 0; kg < DH / 8; ++kg) buf_load<4>(src, attn_off(row, ld, col + kg * 8), &f[kg].x);
+}
+// rows(LDS)[32 x 32] * frag^T: tile[row of lds][lane's row]  (A = the LDS rows, one b128 read per four MFMAs; B = the register fragment)
+__device__ __forceinline__ floatx16 attn_tile(const float* __restrict__ lds_rows, int r32, int h, const float4 (&f)[DH / 8]) {
+    floatx16 c;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) c[e] = 0.f;
+#pragma unroll
+    for (int kg = 0; kg < DH / 8; ++kg) {
+        const float4 a = *reinterpret_cast<const float4*>(&lds_rows[r32 * KP + kg * 8 + h * 4]);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, f[kg].x, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, f[kg].y, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, f[kg].z, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, f[kg].w, c, 0, 0, 0);
+    }
+    return c;
+}
+// acc += a^T-chained product: A = the C-layout registers of the previous product, B = rows of `lds_rows` at the C layout's row order
+__device__ __forceinline__ void attn_chain(const float (&a)[16], const float* __restrict__ lds_rows, int r32, int h, floatx16& acc) {
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], lds_rows[c_row(kk, h) * KP + r32], acc, 0, 0, 0);
+}
+__device__ __forceinline__ void attn_bias_tile(const float* __restrict__ tiled, int tile, int lane, float (&b)[16]) {
+    const float4* p = reinterpret_cast<const float4*>(tiled) + (int64_t)tile * 256 + lane;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const float4 v = p[gq * 64];
+        b[4 * gq + 0] = v.x; b[4 * gq + 1] = v.y; b[4 * gq + 2] = v.z; b[4 * gq + 3] = v.w;
+    }
+}
+
+template <int NP>
+__global__ __launch_bounds__(NP == 64 ? 128 : 256, 2) void window_attn_fwd_rs(const AttnGeom g, const float* __restrict__ qkv,
+                                                                          const float* __restrict__ tiledA, float* __restrict__ out,
+                                                                          float2* __restrict__ rowstats) {
+    constexpr int QB = NP / 32, NW = NP == 64 ? 2 : 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;                                   // [NP][KP]
+    float* Vs = Ks + NP * KP;                           // [NP][KP]
+    int* tok = reinterpret_cast<int*>(Vs + NP * KP);    // [NP]
+    const int win = blockIdx.x / g.heads, hd = blockIdx.x - win * g.heads;
+    const int ld = g.heads * 3 * DH, lo = g.heads * DH, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r32 = lane & 31, h = lane >> 5;
+    const BufRsrc rq = make_rsrc(qkv, (int64_t)g.B * g.H * g.W * ld * 4);
+    const BufRsrc rout = make_rsrc(out, (int64_t)g.B * g.H * g.W * lo * 4);
+    attn_token_table<NP>(g, win, tok);
+    __syncthreads();
+    attn_load_rows<NP, NW * 64>(tok, rq, ld, hd * 3 * DH + DH, Ks);
+    attn_load_rows<NP, NW * 64>(tok, rq, ld, hd * 3 * DH + 2 * DH, Vs);
+    __syncthreads();
+    for (int qb = wave; qb < QB; qb += NW) {
+        const int qrow = qb * 32 + r32;
+        float4 qf[DH / 8];
+        attn_row_frag(rq, tok[qrow], ld, hd * 3 * DH + h * 4, qf);
+        const int tile0 = (hd * QB + qb) * QB;
+        float sc[QB][16], bt[16];
+        float lmax = -3.0e38f;
+        attn_bias_tile(tiledA, tile0, lane, bt);
+#pragma unroll
+        for (int kt = 0; kt < QB; ++kt) {
+            const floatx16 st = attn_tile(Ks + kt * 32 * KP, r32, h, qf);         // [key][query = lane]
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float v = st[e] * g.scale + bt[e];                          // padding: -3e38 swallows the (finite) score
+                sc[kt][e] = v;
+                lmax = fmaxf(lmax, v);
+            }
+            // the next tile's bias is requested behind this tile's use of the registers and lands under the next tile's MFMAs (the fence keeps
+            // the compiler from requesting all seven tiles up front: 112 more live registers, spills)
+            asm volatile("" ::: "memory");
+            if (kt + 1 < QB) attn_bias_tile(tiledA, tile0 + kt + 1, lane, bt);
+        }
+        lmax = fmaxf(lmax, __shfl_xor(lmax, 32, 64));
+        float lsum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < QB; ++kt) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pv = __builtin_amdgcn_exp2f((sc[kt][e] - lmax) * kLog2e);      // keys beyond the window: (-3e38 - max) log2(e) = -inf -> 0
+                sc[kt][e] = pv;
+                lsum += pv;
+            }
+        }
+        lsum += __shfl_xor(lsum, 32, 64);
+        const float rinv = 1.f / lsum;
+        floatx16 oacc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[e] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < QB; ++kt) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sc[kt][e] *= rinv;
+            attn_chain(sc[kt], Vs + kt * 32 * KP, r32, h, oacc);
+        }
+        attn_store_tile(oacc, 1.f, tok, qb, h, rout, lo, hd * DH + r32);         // O in C layout: column = channel r32, row = query
+        if (rowstats && h == 0) rowstats[(int64_t)blockIdx.x * NP + qrow] = make_float2(lmax, qrow < g.N ? rinv : 0.f);
+    }
+}
+
+template <int NP>
+__global__ __launch_bounds__(NP == 64 ? 128 : 256, 2) void window_attn_bwd_rs(const AttnGeom g, const float* __restrict__ qkv,
+                                                                          const float* __restrict__ fwd_out, const float2* __restrict__ rowstats,
+                                                                          const float* __restrict__ dout, const float* __restrict__ tiledA,
+                                                                          const float* __restrict__ tiledB, float* __restrict__ dS_out,
+                                                                          float* __restrict__ dqkv) {
+    constexpr int QB = NP / 32, NW = NP == 64 ? 2 : 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* A0 = smem;                                   // [NP][KP]: K in phase A, Q in phase B
+    float* A1 = A0 + NP * KP;                           // [NP][KP]: V in phase A, dO in phase B
+    float* st_m = A1 + NP * KP;                         // [NP] row max, 1 / row sum (0 beyond the window), delta
+    float* st_r = st_m + NP;
+    float* st_d = st_r + NP;
+    int* tok = reinterpret_cast<int*>(st_d + NP);       // [NP]
+    const int win = blockIdx.x / g.heads, hd = blockIdx.x - win * g.heads;
+    const int ld = g.heads * 3 * DH, lo = g.heads * DH, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r32 = lane & 31, h = lane >> 5;
+    float* S = dS_out + (int64_t)blockIdx.x * g.N * g.N;
+    const BufRsrc rq = make_rsrc(qkv, (int64_t)g.B * g.H * g.W * ld * 4);
+    const BufRsrc ro = make_rsrc(dout, (int64_t)g.B * g.H * g.W * lo * 4);
+    const BufRsrc rx = make_rsrc(fwd_out, (int64_t)g.B * g.H * g.W * lo * 4);
+    const BufRsrc rs = make_rsrc(S, (int64_t)g.N * g.N * 4);
+    const BufRsrc rd = make_rsrc(dqkv, (int64_t)g.B * g.H * g.W * ld * 4);
+    attn_token_table<NP>(g, win, tok);
+    __syncthreads();
+    attn_load_rows<NP, NW * 64>(tok, rq, ld, hd * 3 * DH + DH, A0);               // K
+    attn_load_rows<NP, NW * 64>(tok, rq, ld, hd * 3 * DH + 2 * DH, A1);           // V
+    __syncthreads();
+    // ---------------- phase A: query blocks, the query on the lane
+    for (int qb = wave; qb < QB; qb += NW) {
+        const int qrow = qb * 32 + r32;
+        const bool valid = qrow < g.N;
+        const int trow = tok[qrow];
+        float4 qf[DH / 8], of[DH / 8], xf[DH / 8];
+        attn_row_frag(rq, trow, ld, hd * 3 * DH + h * 4, qf);
+        attn_row_frag(ro, trow, lo, hd * DH + h * 4, of);
+        attn_row_frag(rx, trow, lo, hd * DH + h * 4, xf);
+        const float2 ms = rowstats[(int64_t)blockIdx.x * NP + qrow];
+        const float rmax = ms.x, rinv = valid ? ms.y : 0.f;
+        float delta = 0.f;
+#pragma unroll
+        for (int kg = 0; kg < DH / 8; ++kg) delta += of[kg].x * xf[kg].x + of[kg].y * xf[kg].y + of[kg].z * xf[kg].z + of[kg].w * xf[kg].w;
+        delta += __shfl_xor(delta, 32, 64);
+        if (h == 0) { st_m[qrow] = rmax; st_r[qrow] = rinv; st_d[qrow] = delta; }
+        const int tile0 = (hd * QB + qb) * QB;
+        floatx16 dq;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dq[e] = 0.f;
+        float bt[16];
+        attn_bias_tile(tiledA, tile0, lane, bt);
+#pragma unroll 1
+        for (int kt = 0; kt < QB; ++kt) {
+            const floatx16 st = attn_tile(A0 + kt * 32 * KP, r32, h, qf);         // S^T  [key][query = lane]
+            const floatx16 dp = attn_tile(A1 + kt * 32 * KP, r32, h, of);         // dP^T
+            float ds[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float v = st[e] * g.scale + bt[e];
+                const float pv = __builtin_amdgcn_exp2f((v - rmax) * kLog2e) * rinv;      // 0 beyond the window: the bias mask (keys), rinv (queries)
+                ds[e] = pv * (dp[e] - delta);
+            }
+            asm volatile("" ::: "memory");
+            if (kt + 1 < QB) attn_bias_tile(tiledA, tile0 + kt + 1, lane, bt);     // lands under the 16 MFMAs below and the next tile's 32
+            attn_chain(ds, A0 + kt * 32 * KP, r32, h, dq);                        // dQ += dS K
+        }
+        attn_store_tile(dq, g.scale, tok, qb, h, rd, ld, hd * 3 * DH + r32);
+    }
+    __syncthreads();                                    // every wave is done with K and V; the row statistics are complete
+    attn_load_rows<NP, NW * 64>(tok, rq, ld, hd * 3 * DH, A0);                    // Q
+    attn_load_rows<NP, NW * 64>(tok, ro, lo, hd * DH, A1);                        // dO
+    __syncthreads();
+    // ---------------- phase B: key tiles, the key on the lane
+    for (int kt = wave; kt < QB; kt += NW) {
+        const int key = kt * 32 + r32;
+        const bool valid = key < g.N;
+        float4 kf[DH / 8], vf[DH / 8];
+        attn_row_frag(rq, tok[key], ld, hd * 3 * DH + DH + h * 4, kf);
+        attn_row_frag(rq, tok[key], ld, hd * 3 * DH + 2 * DH + h * 4, vf);
+        floatx16 dk, dv;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dk[e] = 0.f; dv[e] = 0.f; }
+        // the bias tile of the NEXT query block is requested at the top of a block, ahead of this block's 16 dS stores: the wait for it (in-order
+        // counter) then never covers a store.  (Requested behind the stores, every block waited for its stores to be acknowledged: the first
+        // version of this kernel ran no faster than the probability-keeping one, matrix pipes 49 % busy, 45 % of the wave cycles in waits.)
+        float ba[16], bb[16];
+        auto block = [&](int qb, const float (&bcur)[16], float (&bnext)[16]) __attribute__((always_inline)) {
+            if (qb + 1 < QB) attn_bias_tile(tiledB, (hd * QB + qb + 1) * QB + kt, lane, bnext);
+            const floatx16 st = attn_tile(A0 + qb * 32 * KP, r32, h, kf);         // S   [query][key = lane]
+            const floatx16 dp = attn_tile(A1 + qb * 32 * KP, r32, h, vf);         // dP
+            float pv[16], ds[16];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 m4 = *reinterpret_cast<const float4*>(&st_m[qb * 32 + 8 * gq + 4 * h]);
+                const float4 r4 = *reinterpret_cast<const float4*>(&st_r[qb * 32 + 8 * gq + 4 * h]);
+                const float4 d4 = *reinterpret_cast<const float4*>(&st_d[qb * 32 + 8 * gq + 4 * h]);
+                const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = 4 * gq + q;
+                    const float v = st[e] * g.scale + bcur[e];
+                    const float p1 = __builtin_amdgcn_exp2f((v - mm[q]) * kLog2e) * rr[q];      // 0 beyond the window: the bias mask (keys), rr (queries)
+                    pv[e] = p1;
+                    ds[e] = p1 * (dp[e] - dd[q]);
+                    const int i = qb * 32 + 8 * gq + 4 * h + q;
+                    // (a buffer store whose offset is pushed out of range beyond the window: no branch per element)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ds[e]), rs, (i < g.N && valid) ? (unsigned)((i * g.N + key) * 4) : kOob, 0, 0);
+                }
+            }
+            attn_chain(ds, A0 + qb * 32 * KP, r32, h, dk);                        // dK += dS^T Q
+            attn_chain(pv, A1 + qb * 32 * KP, r32, h, dv);                        // dV += P^T dO
+        };
+        attn_bias_tile(tiledB, hd * QB * QB + kt, lane, ba);
+#pragma unroll 1
+        for (int qb = 0; qb < QB; qb += 2) {
+            block(qb, ba, bb);
+            if (qb + 1 >= QB) break;
+            block(qb + 1, bb, ba);
+        }
+        attn_store_tile(dk, g.scale, tok, kt, h, rd, ld, hd * 3 * DH + DH + r32);
+        attn_store_tile(dv, 1.f, tok, kt, h, rd, ld, hd * 3 * DH + 2 * DH + r32);
+    }
+}
+
 // dbias_table[h][bias_idx[i][j]] += sum over windows of dS[w][h][i][j]
 // (blockIdx.y selects a chunk of windows: more loads in flight, and the chunks' partial sums meet in the atomic)
 __global__ __launch_bounds__(256) void window_attn_dbias_kernel(const float* __restrict__ dS, const int32_t* __restrict__ bias_idx, int nwin,
@@ -662,6 +961,78 @@ int suhpe_window_attn_bwd(const float* qkv, const float* probs, const float* dou
                            heads, g.N, noff, dbias_table);
     }
     return check_launch("suhpe_window_attn_bwd");
+}
+
+// ---- the recomputing form (row statistics instead of probabilities)
+int64_t suhpe_window_attn_rs_workspace_bytes(int ws, int heads) {
+    const int n = ws * ws, np = n <= 64 ? 64 : 224;
+    return (n <= 224 && heads > 0) ? (int64_t)2 * heads * np * np * (int64_t)sizeof(float) : 0;
+}
+
+int64_t suhpe_window_attn_rowstats_elems(int B, int H, int W, int ws, int heads) {
+    if (ws <= 0 || ws * ws > 224) return 0;
+    const int np = ws * ws <= 64 ? 64 : 224;
+    return (int64_t)B * (H / ws) * (W / ws) * heads * np * 2;
+}
+
+static void attn_tiled_bias(const AttnGeom& g, const float* bias_table, const int32_t* bias_idx, int heads, int noff, float* tiled, hipStream_t st) {
+    const int np = g.N <= 64 ? 64 : 224, qb = np / 32;
+    const int64_t total = (int64_t)heads * np * np;
+    hipLaunchKernelGGL(window_attn_tiled_bias_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, bias_table, bias_idx, heads, g.N, qb, noff,
+                       tiled, tiled + total);
+}
+
+int suhpe_window_attn_fwd_rs(const float* qkv, const float* bias_table, const int32_t* bias_idx, int B, int H, int W, int ws, int heads, int dh,
+                             int noff, float scale, float* out, float* rowstats, void* workspace, suhpe_stream_t stream) {
+    AttnGeom g;
+    int rc = attn_geom(&g, B, H, W, ws, heads, dh, noff, scale, "suhpe_window_attn_fwd_rs");
+    if (rc) return rc;
+    SUHPE_REQUIRE(qkv && bias_table && bias_idx && out && workspace, "suhpe_window_attn_fwd_rs: null pointer");
+    SUHPE_REQUIRE((int64_t)B * H * W * heads * 3 * DH * 4 < 0x7fffffffLL, "suhpe_window_attn_fwd_rs: qkv must be smaller than 2 GiB");
+    float* tiled = static_cast<float*>(workspace);
+    attn_tiled_bias(g, bias_table, bias_idx, heads, noff, tiled, as_stream(stream));
+    const dim3 grid(B * g.nwy * g.nwx * heads);
+    if (g.N <= 64) {
+        hipLaunchKernelGGL(window_attn_fwd_rs<64>, grid, dim3(128), (size_t)(2 * 64 * KP + 64) * sizeof(float), as_stream(stream), g, qkv, tiled, out,
+                           reinterpret_cast<float2*>(rowstats));
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_fwd_rs<224>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // per device
+        hipLaunchKernelGGL(window_attn_fwd_rs<224>, grid, dim3(256), (size_t)(2 * 224 * KP + 224) * sizeof(float), as_stream(stream), g, qkv, tiled, out,
+                           reinterpret_cast<float2*>(rowstats));
+    }
+    return check_launch("suhpe_window_attn_fwd_rs");
+}
+
+int suhpe_window_attn_bwd_rs(const float* qkv, const float* fwd_out, const float* rowstats, const float* dout, const float* bias_table,
+                             const int32_t* bias_idx, int B, int H, int W, int ws, int heads, int dh, int noff, float scale, float* dqkv,
+                             float* dbias_table, void* dS_workspace, void* bias_workspace, suhpe_stream_t stream) {
+    AttnGeom g;
+    int rc = attn_geom(&g, B, H, W, ws, heads, dh, noff, scale, "suhpe_window_attn_bwd_rs");
+    if (rc) return rc;
+    SUHPE_REQUIRE(qkv && fwd_out && rowstats && dout && bias_table && bias_idx && dqkv && dS_workspace && bias_workspace,
+                  "suhpe_window_attn_bwd_rs: null pointer");
+    SUHPE_REQUIRE((int64_t)B * H * W * heads * 3 * DH * 4 < 0x7fffffffLL, "suhpe_window_attn_bwd_rs: qkv must be smaller than 2 GiB");
+    float* tiled = static_cast<float*>(bias_workspace);
+    float* dS = static_cast<float*>(dS_workspace);
+    attn_tiled_bias(g, bias_table, bias_idx, heads, noff, tiled, as_stream(stream));
+    const int np = g.N <= 64 ? 64 : 224, nwin = B * g.nwy * g.nwx;
+    const float* tiledB = tiled + (int64_t)heads * np * np;
+    const float2* rs = reinterpret_cast<const float2*>(rowstats);
+    if (g.N <= 64) {
+        hipLaunchKernelGGL(window_attn_bwd_rs<64>, dim3(nwin * heads), dim3(128), (size_t)(2 * 64 * KP + 4 * 64) * sizeof(float), as_stream(stream), g, qkv,
+                           fwd_out, rs, dout, tiled, tiledB, dS, dqkv);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_bwd_rs<224>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // per device
+        hipLaunchKernelGGL(window_attn_bwd_rs<224>, dim3(nwin * heads), dim3(256), (size_t)(2 * 224 * KP + 4 * 224) * sizeof(float), as_stream(stream), g,
+                           qkv, fwd_out, rs, dout, tiled, tiledB, dS, dqkv);
+    }
+    if (dbias_table) {
+        const int64_t total = (int64_t)heads * g.N * g.N;
+        const int chunks = nwin >= 64 ? 8 : (nwin >= 8 ? 2 : 1);
+        hipLaunchKernelGGL(window_attn_dbias_kernel, dim3((unsigned)ceil_div(total, 256), chunks), dim3(256), 0, as_stream(stream), dS, bias_idx, nwin,
+                           heads, g.N, noff, dbias_table);
+    }
+    return check_launch("suhpe_window_attn_bwd_rs");
 }
 
 int64_t suhpe_window_attn_dbias_workspace_bytes(int ws, int heads) { return (int64_t)8 * heads * ws * ws * ws * ws * (int64_t)sizeof(float); }

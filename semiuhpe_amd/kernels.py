@@ -1491,6 +1491,38 @@ def window_attn_bwd(qkv, probs, dout, bias_idx, B, H, W, ws, heads, noff, scale,
     return dqkv
 
 
+@_memop
+def window_attn_fwd_rs(qkv, bias_table, bias_idx, B, H, W, ws, heads, scale, save_stats=True):
+    """the recomputing form: qkv -> out, rowstats ((windows*heads, NP, 2): row max and 1 / row sum of the softmax; None for inference) -- no N x N
+    probabilities leave the kernel"""
+    _chk(qkv, "qkv"); _chk(bias_table, "bias_table")
+    lib = _lib.load()
+    dh = qkv.shape[-1] // (3 * heads)
+    out = torch.empty((qkv.shape[0], heads * dh), dtype=torch.float32, device=qkv.device)
+    stats = torch.empty(lib.suhpe_window_attn_rowstats_elems(B, H, W, ws, heads), dtype=torch.float32, device=qkv.device) if save_stats else None
+    ws_buf = workspace("attn_bias_rs", max(4, lib.suhpe_window_attn_rs_workspace_bytes(ws, heads)), qkv.device)
+    call("suhpe_window_attn_fwd_rs", ptr(qkv), ptr(bias_table), ptr(bias_idx), B, H, W, ws, heads, dh, bias_table.shape[1], float(scale),
+         ptr(out), ptr(stats), ptr(ws_buf))
+    return out, stats
+
+
+@_memop
+def window_attn_bwd_rs(qkv, out, stats, dout, bias_table, bias_idx, B, H, W, ws, heads, noff, scale, dbias, inverse=None):
+    """backward of window_attn_fwd_rs from the forward's output and row statistics; `inverse` as in window_attn_bwd"""
+    _chk(qkv, "qkv"); _chk(dout, "dout"); _chk(out, "out")
+    lib = _lib.load()
+    dh = qkv.shape[-1] // (3 * heads)
+    dqkv = torch.empty_like(qkv)
+    ws_buf = workspace("attn", lib.suhpe_window_attn_probs_elems(B, H, W, ws, heads) * 4, qkv.device)
+    ws_bias = workspace("attn_bias_rs", max(4, lib.suhpe_window_attn_rs_workspace_bytes(ws, heads)), qkv.device)
+    call("suhpe_window_attn_bwd_rs", ptr(qkv), ptr(out), ptr(stats), ptr(dout), ptr(bias_table), ptr(bias_idx), B, H, W, ws, heads, dh, noff,
+         float(scale), ptr(dqkv), None if inverse is not None else ptr(dbias), ptr(ws_buf), ptr(ws_bias))
+    if inverse is not None:
+        ws2 = workspace("attn_dbias", lib.suhpe_window_attn_dbias_workspace_bytes(ws, heads), qkv.device)
+        call("suhpe_window_attn_dbias", ptr(ws_buf), ptr(inverse[0]), ptr(inverse[1]), B, H, W, ws, heads, noff, ptr(dbias), ptr(ws2))
+    return dqkv
+
+
 # ---------------------------------------------------------------------------------------------- optimiser
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
     call("suhpe_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),

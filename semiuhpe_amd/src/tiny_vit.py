@@ -137,6 +137,10 @@ def attention_bias_index(ws):
 DETERMINISTIC_DBIAS = os.environ.get("SUHPE_ATOMIC_DBIAS", "0") != "1"     # fixed-order bias-table gradient (no atomics)
 
 
+# windowed attention from row statistics (the backward recomputes the probabilities) instead of saved N x N probabilities; 0 = the round-3 kernels
+ATTN_RECOMPUTE = os.environ.get("SUHPE_ATTN_RECOMPUTE", "1") != "0"
+
+
 class Attention(Layer):
     """src/tiny_vit.py:216-286 (attn_ratio = 1): LayerNorm -> qkv -> windowed softmax(q k^T s + bias) v -> proj"""
 
@@ -174,10 +178,16 @@ class Attention(Layer):
         B, H, W, C = x.shape
         xn = self.norm.fwd(x, tape)
         qkv = self.qkv.fwd(xn.view(-1, C), tape)
-        out, probs = K.window_attn_fwd(qkv, self.attention_biases, self._index(x.device), B, H, W, self.window, self.num_heads,
-                                       self.scale, save_probs=tape is not None)
-        if tape is not None:
-            tape.append((qkv, probs, (B, H, W)))
+        if ATTN_RECOMPUTE:
+            out, stats = K.window_attn_fwd_rs(qkv, self.attention_biases, self._index(x.device), B, H, W, self.window, self.num_heads,
+                                              self.scale, save_stats=tape is not None)
+            if tape is not None:
+                tape.append((qkv, (out, stats), (B, H, W)))
+        else:
+            out, probs = K.window_attn_fwd(qkv, self.attention_biases, self._index(x.device), B, H, W, self.window, self.num_heads,
+                                           self.scale, save_probs=tape is not None)
+            if tape is not None:
+                tape.append((qkv, probs, (B, H, W)))
         if residual is not None:
             return self.proj.fwd(out, tape, skip=residual[0], rowscale=residual[1], rows_per_sample=H * W).view(B, H, W, C)
         return self.proj.fwd(out, tape).view(B, H, W, C)
@@ -187,9 +197,13 @@ class Attention(Layer):
         B, H, W, C = dy.shape
         d_out = self.proj.bwd(dy.view(-1, C), tape)
         qkv, probs, _ = tape.pop()
-        dqkv = K.window_attn_bwd(qkv, probs, d_out, self._index(dy.device), B, H, W, self.window, self.num_heads,
-                                 self.attention_biases.shape[1], self.scale, grad_of(self.attention_biases),
-                                 inverse=self._inverse_index(dy.device) if DETERMINISTIC_DBIAS else None)
+        inverse = self._inverse_index(dy.device) if DETERMINISTIC_DBIAS else None
+        if isinstance(probs, tuple):                                   # (forward output, row statistics): the recomputing kernels
+            dqkv = K.window_attn_bwd_rs(qkv, probs[0], probs[1], d_out, self.attention_biases, self._index(dy.device), B, H, W, self.window,
+                                        self.num_heads, self.attention_biases.shape[1], self.scale, grad_of(self.attention_biases), inverse=inverse)
+        else:
+            dqkv = K.window_attn_bwd(qkv, probs, d_out, self._index(dy.device), B, H, W, self.window, self.num_heads,
+                                     self.attention_biases.shape[1], self.scale, grad_of(self.attention_biases), inverse=inverse)
         d_xn = self.qkv.bwd(dqkv, tape)
         return self.norm.bwd(d_xn.view(B, H, W, C), tape, skip=skip)
 

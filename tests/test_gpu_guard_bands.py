@@ -326,6 +326,42 @@ def test_window_attention_stays_inside_its_buffers(cfg):
     assert float((pr.sum(-1) - 1.0).abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize("cfg", ATTN_CASES, ids=str)
+def test_recomputing_window_attention_stays_inside_its_buffers(cfg):
+    """suhpe_window_attn_fwd_rs / _bwd_rs: output, row statistics, the two tile-ordered bias expansions, dqkv, the score-gradient workspace"""
+    _lib, lib, _ = _lib_and_names()
+    from semiuhpe_amd.src.tiny_vit import attention_bias_index
+    for f in ("suhpe_window_attn_rs_workspace_bytes", "suhpe_window_attn_rowstats_elems", "suhpe_window_attn_probs_elems"):
+        getattr(lib, f).restype = ctypes.c_int64
+    B, H, W, ws, heads = cfg
+    dh = 32
+    gen = torch.Generator().manual_seed(sum(cfg) + 1)
+    idx, noff = attention_bias_index(ws)
+    bias_idx = idx.to(torch.int32).cuda().contiguous()
+    qkv = torch.randn(B * H * W, heads * 3 * dh, generator=gen).cuda()
+    table = torch.randn(heads, noff, generator=gen).cuda()
+    dout = torch.randn(B * H * W, heads * dh, generator=gen).cuda()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    np_ = 64 if ws * ws <= 64 else 224
+    assert lib.suhpe_window_attn_rowstats_elems(B, H, W, ws, heads) == B * (H // ws) * (W // ws) * heads * np_ * 2
+    assert lib.suhpe_window_attn_rs_workspace_bytes(ws, heads) == 2 * heads * np_ * np_ * 4
+    out, stats = Guarded(B * H * W * heads * dh), Guarded(lib.suhpe_window_attn_rowstats_elems(B, H, W, ws, heads))
+    wsf = Guarded(lib.suhpe_window_attn_rs_workspace_bytes(ws, heads) // 4)
+    _lib.call("suhpe_window_attn_fwd_rs", P(qkv), P(table), P(bias_idx), B, H, W, ws, heads, dh, noff, ctypes.c_float(dh ** -0.5), out.ptr, stats.ptr, wsf.ptr)
+    out.check("attn_fwd_rs out"); stats.check("attn_fwd_rs row statistics"); wsf.check("attn_fwd_rs bias tiles")
+    dqkv, dS, wsb = Guarded(qkv.numel()), Guarded(lib.suhpe_window_attn_probs_elems(B, H, W, ws, heads)), Guarded(lib.suhpe_window_attn_rs_workspace_bytes(ws, heads) // 4)
+    dtab = Guarded(heads * noff)
+    dtab.payload.zero_()
+    _lib.call("suhpe_window_attn_bwd_rs", P(qkv), out.ptr, stats.ptr, P(dout), P(table), P(bias_idx), B, H, W, ws, heads, dh, noff, ctypes.c_float(dh ** -0.5),
+              dqkv.ptr, dtab.ptr, dS.ptr, wsb.ptr)
+    dqkv.check("attn_bwd_rs dqkv"); dS.check("attn_bwd_rs score gradient"); wsb.check("attn_bwd_rs bias tiles"); dtab.check("attn_bwd_rs bias-table gradient")
+    # inference form: no statistics pointer
+    out2 = Guarded(B * H * W * heads * dh)
+    _lib.call("suhpe_window_attn_fwd_rs", P(qkv), P(table), P(bias_idx), B, H, W, ws, heads, dh, noff, ctypes.c_float(dh ** -0.5), out2.ptr, None, wsf.ptr)
+    out2.check("attn_fwd_rs out (inference)")
+    assert torch.equal(out.payload, out2.payload)
+
+
 @pytest.mark.parametrize("rows,c", [(784 * 3, 192), (49 * 5 + 3, 576), (1000, 100), (37, 384)], ids=str)
 def test_layernorm_stays_inside_its_buffers(rows, c):
     _lib, lib, _ = _lib_and_names()
