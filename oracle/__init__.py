@@ -13,9 +13,16 @@ Parity status (how each part is pinned):
     RepVGG-B1g2, TinyViT-21M, the agent step: PINNED against outputs of the reference itself, run in
     the build container by `tools/make_golden*.py` (import shims only) -> `tests/golden/*.npz`;
     `tests/test_oracle_*.py` check the oracle against those fixtures.
-  * EfficientNetV2-S backbone body: **parity unpinned** — it lives in torchvision 0.14.1
+  * EfficientNetV2-S backbone body: **parity unpinned against torchvision** — it lives in torchvision 0.14.1
     (`src/networks.py:301-303`), which is not installed here and not vendored by the reference.
-    Restated from the published architecture, sanity-pinned by parameter
-    count (20,177,488 backbone) and MAC count only.
+    Restated from the published architecture; pinned as far as the image allows: the
+    state-dict key list and shapes (`tests/golden/effnetv2s_state_dict.json`), parameter count (20,177,488
+    backbone) and MAC count, and the MBConv block (expand / depthwise / squeeze-excitation / project / skip)
+    against an independent implementation on seeded weights -- Hugging Face transformers' EfficientNetBlock
+    (`tools/make_golden_mbconv_hf.py` -> `tests/golden/mbconv_hf.npz`).  FusedMBConv, the stage table and
+    stochastic depth remain restated only.
+  * ResNet-50 body (f3): torchvision absent as well; pinned against transformers' ResNetModel (the same published
+    v1.5 network, independent code) on seeded weights renamed key by key (`tools/make_golden_resnet50_hf.py` ->
+    `tests/golden/resnet50_hf.npz`): a third-party pin, not the reference's own dependency.
   * pytorch3d 0.7.2 `so3_relative_angle` (cos_bound extrapolation): restated, unpinned.
 """

@@ -1,8 +1,9 @@
 """CPU oracle (test infrastructure): the backbones as plain torch.nn modules with the reference's module trees.
 
   * EfficientNetV2S  — torchvision 0.14.1 `efficientnet_v2_s` + the reference's classifier (src/networks.py:301-332).
-                       torchvision is absent here and not vendored by the reference: PARITY UNPINNED, restated from
-                       the published architecture.
+                       torchvision is absent here and not vendored by the reference: PARITY UNPINNED against torchvision, restated
+                       from the published architecture; the state-dict keys / shapes and the MBConv block (against
+                       transformers' EfficientNetBlock, tests/golden/mbconv_hf.npz) are pinned, FusedMBConv and the stage table are not.
   * RepVggNet        — src/networks.py:229-290 + src/repvgg.py:35-76,165-199 (RepVGG-B1g2, train form, never re-parameterised)
   * TinyViT21M       — src/tiny_vit.py:28-591 + head of src/networks.py:407-441
 The latter two are pinned against the imported reference by tests/golden/backbones.npz.
@@ -406,7 +407,8 @@ class Bottleneck(nn.Module):
 
 class ResNet50(nn.Module):
     """torchvision 0.14.1 `resnet50` with `fc` replaced by the reference's regression head (src/networks.py:443-500; released
-    checkpoint DAD-COCOHead-ResNet50-best.pth).  torchvision is absent here: PARITY UNPINNED, restated from the published
+    checkpoint DAD-COCOHead-ResNet50-best.pth).  torchvision is absent here: unpinned against torchvision itself; the body IS pinned against
+    an independent implementation of the same network (transformers' ResNetModel, tests/golden/resnet50_hf.npz).  Restated from the published
     architecture; sanity pin: 25,557,032 parameters with the 1000-class fc."""
 
     def __init__(self, num_classes=9):
