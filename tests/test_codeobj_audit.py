@@ -37,3 +37,22 @@ def test_winograd_kernels_have_no_scratch_no_compiler_waits_and_untouched_load_r
     a = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "debug", "wino_waits.py")], capture_output=True, text=True, timeout=600)
     assert a.returncode == 0, a.stdout[-3000:] + a.stderr[-1000:]
     assert "registers of unseen loads touched before their wait: none" in a.stdout
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"), reason="llvm tools not installed")
+def test_hand_pipelined_kernels_of_the_built_library_have_no_scratch():
+    """The BUILT semiuhpe_amd/csrc/libsuhpe.so (what the GPU box loads), read through its code-object metadata (tools/debug/codeobj_meta.py): the
+    kernels whose memory operations are inline asm with hand-counted waits -- the Winograd tiles, the LDS-DMA GEMM tiles -- and the register-chained
+    attention kernels use no scratch and spill no VGPR (a spill reload is a vector-memory operation the hand counts do not know about; in the
+    attention kernels it would undo the register chaining).  SGPR spills go to VGPR lanes (v_writelane / v_readlane), which is why every asm
+    VMEM statement that reads an SGPR operand starts with `s_nop 4` (conv_dma.inl, conv_wino.hip)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools", "debug"))
+    import codeobj_meta
+    ks = codeobj_meta.kernels()
+    assert len(ks) > 300, len(ks)
+    want = {"gemm_nt_dma": 8, "wino_nt_kernel": 6, "window_attn_fwd_rs": 2, "window_attn_bwd_rs": 2, "wino_wgrad_kernel": 1}
+    for pat, least in want.items():
+        hit = {k: v for k, v in ks.items() if pat in k}
+        assert len(hit) >= least, (pat, sorted(hit))
+        for k, v in hit.items():
+            assert v["scratch"] == 0 and v["vgpr_spill"] == 0, (k, v)
