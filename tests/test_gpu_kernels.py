@@ -138,7 +138,8 @@ def test_tile_menu_every_pinned_tile_matches(K, cfg):
 
 
 @pytest.mark.parametrize("n,c,hw,stride,act,seg", [(8, 96, 14, 1, "silu", None), (40, 64, 14, 1, "silu", 8), (3, 32, 15, 2, "silu", 1), (2, 24, 9, 1, "gelu", None),
-                                                   (64, 128, 7, 1, "silu", 13), (160, 256, 14, 1, "silu", 32), (6, 20, 6, 1, "silu", 4)])
+                                                   (64, 128, 7, 1, "silu", 13), (160, 256, 14, 1, "silu", 32), (6, 20, 6, 1, "silu", 4),
+                                                   (6, 96, 28, 1, "gelu", 2), (3, 64, 56, 1, "gelu", None), (4, 32, 28, 1, "silu", 1)])
 def test_depthwise_with_folded_batchnorm_input(K, n, c, hw, stride, act, seg):
     """suhpe_dwconv_bnact_fwd / _wgrad: depthwise conv (and its filter gradient) of act(BN(x)) computed from x while loading
     == the unfused bn_act_fwd -> depthwise chain (zero padding applied after the activation); with batch segments each
@@ -594,7 +595,7 @@ def test_mbconv_dw_bn_se_section_fused_matches_layerwise(seg, stride, cin, cout)
 
 
 @pytest.mark.parametrize("n,h,c,stride,seg", [(6, 14, 64, 1, None), (6, 14, 64, 1, 2), (5, 15, 48, 2, 2), (160, 14, 512, 1, 32), (40, 28, 256, 2, 8),
-                                               (3, 7, 1536, 1, 1)])
+                                               (3, 7, 1536, 1, 1), (5, 28, 64, 1, 2), (3, 56, 96, 1, None)])
 def test_dwconv_statistics_epilogue(n, h, c, stride, seg):
     """suhpe_dwconv_fwd_stats: same output bits as suhpe_dwconv_fwd, and its (S, Q, k, n) records finalise to the BatchNorm
     statistics (mean, rstd, running statistics) a separate statistics pass over the output gives -- one and two batch segments,
@@ -1130,7 +1131,8 @@ def test_lds_dma_tile_is_refused_where_it_cannot_run(K):
         assert got == want, (shape, wshape, groups, got)
 
 
-@pytest.mark.parametrize("n,h,c,seg,act", [(160, 14, 512, 32, "silu"), (160, 7, 1536, None, "silu"), (160, 28, 256, 8, "relu"), (80, 14, 960, 5, "silu")])
+@pytest.mark.parametrize("n,h,c,seg,act", [(160, 14, 512, 32, "silu"), (160, 7, 1536, None, "silu"), (160, 28, 256, 8, "relu"), (80, 14, 960, 5, "silu"),
+                                           (160, 56, 128, 32, "gelu"), (9, 14, 192, None, "gelu")])
 def test_depthwise_dgrad_reduces_producer_batchnorm_sums(K, n, h, c, seg, act):
     """suhpe_dwconv_dgrad_bnsums: the depthwise input gradient is bit-equal to suhpe_dwconv_dgrad's, and the BatchNorm backward built from
     the sums it reduces (one or two batch segments) + the apply pass equals the stand-alone three-pass BatchNorm backward (same dx up to the
@@ -1166,7 +1168,12 @@ def test_depthwise_dgrad_reduces_producer_batchnorm_sums(K, n, h, c, seg, act):
     for i, (lo, hi) in enumerate(parts):
         xh = (xs[lo:hi] - m64[i]) * r64[i]
         u = xh * gamma.double().cpu() + beta.double().cpu()
-        ga = (torch.sigmoid(u) * (1 + u * (1 - torch.sigmoid(u)))) if act == "silu" else (u > 0).double()
+        if act == "silu":
+            ga = torch.sigmoid(u) * (1 + u * (1 - torch.sigmoid(u)))
+        elif act == "gelu":
+            ga = 0.5 * (1 + torch.erf(u / 2 ** 0.5)) + u * torch.exp(-0.5 * u * u) / (2 * torch.pi) ** 0.5
+        else:
+            ga = (u > 0).double()
         gg = d_ref.double().cpu().reshape(rows, c)[lo:hi] * ga
         s = sums.reshape(-1, c, 2)[i].double().cpu()
         assert rel(s[:, 0], gg.sum(0)) < 2e-5 and rel(s[:, 1], (gg * xh).sum(0)) < 2e-5
