@@ -331,6 +331,14 @@ int suhpe_bn_act_skip_bwd(const float* x, const float* dy, int64_t rows, int c, 
  * dgamma[j] / dbeta[j] += (always accumulated).  workspace >= suhpe_bn_workspace_bytes(c). */
 int suhpe_repvgg_bn_fwd(const float* const* x, const float* const* mean, const float* const* rstd, const float* const* gamma,
                         const float* const* beta, int nb, int64_t rows, int64_t rows_a, int c, float* y, suhpe_stream_t stream);
+/* The same forward, also emitting the BatchNorm statistics records of its OUTPUT (round 5): the next RepVGG block's identity branch normalises
+ * exactly this tensor, so its statistics come from the records (suhpe_bn_stats_from_partials / _seg) instead of a pass of their own.
+ * stats: suhpe_repvgg_bn_fwd_stats_blocks(rows, rows_a, c, &first) records of [c] float4 (S, Q, k, n), the first `first` of them covering the rows
+ * of the first batch segment (all of them for rows_a == 0); tensors 16-byte aligned when c % 4 == 0. */
+int suhpe_repvgg_bn_fwd_stats_blocks(int64_t rows, int64_t rows_a, int c, int32_t* first_records);
+int suhpe_repvgg_bn_fwd_stats(const float* const* x, const float* const* mean, const float* const* rstd, const float* const* gamma,
+                              const float* const* beta, int nb, int64_t rows, int64_t rows_a, int c, float* y, float* stats,
+                              suhpe_stream_t stream);
 int suhpe_repvgg_bn_bwd(const float* const* x, const float* const* mean, const float* const* rstd, const float* const* gamma, int nb,
                         const float* dout, const float* y, int64_t rows, int64_t rows_a, int c, float* const* dx,
                         float* const* dgamma, float* const* dbeta, void* workspace, suhpe_stream_t stream);

@@ -707,19 +707,26 @@ struct Bn3 {
     int nb;                                              // 2 or 3 branches
 };
 
-template <int VEC>
+// STATS (round 5): the kernel also emits the (S, Q, k, n) statistics records of its OUTPUT per (row block, channel) -- bn_stats_partial's format, the
+// shift k = the output at the block's first row, computed by every thread of a channel column from the same three loads -- so that the NEXT RepVGG
+// block's identity BatchNorm (whose input is this output) needs no statistics pass of its own over the tensor (bn_stats_partial: 33 us x 50 per C3 step).
+template <int VEC, bool STATS = false>
 __global__ __launch_bounds__(256) void bn3_act_fwd_kernel(Bn3 b, int rows, int c, int cw, int rp, int rows_per_block, float* __restrict__ y,
-                                                          const SegArgs sg) {
+                                                          const SegArgs sg, float* __restrict__ part = nullptr) {
+    __shared__ float lds[STATS ? 256 * 2 * VEC : 1];
     int64_t rows_s = rows, row_off;
     int set;
     const int bx = seg_select(sg, &rows_s, &row_off, &set);
     rows = (int)rows_s;
     y += row_off * c;
-#undef EW_BX
-#define EW_BX bx
-    EW_THREAD_SETUP(VEC)
-#undef EW_BX
-#define EW_BX blockIdx.x
+    const int t = threadIdx.x, col = t % cw, rsub = t / cw;
+    const int cv = c / VEC, vc = blockIdx.y * cw + col;
+    const bool active = rsub < rp && vc < cv;
+    if (!STATS && !active) return;
+    const int ch = active ? vc * VEC : 0;
+    const int r0 = bx * rows_per_block;
+    int r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
     float sc[3][VEC], sh[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) sh[v] = 0.f;
@@ -738,8 +745,25 @@ __global__ __launch_bounds__(256) void bn3_act_fwd_kernel(Bn3 b, int rows, int c
             for (int v = 0; v < VEC; ++v) sc[j][v] = 0.f;
         }
     }
+    float s0[VEC], s1[VEC], k[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { s0[v] = 0.f; s1[v] = 0.f; k[v] = 0.f; }
+    if (STATS && active && r0 < r1) {                        // the shift: this channel's output at the block's first row
+        float xk[3][VEC];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (j < b.nb) vload<VEC>(b.x[j] + ((int64_t)r0 * cv + vc) * VEC, xk[j]);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            float a = sh[v];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (j < b.nb) a += xk[j][v] * sc[j][v];
+            k[v] = a > 0.f ? a : 0.f;
+        }
+    }
     constexpr int U = 4;
-    for (int r = r0 + rsub; r < r1; r += U * rp) {
+    for (int r = r0 + rsub; active && r < r1; r += U * rp) {
         float xv[3][U][VEC];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -761,10 +785,12 @@ __global__ __launch_bounds__(256) void bn3_act_fwd_kernel(Bn3 b, int rows, int c
                 for (int j = 0; j < 3; ++j)
                     if (j < b.nb) a += xv[j][u][v] * sc[j][v];
                 o[v] = a > 0.f ? a : 0.f;
+                if (STATS) { const float d = o[v] - k[v]; s0[v] += d; s1[v] += d * d; }
             }
             vstore<VEC>(y + ((int64_t)rr * cv + vc) * VEC, o);
         }
     }
+    if (STATS) block_combine<VEC>(s0, s1, cw, rp, blockIdx.y * cw, c, blockIdx.x, part, lds, k, r1 > r0 ? (float)(r1 - r0) : 0.f);
 }
 
 // records per (row block, channel): (sum g, sum g xhat_a, sum g xhat_b, sum g xhat_c)
@@ -2177,6 +2203,43 @@ int suhpe_repvgg_bn_fwd(const float* const* x, const float* const* mean, const f
     if (vec == 4) LAUNCH(bn3_act_fwd_kernel<4>, dim3(gx, g.ny), dim3(256), stream, b, (int)rows, c, g.cw, g.rp, g.rows_per_block, y, sg);
     else LAUNCH(bn3_act_fwd_kernel<1>, dim3(gx, g.ny), dim3(256), stream, b, (int)rows, c, g.cw, g.rp, g.rows_per_block, y, sg);
     return check_launch("suhpe_repvgg_bn_fwd");
+}
+
+// the statistics-emitting form: `stats` receives suhpe_repvgg_bn_fwd_stats_blocks() records of (S, Q, k, n) per channel ([record][c] float4), the first
+// *first_records of them covering the first batch segment (all of them when rows_a == 0): what suhpe_bn_stats_from_partials[_seg] finalises
+static void bn3_stats_grid(int64_t rows, int64_t rows_a, int c, EwGeom* g, int* gx, int* gx_a) {
+    *g = ew_geom(rows, c, c % 4 == 0 ? 4 : 1);
+    *gx = g->gx; *gx_a = g->gx;
+    if (rows_a > 0) {
+        *gx_a = (int)ceil_div(rows_a, (int64_t)g->rows_per_block);
+        *gx = *gx_a + (int)ceil_div(rows - rows_a, (int64_t)g->rows_per_block);
+    }
+}
+
+int suhpe_repvgg_bn_fwd_stats_blocks(int64_t rows, int64_t rows_a, int c, int32_t* first_records) {
+    if (rows <= 0 || rows >= (1LL << 31) || c <= 0 || rows_a < 0 || rows_a >= rows) return 0;
+    EwGeom g;
+    int gx, gx_a;
+    bn3_stats_grid(rows, rows_a, c, &g, &gx, &gx_a);
+    if (first_records) *first_records = gx_a;
+    return gx;
+}
+
+int suhpe_repvgg_bn_fwd_stats(const float* const* x, const float* const* mean, const float* const* rstd, const float* const* gamma,
+                              const float* const* beta, int nb, int64_t rows, int64_t rows_a, int c, float* y, float* stats, suhpe_stream_t stream) {
+    Bn3 b;
+    SUHPE_REQUIRE(bn3_fill(&b, x, mean, rstd, gamma, beta, nb) && beta && y && stats && rows > 0 && rows < (1LL << 31) && c > 0 && rows_a >= 0 &&
+                      rows_a < rows, "suhpe_repvgg_bn_fwd_stats: bad arguments");
+    const int vec = c % 4 == 0 ? 4 : 1;
+    SUHPE_REQUIRE(vec == 1 || (vec4_ok(c, b.x[0], b.x[1], y) && vec4_ok(c, b.x[2]) && (reinterpret_cast<uintptr_t>(stats) & 15) == 0), "suhpe_repvgg_bn_fwd_stats: 16-byte aligned tensors");
+    EwGeom g;
+    int gx, gx_a;
+    bn3_stats_grid(rows, rows_a, c, &g, &gx, &gx_a);
+    SegArgs sg{0, 0, 0};
+    if (rows_a > 0) sg = SegArgs{rows_a, gx_a, 0};
+    if (vec == 4) LAUNCH((bn3_act_fwd_kernel<4, true>), dim3(gx, g.ny), dim3(256), stream, b, (int)rows, c, g.cw, g.rp, g.rows_per_block, y, sg, stats);
+    else LAUNCH((bn3_act_fwd_kernel<1, true>), dim3(gx, g.ny), dim3(256), stream, b, (int)rows, c, g.cw, g.rp, g.rows_per_block, y, sg, stats);
+    return check_launch("suhpe_repvgg_bn_fwd_stats");
 }
 
 int suhpe_repvgg_bn_bwd(const float* const* x, const float* const* mean, const float* const* rstd, const float* const* gamma, int nb,

@@ -1031,13 +1031,23 @@ def _ptr_array(tensors):
 
 
 @_memop
-def repvgg_bn_fwd(xs, means, rstds, gammas, betas, rows_a, c):
-    """y = relu(sum_j BN_j(xs[j])) for the 2 or 3 branches of a RepVGG block in one pass; statistics [c] or [2, c] (rows_a > 0)"""
+def repvgg_bn_fwd(xs, means, rstds, gammas, betas, rows_a, c, emit_stats=False):
+    """y = relu(sum_j BN_j(xs[j])) for the 2 or 3 branches of a RepVGG block in one pass; statistics [c] or [2, c] (rows_a > 0).
+    emit_stats: -> (y, partials) with the BatchNorm statistics records of y in the form _BatchNorm.train_stats(partials=...) takes: the next
+    block's identity BatchNorm normalises y and then needs no statistics pass of its own"""
     for t in xs:
         _chk(t, "x")
     y = torch.empty_like(xs[0])
+    rows = xs[0].numel() // c
+    if emit_stats:
+        first = ctypes.c_int32(0)
+        tiles = _lib.load().suhpe_repvgg_bn_fwd_stats_blocks(rows, int(rows_a), c, ctypes.byref(first))
+        part = torch.empty((tiles, c, 4), dtype=torch.float32, device=y.device)
+        call("suhpe_repvgg_bn_fwd_stats", _ptr_array(xs), _ptr_array(means), _ptr_array(rstds), _ptr_array(gammas), _ptr_array(betas), len(xs),
+             rows, int(rows_a), c, ptr(y), ptr(part))
+        return y, ((part, tiles, (first.value, None)) if rows_a else (part, tiles))
     call("suhpe_repvgg_bn_fwd", _ptr_array(xs), _ptr_array(means), _ptr_array(rstds), _ptr_array(gammas), _ptr_array(betas), len(xs),
-         xs[0].numel() // c, int(rows_a), c, ptr(y))
+         rows, int(rows_a), c, ptr(y))
     return y
 
 

@@ -5,6 +5,8 @@ SURVEY.md F11), so the block is the three-branch training form
     out = ReLU( BN(conv3x3(x)) + BN(conv1x1(x)) + [BN(x) if cin == cout and stride == 1] )
 with per-branch batch statistics.  Blocks are Layers with explicit forward/backward over the HIP kernels.
 """
+import os
+
 import torch.nn as nn
 
 from .. import kernels as K
@@ -13,6 +15,9 @@ from ..layers import BatchNorm2d, Conv2d, GlobalAvgPool, Layer, Network, Sequent
 
 # training: the three BatchNorm applies + ReLU of a block (and their backward) run as one kernel each (suhpe_repvgg_bn_fwd / _bwd)
 FUSE_BLOCK_TAIL = True
+# the tail kernel of a block whose successor has an identity branch also emits the BatchNorm statistics records of its output: the successor's
+# identity BatchNorm then skips its statistics pass over that tensor (SUHPE_REPVGG_OUT_STATS=0: off)
+OUT_STATS = os.environ.get("SUHPE_REPVGG_OUT_STATS", "1") != "0"
 from .efficientnet_v2 import init_regression_head_, regression_head
 
 
@@ -33,6 +38,7 @@ class RepVGGBlock(Layer):
         self.rbr_1x1 = _ConvBN(in_channels, out_channels, 1, stride, 0, groups)
         self.rbr_dense.bn.act = "relu"           # the block's ReLU is fused into the last kernel of the sum
         self.need_input_grad = True
+        self.feeds_identity = False              # set by the network: the next block normalises this block's output in its identity branch
 
     def fwd(self, x, tape):
         train = self.rbr_dense.bn.training
@@ -63,9 +69,15 @@ class RepVGGBlock(Layer):
         t3, p3 = self.rbr_dense.conv.fwd_stats(x, tape)
         t1, p1 = self.rbr_1x1.conv.fwd_stats(x, tape)
         xs = [t3, t1] + ([x] if self.rbr_identity is not None else [])
-        stats = [bns[0].train_stats(t3, p3), bns[1].train_stats(t1, p1)] + ([bns[2].train_stats(x)] if len(bns) == 3 else [])
+        # the identity BatchNorm's statistics: from the records the PREVIOUS block's tail kernel wrote for its output (= x), when it did
+        xp = getattr(x, "suhpe_out_partials", None) if OUT_STATS else None
+        stats = [bns[0].train_stats(t3, p3), bns[1].train_stats(t1, p1)] + ([bns[2].train_stats(x, xp)] if len(bns) == 3 else [])
         means, rstds, rows_a = [s[0] for s in stats], [s[1] for s in stats], stats[0][2]
-        y = K.repvgg_bn_fwd(xs, means, rstds, [b.weight for b in bns], [b.bias for b in bns], rows_a, bns[0].num_features)
+        if OUT_STATS and self.feeds_identity:
+            y, yp = K.repvgg_bn_fwd(xs, means, rstds, [b.weight for b in bns], [b.bias for b in bns], rows_a, bns[0].num_features, emit_stats=True)
+            y.suhpe_out_partials = yp          # (an attribute of this tensor object: consumed by the next block of the stage, in this pass)
+        else:
+            y = K.repvgg_bn_fwd(xs, means, rstds, [b.weight for b in bns], [b.bias for b in bns], rows_a, bns[0].num_features)
         if tape is not None:
             tape.append(("fused_tail", xs, means, rstds, rows_a, y))
         return y
@@ -128,6 +140,9 @@ class RepVggNet(Network):
         self.layer0.need_input_grad = False
         for i in range(1, 5):
             setattr(self, f"layer{i}", Sequential(*[RepVGGBlock(*c) for c in st[i]]))
+        blocks = [b for st_ in self._stages() for b in ([st_] if isinstance(st_, RepVGGBlock) else list(st_))]
+        for prev, nxt in zip(blocks, blocks[1:]):
+            prev.feeds_identity = nxt.rbr_identity is not None
         self.gap = GlobalAvgPool()
         self.linear_reg = regression_head(2048, 512, 128, num_classes)
         self.init_like_reference_()

@@ -424,3 +424,29 @@ def test_squeeze_excitation_section_stays_inside_its_buffers(n, c, csq, hw):
     _lib.call("suhpe_se_bn_bwd_apply", P(x), P(dout), ctypes.c_int64(rows), ctypes.c_int64(0), c, hw, P(mean), P(rstd), P(gamma), P(beta), 3, s.ptr, dp.ptr, chan.ptr,
               1, dyo.ptr)
     dyo.check("se_bn_bwd_apply")
+
+
+@pytest.mark.parametrize("n,hw,c,seg,nb", [(6, 196, 512, 2, 3), (5, 49, 2048, 0, 2), (4, 25, 6, 3, 3), (3, 784, 132, 1, 3)], ids=str)
+def test_repvgg_block_tail_stays_inside_its_buffers(n, hw, c, seg, nb):
+    """suhpe_repvgg_bn_fwd / _fwd_stats: the output and the statistics records (exactly suhpe_repvgg_bn_fwd_stats_blocks() of them, every one written)"""
+    _lib, lib, _ = _lib_and_names()
+    gen = torch.Generator().manual_seed(n * hw + c)
+    rows, rows_a = n * hw, seg * hw
+    xs = [torch.randn(rows, c, generator=gen).cuda() for _ in range(nb)]
+    k = 2 if seg else 1
+    mean = [torch.randn(k, c, generator=gen).cuda() * 0.1 for _ in range(nb)]
+    rstd = [(torch.rand(k, c, generator=gen) + 0.5).cuda() for _ in range(nb)]
+    gam = [(torch.rand(c, generator=gen) + 0.5).cuda() for _ in range(nb)]
+    bet = [torch.randn(c, generator=gen).cuda() for _ in range(nb)]
+    arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    first = ctypes.c_int32(0)
+    tiles = lib.suhpe_repvgg_bn_fwd_stats_blocks(ctypes.c_int64(rows), ctypes.c_int64(rows_a), c, ctypes.byref(first))
+    assert tiles > 0 and (0 < first.value < tiles if seg else first.value == tiles)
+    y0, y1, st = Guarded(rows * c), Guarded(rows * c), Guarded(tiles * c * 4)
+    _lib.call("suhpe_repvgg_bn_fwd", arr(xs), arr(mean), arr(rstd), arr(gam), arr(bet), nb, ctypes.c_int64(rows), ctypes.c_int64(rows_a), c, y0.ptr)
+    y0.check("repvgg_bn_fwd y")
+    _lib.call("suhpe_repvgg_bn_fwd_stats", arr(xs), arr(mean), arr(rstd), arr(gam), arr(bet), nb, ctypes.c_int64(rows), ctypes.c_int64(rows_a), c, y1.ptr, st.ptr)
+    y1.check("repvgg_bn_fwd_stats y"); st.check("repvgg_bn_fwd_stats records")
+    assert torch.equal(y0.payload, y1.payload)
+    rec = st.payload.view(tiles, c, 4)
+    assert float(rec[:first.value, :, 3].sum(0).min()) == float(rec[:first.value, :, 3].sum(0).max()) == float(rows_a if seg else rows)     # the counts add up to the rows

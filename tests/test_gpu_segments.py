@@ -270,6 +270,78 @@ def test_repvgg_block_tail_fused_batchnorms(hw, c, n, seg, nb):
         assert rel_err(dg1[j], dg2[j]) < 2e-5 and rel_err(db1[j], db2[j]) < 2e-5, j
 
 
+@pytest.mark.parametrize("hw,c,n,seg,nb", [(196, 512, 6, 2, 3), (49, 2048, 5, 0, 2), (25, 6, 4, 3, 3), (784, 128, 40, 8, 3), (3136, 128, 20, 0, 3)])
+def test_repvgg_block_tail_emits_the_statistics_of_its_output(hw, c, n, seg, nb):
+    """suhpe_repvgg_bn_fwd_stats: the same output bits as suhpe_repvgg_bn_fwd, and (S, Q, k, n) records of that output which finalise to the
+    BatchNorm statistics a separate pass over it gives (one and two batch segments; a post-ReLU channel with a large mean and a tiny spread
+    is where an unshifted sum of squares would lose the variance)"""
+    from semiuhpe_amd import kernels as K
+    g = torch.Generator().manual_seed(hw * 3 + c + nb)
+    xs = [(torch.randn(n, hw, 1, c, generator=g) * (1 + j) + 0.3 * j).cuda() for j in range(nb)]
+    xs[0][..., 0] = 40.0 + 0.01 * torch.randn(n, hw, 1, generator=g).cuda()          # channel 0: mean ~ 40 sigma, spread 1e-2
+    gam = [(torch.rand(c, generator=g) + 0.5).cuda() for _ in range(nb)]
+    bet = [torch.randn(c, generator=g).cuda() for _ in range(nb)]
+    rows, rows_a = n * hw, seg * hw
+    st = [K.bn_stats_seg(x, rows_a, c, 1e-5, 0.1) if seg else K.bn_stats(x, c, 1e-5, 0.1) for x in xs]
+    means, rstds = [s_[0] for s_ in st], [s_[1] for s_ in st]
+    y0 = K.repvgg_bn_fwd(xs, means, rstds, gam, bet, rows_a, c)
+    y, partials = K.repvgg_bn_fwd(xs, means, rstds, gam, bet, rows_a, c, emit_stats=True)
+    assert torch.equal(y, y0)
+    rm0, rv0, rm1, rv1 = (torch.zeros(c).cuda(), torch.ones(c).cuda(), torch.zeros(c).cuda(), torch.ones(c).cuda())
+    nb0, nb1 = torch.zeros(1, dtype=torch.long).cuda(), torch.zeros(1, dtype=torch.long).cuda()
+    if seg:
+        part, tiles, (first, boundary) = partials
+        assert boundary is None and 0 < first < tiles
+        m1, r1 = K.bn_stats_from_partials_seg(part, tiles, first, None, rows, rows_a, c, 1e-5, 0.1, rm1, rv1, nb1)
+        m0, r0 = K.bn_stats_seg(y, rows_a, c, 1e-5, 0.1, rm0, rv0, nb0)
+    else:
+        part, tiles = partials
+        m1, r1 = K.bn_stats_from_partials(part, tiles, rows, c, 1e-5, 0.1, rm1, rv1, nb1)
+        m0, r0 = K.bn_stats(y, c, 1e-5, 0.1, rm0, rv0, nb0)
+    assert float((m1 - m0).abs().max()) < 2e-6 * max(1.0, float(m0.abs().max())) and rel_err(r1, r0) < 2e-5
+    assert rel_err(rm1, rm0) < 2e-6 and rel_err(rv1, rv0) < 2e-5 and int(nb1) == int(nb0)
+
+
+def test_repvgg_stage_uses_the_emitted_statistics(monkeypatch):
+    """a stage of RepVGG blocks: with the output statistics handed from block to block (default) the step gives the results of the form in which
+    every identity BatchNorm runs its own statistics pass (SUHPE_REPVGG_OUT_STATS=0) -- outputs, input gradient, every parameter gradient and the
+    running statistics -- and launches no bn_stats pass for the identity branches"""
+    from semiuhpe_amd import kernels as K
+    from semiuhpe_amd.src import repvgg as R
+    from semiuhpe_amd import layers as L
+    torch.manual_seed(7)
+    net = R.RepVggNet().cuda().train()
+    stage = net.layer2                                      # 128 -> 256 (stride 2), then five blocks with an identity branch
+    x = torch.randn(6, 28, 28, 128, device="cuda")
+    dy = torch.randn(6, 14, 14, 256, device="cuda")
+
+    def run(flag):
+        monkeypatch.setattr(R, "OUT_STATS", flag)
+        for p in stage.parameters():
+            p.grad = None
+        state = {k: v.clone() for k, v in stage.state_dict().items()}
+        calls = []
+        orig = K.bn_stats_seg
+        monkeypatch.setattr(K, "bn_stats_seg", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+        with L.batch_segments(2):
+            tape = []
+            y = stage.fwd(x, tape)
+            dx = stage.bwd(dy, tape)
+        monkeypatch.setattr(K, "bn_stats_seg", orig)
+        out = (y, dx, {k: p.grad.clone() for k, p in stage.named_parameters()}, {k: v.clone() for k, v in stage.state_dict().items() if "running" in k})
+        stage.load_state_dict(state)
+        return out, len(calls)
+
+    (y1, dx1, g1, r1), n1 = run(True)
+    (y0, dx0, g0, r0), n0 = run(False)
+    assert n1 == 0 and n0 == 5                              # layer2: a stride-2 block, then five blocks with an identity branch, each fed records
+    assert rel_err(y1, y0) < 1e-5 and rel_err(dx1, dx0) < 1e-4
+    for k in g0:
+        assert rel_err(g1[k], g0[k]) < 2e-4, k
+    for k in r0:
+        assert rel_err(r1[k], r0[k]) < 1e-5, k
+
+
 def test_agent_step_with_no_pseudo_label_selected(tmp_path):
     """Edge of the pseudo-label filter (reference src/agent.py:163-168): when no unlabeled sample passes the entropy threshold the
     unsupervised loss is exactly 0 (not NaN), mask_ratio is 0, loss_all equals the supervised loss and every gradient stays finite."""
