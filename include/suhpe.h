@@ -343,6 +343,12 @@ int suhpe_repvgg_bn_bwd(const float* const* x, const float* const* mean, const f
                         const float* dout, const float* y, int64_t rows, int64_t rows_a, int c, float* const* dx,
                         float* const* dgamma, float* const* dbeta, void* workspace, suhpe_stream_t stream);
 
+/* suhpe_repvgg_bn_bwd without the output tensor (round 5): the ReLU mask y > 0 is recomputed from the branch inputs with the forward's own
+ * arithmetic (explicit fused multiply-adds in one fixed order: the same bits), one stream less in each of the two passes. */
+int suhpe_repvgg_bn_bwd_remask(const float* const* x, const float* const* mean, const float* const* rstd, const float* const* gamma,
+                               const float* const* beta, int nb, const float* dout, int64_t rows, int64_t rows_a, int c,
+                               float* const* dx, float* const* dgamma, float* const* dbeta, void* workspace, suhpe_stream_t stream);
+
 /* Two batch segments in one launch: rows [0, rows_a) and [rows_a, rows) of x are normalised with separate statistics (the
  * labeled and the strong batch of a step run through the network as one, layers.batch_segments).  mean / rstd are [2][c];
  * the running statistics take the two momentum updates in order and num_batches_tracked += 2; dgamma / dbeta receive the sum

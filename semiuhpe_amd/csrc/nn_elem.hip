@@ -707,6 +707,33 @@ struct Bn3 {
     int nb;                                              // 2 or 3 branches
 };
 
+// The block's pre-activation a = sum_j BN_j(x_j) as one affine form, written with explicit fmaf so that the forward kernel and the two backward
+// kernels (which recompute the ReLU mask a > 0 from the branch inputs instead of reading the output tensor: one stream of five / eight less)
+// round identically whatever the compiler contracts elsewhere:
+//   sc_j = rstd_j gamma_j,  sh = sum_j (beta_j - mean_j sc_j)  (j ascending),  a = fma(x_2, sc_2, fma(x_1, sc_1, fma(x_0, sc_0, sh)))
+template <int VEC>
+__device__ __forceinline__ void bn3_affine(const Bn3& b, int set, int c, int ch, float (&sc)[3][VEC], float (&sh)[VEC]) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) sh[v] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            if (j < b.nb) {
+                sc[j][v] = b.rstd[j][set * c + ch + v] * b.gamma[j][ch + v];
+                sh[v] = sh[v] + fmaf(-b.mean[j][set * c + ch + v], sc[j][v], b.beta[j][ch + v]);
+            } else {
+                sc[j][v] = 0.f;
+            }
+        }
+    }
+}
+__device__ __forceinline__ float bn3_pre(int nb, float x0, float x1, float x2, float sc0, float sc1, float sc2, float sh) {
+    float a = fmaf(x1, sc1, fmaf(x0, sc0, sh));
+    if (nb == 3) a = fmaf(x2, sc2, a);
+    return a;
+}
+
 // STATS (round 5): the kernel also emits the (S, Q, k, n) statistics records of its OUTPUT per (row block, channel) -- bn_stats_partial's format, the
 // shift k = the output at the block's first row, computed by every thread of a channel column from the same three loads -- so that the NEXT RepVGG
 // block's identity BatchNorm (whose input is this output) needs no statistics pass of its own over the tensor (bn_stats_partial: 33 us x 50 per C3 step).
@@ -728,23 +755,10 @@ __global__ __launch_bounds__(256) void bn3_act_fwd_kernel(Bn3 b, int rows, int c
     int r1 = r0 + rows_per_block;
     if (r1 > rows) r1 = rows;
     float sc[3][VEC], sh[VEC];
+    bn3_affine<VEC>(b, set, c, ch, sc, sh);
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) sh[v] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        if (j < b.nb) {
-            b.x[j] += row_off * c;
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                const float g = b.gamma[j][ch + v];
-                sc[j][v] = b.rstd[j][set * c + ch + v] * g;
-                sh[v] += b.beta[j][ch + v] - b.mean[j][set * c + ch + v] * sc[j][v];
-            }
-        } else {
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) sc[j][v] = 0.f;
-        }
-    }
+    for (int j = 0; j < 3; ++j)
+        if (j < b.nb) b.x[j] += row_off * c;
     float s0[VEC], s1[VEC], k[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) { s0[v] = 0.f; s1[v] = 0.f; k[v] = 0.f; }
@@ -755,10 +769,7 @@ __global__ __launch_bounds__(256) void bn3_act_fwd_kernel(Bn3 b, int rows, int c
             if (j < b.nb) vload<VEC>(b.x[j] + ((int64_t)r0 * cv + vc) * VEC, xk[j]);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-            float a = sh[v];
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-                if (j < b.nb) a += xk[j][v] * sc[j][v];
+            const float a = bn3_pre(b.nb, xk[0][v], xk[1][v], b.nb == 3 ? xk[2][v] : 0.f, sc[0][v], sc[1][v], sc[2][v], sh[v]);
             k[v] = a > 0.f ? a : 0.f;
         }
     }
@@ -780,10 +791,7 @@ __global__ __launch_bounds__(256) void bn3_act_fwd_kernel(Bn3 b, int rows, int c
             float o[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
-                float a = sh[v];
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    if (j < b.nb) a += xv[j][u][v] * sc[j][v];
+                const float a = bn3_pre(b.nb, xv[0][u][v], xv[1][u][v], b.nb == 3 ? xv[2][u][v] : 0.f, sc[0][v], sc[1][v], sc[2][v], sh[v]);
                 o[v] = a > 0.f ? a : 0.f;
                 if (STATS) { const float d = o[v] - k[v]; s0[v] += d; s1[v] += d * d; }
             }
@@ -794,7 +802,8 @@ __global__ __launch_bounds__(256) void bn3_act_fwd_kernel(Bn3 b, int rows, int c
 }
 
 // records per (row block, channel): (sum g, sum g xhat_a, sum g xhat_b, sum g xhat_c)
-template <int VEC>
+// REMASK: the ReLU mask is recomputed from the branch inputs (bn3_pre > 0, the forward's own arithmetic) -- yout is not read
+template <int VEC, bool REMASK = false>
 __global__ __launch_bounds__(256) void bn3_bwd_partial(Bn3 b, const float* __restrict__ dout, const float* __restrict__ yout, int64_t rows, int c,
                                                        int cw, int rp, int64_t rows_per_block, float* __restrict__ part, const SegArgs sg) {
     __shared__ float lds[256 * 4 * VEC];
@@ -812,7 +821,8 @@ __global__ __launch_bounds__(256) void bn3_bwd_partial(Bn3 b, const float* __res
         for (int v = 0; v < VEC; ++v) s[k][v] = 0.f;
     if (rsub < rp && col0 + col < cv) {
         const int ch = (col0 + col) * VEC;
-        float mu[3][VEC], rs[3][VEC];
+        float mu[3][VEC], rs[3][VEC], sc[3][VEC], sh[VEC];
+        if (REMASK) bn3_affine<VEC>(b, set, c, ch, sc, sh);
 #pragma unroll
         for (int j = 0; j < 3; ++j)
             if (j < b.nb) {
@@ -831,7 +841,7 @@ __global__ __launch_bounds__(256) void bn3_bwd_partial(Bn3 b, const float* __res
                 const int64_t rr = r + u * (int64_t)rp;
                 const int64_t off = ((rr < r1 ? rr : r1 - 1) * cv + col0 + col) * VEC;
                 vload<VEC>(dout + off, dv[u]);
-                vload<VEC>(yout + off, yv[u]);
+                if (!REMASK) vload<VEC>(yout + off, yv[u]);
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
                     if (j < b.nb) vload<VEC>(b.x[j] + off, xv[j][u]);
@@ -841,6 +851,7 @@ __global__ __launch_bounds__(256) void bn3_bwd_partial(Bn3 b, const float* __res
                 const bool ok = r + u * (int64_t)rp < r1;
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
+                    if (REMASK) yv[u][v] = bn3_pre(b.nb, xv[0][u][v], xv[1][u][v], b.nb == 3 ? xv[2][u][v] : 0.f, sc[0][v], sc[1][v], sc[2][v], sh[v]);
                     const float g = (ok && yv[u][v] > 0.f) ? dv[u][v] : 0.f;
                     s[0][v] += g;
 #pragma unroll
@@ -912,7 +923,7 @@ __global__ __launch_bounds__(kFinThreads) void bn3_bwd_finalize(const float* __r
 }
 
 struct Bn3Out { float* dx[3]; };
-template <int VEC>
+template <int VEC, bool REMASK = false>
 __global__ __launch_bounds__(256) void bn3_bwd_apply(Bn3 b, const float* __restrict__ dout, const float* __restrict__ yout, int rows, int c, int cw,
                                                      int rp, int rows_per_block, const float* __restrict__ sums, float inv_rows_a, float inv_rows_b,
                                                      Bn3Out o, const SegArgs sg) {
@@ -927,7 +938,8 @@ __global__ __launch_bounds__(256) void bn3_bwd_apply(Bn3 b, const float* __restr
     EW_THREAD_SETUP(VEC)
 #undef EW_BX
 #define EW_BX blockIdx.x
-    float mu[3][VEC], rs[3][VEC], ga[3][VEC], m1[3][VEC], m0[VEC];
+    float mu[3][VEC], rs[3][VEC], ga[3][VEC], m1[3][VEC], m0[VEC], sc[3][VEC], sh[VEC];
+    if (REMASK) bn3_affine<VEC>(b, set, c, ch, sc, sh);
 #pragma unroll
     for (int v = 0; v < VEC; ++v) m0[v] = sums[((int64_t)set * 4 + 0) * c + ch + v] * inv_rows;
 #pragma unroll
@@ -951,7 +963,7 @@ __global__ __launch_bounds__(256) void bn3_bwd_apply(Bn3 b, const float* __restr
             const int rr = r + u * rp < r1 ? r + u * rp : r1 - 1;
             const int64_t off = ((int64_t)rr * cv + vc) * VEC;
             vload<VEC>(dout + off, dv[u]);
-            vload<VEC>(yout + off, yv[u]);
+            if (!REMASK) vload<VEC>(yout + off, yv[u]);
 #pragma unroll
             for (int j = 0; j < 3; ++j)
                 if (j < b.nb) vload<VEC>(b.x[j] + off, xv[j][u]);
@@ -960,6 +972,11 @@ __global__ __launch_bounds__(256) void bn3_bwd_apply(Bn3 b, const float* __restr
         for (int u = 0; u < U; ++u) {
             const int rr = r + u * rp;
             if (rr >= r1) break;
+            if (REMASK) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    yv[u][v] = bn3_pre(b.nb, xv[0][u][v], xv[1][u][v], b.nb == 3 ? xv[2][u][v] : 0.f, sc[0][v], sc[1][v], sc[2][v], sh[v]);
+            }
 #pragma unroll
             for (int j = 0; j < 3; ++j)
                 if (j < b.nb) {
@@ -2242,12 +2259,14 @@ int suhpe_repvgg_bn_fwd_stats(const float* const* x, const float* const* mean, c
     return check_launch("suhpe_repvgg_bn_fwd_stats");
 }
 
-int suhpe_repvgg_bn_bwd(const float* const* x, const float* const* mean, const float* const* rstd, const float* const* gamma, int nb,
-                        const float* dout, const float* y, int64_t rows, int64_t rows_a, int c, float* const* dx, float* const* dgamma,
-                        float* const* dbeta, void* workspace, suhpe_stream_t stream) {
+// beta != nullptr: the ReLU mask is recomputed from the branch inputs (y is not read and may be null); beta == nullptr: the mask is y > 0
+static int repvgg_bn_bwd_impl(const float* const* x, const float* const* mean, const float* const* rstd, const float* const* gamma,
+                              const float* const* beta, int nb, const float* dout, const float* y, int64_t rows, int64_t rows_a, int c,
+                              float* const* dx, float* const* dgamma, float* const* dbeta, void* workspace, suhpe_stream_t stream) {
     Bn3 b;
-    SUHPE_REQUIRE(bn3_fill(&b, x, mean, rstd, gamma, nullptr, nb) && dout && y && dx && dgamma && dbeta && workspace && rows > 0 && rows < (1LL << 31) &&
-                      c > 0 && rows_a >= 0 && rows_a < rows,
+    const bool remask = beta != nullptr;
+    SUHPE_REQUIRE(bn3_fill(&b, x, mean, rstd, gamma, beta, nb) && dout && (y || remask) && dx && dgamma && dbeta && workspace && rows > 0 &&
+                      rows < (1LL << 31) && c > 0 && rows_a >= 0 && rows_a < rows,
                   "suhpe_repvgg_bn_bwd: bad arguments");
     Bn3Grads gr;
     Bn3Out out;
@@ -2258,7 +2277,7 @@ int suhpe_repvgg_bn_bwd(const float* const* x, const float* const* mean, const f
     }
     float* part = static_cast<float*>(workspace);
     float* sums = bn_sums_of(workspace, c);
-    const int vec = (vec4_ok(c, b.x[0], b.x[1], dout) && vec4_ok(c, b.x[2], y) && vec4_ok(c, out.dx[0], out.dx[1], out.dx[2])) ? 4 : 1;
+    const int vec = (vec4_ok(c, b.x[0], b.x[1], dout) && vec4_ok(c, b.x[2], remask ? dout : y) && vec4_ok(c, out.dx[0], out.dx[1], out.dx[2])) ? 4 : 1;
     const ColGeom g = col_geom(rows, c, vec);
     const EwGeom e = ew_geom(rows, c, vec);
     int gx_a = g.gx, gx = g.gx, ex = e.gx;
@@ -2274,16 +2293,31 @@ int suhpe_repvgg_bn_bwd(const float* const* x, const float* const* mean, const f
         inv_a = 1.0f / (float)rows_a;
         inv_b = 1.0f / (float)(rows - rows_a);
     }
-    if (vec == 4) {
-        LAUNCH(bn3_bwd_partial<4>, dim3(gx, g.ny), dim3(256), stream, b, dout, y, rows, c, g.cw, g.rp, g.rows_per_block, part, sg);
-        LAUNCH(bn3_bwd_finalize, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, gx_a, gx, c, sums, gr);
-        LAUNCH(bn3_bwd_apply<4>, dim3(ex, e.ny), dim3(256), stream, b, dout, y, (int)rows, c, e.cw, e.rp, e.rows_per_block, sums, inv_a, inv_b, out, se);
-    } else {
-        LAUNCH(bn3_bwd_partial<1>, dim3(gx, g.ny), dim3(256), stream, b, dout, y, rows, c, g.cw, g.rp, g.rows_per_block, part, sg);
-        LAUNCH(bn3_bwd_finalize, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, gx_a, gx, c, sums, gr);
-        LAUNCH(bn3_bwd_apply<1>, dim3(ex, e.ny), dim3(256), stream, b, dout, y, (int)rows, c, e.cw, e.rp, e.rows_per_block, sums, inv_a, inv_b, out, se);
-    }
+#define BN3_BWD(VEC, RM)                                                                                                                             \
+    do {                                                                                                                                             \
+        LAUNCH((bn3_bwd_partial<VEC, RM>), dim3(gx, g.ny), dim3(256), stream, b, dout, y, rows, c, g.cw, g.rp, g.rows_per_block, part, sg);           \
+        LAUNCH(bn3_bwd_finalize, dim3((c + kFinCh - 1) / kFinCh), dim3(kFinThreads), stream, part, gx_a, gx, c, sums, gr);                           \
+        LAUNCH((bn3_bwd_apply<VEC, RM>), dim3(ex, e.ny), dim3(256), stream, b, dout, y, (int)rows, c, e.cw, e.rp, e.rows_per_block, sums, inv_a,      \
+               inv_b, out, se);                                                                                                                      \
+    } while (0)
+    if (vec == 4) { if (remask) BN3_BWD(4, true); else BN3_BWD(4, false); }
+    else { if (remask) BN3_BWD(1, true); else BN3_BWD(1, false); }
+#undef BN3_BWD
     return check_launch("suhpe_repvgg_bn_bwd");
+}
+
+int suhpe_repvgg_bn_bwd(const float* const* x, const float* const* mean, const float* const* rstd, const float* const* gamma, int nb,
+                        const float* dout, const float* y, int64_t rows, int64_t rows_a, int c, float* const* dx, float* const* dgamma,
+                        float* const* dbeta, void* workspace, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(y, "suhpe_repvgg_bn_bwd: y is required (suhpe_repvgg_bn_bwd_remask recomputes the mask instead)");
+    return repvgg_bn_bwd_impl(x, mean, rstd, gamma, nullptr, nb, dout, y, rows, rows_a, c, dx, dgamma, dbeta, workspace, stream);
+}
+
+int suhpe_repvgg_bn_bwd_remask(const float* const* x, const float* const* mean, const float* const* rstd, const float* const* gamma,
+                               const float* const* beta, int nb, const float* dout, int64_t rows, int64_t rows_a, int c, float* const* dx,
+                               float* const* dgamma, float* const* dbeta, void* workspace, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(beta, "suhpe_repvgg_bn_bwd_remask: beta is required");
+    return repvgg_bn_bwd_impl(x, mean, rstd, gamma, beta, nb, dout, nullptr, rows, rows_a, c, dx, dgamma, dbeta, workspace, stream);
 }
 
 int suhpe_layernorm_fwd(const float* x, int64_t rows, int c, float eps, const float* gamma, const float* beta, float* y,

@@ -1052,11 +1052,17 @@ def repvgg_bn_fwd(xs, means, rstds, gammas, betas, rows_a, c, emit_stats=False):
 
 
 @_memop
-def repvgg_bn_bwd(xs, means, rstds, gammas, dout, y, rows_a, c, dgammas, dbetas):
-    """-> [dx_j]: BatchNorm backward of every branch on the shared g = dout * (y > 0); dgammas / dbetas are accumulated"""
-    _chk(dout, "dout"); _chk(y, "y")
+def repvgg_bn_bwd(xs, means, rstds, gammas, dout, y, rows_a, c, dgammas, dbetas, betas=None):
+    """-> [dx_j]: BatchNorm backward of every branch on the shared g = dout * (y > 0); dgammas / dbetas are accumulated.
+    betas: the ReLU mask is recomputed from the branch inputs (the forward's arithmetic, same bits) and y is not read"""
+    _chk(dout, "dout")
     dxs = [torch.empty_like(t) for t in xs]
     ws = workspace("bn", _lib.load().suhpe_bn_workspace_bytes(c), dout.device)
+    if betas is not None:
+        call("suhpe_repvgg_bn_bwd_remask", _ptr_array(xs), _ptr_array(means), _ptr_array(rstds), _ptr_array(gammas), _ptr_array(betas), len(xs),
+             ptr(dout), xs[0].numel() // c, int(rows_a), c, _ptr_array(dxs), _ptr_array(dgammas), _ptr_array(dbetas), ptr(ws))
+        return dxs
+    _chk(y, "y")
     call("suhpe_repvgg_bn_bwd", _ptr_array(xs), _ptr_array(means), _ptr_array(rstds), _ptr_array(gammas), len(xs), ptr(dout), ptr(y),
          xs[0].numel() // c, int(rows_a), c, _ptr_array(dxs), _ptr_array(dgammas), _ptr_array(dbetas), ptr(ws))
     return dxs

@@ -18,6 +18,7 @@ FUSE_BLOCK_TAIL = True
 # the tail kernel of a block whose successor has an identity branch also emits the BatchNorm statistics records of its output: the successor's
 # identity BatchNorm then skips its statistics pass over that tensor (SUHPE_REPVGG_OUT_STATS=0: off)
 OUT_STATS = os.environ.get("SUHPE_REPVGG_OUT_STATS", "1") != "0"
+REMASK = os.environ.get("SUHPE_REPVGG_REMASK", "1") != "0"     # the tail's backward recomputes the ReLU mask instead of reading the block output
 from .efficientnet_v2 import init_regression_head_, regression_head
 
 
@@ -85,8 +86,9 @@ class RepVGGBlock(Layer):
     def _bwd_fused_tail(self, dout, tape):
         _, xs, means, rstds, rows_a, y = tape.pop()
         bns = [self.rbr_dense.bn, self.rbr_1x1.bn] + ([self.rbr_identity] if self.rbr_identity is not None else [])
+        # (REMASK: the ReLU mask is recomputed from the three branch inputs -- the weights have not moved since the forward -- and y is not read)
         dxs = K.repvgg_bn_bwd(xs, means, rstds, [b.weight for b in bns], dout.contiguous(), y, rows_a, bns[0].num_features,
-                              [grad_of(b.weight) for b in bns], [grad_of(b.bias) for b in bns])
+                              [grad_of(b.weight) for b in bns], [grad_of(b.bias) for b in bns], betas=[b.bias for b in bns] if REMASK else None)
         self.rbr_1x1.conv.need_input_grad = self.rbr_dense.conv.need_input_grad = self.need_input_grad
         return self._branch_dgrads(dxs[0], dxs[1], dxs[2] if len(dxs) == 3 else None, tape)
 

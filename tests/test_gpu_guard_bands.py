@@ -439,6 +439,7 @@ def test_repvgg_block_tail_stays_inside_its_buffers(n, hw, c, seg, nb):
     gam = [(torch.rand(c, generator=gen) + 0.5).cuda() for _ in range(nb)]
     bet = [torch.randn(c, generator=gen).cuda() for _ in range(nb)]
     arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
     first = ctypes.c_int32(0)
     tiles = lib.suhpe_repvgg_bn_fwd_stats_blocks(ctypes.c_int64(rows), ctypes.c_int64(rows_a), c, ctypes.byref(first))
     assert tiles > 0 and (0 < first.value < tiles if seg else first.value == tiles)
@@ -450,3 +451,22 @@ def test_repvgg_block_tail_stays_inside_its_buffers(n, hw, c, seg, nb):
     assert torch.equal(y0.payload, y1.payload)
     rec = st.payload.view(tiles, c, 4)
     assert float(rec[:first.value, :, 3].sum(0).min()) == float(rec[:first.value, :, 3].sum(0).max()) == float(rows_a if seg else rows)     # the counts add up to the rows
+    # the backward, mask from y and mask recomputed: three input gradients each, the workspace of suhpe_bn_workspace_bytes(c)
+    lib.suhpe_bn_workspace_bytes.restype = ctypes.c_int64
+    dout = torch.randn(rows, c, generator=gen).cuda()
+    marr = lambda gs: (ctypes.c_void_p * len(gs))(*[g_.ptr.value for g_ in gs])
+    for remask in (False, True):
+        dxs = [Guarded(rows * c) for _ in range(nb)]
+        dgs, dbs = [Guarded(c) for _ in range(nb)], [Guarded(c) for _ in range(nb)]
+        for g_ in dgs + dbs:
+            g_.payload.zero_()
+        ws = Guarded(lib.suhpe_bn_workspace_bytes(c) // 4)
+        if remask:
+            _lib.call("suhpe_repvgg_bn_bwd_remask", arr(xs), arr(mean), arr(rstd), arr(gam), arr(bet), nb, P(dout), ctypes.c_int64(rows), ctypes.c_int64(rows_a), c,
+                      marr(dxs), marr(dgs), marr(dbs), ws.ptr)
+        else:
+            _lib.call("suhpe_repvgg_bn_bwd", arr(xs), arr(mean), arr(rstd), arr(gam), nb, P(dout), y0.ptr, ctypes.c_int64(rows), ctypes.c_int64(rows_a), c,
+                      marr(dxs), marr(dgs), marr(dbs), ws.ptr)
+        for j in range(nb):
+            dxs[j].check(f"repvgg_bn_bwd dx[{j}] remask={remask}"); dgs[j].check("repvgg_bn_bwd dgamma"); dbs[j].check("repvgg_bn_bwd dbeta")
+        ws.check("repvgg_bn_bwd workspace", fully_written=False)

@@ -268,6 +268,24 @@ def test_repvgg_block_tail_fused_batchnorms(hw, c, n, seg, nb):
     for j in range(nb):
         assert rel_err(dxs[j], refs[j]) < 2e-5, j
         assert rel_err(dg1[j], dg2[j]) < 2e-5 and rel_err(db1[j], db2[j]) < 2e-5, j
+    # suhpe_repvgg_bn_bwd_remask: the ReLU mask recomputed from the branch inputs (the forward's arithmetic) instead of read from y.  The MASK is
+    # the same bit for bit -- dbeta = sum of the masked gradient is identical --; the two template instantiations may contract the arithmetic
+    # behind it differently (one ulp on some elements of one branch was seen)
+    dg3 = [torch.zeros(c).cuda() for _ in range(nb)]; db3 = [torch.zeros(c).cuda() for _ in range(nb)]
+    dxr = K.repvgg_bn_bwd(xs, means, rstds, gam, dout, None, rows_a, c, dg3, db3, betas=bet)
+    for j in range(nb):
+        assert torch.equal(db3[j], db1[j]), j
+        assert rel_err(dxr[j], dxs[j]) < 1e-6 and rel_err(dg3[j], dg1[j]) < 1e-6, j
+    # ... also where pre-activations sit exactly on the ReLU's edge: all-zero inputs with beta = 0 give a == 0 -> mask off in both forms
+    zs = [torch.zeros_like(x) for x in xs]
+    zb = [torch.zeros(c).cuda() for _ in range(nb)]
+    zm = [torch.zeros_like(m) for m in means]
+    y0 = K.repvgg_bn_fwd(zs, zm, rstds, gam, zb, rows_a, c)
+    assert float(y0.abs().max()) == 0.0
+    da = K.repvgg_bn_bwd(zs, zm, rstds, gam, dout, y0, rows_a, c, [torch.zeros(c).cuda() for _ in range(nb)], [torch.zeros(c).cuda() for _ in range(nb)])
+    db_ = K.repvgg_bn_bwd(zs, zm, rstds, gam, dout, None, rows_a, c, [torch.zeros(c).cuda() for _ in range(nb)], [torch.zeros(c).cuda() for _ in range(nb)], betas=zb)
+    for j in range(nb):
+        assert rel_err(da[j], db_[j]) < 1e-6, j
 
 
 @pytest.mark.parametrize("hw,c,n,seg,nb", [(196, 512, 6, 2, 3), (49, 2048, 5, 0, 2), (25, 6, 4, 3, 3), (784, 128, 40, 8, 3), (3136, 128, 20, 0, 3)])
