@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsuhpe.so")
-SOURCES = ["common.hip", "head.hip", "nn_elem.hip", "layout_aug.hip", "conv_igemm.hip", "conv_wino.hip", "dwconv.hip", "attention.hip", "se_fused.hip", "augment.hip", "comm.hip", "raster.hip"]
+SOURCES = ["common.hip", "head.hip", "nn_elem.hip", "layout_aug.hip", "conv_igemm.hip", "conv_wino.hip", "conv_wino_small.hip", "dwconv.hip", "attention.hip", "se_fused.hip", "augment.hip", "comm.hip", "raster.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 

@@ -109,10 +109,44 @@ inline void magic_div(unsigned d, unsigned* mul, unsigned* shr) {
 }
 
 
+// ---- shared by the Winograd translation units (conv_wino.hip, conv_wino_small.hip)
+constexpr int WN_XI = 512;               // floats per transform position of one LDS image: 64 rows x 8 channels
+constexpr int WN_IMG = 16 * WN_XI;       // floats per image (V or U) = 32 KB
+
+// A 16-byte store hipcc does not see.  The compiler waits (s_waitcnt vmcnt(0)) before it reuses the data registers of a store IT issued, and inside the
+// persistent chunk loop every such wait also drains the hand-managed prefetch queue: the round-4 epilogue sat through eight of them per item (one per
+// statistics record round).  The hardware reads a store's data registers right after issue: two wait states (s_nop 1) cover it.
+__device__ __forceinline__ void store4_unseen(float* ptr, float a, float b, float c, float d) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 v = {a, b, c, d};
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(ptr), "v"(v) : "memory");
+}
+
+template <int CTRL> __device__ __forceinline__ float quad_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+// LDS image of one operand chunk: 8 position PAIRS m = xi >> 1, each [64 rows][4 slots of 16 bytes]; slot kg of a row holds channels (2 kg, 2 kg + 1)
+// of position 2 m followed by the same channels of position 2 m + 1, so that ONE ds_read_b128 hands a lane (row = lane & 15, k-group kg = lane >> 4)
+// the operands of four MFMAs (two k-steps of two positions).  Swizzle (i = m >> 1 = the patch row that writes the pair):
+//   slot (row, kg) of pair m sits at row ^ (i & 1), slot kg ^ g(row) ^ (i >> 1), g(row) = (-(row >> 2)) & 3.
+// Reads (ds_read_b128: 16-lane groups {rows 0-3, 12-15 of k-group a, rows 4-11 of k-group a + 1}) then cover the 64 banks exactly once, writes
+// (ds_write_b128: 8-lane groups = one row, 2 channel vectors, 4 patch rows) the 32 banks of their window.  (A first version used ds_read_b64 per
+// position: the compiler fused pairs of them into ds_read2st64_b64, which runs at half the LDS rate and broke the swizzle: 45 % of the LDS cycles
+// were bank conflicts.)
+__host__ __device__ __forceinline__ int wino_slot_off(int m, int row, int kg) {
+    const int i = m >> 1;
+    return m * 1024 + ((row ^ (i & 1)) << 4) + (((kg ^ ((-(row >> 2)) & 3) ^ (i >> 1)) & 3) << 2);
+}
+
+
 // conv_wino.hip: Winograd F(2x2, 3x3) kernel for 3x3 / stride 1 / pad 1 forward and input-gradient GEMMs
 bool wino_geom_ok(const GatherGeom& g, int Ng);
 bool wino_preferred();          // SUHPE_WINOGRAD=2: unpinned eligible shapes run the Winograd tiles
 bool launch_wino(const NtParams& p, int groups, hipStream_t st);
+// conv_wino_small.hip: the same arithmetic with the transformed filter in registers (16 / 24 / 32 input channels, at most 32 output channels; training forms);
+// false = not this form's shape / epilogue (launch_wino, which has checked wino_params_ok, goes on to wino_nt_kernel)
+bool launch_wino_small(const NtParams& p, int groups, hipStream_t st);
 int64_t wino_filter_floats(int groups, int NR, int NK);
 // w: the filter as stored, [groups * ng_w][3][3][cg_w]; pass 0: NR = ng_w rows, NK = cg_w channels; pass 1 (input gradient): NR = cg_w, NK = ng_w
 void launch_wino_filter(const float* w, float* fw, int groups, int NR, int NK, int ng_w, int cg_w, int pass, hipStream_t st);

@@ -8,7 +8,10 @@ lib.suhpe_conv2d_tile_name.restype = ctypes.c_char_p
 names = [lib.suhpe_conv2d_tile_name(0, i).decode() for i in range(lib.suhpe_conv2d_tile_count(0))]
 flush = torch.empty(1 << 26, dtype=torch.float32, device="cuda")
 out = []
-for cin, cout, g, hw, n in ((48, 192, 1, 56, 160), (64, 256, 1, 28, 160), (512, 512, 1, 14, 320)):
+SHAPES = ((48, 192, 1, 56, 160), (64, 256, 1, 28, 160), (512, 512, 1, 14, 320))
+if os.environ.get("WINO_TIME_SHAPES"):      # "cin,cout,groups,hw,n;..."
+    SHAPES = [tuple(int(v) for v in sh.split(",")) for sh in os.environ["WINO_TIME_SHAPES"].split(";")]
+for cin, cout, g, hw, n in SHAPES:
     x = torch.randn(n, hw, hw, cin, device="cuda")
     w = K.to_filter_layout(torch.randn(cout, cin // g, 3, 3, device="cuda") * 0.05)
     d = K.conv_desc(x.shape, w.shape, 1, 1, g)
