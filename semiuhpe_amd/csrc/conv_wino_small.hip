@@ -397,8 +397,14 @@ __global__ __launch_bounds__(256, 2) void wino_small_kernel(const NtParams p, co
         b = bn;
         buf ^= 1;
     }
+    // the last pass requested the patch rows of a block that does not exist (zeros from beyond the descriptor): they must have landed before their
+    // registers are used for anything else
+    if constexpr (KS == 6)
+        asm volatile("s_waitcnt vmcnt(0) ; covers-loads" : "+v"(ra4[0]), "+v"(ra4[1]), "+v"(ra4[2]), "+v"(rb4[0]), "+v"(rb4[1]), "+v"(rb4[2]),
+                     "+v"(ra2[0]), "+v"(ra2[1]), "+v"(ra2[2]), "+v"(rb2[0]), "+v"(rb2[1]), "+v"(rb2[2]), "+v"(resp[0]), "+v"(resp[1]) :: "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0) ; covers-loads" : "+v"(ra4[0]), "+v"(ra4[1]), "+v"(ra4[2]), "+v"(rb4[0]), "+v"(rb4[1]), "+v"(rb4[2]), "+v"(resp[0]), "+v"(resp[1]) :: "memory");
 #if !(WS_ABLATE & 4)
-    if constexpr (RES) asm volatile("s_waitcnt vmcnt(0) ; covers-loads" : "+v"(resp[0]), "+v"(resp[1]) :: "memory");
     finish_block(bp, yoff_p);
 #endif
 }

@@ -46,7 +46,9 @@ def _lib_and_names():
 
 # n, cin, cout, groups, h, w, images of the first batch segment
 CASES = [(3, 8, 12, 1, 6, 6, 1), (5, 20, 36, 1, 10, 10, 2), (7, 16, 16, 2, 4, 4, 3), (2, 24, 24, 1, 18, 14, 1), (3, 48, 72, 1, 14, 22, 1),
-         (5, 64, 200, 1, 6, 10, 2), (2, 136, 44, 1, 8, 8, 1), (9, 32, 32, 4, 2, 2, 4)]
+         (5, 64, 200, 1, 6, 10, 2), (2, 136, 44, 1, 8, 8, 1), (9, 32, 32, 4, 2, 2, 4),
+         # the register-resident form (conv_wino_small.hip): ragged last block, segment boundary inside a block, 20 / 8 output channels, groups of 24
+         (5, 24, 24, 1, 10, 10, 2), (3, 16, 20, 1, 6, 6, 1), (3, 48, 48, 2, 8, 8, 1), (2, 16, 8, 1, 14, 14, 1), (3, 24, 32, 1, 4, 36, 2)]
 
 
 @pytest.mark.parametrize("cfg", CASES, ids=str)

@@ -62,6 +62,13 @@ SHAPES = [
     (8, 256, 256, 1, 10, 10, 3),     # ResNet-50 layer3 conv2 at 160-pixel inputs: 200 tiles, four filter-gradient slabs, 4 x 4 channel blocks
     (16, 16, 16, 1, 32, 32, 5),      # many tiles, one channel block: 64 split-K slabs of the filter gradient (the sixteen-wavefront finish kernel)
     (2, 16, 64, 1, 2, 18, 1),        # one row of tiles per image (odd heights / widths -- ResNet-50's layer4 at 7 x 7 -- are refused: tests/test_cabi.py)
+    # the register-resident form (conv_wino_small.hip: 16 / 24 input channels, at most 32 outputs; the two 16 / 24-channel shapes above take it too)
+    (5, 24, 24, 1, 10, 10, 2),       # 125 tiles = 7.8 blocks of 16, segment boundary at tile 50 = inside block 3 (both records of that block)
+    (3, 48, 48, 2, 8, 8, 1),         # groups of 24 channels
+    (4, 16, 20, 1, 6, 6, 1),         # 20 output channels: a partial second channel block
+    (4, 24, 32, 1, 12, 12, 3),       # 32 output channels, boundary at tile 108 = inside block 6
+    (2, 16, 8, 1, 14, 14, 1),        # 8 output channels: half of the epilogue lanes store nothing
+    (3, 24, 24, 1, 4, 36, 1),        # two rows of 18 tiles per image: neighbour tiles across a 16-tile block and across the image border
 ]
 
 

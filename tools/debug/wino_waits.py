@@ -1,18 +1,26 @@
 """Compiler-inserted s_waitcnt vmcnt(..) inside the chunk loops of wino_nt_kernel<*> (outside the hand-written ASMSTART/ASMEND blocks).
     python tools/debug/wino_waits.py [extra -D flags]
+    python tools/debug/wino_waits.py --small [extra -D flags]      wino_small_kernel<*> (conv_wino_small.hip): its prologue reads the filter image with
+                                                                   loads hipcc sees, so compiler waits OUTSIDE the block loop are expected there
 Every wait the compiler adds inside the loop drains the prefetch queue the kernel manages by hand."""
 import re, subprocess, sys, os
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
-src = os.path.join(ROOT, "semiuhpe_amd", "csrc", "conv_wino.hip")
-out = "/tmp/wino_waits.s"
+SMALL = "--small" in sys.argv
+if SMALL:
+    sys.argv.remove("--small")
+src = os.path.join(ROOT, "semiuhpe_amd", "csrc", "conv_wino_small.hip" if SMALL else "conv_wino.hip")
+out = "/tmp/wino_waits_small.s" if SMALL else "/tmp/wino_waits.s"
+KERNEL = r"^(_ZN5suhpe17wino_small_kernelILi(\d)ELb([01])ELb([01])E\S*):" if SMALL else r"^(_ZN5suhpe14wino_nt_kernelILi(\d)E\S*):"
+def kernel_id(m):
+    return int(m.group(2)) * 100 + int(m.group(3)) * 10 + int(m.group(4)) if SMALL else int(m.group(2))
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-S", "--cuda-device-only", "-I" + os.path.dirname(src),
                        "-o", out, src] + sys.argv[1:], stderr=subprocess.DEVNULL)
 lines = open(out).read().split("\n")
 cur, in_asm, res = None, False, {}
 for i, l in enumerate(lines):
-    m = re.match(r"^(_ZN5suhpe14wino_nt_kernelILi(\d)E\S*):", l)
+    m = re.match(KERNEL, l)
     if m:
-        cur = int(m.group(2)); res[cur] = []
+        cur = kernel_id(m); res[cur] = []
     if cur is None:
         continue
     if "s_endpgm" in l:
@@ -44,9 +52,9 @@ def regs_of(text):
 
 cur, in_asm, pending, bad = None, False, set(), []
 for i, l in enumerate(lines):
-    m = re.match(r"^(_ZN5suhpe14wino_nt_kernelILi(\d)E\S*):", l)
+    m = re.match(KERNEL, l)
     if m:
-        cur, pending = int(m.group(2)), set()
+        cur, pending = kernel_id(m), set()
     if cur is None:
         continue
     if "s_endpgm" in l:
@@ -58,7 +66,7 @@ for i, l in enumerate(lines):
         continue
     covers = "covers-loads" in l
     if in_asm:
-        m2 = re.match(r"(buffer_load_dwordx4|global_load_dwordx4)\s+v\[(\d+):(\d+)\]", t)
+        m2 = re.match(r"(buffer_load_dwordx4|buffer_load_dwordx2|global_load_dwordx4)\s+v\[(\d+):(\d+)\]", t)
         if m2:
             pending.update(range(int(m2.group(2)), int(m2.group(3)) + 1))
         if t.startswith("s_waitcnt") and "vmcnt" in t and covers:
@@ -66,4 +74,7 @@ for i, l in enumerate(lines):
     elif pending and (regs_of(t) & pending):
         bad.append((cur, i + 1, t))
 print("registers of unseen loads touched before their wait:", bad if bad else "none")
+if SMALL:
+    print("kernels:", len(res))
+    sys.exit(1 if bad or len(res) != 8 or any(r[2] != "outside" for v in res.values() for r in v) else 0)
 sys.exit(1 if bad or any(res.values()) else 0)
