@@ -151,6 +151,21 @@ int64_t wino_filter_floats(int groups, int NR, int NK);
 // w: the filter as stored, [groups * ng_w][3][3][cg_w]; pass 0: NR = ng_w rows, NK = cg_w channels; pass 1 (input gradient): NR = cg_w, NK = ng_w
 void launch_wino_filter(const float* w, float* fw, int groups, int NR, int NK, int ng_w, int cg_w, int pass, hipStream_t st);
 
+struct WinoWgradParams {
+    const float* x; const float* dy; float* part;      // part: [splits][16][cout_all][Cg]
+    int64_t x_bytes, dy_bytes;
+    int N, H, W;                 // image size (input = output size)
+    int ldx, lddy;               // pixel strides (all channels of all groups)
+    int Cg, Ng;                  // channels per group: input, output
+    int TX, TPI, MT;
+    unsigned div_tpi_mul, div_tpi_shr, div_tx_mul, div_tx_shr;
+    int ci_blocks, co_blocks, splits, tiles_per_split;      // tiles_per_split: multiple of 8
+    int cout_all;
+};
+// conv_wino_small.hip: the filter gradient of convs with at most 32 channels on both sides, operands made in registers; splits = 0: not that form
+int wino_small_wgrad_splits(int n, int h, int w, int cg, int ng, int groups);
+void launch_wino_small_wgrad(const WinoWgradParams& p, int groups, hipStream_t st);      // p.splits / p.tiles_per_split as wino_small_wgrad_splits / launch_wino_wgrad set them
+
 // Winograd filter gradient F(3x3, 2x2): workspace = one filter-shaped slab [cout][3][3][cin/groups] (complete after the launch) + the split-K partial sums
 bool wino_wgrad_geom_ok(int n, int h, int w, int ho, int wo, int cin, int cout, int r, int s, int stride, int pad, int groups);
 int64_t wino_wgrad_workspace_floats(int n, int h, int w, int cin, int cout, int groups);

@@ -575,17 +575,6 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restric
 //   MFMA    wavefront w owns positions 2w, 2w+1 for the whole 64 x 64 block: reduction index = tile (4 per v_mfma_f32_16x16x4_f32), a lane's
 //           ds_read_b128 of a tile row hands it four channel sub-blocks at once (channel 4 * (lane & 15) + a <-> sub-block a), 16 MFMAs per pair
 //           of reads, 64 MFMAs per chunk; accumulators 2 x 16 sub-blocks x 4 registers.
-struct WinoWgradParams {
-    const float* x; const float* dy; float* part;      // part: [splits][16][cout_all][Cg]
-    int64_t x_bytes, dy_bytes;
-    int N, H, W;                 // image size (input = output size)
-    int ldx, lddy;               // pixel strides (all channels of all groups)
-    int Cg, Ng;                  // channels per group: input, output
-    int TX, TPI, MT;
-    unsigned div_tpi_mul, div_tpi_shr, div_tx_mul, div_tx_shr;
-    int ci_blocks, co_blocks, splits, tiles_per_split;      // tiles_per_split: multiple of 8
-    int cout_all;
-};
 
 constexpr int WW_IMG = 16 * 8 * 64;      // floats per image (dM or V): 16 positions x 8 tiles x 64 channels = 32 KB
 
@@ -897,6 +886,7 @@ bool wino_wgrad_geom_ok(int n, int h, int w, int ho, int wo, int cin, int cout, 
 }
 static int wino_wgrad_splits(int n, int h, int w, int cin, int cout, int groups) {
     const int cg = cin / groups, ng = cout / groups;
+    if (const int ss = wino_small_wgrad_splits(n, h, w, cg, ng, groups)) return ss;      // few channels on both sides: conv_wino_small.hip
     const int64_t blocks = ceil_div(cg, 64) * ceil_div(ng, 64) * groups;
     const int64_t MT = (int64_t)n * (h / 2) * (w / 2);
     int64_t splits = 256 / blocks;                            // ONE generation of workgroups (a workgroup per CU: 128 KB of LDS); never a 257th
@@ -926,7 +916,9 @@ void launch_wino_wgrad(const float* x, const float* dy, float* workspace, int n,
     p.cout_all = cout;
     const dim3 grid((unsigned)(p.ci_blocks * p.co_blocks * p.splits), 1, groups), block(512);
     const size_t lds = (size_t)4 * WW_IMG * sizeof(float);
-    if (cg % 64 == 48 && p.ci_blocks == 1) {                     // (one block of 48 input channels)
+    if (wino_small_wgrad_splits(n, h, w, cg, ng, groups)) {
+        launch_wino_small_wgrad(p, groups, st);
+    } else if (cg % 64 == 48 && p.ci_blocks == 1) {                     // (one block of 48 input channels)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wgrad_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(wino_wgrad_kernel<3>, grid, block, lds, st, p);
     } else {

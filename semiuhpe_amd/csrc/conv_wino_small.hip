@@ -454,4 +454,172 @@ bool launch_wino_small(const NtParams& p_in, int groups, hipStream_t st) {
     return true;
 }
 
+// ================================================================================================================================
+// Filter gradient of the same few-channel convolutions, F(3x3, 2x2) (conv_wino.hip, wino_wgrad_kernel, has the algebra and the sign conventions:
+// dU_xi[cout][cin] = sum over tiles of dM_xi[tile][cout] V_xi[tile][cin], rows 3 / columns 3 negated on both operands), with both operands made in
+// registers: no LDS, no barrier.  Wavefront w owns patch row i = w (positions (i, jx)) for ALL channel pairs: 4 positions x 2 x 2 blocks of 16 x 16
+// = 16 accumulators; the reduction index of v_mfma_f32_16x16x4_f32 is the tile (k-group kg = lane >> 4 = tile 4 step + kg), lane & 15 the channel:
+// a lane reads the 2x2 block of dy of its tile at output channel 16 cb + (lane & 15) and the two patch rows of x at input channel 16 nb + (lane & 15)
+// (dword loads, 64 contiguous bytes per tile; zero beyond the channels, the image and the slab through the descriptor), forms row i of A dY A^T and of
+// B^T d B in-lane and issues 16 MFMAs per step; the loads of the next step are requested before them.  Matrix work is padded 24 -> 32 on both sides
+// (56 % useful) and still a third of the direct kernel's.  One slab of partial sums per workgroup (split-K over the tiles, two workgroups per compute
+// unit), added in a fixed order by wino_wgrad_finish_kernel.
+__global__ __launch_bounds__(256, 2) void wino_small_wgrad_kernel(const WinoWgradParams p) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int grp = blockIdx.z, split = blockIdx.x;
+    const int m = lane & 15, kg = lane >> 4;
+    const BufRsrc xr = make_rsrc(p.x + (int64_t)grp * p.Cg, p.x_bytes - (int64_t)grp * p.Cg * 4);
+    const BufRsrc yr = make_rsrc(p.dy + (int64_t)grp * p.Ng, p.dy_bytes - (int64_t)grp * p.Ng * 4);
+    const int tile_lo = split * p.tiles_per_split;
+    int tile_hi = tile_lo + p.tiles_per_split;
+    if (tile_hi > p.MT) tile_hi = p.MT;
+    const int nsteps = tile_lo < tile_hi ? (tile_hi - tile_lo + 3) >> 2 : 0;
+    const int ra = wave, rb = wave < 2 ? 2 : 1;
+    const float sgn = wave == 1 ? 1.f : -1.f;                   // V's row i: patch row ra + sgn * patch row rb (row 3 negated)
+    const float c0 = wave == 3 ? 0.f : 1.f, c1 = wave == 0 ? 0.f : (wave == 2 ? -1.f : 1.f);      // (A dY)'s row i: c0 dy row 0 + c1 dy row 1 (row 3 negated)
+    const unsigned ldx4 = (unsigned)p.ldx * 4u, ldy4 = (unsigned)p.lddy * 4u;
+    // (patch rows start one pixel left of the tile: that pixel gets its own offset register -- a load's scalar offset is not part of the bounds check,
+    //  so the register offset itself must never be 'negative')
+    const unsigned row_a = (unsigned)((ra - 1) * p.W * p.ldx * 4), row_b = (unsigned)((rb - 1) * p.W * p.ldx * 4);
+
+    struct Raw { float dyv[2][4], xa[2][4], xb[2][4]; };        // [channel block][pixel]
+    // Loader state of this lane's tile (tile_lo + 4 step + kg), advanced by four tiles per step WITHOUT divisions: the tile's column, row and the
+    // byte offsets of its first pixel in dy and x.  fp32 MFMAs run on the vector ALU itself (tools/micro/coissue_probe.hip: a v_fma behind a
+    // v_mfma_f32_16x16x4_f32 costs its full four cycles), so every vector instruction of the loop is paid for in matrix throughput: the pixel /
+    // channel-block offsets ride in the loads' scalar offset and immediate fields, and channels beyond Cg / Ng are NOT masked -- a padding lane of
+    // A (B) only feeds rows (columns) of the accumulators that are never stored, and what it reads is mapped memory or the descriptor's zero.
+    int lT = tile_lo + kg;
+    unsigned ltx, lty, lxb, lyb;
+    {
+        const unsigned Tn = (unsigned)(lT < p.MT ? lT : 0);
+        const unsigned n = div_nz(Tn, p.div_tpi_mul, p.div_tpi_shr);
+        const unsigned rem = Tn - __umul24(n, (unsigned)p.TPI);
+        lty = div_nz(rem, p.div_tx_mul, p.div_tx_shr);
+        ltx = rem - __umul24(lty, (unsigned)p.TX);
+        const unsigned pix0 = __umul24(__umul24(n, (unsigned)p.H) + 2u * lty, (unsigned)p.W) + 2u * ltx;
+        lyb = __umul24(pix0, ldy4) + (unsigned)m * 4u;
+        lxb = __umul24(pix0, ldx4) + (unsigned)m * 4u;
+    }
+    const unsigned TYm1 = (unsigned)(p.H >> 1) - 1u;
+    const int sy1 = (int)ldy4, sy2 = (int)((unsigned)p.W * ldy4), sy3 = (int)((unsigned)(p.W + 1) * ldy4);
+    const int sx1 = (int)ldx4, sx2 = (int)(2u * ldx4);
+    auto load_step = [&](Raw& r) __attribute__((always_inline)) {
+        const bool tv = lT < tile_hi;
+        const bool oka = tv & ((ra != 0) | (lty != 0)) & ((ra != 3) | (lty != TYm1));
+        const bool x0 = ltx != 0, x3 = ltx != (unsigned)p.TX - 1u;
+        const unsigned vy = tv ? lyb : kOob;
+        const unsigned va = oka ? lxb + row_a : kOob, vb = tv ? lxb + row_b : kOob;
+        const unsigned va0 = x0 ? va - ldx4 : kOob, va3 = x3 ? va : kOob, vb0 = x0 ? vb - ldx4 : kOob, vb3 = x3 ? vb : kOob;      // (kOob - a pixel: x0 is false there)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            r.dyv[cb][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yr, vy + 64u * cb, 0, 0));
+            r.dyv[cb][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yr, vy + 64u * cb, sy1, 0));
+            r.dyv[cb][2] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yr, vy + 64u * cb, sy2, 0));
+            r.dyv[cb][3] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yr, vy + 64u * cb, sy3, 0));
+        }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            r.xa[nb][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, va0 + 64u * nb, 0, 0));
+            r.xa[nb][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, va + 64u * nb, 0, 0));
+            r.xa[nb][2] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, va + 64u * nb, sx1, 0));
+            r.xa[nb][3] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, va3 + 64u * nb, sx2, 0));
+            r.xb[nb][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, vb0 + 64u * nb, 0, 0));
+            r.xb[nb][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, vb + 64u * nb, 0, 0));
+            r.xb[nb][2] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, vb + 64u * nb, sx1, 0));
+            r.xb[nb][3] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, vb3 + 64u * nb, sx2, 0));
+        }
+        // four tiles on (TX >= 4: at most one row of tiles is crossed): the next row of tiles starts one image row further than 8 pixels on
+        // (pixel indices run on linearly from the last rows of an image into the next image)
+        lT += 4;
+        ltx += 4u;
+        const bool wrap = ltx >= (unsigned)p.TX;
+        ltx -= wrap ? (unsigned)p.TX : 0u;
+        lty = wrap ? (lty == TYm1 ? 0u : lty + 1u) : lty;
+        lyb += 8u * ldy4 + (wrap ? (unsigned)p.W * ldy4 : 0u);
+        lxb += 8u * ldx4 + (wrap ? (unsigned)p.W * ldx4 : 0u);
+    };
+    floatx4s acc[4][2][2];
+#pragma unroll
+    for (int jx = 0; jx < 4; ++jx)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[jx][cb][nb][e] = 0.f;
+    // one step: operands from the registers requested two steps ago, the request for the step after next into the same registers, 16 MFMAs
+    auto do_step = [&](Raw& r) __attribute__((always_inline)) {
+        float A[4][2], B[4][2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const float r0 = fmaf(c1, r.dyv[cb][2], c0 * r.dyv[cb][0]), r1 = fmaf(c1, r.dyv[cb][3], c0 * r.dyv[cb][1]);
+            A[0][cb] = r0; A[1][cb] = r0 + r1; A[2][cb] = r0 - r1; A[3][cb] = r1;                       // (column 3 negated)
+        }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const float t0 = fmaf(sgn, r.xb[nb][0], r.xa[nb][0]), t1 = fmaf(sgn, r.xb[nb][1], r.xa[nb][1]);
+            const float t2 = fmaf(sgn, r.xb[nb][2], r.xa[nb][2]), t3 = fmaf(sgn, r.xb[nb][3], r.xa[nb][3]);
+            B[0][nb] = t0 - t2; B[1][nb] = t1 + t2; B[2][nb] = t2 - t1; B[3][nb] = t3 - t1;             // (column 3 negated)
+        }
+        load_step(r);                                            // (the step after next; past the slab: every lane out of range, zeros)
+#pragma unroll
+        for (int jx = 0; jx < 4; ++jx)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) acc[jx][cb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[jx][cb], B[jx][nb], acc[jx][cb][nb], 0, 0, 0);
+    };
+    Raw r0, r1;
+    load_step(r0);
+    load_step(r1);
+    for (int step = 0; step < nsteps; step += 2) {               // (an odd count runs one step of zeros: its loads are out of range)
+        do_step(r0);
+        do_step(r1);
+    }
+    // ---- partial sums: part[split][position][cout][cin]; lane holds couts 16 cb + 4 kg + e, cin 16 nb + m
+    float* part = p.part + (int64_t)split * 16 * p.cout_all * p.Cg;
+#pragma unroll
+    for (int jx = 0; jx < 4; ++jx) {
+        const int xi = 4 * wave + jx;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = 16 * cb + 4 * kg + e;
+                if (co >= p.Ng) continue;
+                float* dst = &part[((int64_t)xi * p.cout_all + grp * p.Ng + co) * p.Cg];
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    if (16 * nb + m < p.Cg) dst[16 * nb + m] = acc[jx][cb][nb][e];
+            }
+    }
+}
+
+static const bool kWinoSmallWgrad = !(getenv("SUHPE_WINO_SMALL_WGRAD") && atoi(getenv("SUHPE_WINO_SMALL_WGRAD")) == 0);
+
+// slabs of the small filter-gradient kernel (0: the conv is not its shape); the caller has checked wino_wgrad_geom_ok
+int wino_small_wgrad_splits(int n, int h, int w, int cg, int ng, int groups) {
+    if (!kWinoSmall || !kWinoSmallWgrad || cg > 32 || ng > 32 || h < 4 || w < 8 || (int64_t)n * h * w >= (1 << 24)) return 0;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (cus <= 0) cus = 256;
+    }
+    const int64_t MT = (int64_t)n * (h / 2) * (w / 2);
+    static const int wgs = getenv("SUHPE_WINO_SMALL_WGRAD_WGS") ? atoi(getenv("SUHPE_WINO_SMALL_WGRAD_WGS")) : 3;
+    int64_t splits = (int64_t)cus * wgs / groups;               // workgroups per compute unit
+    const int64_t max_by_k = ceil_div(MT, 64);                   // at least 16 steps per slab
+    if (splits > max_by_k) splits = max_by_k;
+    if (splits < 1) splits = 1;
+    return (int)splits;
+}
+
+void launch_wino_small_wgrad(const WinoWgradParams& p_in, int groups, hipStream_t st) {
+    WinoWgradParams p = p_in;
+    p.tiles_per_split = (int)(ceil_div(ceil_div(p.MT, p.splits), 4) * 4);
+    hipLaunchKernelGGL(wino_small_wgrad_kernel, dim3((unsigned)p.splits, 1, groups), dim3(256), 0, st, p);
+}
+
 }  // namespace suhpe
