@@ -137,7 +137,9 @@ __global__ __launch_bounds__(256, 2) void wino_small_kernel(const NtParams p, co
     const u32x4s xrs = rsrc_scalars(p.x + (int64_t)grp * g.Cg, p.x_bytes - (int64_t)grp * g.Cg * 4);
     const u32x4s rrs = rsrc_scalars(RES ? p.residual + (int64_t)grp * p.Ng : nullptr, RES ? (int64_t)g.M * p.ldy * 4 - (int64_t)grp * p.Ng * 4 : 0);
     constexpr int NL = KS == 6 ? 12 : 6;                         // loads of a block's patch rows
-    constexpr int NS = 2 + (STATS ? 4 : 0);                      // stores of a block (every one of them issues, absent lanes / records at kOob)
+    constexpr int NS = 2 + (STATS ? 2 : 0);                      // stores of a block that ALWAYS issue (absent lanes / records at kOob); the block with the segment
+                                                                 // boundary issues two more: the counted waits then leave two more operations in flight than they
+                                                                 // assume -- they wait LONGER, never shorter (a count is an upper bound on what may be pending)
     constexpr int NR = RES ? 2 : 0;                              // skip-value loads of a block
     // Requests the patch rows of block blk_id (live = false: a block that does not exist -- every lane reads zeros from beyond the descriptor, so the
     // loop body has no conditional load).  A tile's patch spans pixel columns 2 tx - 1 .. 2 tx + 2; columns 2 tx and 2 tx + 1 are the tile's OWN, the
@@ -276,17 +278,28 @@ __global__ __launch_bounds__(256, 2) void wino_small_kernel(const NtParams p, co
                 as[e] = a + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(a), 0x401F));           // + lane ^ 16: the tile's other output row
                 qs[e] = qq + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(qq), 0x401F));
             }
+            float sa[2], sq[2], sk[2];
+#pragma unroll
+            for (int ee = 0; ee < 2; ++ee) { sa[ee] = opy ? as[2 + ee] : as[ee]; sq[ee] = opy ? qs[2 + ee] : qs[ee]; sk[ee] = opy ? ks[2 + ee] : ks[ee]; }
 #pragma unroll
             for (int ee = 0; ee < 2; ++ee) {
-                const float a = opy ? as[2 + ee] : as[ee], qq = opy ? qs[2 + ee] : qs[ee], k = opy ? ks[2 + ee] : ks[ee];
-                float a1 = first ? a : 0.f, q1 = first ? qq : 0.f, a2 = second ? a : 0.f, q2 = second ? qq : 0.f;
-                a1 += quad_dpp<0x128>(a1); q1 += quad_dpp<0x128>(q1); a2 += quad_dpp<0x128>(a2); q2 += quad_dpp<0x128>(q2);      // row_ror 8, 4, 2, 1
-                a1 += quad_dpp<0x124>(a1); q1 += quad_dpp<0x124>(q1); a2 += quad_dpp<0x124>(a2); q2 += quad_dpp<0x124>(q2);
-                a1 += quad_dpp<0x122>(a1); q1 += quad_dpp<0x122>(q1); a2 += quad_dpp<0x122>(a2); q2 += quad_dpp<0x122>(q2);
-                a1 += quad_dpp<0x121>(a1); q1 += quad_dpp<0x121>(q1); a2 += quad_dpp<0x121>(a2); q2 += quad_dpp<0x121>(q2);
-                const bool co_ok = rco + ee < p.Ng;
-                store4_buf(srs, co_ok & (rec != kOob) ? rec + 16u * ee : kOob, a1, q1, k, 4.f * (float)n1);
-                store4_buf(srs2, co_ok & (rec2 != kOob) ? rec2 + 16u * ee : kOob, a2, q2, k, 4.f * (float)(nvalid - n1));
+                float a1 = first ? sa[ee] : 0.f, q1 = first ? sq[ee] : 0.f;
+                a1 += quad_dpp<0x128>(a1); q1 += quad_dpp<0x128>(q1);       // row_ror 8, 4, 2, 1: every lane of the row ends with the row's sum
+                a1 += quad_dpp<0x124>(a1); q1 += quad_dpp<0x124>(q1);
+                a1 += quad_dpp<0x122>(a1); q1 += quad_dpp<0x122>(q1);
+                a1 += quad_dpp<0x121>(a1); q1 += quad_dpp<0x121>(q1);
+                store4_buf(srs, (rco + ee < p.Ng) & (rec != kOob) ? rec + 16u * ee : kOob, a1, q1, sk[ee], 4.f * (float)n1);
+            }
+            if (straddle) {                                      // (one block of the launch at most: the only branch of the loop body, behind everything else)
+#pragma unroll
+                for (int ee = 0; ee < 2; ++ee) {
+                    float a2 = second ? sa[ee] : 0.f, q2 = second ? sq[ee] : 0.f;
+                    a2 += quad_dpp<0x128>(a2); q2 += quad_dpp<0x128>(q2);
+                    a2 += quad_dpp<0x124>(a2); q2 += quad_dpp<0x124>(q2);
+                    a2 += quad_dpp<0x122>(a2); q2 += quad_dpp<0x122>(q2);
+                    a2 += quad_dpp<0x121>(a2); q2 += quad_dpp<0x121>(q2);
+                    store4_buf(srs2, (rco + ee < p.Ng) & (rec2 != kOob) ? rec2 + 16u * ee : kOob, a2, q2, sk[ee], 4.f * (float)(nvalid - n1));
+                }
             }
         }
     };

@@ -1,7 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for i in 1 2; do
-echo "== new DB (small fwd/dgrad/wgrad)"; python tools/step_bench.py effinetv2 32 128 5 20 2>&1 | tail -1
-echo "== small wgrad off"; SUHPE_WINO_SMALL_WGRAD=0 SUHPE_TILE_DB=$PWD/tools/debug/data/tiles_wgrad_direct.json python tools/step_bench.py effinetv2 32 128 5 20 2>&1 | tail -1
-echo "== old DB"; SUHPE_TILE_DB=$PWD/tools/debug/data/tiles_pre_small.json python tools/step_bench.py effinetv2 32 128 5 20 2>&1 | tail -1
-done > gpurun_out/step_ab.txt 2>&1
-cat gpurun_out/step_ab.txt
+export WINO_SHAPES="24,24,1,10,5,2;24,32,1,12,4,3;24,24,1,112,160,32"
+timeout 600 python tools/wino_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-700 > gpurun_out/wsmall_on.txt
+cat gpurun_out/wsmall_on.txt
+timeout 900 python -m pytest tests/test_gpu_winograd.py tests/test_gpu_guard_bands.py -x -q 2>&1 | tail -3
