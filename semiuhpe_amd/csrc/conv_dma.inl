@@ -280,15 +280,22 @@ __global__ __launch_bounds__(512) void gemm_nt_dma(const NtParams p, int total_v
                     const float k = __shfl(acc[0][j][0], r32, 64);
                     auto emit = [&](int lo, int hi, const dma_u32x4& rs, unsigned off) __attribute__((always_inline)) {
                         float a = 0.f, q = 0.f;
+                        if (lo <= 0 && hi >= UR) {               // every row of the unit counts: no per-element range tests (the vector ALU is the matrix pipe)
 #pragma unroll
-                        for (int i = 0; i < TM; ++i)
+                            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                            for (int e = 0; e < 16; ++e) {
-                                const int lr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                                const float v = (lr >= lo && lr < hi) ? acc[i][j][e] - k : 0.f;
-                                a += v;
-                                q += v * v;
-                            }
+                                for (int e = 0; e < 16; ++e) { const float v = acc[i][j][e] - k; a += v; q += v * v; }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                                for (int e = 0; e < 16; ++e) {
+                                    const int lr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                                    const float v = (lr >= lo && lr < hi) ? acc[i][j][e] - k : 0.f;
+                                    a += v;
+                                    q += v * v;
+                                }
+                        }
                         a += __shfl_xor(a, 32, 64);
                         q += __shfl_xor(q, 32, 64);
                         const f4 rec = {a, q, k, (float)(hi - lo)};

@@ -324,19 +324,27 @@ void igemm_nt3x3_kernel(const NtParams p, const HaloGeom hg) {
         __syncthreads();
         auto emit = [&](int64_t lo, int64_t hi, float4* dst0) __attribute__((always_inline)) {
             const int64_t wlo = lo - wm * WM, whi = hi - wm * WM;
+            const bool full = wlo <= 0 && whi >= WM;            // (as in igemm_nt_kernel: no range tests where every row counts)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const float k = kk[wn * WN + j * 32 + r32];
                 float a = 0.f, q = 0.f;
+                if (full) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int lr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        const float v = (lr >= wlo && lr < whi) ? acc[i][j][e] - k : 0.f;
-                        a += v;
-                        q += v * v;
-                    }
+                        for (int e = 0; e < 16; ++e) { const float v = acc[i][j][e] - k; a += v; q += v * v; }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int lr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                            const float v = (lr >= wlo && lr < whi) ? acc[i][j][e] - k : 0.f;
+                            a += v;
+                            q += v * v;
+                        }
+                }
                 a += __shfl_xor(a, 32, 64);
                 q += __shfl_xor(q, 32, 64);
                 if (h == 0) {

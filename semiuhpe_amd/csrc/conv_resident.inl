@@ -159,15 +159,22 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_nt_resident(const NtPara
             // sums over the unit's rows [lo, hi)
             auto emit = [&](int lo, int hi, float4* dst) __attribute__((always_inline)) {
                 float a = 0.f, q = 0.f;
+                if (lo <= 0 && hi >= UR) {                     // every row of the unit counts: no per-element range tests (the vector ALU is the matrix pipe)
 #pragma unroll
-                for (int i = 0; i < TMU; ++i)
+                    for (int i = 0; i < TMU; ++i)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int lr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        const float v = (lr >= lo && lr < hi) ? acc[i][e] - k : 0.f;
-                        a += v;
-                        q += v * v;
-                    }
+                        for (int e = 0; e < 16; ++e) { const float v = acc[i][e] - k; a += v; q += v * v; }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TMU; ++i)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int lr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                            const float v = (lr >= lo && lr < hi) ? acc[i][e] - k : 0.f;
+                            a += v;
+                            q += v * v;
+                        }
+                }
                 a += __shfl_xor(a, 32, 64);
                 q += __shfl_xor(q, 32, 64);
                 if (h == 0 && okc) *dst = make_float4(a, q, k, (float)(hi - lo));

@@ -1,5 +1,6 @@
 cd $GRAFT_REPO_ROOT
-export WINO_SHAPES="24,24,1,10,5,2;24,32,1,12,4,3;24,24,1,112,160,32"
-timeout 600 python tools/wino_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-700 > gpurun_out/wsmall_on.txt
-cat gpurun_out/wsmall_on.txt
-timeout 900 python -m pytest tests/test_gpu_winograd.py tests/test_gpu_guard_bands.py -x -q 2>&1 | tail -3
+for i in 1 2 3; do python tools/step_bench.py effinetv2 32 128 5 20 2>&1 | tail -1; done > gpurun_out/step_ab.txt 2>&1
+python tools/step_bench.py repvgg 64 256 3 8 2>&1 | tail -1 >> gpurun_out/step_ab.txt
+python tools/step_bench.py tinyvit 32 128 3 8 2>&1 | tail -1 >> gpurun_out/step_ab.txt
+cat gpurun_out/step_ab.txt
+timeout 1200 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_segments.py tests/test_gpu_guard_bands.py tests/test_gpu_effnet.py -x -q 2>&1 | tail -3
