@@ -353,61 +353,71 @@ void igemm_nt_kernel(const NtParams p) {
             const float bv = (!AFF_ && p.bias) ? p.bias[grp * p.Ng + col] : 0.f;
             const float sc = AFF_ ? p.scale[grp * p.Ng + col] : 1.f;
             const float sh = AFF_ ? p.shift[grp * p.Ng + col] : 0.f;
+            // fp32 MFMAs run on the vector ALU (tools/micro/coissue_probe.hip), so this loop is paid in matrix throughput: the element's offset is
+            // ONE 64-bit product per 32-row block plus a scalar multiple of the row pitch (the first version multiplied 64-bit row x pitch per
+            // element: ~25 vector instructions each), and a tile whose rows all exist -- all but the last -- runs the copy without row tests
+            auto rows_of = [&](auto full_t) __attribute__((always_inline)) {
+                constexpr bool FULL = decltype(full_t)::value;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                auto out_row = [&](int e, int64_t* row) __attribute__((always_inline)) -> int64_t {
-                    *row = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (MODE != 3) return *row;
-                    // sub-grid row (n,a,b) -> pixel (n, a*om+ph, b*om+pw) of the full output
-                    const unsigned n = fast_div((unsigned)*row, g.div_hw_mul, g.div_hw_shr);
-                    const unsigned rem = (unsigned)*row - n * (unsigned)(g.OH * g.OW);
-                    const unsigned a = fast_div(rem, g.div_w_mul, g.div_w_shr);
-                    const unsigned bb = rem - a * (unsigned)g.OW;
-                    return ((int64_t)n * g.YH + a * g.om + g.ph) * g.YW + bb * g.om + g.pw;
-                };
-                // the residual operand of the block (skip gradient, pre-activation, BatchNorm input): every load is issued BEFORE the first
-                // store -- residual and y may alias as far as the compiler knows, so a load inside the store loop waits for the store ahead of it
-                float rv[16];
-                if (p.res_mode) {
+                for (int i = 0; i < TM; ++i) {
+                    const int64_t row0 = m0 + wm * WM + i * 32 + 4 * h;
+                    const int64_t off0 = row0 * p.ldy;          // (MODE != 3: output row = GEMM row)
+                    auto out_off = [&](int e, int64_t* row) __attribute__((always_inline)) -> int64_t {
+                        const int lr = (e & 3) + 8 * (e >> 2);
+                        *row = row0 + lr;
+                        if (MODE != 3) return off0 + (int64_t)lr * p.ldy;
+                        // sub-grid row (n,a,b) -> pixel (n, a*om+ph, b*om+pw) of the full output
+                        const unsigned n = fast_div((unsigned)*row, g.div_hw_mul, g.div_hw_shr);
+                        const unsigned rem = (unsigned)*row - n * (unsigned)(g.OH * g.OW);
+                        const unsigned a = fast_div(rem, g.div_w_mul, g.div_w_shr);
+                        const unsigned bb = rem - a * (unsigned)g.OW;
+                        return (((int64_t)n * g.YH + a * g.om + g.ph) * g.YW + bb * g.om + g.pw) * p.ldy;
+                    };
+                    // the residual operand of the block (skip gradient, pre-activation, BatchNorm input): every load is issued BEFORE the first
+                    // store -- residual and y may alias as far as the compiler knows, so a load inside the store loop waits for the store ahead of it
+                    float rv[16];
+                    if (p.res_mode) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            int64_t row;
+                            const int64_t off = out_off(e, &row);
+                            rv[e] = (FULL || row < g.M) ? p.residual[off + grp * p.Ng + col] : 0.f;
+                        }
+                    }
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         int64_t row;
-                        const int64_t orow = out_row(e, &row);
-                        rv[e] = row < g.M ? p.residual[orow * p.ldy + grp * p.Ng + col] : 0.f;
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    int64_t row;
-                    const int64_t orow = out_row(e, &row);
-                    if (row >= g.M) continue;
-                    if constexpr (ACT2) {
-                        float v = acc[i][j][e] + bv;
-                        if (p.res_mode == 5) {
-                            const bool second = p.seg_row > 0 && row >= p.seg_row;
-                            const float xv = rv[e];
-                            const float xh = xv * (second ? bn5[j][1][0] : bn5[j][0][0]) + (second ? bn5[j][1][1] : bn5[j][0][1]);
-                            v *= act_grad(xv * (second ? bn5[j][1][2] : bn5[j][0][2]) + (second ? bn5[j][1][3] : bn5[j][0][3]), p.act);
-                            sum5[j][second ? 2 : 0] += v;
-                            sum5[j][second ? 3 : 1] += v * xh;
+                        const int64_t off = out_off(e, &row);
+                        if (!FULL && row >= g.M) continue;
+                        if constexpr (ACT2) {
+                            float v = acc[i][j][e] + bv;
+                            if (p.res_mode == 5) {
+                                const bool second = p.seg_row > 0 && row >= p.seg_row;
+                                const float xv = rv[e];
+                                const float xh = xv * (second ? bn5[j][1][0] : bn5[j][0][0]) + (second ? bn5[j][1][1] : bn5[j][0][1]);
+                                v *= act_grad(xv * (second ? bn5[j][1][2] : bn5[j][0][2]) + (second ? bn5[j][1][3] : bn5[j][0][3]), p.act);
+                                sum5[j][second ? 2 : 0] += v;
+                                sum5[j][second ? 3 : 1] += v * xh;
+                            }
+                            if (p.res_mode == 4) v *= act_grad(rv[e], p.act);
+                            y[off + col] = v;
+                            if (p.y2) p.y2[off + grp * p.Ng + col] = act_apply(v, p.act);
+                        } else if constexpr (!AFF_) {
+                            // res_mode 3: plain skip-connection add (input gradient + the gradient that bypassed the block; forward: x + keep * f(x))
+                            float v = acc[i][j][e] + bv;
+                            if (p.o_rowscale) v *= p.o_rowscale[fast_div((unsigned)row, p.o_div_mul, p.o_div_shr)];
+                            y[off + col] = v + (p.res_mode == 3 ? rv[e] : 0.f);
+                        } else {
+                            float v = acc[i][j][e] * sc + sh;
+                            if (p.res_mode == 1) v += rv[e];
+                            v = act_apply(v, p.act);
+                            if (p.res_mode == 2) v += rv[e];
+                            y[off + col] = v;
                         }
-                        if (p.res_mode == 4) v *= act_grad(rv[e], p.act);
-                        y[orow * p.ldy + col] = v;
-                        if (p.y2) p.y2[orow * p.ldy + grp * p.Ng + col] = act_apply(v, p.act);
-                    } else if constexpr (!AFF_) {
-                        // res_mode 3: plain skip-connection add (input gradient + the gradient that bypassed the block; forward: x + keep * f(x))
-                        float v = acc[i][j][e] + bv;
-                        if (p.o_rowscale) v *= p.o_rowscale[fast_div((unsigned)row, p.o_div_mul, p.o_div_shr)];
-                        y[orow * p.ldy + col] = v + (p.res_mode == 3 ? rv[e] : 0.f);
-                    } else {
-                        float v = acc[i][j][e] * sc + sh;
-                        if (p.res_mode == 1) v += rv[e];
-                        v = act_apply(v, p.act);
-                        if (p.res_mode == 2) v += rv[e];
-                        y[orow * p.ldy + col] = v;
                     }
                 }
-            }
+            };
+            if (m0 + BM <= g.M) rows_of(std::true_type{}); else rows_of(std::false_type{});
         }
     };
     store_out(std::integral_constant<bool, AFF>{});       // AFF: a separate instantiation, so the plain kernel carries no affine code
