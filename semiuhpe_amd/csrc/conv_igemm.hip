@@ -662,26 +662,35 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM * BN >= 128 * 128) 
                 const float bv = (!AFF_ && p.bias) ? p.bias[grp * p.Ng + col] : 0.f;
                 const float sc = AFF_ ? p.scale[grp * p.Ng + col] : 1.f;
                 const float sh = AFF_ ? p.shift[grp * p.Ng + col] : 0.f;
+                // (as in igemm_nt_kernel: one 64-bit row product per 32-row block, scalar multiples of the row pitch per element, no row tests in a full tile)
+                auto rows_of = [&](auto full_t) __attribute__((always_inline)) {
+                    constexpr bool FULL = decltype(full_t)::value;
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i) {
+                        const int row0 = m0 + wm * WM + i * 32 + 4 * h;
+                        const int64_t off0 = (int64_t)row0 * p.ldy;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int row = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        if (row >= M) continue;
-                        if constexpr (!AFF_) {
+                        for (int e = 0; e < 16; ++e) {
+                            const int lr = (e & 3) + 8 * (e >> 2);
+                            if (!FULL && row0 + lr >= M) continue;
+                            const int64_t off = off0 + (int64_t)lr * p.ldy;
+                            if constexpr (!AFF_) {
 #if SUHPE_PROBE == 4
-                            if (acc[i][j][e] == 12345.678f)
+                                if (acc[i][j][e] == 12345.678f)
 #endif
-                            y[(int64_t)row * p.ldy + col] = acc[i][j][e] + bv + (p.res_mode == 3 ? p.residual[(int64_t)row * p.ldy + grp * p.Ng + col] : 0.f);
-                        } else {
-                            float v = acc[i][j][e] * sc + sh;
-                            const float rv = p.res_mode ? p.residual[(int64_t)row * p.ldy + grp * p.Ng + col] : 0.f;
-                            if (p.res_mode == 1) v += rv;
-                            v = act_apply(v, p.act);
-                            if (p.res_mode == 2) v += rv;
-                            y[(int64_t)row * p.ldy + col] = v;
+                                y[off + col] = acc[i][j][e] + bv + (p.res_mode == 3 ? p.residual[off + grp * p.Ng + col] : 0.f);
+                            } else {
+                                float v = acc[i][j][e] * sc + sh;
+                                const float rv = p.res_mode ? p.residual[off + grp * p.Ng + col] : 0.f;
+                                if (p.res_mode == 1) v += rv;
+                                v = act_apply(v, p.act);
+                                if (p.res_mode == 2) v += rv;
+                                y[off + col] = v;
+                            }
                         }
                     }
+                };
+                if (m0 + BM <= M) rows_of(std::true_type{}); else rows_of(std::false_type{});
             }
         };
         store_out(std::integral_constant<bool, AFF>{});
