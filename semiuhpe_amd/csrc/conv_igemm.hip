@@ -913,6 +913,31 @@ void igemm_tn_kernel(const TnParams p) {
             }
         }
     };
+    // Pointwise form (1x1, stride 1, no padding, no input transform -- every filter gradient of an MBConv expand / project conv and every Linear):
+    // both operands are plain row-major matrices, so a thread's byte offsets just advance by BK rows per slab.  fp32 MFMAs run on the vector ALU
+    // (tools/micro/coissue_probe.hip): the general gather above costs ~70 vector instructions per slab, 14 of them quarter-rate multiplies, beside
+    // 16 MFMAs -- a third of the slab.  Here: one v_add per load; rows beyond the split are cut off by the descriptors' extents, not by compares.
+    const bool pw = !XF && g.R * g.S == 1 && g.stride == 1 && g.pad == 0 && g.GH == g.OH && g.GW == g.OW;
+    unsigned a_off[A_IT], b_off[B_IT];
+    const BufRsrc dyr_pw = make_rsrc(p.dy + (int64_t)grp * p.Ng, mend * (int64_t)p.lddy * 4 - (int64_t)grp * p.Ng * 4 < p.dy_bytes - (int64_t)grp * p.Ng * 4
+                                                                      ? mend * (int64_t)p.lddy * 4 - (int64_t)grp * p.Ng * 4 : p.dy_bytes - (int64_t)grp * p.Ng * 4);
+    const BufRsrc xr_pw = make_rsrc(p.x + (int64_t)grp * g.Cg, mend * (int64_t)g.ldg * 4 - (int64_t)grp * g.Cg * 4 < p.x_bytes - (int64_t)grp * g.Cg * 4
+                                                                    ? mend * (int64_t)g.ldg * 4 - (int64_t)grp * g.Cg * 4 : p.x_bytes - (int64_t)grp * g.Cg * 4);
+    if (pw) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i)
+            a_off[i] = (a_valid_col && (BK % RA == 0 || a_row + i * RA < BK)) ? ((unsigned)(mbeg + a_row + i * RA) * (unsigned)p.lddy + (unsigned)(i0 + a_col)) * 4u : kOob;
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            b_off[i] = (kq_valid && (BK % RB == 0 || b_row + i * RB < BK)) ? ((unsigned)(mbeg + b_row + i * RB) * (unsigned)g.ldg + (unsigned)kq) * 4u : kOob;
+    }
+    const unsigned a_step = (unsigned)BK * (unsigned)p.lddy * 4u, b_step = (unsigned)BK * (unsigned)g.ldg * 4u;
+    auto load_tiles_pw = [&]() {                                // (kOob + the steps of a whole split stays out of range: a split's rows span < 2^31 bytes)
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) { buf_load<VECA>(dyr_pw, a_off[i], a_reg[i]); a_off[i] += a_step; }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) { buf_load<VECB>(xr_pw, b_off[i], b_reg[i]); b_off[i] += b_step; }
+    };
     auto store_tiles = [&]() {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
@@ -950,12 +975,12 @@ void igemm_tn_kernel(const TnParams p) {
 
     const int r32 = lane & 31, h = lane >> 5;
     if (mbeg < mend) {
-        load_tiles(mbeg);
+        if (pw) load_tiles_pw(); else load_tiles(mbeg);
         store_tiles();
         __syncthreads();
         for (int64_t mb = mbeg; mb < mend; mb += BK) {
             const bool more = mb + BK < mend;
-            if (more) load_tiles(mb + BK);
+            if (more) { if (pw) load_tiles_pw(); else load_tiles(mb + BK); }
             // fragments in groups of four k-pairs, two register sets: the LDS reads of group q+1 are in flight under the
             // MFMAs of group q (with one set the compiler waits for every pair of reads right before its two MFMAs)
             constexpr int GQ = 4;
