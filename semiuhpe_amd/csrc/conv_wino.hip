@@ -607,25 +607,35 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WinoWgradParam
     const int nchunks = tile_lo < tile_hi ? (tile_hi - tile_lo + 7) >> 3 : 0;
 
     float xr_[4][4], dr_[4][4];
+    // A chunk's tile is its WAVEFRONT's (tile_lo + 8 c + wave): decomposing it is scalar work, and the lane-dependent part of every offset -- patch row,
+    // channel vector -- is a constant of the launch.  fp32 MFMAs run on the vector ALU (tools/micro/coissue_probe.hip), and the first version of this
+    // loader paid 28 quarter-rate vector multiplies + ~50 vector instructions per chunk beside its 64 MFMAs (a third of the chunk): now one vector
+    // add per load, the validity of rows / columns / the slab's end as scalar conditions on precomputed lane constants.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned ldx4 = (unsigned)p.ldx * 4u, lddy4 = (unsigned)p.lddy * 4u;
+    const unsigned lane_x = (unsigned)(((si - 1) * p.W - 1) * p.ldx * 4 + (cin0 + 4 * sv) * 4);      // (may wrap: the sum with the tile's pixel offset does not, where the load is valid)
+    const unsigned lane_y = (unsigned)((cout0 + 4 * sv) * 4);
+    const bool l_top = si == 0, l_bot = si == 3;
     auto load_chunk = [&](int c) __attribute__((always_inline)) {
-        const int T = tile_lo + c * 8 + wave;                      // (wave-uniform)
+        const int T = tile_lo + c * 8 + wave_u;                    // (scalar)
         const bool tv = T < tile_hi;
         const unsigned Tn = (unsigned)(tv ? T : 0);
         const unsigned n = fast_div(Tn, p.div_tpi_mul, p.div_tpi_shr);
         const unsigned rem = Tn - n * (unsigned)p.TPI;
         const unsigned ty = fast_div(rem, p.div_tx_mul, p.div_tx_shr), tx = rem - ty * (unsigned)p.TX;
-        const int iy = 2 * (int)ty - 1 + si, ix0 = 2 * (int)tx - 1;
-        const bool rowok = tv && civ && (unsigned)iy < (unsigned)p.H;
+        const unsigned pix = (n * (unsigned)p.H + 2u * ty) * (unsigned)p.W + 2u * tx;      // the tile's first own pixel (scalar)
+        const bool top = ty == 0, bot = (int)ty == (p.H >> 1) - 1, left = tx == 0, right = (int)tx == p.TX - 1;
+        const bool rowok = tv & civ & !(l_top & top) & !(l_bot & bot);
+        const unsigned xb = pix * ldx4 + lane_x;
 #pragma unroll
         for (int c4 = 0; c4 < 4; ++c4) {
-            const bool ok = rowok && (unsigned)(ix0 + c4) < (unsigned)p.W;
-            buf_load<4>(xr, ok ? ((unsigned)(((int)n * p.H + iy) * p.W + ix0 + c4) * (unsigned)p.ldx + (unsigned)(cin0 + 4 * sv)) * 4u : kOob, xr_[c4]);
+            const bool ok = rowok & !(c4 == 0 && left) & !(c4 == 3 && right);
+            buf_load<4>(xr, ok ? xb + (unsigned)c4 * ldx4 : kOob, xr_[c4]);
         }
+        const unsigned yb = pix * lddy4 + lane_y;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const bool ok = tv && cov;
-            buf_load<4>(yr, ok ? ((unsigned)(((int)n * p.H + 2 * (int)ty + (q >> 1)) * p.W + 2 * (int)tx + (q & 1)) * (unsigned)p.lddy + (unsigned)(cout0 + 4 * sv)) * 4u : kOob, dr_[q]);
-        }
+        for (int q = 0; q < 4; ++q)
+            buf_load<4>(yr, tv & cov ? yb + (unsigned)((q >> 1) * p.W + (q & 1)) * lddy4 : kOob, dr_[q]);
     };
     auto stage_chunk = [&](int buf) __attribute__((always_inline)) {
         float* Ds = smem + buf * 2 * WW_IMG;
