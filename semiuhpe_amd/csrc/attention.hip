@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void window_attn_fwd_kernel(const AttnGeom g, 
     float* qb = Vs + g.N * PITCH;           // [4][DH]
     float* pb = qb + 4 * DH;                // [4][MAXN]
     const int win = blockIdx.x / g.heads, h = blockIdx.x - win * g.heads;
-    const int ld = g.heads * 3 * DH, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ld = g.heads * 3 * DH, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     load_slice(g, win, qkv, ld, h * 3 * DH + DH, Ks);
     load_slice(g, win, qkv, ld, h * 3 * DH + 2 * DH, Vs);
     __syncthreads();
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(NP == 64 ? 128 : 256, 2) void window_attn_fwd_mfma(
     float* Vt = Ks + NP * KP;                           // [DH][VP]
     float* Pst = Vt + DH * VP;                          // [NW][32][PP]
     const int win = blockIdx.x / g.heads, hd = blockIdx.x - win * g.heads;
-    const int ld = g.heads * 3 * DH, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int ld = g.heads * 3 * DH, t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane((int)(t >> 6));
     const int r32 = lane & 31, h = lane >> 5;
     // every qkv read is a buffer load whose offset is pushed out of range for tokens beyond the window (-> zeros): no
     // branches around the loads, so they are all in flight together
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const AttnGeom g, 
     float* b0 = Os + g.N * PITCH;           // [4][MAXN]
     float* b1 = b0 + 4 * MAXN;              // [4][MAXN]
     const int win = blockIdx.x / g.heads, h = blockIdx.x - win * g.heads;
-    const int ld = g.heads * 3 * DH, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ld = g.heads * 3 * DH, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     load_slice(g, win, qkv, ld, h * 3 * DH, Qs);
     load_slice(g, win, qkv, ld, h * 3 * DH + DH, Ks);
     load_slice(g, win, qkv, ld, h * 3 * DH + 2 * DH, Vs);
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(NP == 64 ? 128 : 512, 2) void window_attn_bwd_mfma(
     float* stS = Os + NP * KP;                          // [NW][32][PP]
     float* delta = stS + NW * 32 * PP;                  // [NP]
     const int win = blockIdx.x / g.heads, hd = blockIdx.x - win * g.heads;
-    const int ld = g.heads * 3 * DH, lo = g.heads * DH, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int ld = g.heads * 3 * DH, lo = g.heads * DH, t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane((int)(t >> 6));
     const int r32 = lane & 31, h = lane >> 5;
     const float* P = probs + (int64_t)blockIdx.x * g.N * g.N;
     float* S = dS_out + (int64_t)blockIdx.x * g.N * g.N;
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(NP == 64 ? 128 : 256, 2) void window_attn_fwd_rs(co
     float* Vs = Ks + NP * KP;                           // [NP][KP]
     int* tok = reinterpret_cast<int*>(Vs + NP * KP);    // [NP]
     const int win = blockIdx.x / g.heads, hd = blockIdx.x - win * g.heads;
-    const int ld = g.heads * 3 * DH, lo = g.heads * DH, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int ld = g.heads * 3 * DH, lo = g.heads * DH, t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane((int)(t >> 6));
     const int r32 = lane & 31, h = lane >> 5;
     const BufRsrc rq = make_rsrc(qkv, (int64_t)g.B * g.H * g.W * ld * 4);
     const BufRsrc rout = make_rsrc(out, (int64_t)g.B * g.H * g.W * lo * 4);
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(NP == 64 ? 128 : 256, 2) void window_attn_bwd_rs(co
     float* st_d = st_r + NP;
     int* tok = reinterpret_cast<int*>(st_d + NP);       // [NP]
     const int win = blockIdx.x / g.heads, hd = blockIdx.x - win * g.heads;
-    const int ld = g.heads * 3 * DH, lo = g.heads * DH, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int ld = g.heads * 3 * DH, lo = g.heads * DH, t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane((int)(t >> 6));
     const int r32 = lane & 31, h = lane >> 5;
     float* S = dS_out + (int64_t)blockIdx.x * g.N * g.N;
     const BufRsrc rq = make_rsrc(qkv, (int64_t)g.B * g.H * g.W * ld * 4);

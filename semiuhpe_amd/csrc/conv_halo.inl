@@ -67,7 +67,7 @@ void igemm_nt3x3_kernel(const NtParams p, const HaloGeom hg) {
     float* Bs = smem + (size_t)hg.nslots * LDP;      // [BN][LDP]
 
     const GatherGeom& g = p.g;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane((int)(t >> 6));
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int grp = blockIdx.z;
     // XCD-aware order as igemm_nt_kernel (spatial footprint: each XCD takes one contiguous run of row tiles)
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void igemm_nt3x3_n48_kernel(const NtParams 
     float* As = smem;                                // [240][LDP]
     float* Bs = smem + (size_t)hg.nslots * LDP;      // [48][LDP]
     const GatherGeom& g = p.g;
-    const int t = threadIdx.x, lane = t & 63, wm = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wm = __builtin_amdgcn_readfirstlane((int)(t >> 6));
     const int grp = blockIdx.z;
     const int b = blockIdx.x, jx = b >> 3, col_tile = jx % p.col_tiles;
     int row_tile;

@@ -80,7 +80,7 @@ void igemm_nt_kernel(const NtParams p) {
     __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
 
     const GatherGeom& g = p.g;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane((int)(t >> 6));      // (uniform: wave-level index arithmetic on the scalar ALU)
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int grp = blockIdx.z;
     // XCD-aware tile order: workgroups b and b+8 share an XCD (round-robin dispatch, speed only).  Column tiles of one
@@ -538,7 +538,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM * BN >= 128 * 128) 
     __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
 
     const GatherGeom& g = p.g;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane((int)(t >> 6));      // (uniform: wave-level index arithmetic on the scalar ALU)
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int grp = blockIdx.z;
     const BufRsrc xr = make_rsrc(p.x + (int64_t)grp * g.Cg, p.x_bytes - (int64_t)grp * g.Cg * 4);
@@ -828,7 +828,7 @@ void igemm_tn_kernel(const TnParams p) {
     __shared__ __attribute__((aligned(16))) float Bs[BK * BN];   // [m][k']
 
     const GatherGeom& g = p.g;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane((int)(t >> 6));      // (uniform: wave-level index arithmetic on the scalar ALU)
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int grp = blockIdx.z;
     // XCD-aware order: all output tiles of one m-split run consecutively on one XCD (they stream the same dy / x rows)
