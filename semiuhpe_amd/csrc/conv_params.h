@@ -147,6 +147,7 @@ bool launch_wino(const NtParams& p, int groups, hipStream_t st);
 // conv_wino_small.hip: the same arithmetic with the transformed filter in registers (16 / 24 / 32 input channels, at most 32 output channels; training forms);
 // false = not this form's shape / epilogue (launch_wino, which has checked wino_params_ok, goes on to wino_nt_kernel)
 bool launch_wino_small(const NtParams& p, int groups, hipStream_t st);
+bool wino_small_desc_ok(int cg, int ng, int64_t M, int oh, int ow);      // the shapes of that form (per-group channels in / out, output rows, output image)
 int64_t wino_filter_floats(int groups, int NR, int NK);
 // w: the filter as stored, [groups * ng_w][3][3][cg_w]; pass 0: NR = ng_w rows, NK = cg_w channels; pass 1 (input gradient): NR = cg_w, NK = ng_w
 void launch_wino_filter(const float* w, float* fw, int groups, int NR, int NK, int ng_w, int cg_w, int pass, hipStream_t st);

@@ -425,10 +425,16 @@ __global__ __launch_bounds__(256, 2) void wino_small_kernel(const NtParams p, co
 static const bool kWinoSmall = !(getenv("SUHPE_WINO_SMALL") && atoi(getenv("SUHPE_WINO_SMALL")) == 0);
 static const int kWinoSmallWgs = getenv("SUHPE_WINO_SMALL_WGS") ? atoi(getenv("SUHPE_WINO_SMALL_WGS")) : 2;      // workgroups per compute unit
 
+// descriptor-level eligibility (channels of the gathered tensor / of the output, per group; output rows and image size): what suhpe_conv2d_kernel_name
+// reports and launch_wino_small requires (the launch adds: no bias, no eval-mode epilogue, an 8-byte aligned skip tensor)
+bool wino_small_desc_ok(int cg, int ng, int64_t M, int oh, int ow) {
+    return kWinoSmall && (cg == 16 || cg == 24) && ng <= 32 && ng % 2 == 0 && M < (1 << 24) && ow >= 4 && oh >= 4;
+}
+
 // the caller (launch_wino) has checked wino_params_ok: geometry, alignment, fw present, res_mode 0 / 3 or the eval-mode form
 bool launch_wino_small(const NtParams& p_in, int groups, hipStream_t st) {
     const GatherGeom& g = p_in.g;
-    if (!kWinoSmall || p_in.scale || p_in.bias || p_in.Ng > 32 || p_in.Ng % 2 || g.M >= (1 << 24) || g.OW < 4 || g.OH < 4 || !(g.Cg == 16 || g.Cg == 24)) return false;
+    if (!wino_small_desc_ok(g.Cg, p_in.Ng, g.M, g.OH, g.OW) || p_in.scale || p_in.bias) return false;
     if (p_in.residual && (reinterpret_cast<uintptr_t>(p_in.residual) & 7)) return false;
     NtParams p = p_in;
     WinoSmallGeom wg;

@@ -94,7 +94,7 @@ def test_winograd_kernels_match_float64(K, cfg):
     _pin(K, d, names, True)
     try:
         assert lib.suhpe_conv2d_wino_pinned(ctypes.byref(d), 0) == 1 and lib.suhpe_conv2d_wino_pinned(ctypes.byref(d), 1) == 1
-        assert lib.suhpe_conv2d_kernel_name(ctypes.byref(d), 2).decode() == "wino_wgrad_kernel<64,64>"
+        assert lib.suhpe_conv2d_kernel_name(ctypes.byref(d), 2).decode() in ("wino_wgrad_kernel<64,64>", "wino_small_wgrad_kernel")      # (the second: at most 32 channels on both sides)
         nhwc = lambda t: t.permute(0, 2, 3, 1)
         y = K.conv2d_fwd(xg, wg, None, 1, 1, g)
         assert rel(y, nhwc(y_ref)) < 2e-5

@@ -35,6 +35,8 @@ def normalize(name):
         return "wino_nt_kernel<64,64>"
     if re.match(r"wino_wgrad_kernel<\d+>", name):
         return "wino_wgrad_kernel<64,64>"
+    if re.match(r"wino_small_kernel<", name):                        # (KS, statistics, skip add): one name, as suhpe_conv2d_kernel_name reports it
+        return "wino_small_kernel"
     return name
 
 
