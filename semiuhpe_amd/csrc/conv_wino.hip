@@ -132,6 +132,8 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
     int lu_item = blockIdx.x, lu_chunk = 0, lu_ub = 0;          // U cursor: next chunk to copy, into U image lu_ub (0..2)
     int lv_item = blockIdx.x, lv_sc = 0;                        // V cursor: next super-chunk to load
     unsigned voff[4];
+    // channels 16 s + 8 sv + 4 hh .. + 3 of the last super-chunk s = nchunks / 2 - 1 do not exist (launch constants of the lane)
+    const bool tail_off[2] = {((wg.nchunks >> 1) - 1) * 16 + 8 * sv >= g.Cg, ((wg.nchunks >> 1) - 1) * 16 + 8 * sv + 4 >= g.Cg};
     const float* ufw = nullptr;                                 // Winograd-domain filter image of (lu_item's cout block, chunk 0)
     auto setup_v = [&]() __attribute__((always_inline)) {
         const int t = wave * 64 + lane_now(), si = t & 3, sv = (t >> 2) & 1, stl = t >> 3;      // (re-made, see above)
@@ -162,18 +164,21 @@ __global__ __launch_bounds__(512, 2) void wino_nt_kernel(const NtParams p, const
     // what may still be in flight behind the operation they need.)
     floatx4w raw[4][2];                                          // [pixel of the patch row][half of the 8 channels]
     auto issue_v = [&]() __attribute__((always_inline)) {        // the V cursor's super-chunk: 8 loads
+        // The super-chunk's byte offset rides in the load's SCALAR offset and the half's 16 bytes in its immediate field; a lane whose channels do not
+        // exist -- only in the LAST super-chunk of a layer with Cg % 16 != 0 (24 / 48 channels) -- is sent out of range by ONE select on a launch-constant
+        // lane mask: one vector instruction per load instead of an add, a compare and a select (fp32 MFMAs run on the vector ALU: tools/micro/
+        // coissue_probe.hip).  The scalar offset is outside the descriptor's bounds check, but voff is in range or kOob by itself.
         const unsigned cb = (unsigned)lv_sc * 64u;
+        const bool last_sc = lv_sc + 1 == (wg.nchunks >> 1);
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const bool cok = lv_sc * 16 + 8 * sv + 4 * hh < g.Cg;
-                const unsigned off = cok ? voff[c] + cb + 16u * hh : kOob;
-                // (s_nop 4: five wait states between a vector instruction that may have just written the descriptor's scalar registers -- the compiler
-                //  parks scalars in vector registers under pressure and brings them back with v_readlane -- and the load that reads them; hipcc pads
-                //  that hazard only for instructions it can see)
-                asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(raw[c][hh]) : "v"(off), "s"(xrs) : "memory");
-            }
+        for (int c = 0; c < 4; ++c) {
+            const unsigned o0 = last_sc & tail_off[0] ? kOob : voff[c], o1 = last_sc & tail_off[1] ? kOob : voff[c];
+            // (s_nop 4: five wait states between a vector instruction that may have just written the descriptor's scalar registers -- the compiler
+            //  parks scalars in vector registers under pressure and brings them back with v_readlane -- and the load that reads them; hipcc pads
+            //  that hazard only for instructions it can see)
+            asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(raw[c][0]) : "v"(o0), "s"(xrs), "s"(cb) : "memory");
+            asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=v"(raw[c][1]) : "v"(o1), "s"(xrs), "s"(cb) : "memory");
+        }
         if (++lv_sc == (wg.nchunks >> 1)) {
             lv_sc = 0;
             lv_item += gridDim.x;

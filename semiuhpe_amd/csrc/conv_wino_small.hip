@@ -1,35 +1,39 @@
-// Winograd F(2x2, 3x3) for 3x3 / stride 1 / pad 1 convolutions with FEW channels on both sides (16 / 24 in, at most 32 out: the
-// 24 -> 24 stage of EfficientNetV2-S at 112 x 112, torchvision FusedMBConv with expand ratio 1 via src/networks.py:303) -- forward and input
-// gradient, the same arithmetic and the same Winograd-domain filter image as wino_nt_kernel (conv_wino.hip), another data path.
+// Winograd F(2x2, 3x3) / F(3x3, 2x2) for 3x3 / stride 1 / pad 1 convolutions with FEW channels on both sides (forward / input gradient: 16 or 24 in, at
+// most 32 out; filter gradient: at most 32 on both sides): the 24 -> 24 stage of EfficientNetV2-S at 112 x 112 (torchvision FusedMBConv with expand
+// ratio 1 via src/networks.py:303).  The same arithmetic and the same Winograd-domain filter image as wino_nt_kernel / wino_wgrad_kernel
+// (conv_wino.hip), another data path.
 //
 // wino_nt_kernel streams U and V images of 8-channel chunks through LDS; with 24 channels an item has three or four chunks and then an epilogue
 // in which all eight wavefronts stop, the matrix work is padded 24 -> 32 on BOTH sides (56 % useful), and the workgroup owns a compute unit
-// (160 KB of LDS).  Here the whole transformed filter lives in REGISTERS and nothing but a 16 KB exchange buffer in LDS:
+// (160 KB of LDS).  Here the whole transformed filter lives in REGISTERS and nothing but a 32 KB exchange buffer in LDS.  fp32 MFMAs execute on the
+// vector ALU (tools/micro/coissue_probe.hip: a vector instruction behind an MFMA costs its full issue time), so this file counts vector instructions:
 //
+// wino_small_kernel<KS, STATS, RES> (forward / input gradient):
 //   wavefront w of a workgroup (4 wavefronts) owns patch row i = w: the four transform positions (i, jx), jx = 0..3, of every tile.  Its A operands
 //   U_(i,jx)[cout][c] -- 4 positions x 2 blocks of 16 output channels x KS k-steps = 8 KS registers per lane -- are read ONCE from the filter image.
-//   A lane is (tile = lane & 15, k-group kg = lane >> 4) and carries channels kg KS .. kg KS + KS - 1 (k-step s <-> channel kg KS + s), so the B
-//   operand V_(i,jx)[tile][c] is made in the lane that needs it: row i of B^T d B takes two patch rows (0: r0 - r2, 1: r1 + r2, 2: r2 - r1,
-//   3: r3 - r1; row 3 negated on both operands as in conv_wino.hip), i.e. 8 pixels x KS contiguous channels by 8-byte buffer loads straight from
-//   the tensor (zero outside the image through the descriptor's bounds check), the vertical pass is one multiply-add, the horizontal one in-lane.
-//   No LDS image, no barrier in front of the MFMAs; 8 KS MFMAs (v_mfma_f32_16x16x4_f32, 8 independent accumulators) per 16-tile block.
-//   Padding: output channels 24 -> 32 only (75 % useful), the reduction is exact.
+//   A lane is (tile = lane & 15, k-group kg = lane >> 4) and carries channels 4 kg .. 4 kg + 3 and (24 channels) 16 + 2 kg, 17 + 2 kg: the four lanes of
+//   a tile read one aligned 64-byte and one aligned 32-byte piece of a pixel.  The B operand V_(i,jx)[tile][c] is made in the lane that feeds it to the
+//   MFMA: row i of B^T d B takes two patch rows (0: r0 - r2, 1: r1 + r2, 2: r2 - r1, 3: r3 - r1; row 3 negated on both operands as in conv_wino.hip);
+//   a lane loads only its tile's OWN two pixel columns, the outer two are the neighbour tiles' own columns and arrive by DPP row shifts (lanes 0 / 15 of
+//   a 16-tile row load theirs; at the image border the column is zero, which is also where consecutive tiles stop being neighbours); vertical pass =
+//   one multiply-add, horizontal pass in-lane.  No LDS image, no barrier in front of the MFMAs; 8 KS MFMAs (v_mfma_f32_16x16x4_f32, 8 independent
+//   accumulators) per 16-tile block.  Padding: output channels 24 -> 32 only (75 % useful), the reduction is exact.
 //   Output transform: the horizontal half (over jx) in registers; the vertical half sums over the patch rows = over the wavefronts: every wavefront
-//   leaves its two half-transformed columns in LDS (16 floats per lane, double-buffered: ONE barrier per block), then wavefront w finishes the 2x2
-//   pixels of output channels 16 (w >> 1) + 4 kg + 2 (w & 1) + {0, 1}: stores, skip add, BatchNorm statistics records (the (S, Q, k, n) format and
-//   segment rule of wino_nt_kernel: one record per 16-tile block and channel).
-//   Blocks of 16 tiles are dealt to persistent workgroups in XCD-contiguous runs (vertically adjacent tiles share two of four patch rows in L2); the
-//   next block's patch rows are requested before the current block's MFMAs.  Two or three workgroups share a compute unit, out of phase by
-//   construction (no common barrier), and leave the rest of it to whatever the other stream runs.
+//   leaves its two half-transformed columns in LDS (16 floats per lane as four 16-byte stores, double-buffered: ONE barrier per block), then a lane of
+//   wavefront w finishes output row py = kg & 1 of tile j16 for the four channels 16 (w >> 1) + 4 (2 (w & 1) + (kg >> 1)) + e: two 16-byte stores, skip
+//   add, BatchNorm statistics records (the (S, Q, k, n) format and segment rule of wino_nt_kernel: one record per 16-tile block and channel).
+//   The block loop is ONE basic block: absent lanes / blocks / records store to an out-of-range descriptor offset instead of branching (only the one
+//   block that holds the segment boundary branches, to its second record).  Loads and stores are inline asm behind hand-counted waits, and the loop is
+//   skewed -- outputs stored one block later, skip values requested one block earlier -- because the vector-memory queue completes in order.
+//   Blocks of 16 tiles are dealt to persistent workgroups in XCD-contiguous runs (vertically adjacent tiles share two of four patch rows in L2).
+//
+// wino_small_wgrad_kernel (filter gradient): at the end of the file.
 #include "conv_params.h"
 #include <cstdlib>
 #include <type_traits>
 // timing experiments (any bit set = wrong results): 1 no patch-row loads, 2 no MFMAs, 4 no stores / statistics / skip loads, 8 no barrier
 #ifndef WS_ABLATE
 #define WS_ABLATE 0
-#endif
-#ifndef WS_VALU_PER_MFMA
-#define WS_VALU_PER_MFMA 4
 #endif
 
 namespace suhpe {
@@ -44,7 +48,6 @@ struct WinoSmallGeom {
     int nblocks;                 // ceil(MT / 16)
     int per_xcd;                 // blocks of one XCD's run
     int seg_tile;                // first tile of the second batch segment (0: one segment)
-    int kchunks;                 // chunks of the filter image (2 * ceil(Cg / 16))
     int fw_group_stride;
 };
 
@@ -365,16 +368,6 @@ __global__ __launch_bounds__(256, 2) void wino_small_kernel(const NtParams p, co
                 acc[jx][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ureg[jx][1][s], V[jx][s], acc[jx][1], 0, 0, 0);
             }
 #endif
-        // one MFMA, then a few vector-ALU instructions of the neighbouring blocks' bookkeeping (addresses, statistics), 8 KS times: a wavefront issues in
-        // order, so whatever is to run in the shadow of an MFMA has to stand behind it in the instruction stream (left alone hipcc puts the whole
-        // statistics section in front of the first MFMA)
-#if !(WS_ABLATE & 2) && !defined(WS_NO_GROUPS)
-#pragma unroll
-        for (int i = 0; i < 8 * KS; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, WS_VALU_PER_MFMA, 0);
-        }
-#endif
         // ---- horizontal half of A^T M A, to LDS: slot (i 2 + px) 2 + blk holds the lane's four couts
         float* xw = xch + buf * (16 * 64 * 4);
 #pragma unroll
@@ -447,8 +440,7 @@ bool launch_wino_small(const NtParams& p_in, int groups, hipStream_t st) {
     wg.per_xcd = (int)ceil_div(wg.nblocks, 8);
     wg.seg_tile = (p.stats && p.seg_row > 0) ? (int)(p.seg_row / 4) : 0;
     if (p.stats && (int64_t)wg.nblocks * p.stat_cout * 16 >= (1LL << 31)) return false;      // (32-bit record offsets)
-    wg.kchunks = 2 * ((g.Cg + 15) / 16);
-    wg.fw_group_stride = (int)ceil_div(p.Ng, 64) * wg.kchunks * WN_IMG;
+    wg.fw_group_stride = (int)ceil_div(p.Ng, 64) * (2 * ((g.Cg + 15) / 16)) * WN_IMG;      // (wino_filter_kernel's image: row blocks of 64 x chunks of 8 channels)
     static int cus = 0;
     if (cus == 0) {
         int dev = 0;
