@@ -1,3 +1,8 @@
+#!/bin/bash
+# Vector-ALU against MFMA activity of the Winograd kernels (DESIGN.md 3.1 "Round 5" (7): fp32 MFMAs run on the vector ALU, so a kernel's time on a SIMD is
+# MFMA cycles + ~4.5 cycles per other vector instruction): two rocprofv3 --pmc passes per kernel (SQ activity / instruction counts), the last launch of each.
+#   bash tools/debug/valu_mfma_pmc.sh        (from the repo root through gpurun; writes gpurun_out/r05_wino_bench.txt and gpurun_out/r05_valu_mfma_pmc.txt)
+# Do NOT add TA_* counters: that group hung rocprofv3 on this pool.
 R=$GRAFT_REPO_ROOT; cd $R
 python tools/wino_bench.py all 2>&1 | grep -v amdgpu.ids > gpurun_out/r05_wino_bench.txt
 cd /tmp && export TMPDIR=/tmp PYTHONPATH=$R
