@@ -64,9 +64,20 @@ def gpu_leg(args, rank, world, device):
     # dynamic threshold at warm-up: the batch's left_ratio quantile of teacher entropies, so ~95% pass the filter
     cfg.conf_thres = float(agent.compute_dynamic_entropy_threshold([ulb]))
     torch.manual_seed(100 + rank)
-    for _ in range(args.warmup):
-        agent.train_func(data, ulb)
+    # ... and re-taken from the teacher AS THE STEP RUNS IT (train mode: batch statistics) on the first untimed step: the eval-mode scan
+    # above uses the running statistics, its entropies sit elsewhere and every sample passed the filter (mask_ratio 1.0).  One untimed
+    # step more than --warmup when --warmup is 0; the same scalar on every rank (max over ranks: a rank-local quantile would split the replicas'
+    # thresholds -- they still filter per-rank batches).
+    for i in range(max(args.warmup, 1)):
+        fd, fu, out = agent.train_func(data, ulb)
         agent.clock.tick()
+        if i == 0:
+            ent = fu["entropy"].detach().float().cpu().numpy().copy()
+            ent.sort()
+            thr = torch.tensor([float(ent[min(int(len(ent) * cfg.left_ratio), len(ent) - 1)])], dtype=torch.float64, device=device)
+            if world > 1:
+                dist.all_reduce(thr, op=dist.ReduceOp.MAX)
+            cfg.conf_thres = float(thr.item())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

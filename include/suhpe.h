@@ -201,6 +201,9 @@ int suhpe_transpose_filters_batched(const void* jobs_dev, const int64_t* chunk_s
                                     suhpe_stream_t stream);
 /* name of the kernel instance a call dispatches to (pass 0 fwd, 1 dgrad, 2 wgrad) — for profiling/roofline reports */
 const char* suhpe_conv2d_kernel_name(const suhpe_conv_t* d, int pass);
+/* name of the dense-conv kernel the LAST suhpe_conv2d_* / suhpe_linear_* call of this thread actually launched (the prediction above is made
+ * from the descriptor alone; run-time facts -- a bias, an unaligned skip tensor -- can send a call to another kernel).  "" before the first call. */
+const char* suhpe_last_kernel_name(void);
 /* filter gradient; dw += sum (accumulate != 0) or dw = sum.  workspace: device scratch */
 int64_t suhpe_conv2d_wgrad_workspace_bytes(const suhpe_conv_t* d);
 int suhpe_conv2d_wgrad(const suhpe_conv_t* d, const float* x, const float* dy, float* dw, int accumulate,

@@ -25,6 +25,7 @@ struct Rccl {
     int (*Broadcast)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     bool ok = false;
+    char why[384] = "librccl.so.1 not found (dlopen)";
 };
 
 static Rccl& rccl() {
@@ -34,7 +35,12 @@ static Rccl& rccl() {
         // SUHPE_RCCL_LIB: another build of the collective library (any shared object that exports the seven nccl* entry points used below);
         // tests/test_comm_abi_two_ranks.py points it at a host-memory transport to drive this ABI with two ranks on a box without GPUs
         const char* override_path = getenv("SUHPE_RCCL_LIB");
-        if (override_path && *override_path) r.handle = dlopen(override_path, RTLD_NOW | RTLD_GLOBAL);
+        if (override_path && *override_path) {
+            // an override that does not load is an ERROR, never a silent fall back to the system RCCL (a typo would run the host-buffer
+            // tests against real RCCL with host pointers): the communicator stays unavailable and every suhpe_comm_* call says why
+            r.handle = dlopen(override_path, RTLD_NOW | RTLD_GLOBAL);
+            if (!r.handle) { const char* why = dlerror(); snprintf(r.why, sizeof(r.why), "SUHPE_RCCL_LIB=%s did not load (%s)", override_path, why ? why : "?"); return; }
+        }
         if (!r.handle)
             for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
                 r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
@@ -71,7 +77,7 @@ int suhpe_comm_available(void) { return rccl().ok ? 1 : 0; }
 
 int suhpe_comm_unique_id(void* id128) {
     SUHPE_REQUIRE(id128, "suhpe_comm_unique_id: null pointer");
-    SUHPE_REQUIRE(rccl().ok, "suhpe_comm_unique_id: librccl.so.1 not found (dlopen)");
+    SUHPE_REQUIRE(rccl().ok, "suhpe_comm_unique_id: %s", rccl().why);
     UniqueId id;
     const int rc = rccl_rc(rccl().GetUniqueId(&id), "suhpe_comm_unique_id");
     if (rc == SUHPE_OK) memcpy(id128, id.bytes, sizeof(id.bytes));
@@ -81,7 +87,7 @@ int suhpe_comm_unique_id(void* id128) {
 int suhpe_comm_init(suhpe_comm_t* comm, const void* id128, int rank, int world) {
     SUHPE_REQUIRE(comm && id128, "suhpe_comm_init: null pointer");
     SUHPE_REQUIRE(world >= 1 && rank >= 0 && rank < world, "suhpe_comm_init: rank %d outside a world of %d", rank, world);
-    SUHPE_REQUIRE(rccl().ok, "suhpe_comm_init: librccl.so.1 not found (dlopen)");
+    SUHPE_REQUIRE(rccl().ok, "suhpe_comm_init: %s", rccl().why);
     UniqueId id;
     memcpy(id.bytes, id128, sizeof(id.bytes));
     Comm c = nullptr;

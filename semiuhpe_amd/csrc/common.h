@@ -11,6 +11,10 @@ namespace suhpe {
 constexpr int kWave = 64;   // CDNA4 wavefront
 
 void set_error(const char* fmt, ...);
+// the dense-conv launchers report which kernel they ACTUALLY launched on this thread (suhpe_last_kernel_name: per-kernel profiles key on it;
+// suhpe_conv2d_kernel_name predicts from the descriptor alone and cannot see run-time fallbacks such as a bias on a register-resident Winograd shape)
+void note_kernel(const char* name);
+const char* last_kernel();
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();

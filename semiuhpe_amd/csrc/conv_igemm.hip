@@ -1325,11 +1325,11 @@ static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st
         tile = p.stats ? NT_64x64 : choose_nt(p.g.M, p.Ng, vec4, -1, halo_ok(p.g, vec4));
     }
     if (tile == NT_D128x128) {
-        if (!act2 && dma_ok(p, groups, vec4, false)) { launch_dma(p, st); return; }
+        if (!act2 && dma_ok(p, groups, vec4, false)) { launch_dma(p, st); note_kernel(kNtNames[NT_D128x128]); return; }
         tile = NT_64x64;                                    // an epilogue / operand form the DMA kernel lacks: the direct tile of the same record height
     }
     if (tile == NT_D256x64) {
-        if (!act2 && dma_ok(p, groups, vec4, true)) { launch_dma_narrow(p, st); return; }
+        if (!act2 && dma_ok(p, groups, vec4, true)) { launch_dma_narrow(p, st); note_kernel(kNtNames[NT_D256x64]); return; }
         // no other tile writes 32-row statistics records: with statistics asked for, a form this kernel lacks is an error, never a silent mismatch
         if (p.stats) { g_nt_unsupported = true; return; }
         tile = NT_64x64;
@@ -1337,16 +1337,17 @@ static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st
     if (act2 && tile >= NT_R128x16) tile = NT_64x64;
     if (act2 && tile >= NT_W128x128) tile = tile == NT_W128x128 ? NT_128x128 : NT_128x64;
     if (tile >= NT_R128x16) {
-        if (tile == NT_R128x16 && resident_ok(p, vec4, 128)) { launch_resident<128, 2, 16>(p, groups, st); return; }
-        if (tile == NT_R64x8 && resident_ok(p, vec4, 64)) { launch_resident<64, 2, 8>(p, groups, st); return; }
-        if (tile == NT_R64x16 && resident_ok(p, vec4, 64)) { launch_resident<64, 2, 16>(p, groups, st); return; }
+        if (tile == NT_R128x16 && resident_ok(p, vec4, 128)) { launch_resident<128, 2, 16>(p, groups, st); note_kernel(kNtNames[tile]); return; }
+        if (tile == NT_R64x8 && resident_ok(p, vec4, 64)) { launch_resident<64, 2, 8>(p, groups, st); note_kernel(kNtNames[tile]); return; }
+        if (tile == NT_R64x16 && resident_ok(p, vec4, 64)) { launch_resident<64, 2, 16>(p, groups, st); note_kernel(kNtNames[tile]); return; }
         tile = NT_64x64;                                    // (same statistics-record height as the resident tiles)
     }
     if (tile >= NT_W128x128 && p.a_scale) tile = tile == NT_W128x128 ? NT_128x128 : NT_128x64;     // (no input-transform form of the wide-accumulator tiles)
-    if (tile == NT_W128x128) { launch_nt<128, 128, 64, 64, 4>(p, groups, st); return; }
-    if (tile == NT_W128x64) { launch_nt<128, 64, 64, 32, 4>(p, groups, st); return; }
+    if (tile == NT_W128x128) { launch_nt<128, 128, 64, 64, 4>(p, groups, st); note_kernel(kNtNames[tile]); return; }
+    if (tile == NT_W128x64) { launch_nt<128, 64, 64, 32, 4>(p, groups, st); note_kernel(kNtNames[tile]); return; }
     if (tile >= NT_H64x64) {
         bool done = false;
+        const NtTile halo_tile = tile;
         switch (tile) {
             case NT_H64x64: done = launch_halo<64, 64, 32, 32>(p, groups, st); tile = NT_64x64; break;
             case NT_H128x32: done = launch_halo<128, 32, 32, 32>(p, groups, st); tile = NT_128x32; break;
@@ -1354,11 +1355,12 @@ static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st
             case NT_H128x48: done = launch_halo_n48(p, groups, st); tile = NT_128x64; break;
             default: done = launch_halo<128, 128, 64, 32>(p, groups, st); tile = NT_128x128; break;
         }
-        if (done) return;                                   // otherwise: the igemm tile of the same size (same row-tile height)
+        if (done) { note_kernel(kNtNames[halo_tile]); return; }   // otherwise: the igemm tile of the same size (same row-tile height)
     }
     if (tile >= NT_P64x64) {
         const bool plain = nt_mode(p.g) == 1 && p.g.M < (1LL << 31) && !p.a_scale && !act2;   // (input transform / activation epilogues live in igemm_nt_kernel)
         if (plain) {
+            note_kernel(kNtNames[tile]);
             switch (tile) {
                 case NT_P64x64: launch_persistent<64, 64, 32, 32>(p, groups, st); return;
                 case NT_P128x32: launch_persistent<128, 32, 32, 32>(p, groups, st); return;
@@ -1368,6 +1370,7 @@ static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st
         }
         tile = effective_nt(tile, false);
     }
+    note_kernel(kNtNames[tile]);
     switch (tile) {
         case NT_64x64_S: launch_nt<64, 64, 32, 32, 1>(p, groups, st); break;
         case NT_64x64: launch_nt<64, 64, 32, 32, 4>(p, groups, st); break;
@@ -1377,6 +1380,19 @@ static void dispatch_nt(const NtParams& p, int groups, bool vec4, hipStream_t st
         case NT_256x32: launch_nt<256, 32, 64, 32, 4>(p, groups, st); break;
         default: break;
     }
+}
+
+// Every entry point goes through this: a (tile, operand / epilogue form) without an instantiation is SUHPE_EINVAL, never a launch that silently
+// did not happen (suhpe_conv2d_fwd_wino reached the 32-row-record rule of gemm_nt_dma<256,64> without looking at the flag).
+static int dispatch_nt_checked(const NtParams& p, int groups, bool vec4, hipStream_t st, int pinned, const char* who) {
+    g_nt_unsupported = false;
+    dispatch_nt(p, groups, vec4, st, pinned);
+    if (g_nt_unsupported) {
+        g_nt_unsupported = false;
+        set_error("%s: the selected tile has no instantiation for this operand / epilogue form (bias, alignment, size): unpin it (suhpe_conv2d_set_tile)", who);
+        return SUHPE_EINVAL;
+    }
+    return SUHPE_OK;
 }
 
 // halo-kernel capability of a (descriptor, pass): pass 0 = forward, 1 = input gradient
@@ -1431,6 +1447,7 @@ int suhpe_conv2d_fwd(const suhpe_conv_t* d, const float* x, const float* w, cons
     SUHPE_REQUIRE(x && w && y, "suhpe_conv2d_fwd: null pointer");
     if (stem_ok(d) && pinned_tile(d, 0) < 0) {               // RGB stem: direct kernel (conv_stem.inl); a pinned tile keeps the GEMM (tile menu tests)
         launch_stem(d, x, w, bias, y, nullptr, nullptr, 0, as_stream(stream));
+        note_kernel(suhpe_conv2d_kernel_name(d, 0));
         return check_launch("suhpe_conv2d_fwd");
     }
     NtParams p;
@@ -1440,7 +1457,7 @@ int suhpe_conv2d_fwd(const suhpe_conv_t* d, const float* x, const float* w, cons
     p.x_bytes = (int64_t)d->n * d->h * d->w * d->cin * 4; p.f_bytes = (int64_t)d->cout * p.g.K * 4;
     p.stats = nullptr; p.stats_extra = nullptr; p.seg_row = 0; p.stat_gx = 0; p.stat_cout = 0; p.scale = p.shift = p.residual = nullptr; p.act = 0; p.res_mode = 0;
     const bool vec4 = (cg % 4 == 0) && (d->cin % 4 == 0) && aligned16(x) && aligned16(w);
-    dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 0));
+    if ((rc = dispatch_nt_checked(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 0), "suhpe_conv2d_fwd"))) return rc;
     return check_launch("suhpe_conv2d_fwd");
 }
 
@@ -1479,7 +1496,7 @@ int suhpe_conv2d_fwd_affine(const suhpe_conv_t* d, const float* x, const float* 
     p.stats = nullptr; p.stats_extra = nullptr; p.seg_row = 0; p.stat_gx = 0; p.stat_cout = 0;
     p.scale = scale; p.shift = shift; p.residual = residual; p.act = act; p.res_mode = residual ? (residual_after_act ? 2 : 1) : 0;
     const bool vec4 = (cg % 4 == 0) && (d->cin % 4 == 0) && aligned16(x) && aligned16(w);
-    dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 0));
+    if ((rc = dispatch_nt_checked(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 0), "suhpe_conv2d_fwd_affine"))) return rc;
     return check_launch("suhpe_conv2d_fwd_affine");
 }
 
@@ -1578,6 +1595,7 @@ static int conv2d_fwd_stats_impl(const suhpe_conv_t* d, const float* x, const fl
     SUHPE_REQUIRE(x && w && y && stats, "suhpe_conv2d_fwd_stats: null pointer");
     if (stem_ok(d) && pinned_tile(d, 0) < 0) {
         launch_stem(d, x, w, nullptr, y, stats, stats_extra, seg_row, as_stream(stream));
+        note_kernel(suhpe_conv2d_kernel_name(d, 0));
         return check_launch("suhpe_conv2d_fwd_stats");
     }
     NtParams p;
@@ -1644,7 +1662,7 @@ int suhpe_conv2d_fwd_wino(const suhpe_conv_t* d, const float* x, const float* w,
     p.scale = p.shift = p.residual = nullptr; p.act = 0; p.res_mode = 0;
     p.fw = fw;
     const bool vec4 = (cg % 4 == 0) && (d->cin % 4 == 0) && aligned16(x) && aligned16(w);
-    dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 0));
+    if ((rc = dispatch_nt_checked(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 0), "suhpe_conv2d_fwd_wino"))) return rc;
     return check_launch("suhpe_conv2d_fwd_wino");
 }
 
@@ -1663,7 +1681,7 @@ int suhpe_conv2d_fwd_affine_wino(const suhpe_conv_t* d, const float* x, const fl
     p.scale = scale; p.shift = shift; p.residual = residual; p.act = act; p.res_mode = residual ? (residual_after_act ? 2 : 1) : 0;
     p.fw = fw;
     const bool vec4 = (cg % 4 == 0) && (d->cin % 4 == 0) && aligned16(x) && aligned16(w);
-    dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 0));
+    if ((rc = dispatch_nt_checked(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 0), "suhpe_conv2d_fwd_affine_wino"))) return rc;
     return check_launch("suhpe_conv2d_fwd_affine_wino");
 }
 
@@ -1685,7 +1703,7 @@ int suhpe_conv2d_dgrad_wino(const suhpe_conv_t* d, const float* dy, const float*
     if (!wt) {                                                // no direct-tile operand: the Winograd kernel must take this launch
         if (!launch_wino(p, d->groups, as_stream(stream))) { set_error("suhpe_conv2d_dgrad_wino: the Winograd kernel cannot run these operands and wt is NULL"); return SUHPE_EINVAL; }
     } else {
-        dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 1));
+        if ((rc = dispatch_nt_checked(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 1), "suhpe_conv2d_dgrad_wino"))) return rc;
     }
     return check_launch("suhpe_conv2d_dgrad_wino");
 }
@@ -1753,7 +1771,7 @@ int suhpe_conv2d_dgrad_add(const suhpe_conv_t* d, const float* dy, const float* 
         p.x = dy; p.f = wt; p.bias = nullptr; p.y = dx; p.Ng = cg; p.ldy = d->cin; p.ldf = p.g.K;
         p.x_bytes = (int64_t)d->n * d->ho * d->wo * d->cout * 4; p.f_bytes = (int64_t)d->cout * cg * d->r * d->s * 4;
         p.stats = nullptr; p.stats_extra = nullptr; p.seg_row = 0; p.stat_gx = 0; p.stat_cout = 0; p.scale = p.shift = nullptr; p.residual = skip; p.act = 0; p.res_mode = skip ? 3 : 0;
-        dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 1));
+        if ((rc = dispatch_nt_checked(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 1), "suhpe_conv2d_dgrad"))) return rc;
     } else {
         // one launch per parity class of the input pixel: only the taps r = (ph+pad) mod stride (+ k*stride) reach it,
         // so no MFMA work is spent on taps that are structurally zero (a masked gather would waste 1 - 1/stride^2).
@@ -1772,7 +1790,7 @@ int suhpe_conv2d_dgrad_add(const suhpe_conv_t* d, const float* dy, const float* 
                 p.x = dy; p.f = wt; p.bias = nullptr; p.y = dx; p.Ng = cg; p.ldy = d->cin; p.ldf = d->r * d->s * ng;
                 p.x_bytes = (int64_t)d->n * d->ho * d->wo * d->cout * 4; p.f_bytes = (int64_t)d->cout * cg * d->r * d->s * 4;
                 p.stats = nullptr; p.stats_extra = nullptr; p.seg_row = 0; p.stat_gx = 0; p.stat_cout = 0; p.scale = p.shift = nullptr; p.residual = skip; p.act = 0; p.res_mode = skip ? 3 : 0;
-                dispatch_nt(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 1));
+                if ((rc = dispatch_nt_checked(p, d->groups, vec4, as_stream(stream), pinned_tile(d, 1), "suhpe_conv2d_dgrad"))) return rc;
             }
     }
     return check_launch("suhpe_conv2d_dgrad");
@@ -1840,6 +1858,8 @@ int suhpe_conv2d_set_tile(const suhpe_conv_t* d, int pass, int tile) {
     return SUHPE_OK;
 }
 
+const char* suhpe_last_kernel_name(void) { return last_kernel(); }
+
 const char* suhpe_conv2d_kernel_name(const suhpe_conv_t* d, int pass) {
     if (!d || d->groups <= 0) return "";
     const int ng = d->cout / d->groups, cg = d->cin / d->groups;
@@ -1887,6 +1907,7 @@ static int wgrad_partial_impl(const suhpe_conv_t* d, const float* x, const float
     if (wgrad_wino(d) && !xf && aligned16(x) && aligned16(dy) && aligned16(workspace)) {
         // Winograd F(3x3, 2x2): the launch leaves ONE complete filter-shaped slab at the start of the workspace (suhpe_conv2d_wgrad_splits = 1)
         launch_wino_wgrad(x, dy, static_cast<float*>(workspace), d->n, d->h, d->w, d->cin, d->cout, d->groups, as_stream(stream));
+        note_kernel(suhpe_conv2d_kernel_name(d, 2));
         return check_launch("suhpe_conv2d_wgrad_partial");
     }
     SUHPE_REQUIRE(!wgrad_wino(d), "suhpe_conv2d_wgrad: the Winograd filter-gradient tile needs 16-byte aligned operands and no input transform");
@@ -1936,6 +1957,7 @@ static int wgrad_partial_impl(const suhpe_conv_t* d, const float* x, const float
     }
 #undef TN_LAUNCH
 #undef TN_LAUNCH_XF
+    note_kernel(suhpe_conv2d_kernel_name(d, 2));
     return check_launch("suhpe_conv2d_wgrad_partial");
 }
 

@@ -851,7 +851,7 @@ void launch_wino_filter(const float* w, float* fw, int groups, int NR, int NK, i
 
 bool launch_wino(const NtParams& p_in, int groups, hipStream_t st) {
     if (!wino_params_ok(p_in)) return false;
-    if (launch_wino_small(p_in, groups, st)) return true;        // few channels on both sides: the register-resident form (conv_wino_small.hip)
+    if (launch_wino_small(p_in, groups, st)) { note_kernel("wino_small_kernel"); return true; }        // few channels on both sides: the register-resident form (conv_wino_small.hip)
     NtParams p = p_in;
     const GatherGeom& g = p.g;
     WinoGeom wg;
@@ -890,6 +890,7 @@ bool launch_wino(const NtParams& p_in, int groups, hipStream_t st) {
     } else {
         if (form == 2) go(std::integral_constant<int, 2>()); else if (form == 1) go(std::integral_constant<int, 1>()); else go(std::integral_constant<int, 0>());
     }
+    note_kernel("wino_nt_kernel<64,64>");
     return true;
 }
 

@@ -92,7 +92,8 @@ class _Prof:
     def __exit__(self, *a):
         if self.on:
             self.rec[4].record()
-            PROFILE.append(self.rec)
+            ran = _lib.load().suhpe_last_kernel_name().decode()      # what the launcher really ran (run-time fallbacks included)
+            PROFILE.append((ran or self.name,) + self.rec[1:])
 
 
 # Optional live profile of the HBM-bound wrappers (tools/mem_profile.py): when MEM_PROFILE is a list every decorated call is
@@ -1540,10 +1541,17 @@ def window_attn_bwd_rs(qkv, out, stats, dout, bias_table, bias_idx, B, H, W, ws,
 
 
 # ---------------------------------------------------------------------------------------------- optimiser
+# Parameter writes that torch's per-tensor _version cannot see (the kernels take raw pointers of the flat buffers): a counter that tapes may record
+# to learn whether the weights moved between a forward and its backward (src/repvgg.py: the recomputed ReLU mask of the fused block tail)
+PARAM_EPOCH = [0]
+
+
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
+    PARAM_EPOCH[0] += 1
     call("suhpe_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
          float(weight_decay), int(step))
 
 
 def ema_update(ema, p, alpha):
+    PARAM_EPOCH[0] += 1
     call("suhpe_ema_update", ptr(ema), ptr(p), ema.numel(), float(alpha))

@@ -80,15 +80,19 @@ class RepVGGBlock(Layer):
         else:
             y = K.repvgg_bn_fwd(xs, means, rstds, [b.weight for b in bns], [b.bias for b in bns], rows_a, bns[0].num_features)
         if tape is not None:
-            tape.append(("fused_tail", xs, means, rstds, rows_a, y))
+            # (the parameter versions: REMASK recomputes the ReLU mask from the LIVE gamma / beta in the backward, which equals the forward's mask
+            #  bit for bit only while no parameter was written in between -- an optimiser / EMA step (kernels.PARAM_EPOCH: raw-pointer writes), load_state_dict (_version); _bwd_fused_tail compares)
+            tape.append(("fused_tail", xs, means, rstds, rows_a, y, (K.PARAM_EPOCH[0],) + tuple(t._version for b in bns for t in (b.weight, b.bias))))
         return y
 
     def _bwd_fused_tail(self, dout, tape):
-        _, xs, means, rstds, rows_a, y = tape.pop()
+        _, xs, means, rstds, rows_a, y, versions = tape.pop()
         bns = [self.rbr_dense.bn, self.rbr_1x1.bn] + ([self.rbr_identity] if self.rbr_identity is not None else [])
-        # (REMASK: the ReLU mask is recomputed from the three branch inputs -- the weights have not moved since the forward -- and y is not read)
+        # REMASK: the ReLU mask is recomputed from the three branch inputs and y is not read -- valid only while gamma / beta are the forward's:
+        # a parameter written since (its _version moved) sends this block to the exact y-based mask
+        remask = REMASK and versions == (K.PARAM_EPOCH[0],) + tuple(t._version for b in bns for t in (b.weight, b.bias))
         dxs = K.repvgg_bn_bwd(xs, means, rstds, [b.weight for b in bns], dout.contiguous(), y, rows_a, bns[0].num_features,
-                              [grad_of(b.weight) for b in bns], [grad_of(b.bias) for b in bns], betas=[b.bias for b in bns] if REMASK else None)
+                              [grad_of(b.weight) for b in bns], [grad_of(b.bias) for b in bns], betas=[b.bias for b in bns] if remask else None)
         self.rbr_1x1.conv.need_input_grad = self.rbr_dense.conv.need_input_grad = self.need_input_grad
         return self._branch_dgrads(dxs[0], dxs[1], dxs[2] if len(dxs) == 3 else None, tape)
 
@@ -106,7 +110,7 @@ class RepVGGBlock(Layer):
         return K.add3(dx3, dx1, d_xid) if d_xid is not None else K.add(dx3, dx1)
 
     def bwd(self, dout, tape):
-        if isinstance(tape[-1], tuple) and len(tape[-1]) == 6 and tape[-1][0] == "fused_tail":
+        if isinstance(tape[-1], tuple) and len(tape[-1]) == 7 and tape[-1][0] == "fused_tail":
             return self._bwd_fused_tail(dout, tape)
         out = tape[-1][4]                                           # forward output kept for the ReLU mask
         d_t3 = self.rbr_dense.bn.bwd(dout, tape)

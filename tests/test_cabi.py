@@ -90,3 +90,32 @@ def test_consuming_finalizer_rejects_inconsistent_segments():
     assert call(10, 11, None, 640, 320) == -1                 # more first-segment records than records
     assert call(0, 0, None, 640, 640) == -1
     assert call(10, 10, None, 640, 0) == -1
+
+
+def test_collective_library_override_that_does_not_load_is_an_error():
+    """SUHPE_RCCL_LIB names another build of the collective library (the host-memory transport of the two-rank tests).  A path that does not
+    load must leave the communicator UNAVAILABLE with a message that names the path -- never a silent fall back to the system RCCL
+     -- and must not disturb the rest of the library.  Own process: the library resolves RCCL once."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import ctypes\n"
+            "from semiuhpe_amd import _lib\n"
+            "lib = _lib.load()\n"
+            "assert lib.suhpe_comm_available() == 0\n"
+            "buf = ctypes.create_string_buffer(128)\n"
+            "assert lib.suhpe_comm_unique_id(buf) == -1\n"
+            "msg = lib.suhpe_last_error()\n"
+            "assert b'/nonexistent/libnot_rccl.so' in msg and b'did not load' in msg, msg\n"
+            "assert lib.suhpe_abi_version() == 1\n"
+            "print('ok')\n")
+    env = dict(os.environ, SUHPE_RCCL_LIB="/nonexistent/libnot_rccl.so", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr
+
+
+def test_last_kernel_name_is_exported_and_empty_before_any_launch():
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "from semiuhpe_amd import _lib\nassert _lib.load().suhpe_last_kernel_name() == b''\nprint('ok')\n"
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PYTHONPATH=root), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr

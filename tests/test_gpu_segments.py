@@ -360,6 +360,51 @@ def test_repvgg_stage_uses_the_emitted_statistics(monkeypatch):
         assert rel_err(r1[k], r0[k]) < 1e-5, k
 
 
+def test_repvgg_tail_backward_falls_back_when_the_weights_moved(monkeypatch):
+    """the fused block tail recomputes its ReLU mask from the LIVE gamma / beta (REMASK): exact only while no parameter was written between the
+    forward and the backward.  A write in between -- torch-side (_version) or by a raw-pointer kernel (kernels.PARAM_EPOCH: Adam, EMA) -- must
+    send the backward to the mask of the stored output: the gradients then equal the SUHPE_REPVGG_REMASK=0 form bit for bit, while a recomputed
+    mask from the moved beta would differ"""
+    from semiuhpe_amd import kernels as K
+    from semiuhpe_amd.src import repvgg as R
+    torch.manual_seed(11)
+    blk = R.RepVGGBlock(64, 64, 1, 1).cuda().train()
+    x = torch.randn(4, 14, 14, 64, device="cuda")
+    dy = torch.randn(4, 14, 14, 64, device="cuda")
+    calls = []
+    orig = K.repvgg_bn_bwd
+    monkeypatch.setattr(K, "repvgg_bn_bwd", lambda *a, **k: (calls.append(k.get("betas") is not None), orig(*a, **k))[1])
+
+    def run(remask, disturb):
+        monkeypatch.setattr(R, "REMASK", remask)
+        state = {k: v.clone() for k, v in blk.state_dict().items()}
+        for p in blk.parameters():
+            p.grad = None
+        tape = []
+        blk.fwd(x, tape)
+        if disturb == "torch":
+            with torch.no_grad():
+                blk.rbr_dense.bn.bias.add_(0.75)                  # moves the pre-activation: a mask recomputed from it is another mask
+        elif disturb == "kernel":
+            K.ema_update(blk.rbr_dense.bn.bias.data, blk.rbr_dense.bn.bias.data + 0.75, 0.0)      # raw-pointer write: only PARAM_EPOCH sees it
+        dx = blk.bwd(dy, tape)
+        out = (dx.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()})
+        blk.load_state_dict(state)
+        return out
+
+    for disturb in ("torch", "kernel"):
+        calls.clear()
+        dx1, g1 = run(True, disturb)
+        dx0, g0 = run(False, disturb)
+        assert calls == [False, False], (disturb, calls)           # both backward passes took the stored-output mask
+        assert torch.equal(dx1, dx0), disturb
+        for k in g0:
+            assert torch.equal(g1[k], g0[k]), (disturb, k)
+    calls.clear()
+    run(True, None)
+    assert calls == [True]                                          # undisturbed: the recomputed mask (the fast path) is what runs
+
+
 def test_agent_step_with_no_pseudo_label_selected(tmp_path):
     """Edge of the pseudo-label filter (reference src/agent.py:163-168): when no unlabeled sample passes the entropy threshold the
     unsupervised loss is exactly 0 (not NaN), mask_ratio is 0, loss_all equals the supervised loss and every gradient stays finite."""
