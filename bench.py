@@ -52,6 +52,30 @@ def synthetic(rank, device, B, muB, size=224):
     return to(data), to(ulb)
 
 
+def warm_up_with_live_threshold(agent, cfg, data, ulb, warm, world=1, device=None):
+    """`warm` untimed SSL steps (at least one) in the regime the timed steps stand for, with the pseudo-label threshold the way a long run holds it:
+      * the EMA decay at its configured 0.999 -- `min(1 - 1 / (k + 1), decay)` of the reference (src/agent.py:277-299) ramps over the first 1 000
+        iterations; at iteration 5 the teacher would still move a sixth of the way to the student per step and its entropies, and with them the
+        share of pseudo-labels that pass, would drift through the timed region;
+      * conf_thres = the left_ratio quantile of the entropies of the teacher AS THE STEP RUNS IT (train mode: batch statistics), taken on
+        the first untimed step.  The eval-mode scan (compute_dynamic_entropy_threshold, what train.py calls) uses the running statistics: on a
+        random-init network its entropies sit elsewhere and every sample passed the filter (mask_ratio 1.0 in the round-5 line).
+        The same scalar on every rank (max over ranks; each rank still filters its own batch)."""
+    agent.clock.iteration = 100000
+    out = None
+    for i in range(max(warm, 1)):
+        out = agent.train_func(data, ulb)
+        agent.clock.tick()
+        if i == 0:
+            ent = out[1]["entropy"].detach().float().cpu().numpy().copy()
+            ent.sort()
+            thr = torch.tensor([float(ent[min(int(len(ent) * cfg.left_ratio), len(ent) - 1)])], dtype=torch.float64, device=device or agent.device)
+            if world > 1:
+                dist.all_reduce(thr, op=dist.ReduceOp.MAX)
+            cfg.conf_thres = float(thr.item())
+    return out
+
+
 def gpu_leg(args, rank, world, device):
     from semiuhpe_amd import kernels as K
     from semiuhpe_amd.src.agent import SSLAgent
@@ -64,20 +88,7 @@ def gpu_leg(args, rank, world, device):
     # dynamic threshold at warm-up: the batch's left_ratio quantile of teacher entropies, so ~95% pass the filter
     cfg.conf_thres = float(agent.compute_dynamic_entropy_threshold([ulb]))
     torch.manual_seed(100 + rank)
-    # ... and re-taken from the teacher AS THE STEP RUNS IT (train mode: batch statistics) on the first untimed step: the eval-mode scan
-    # above uses the running statistics, its entropies sit elsewhere and every sample passed the filter (mask_ratio 1.0).  One untimed
-    # step more than --warmup when --warmup is 0; the same scalar on every rank (max over ranks: a rank-local quantile would split the replicas'
-    # thresholds -- they still filter per-rank batches).
-    for i in range(max(args.warmup, 1)):
-        fd, fu, out = agent.train_func(data, ulb)
-        agent.clock.tick()
-        if i == 0:
-            ent = fu["entropy"].detach().float().cpu().numpy().copy()
-            ent.sort()
-            thr = torch.tensor([float(ent[min(int(len(ent) * cfg.left_ratio), len(ent) - 1)])], dtype=torch.float64, device=device)
-            if world > 1:
-                dist.all_reduce(thr, op=dist.ReduceOp.MAX)
-            cfg.conf_thres = float(thr.item())
+    warm_up_with_live_threshold(agent, cfg, data, ulb, args.warmup, world, device)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -256,9 +267,7 @@ def other_config_leg(network, B, muB, warm=3, steps=8):
     data = {k: v.cuda() for k, v in data.items()}
     ulb = {k: v.cuda() for k, v in ulb.items()}
     cfg.conf_thres = float(agent.compute_dynamic_entropy_threshold([ulb]))
-    for _ in range(warm):
-        agent.train_func(data, ulb)
-        agent.clock.tick()
+    warm_up_with_live_threshold(agent, cfg, data, ulb, warm)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -461,7 +470,8 @@ def main():
                 with open(tpath) as fh:
                     tdoc = json.load(fh)
                 out["mae_parity"]["own_trajectory_trend"] = {"source": "profiles/drift_trend.json", "same_kernel_sources": tdoc.get("csrc_digest") == csrc_digest(),
-                                                             "protocol": tdoc.get("protocol"), "rows": tdoc.get("rows")}
+                                                             "protocol": tdoc.get("protocol"), "rows": tdoc.get("rows"),
+                                                             "held_by": "tests/test_gpu_mae_parity.py::test_own_trajectory_drift_is_held_to_the_control (steps 1-8, HIP drift <= 2 x control drift)"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -306,6 +306,13 @@ int suhpe_repvgg_fuse(const float* w3, const float* w1, const float* const* bn3,
 /* eval: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale (gamma / beta may be NULL) */
 int suhpe_bn_eval_affine(const float* running_mean, const float* running_var, const float* gamma, const float* beta, int c,
                          float eps, float* scale, float* shift, suhpe_stream_t stream);
+/* SyncBN (global-batch BatchNorm statistics over data-parallel ranks with equally many rows; the reference has no multi-GPU code, this is the
+ * opt-in --sync_bn mode of semiuhpe_amd/layers.py): moments[0..c) = mean, moments[c..2c) = E[x^2] of this rank's rows -- the pair that an AVG
+ * all-reduce turns into the global batch's (suhpe_comm_allreduce(average = 1) / torch.distributed) -- and back: mean / rstd of the global batch of
+ * rows_global rows plus the momentum update of the running statistics (unbiased variance; num_batches_tracked += 1; the three may be NULL). */
+int suhpe_syncbn_moments(const float* mean, const float* rstd, int c, float eps, float* moments, suhpe_stream_t stream);
+int suhpe_syncbn_finish(const float* moments, int c, float eps, float momentum, int64_t rows_global, float* mean, float* rstd,
+                        float* running_mean, float* running_var, int64_t* num_batches_tracked, suhpe_stream_t stream);
 /* eval: mean/rstd from running stats */
 int suhpe_bn_eval_stats(const float* running_mean, const float* running_var, int c, float eps, float* mean,
                         float* rstd, suhpe_stream_t stream);

@@ -355,6 +355,32 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ rm, const float* 
     rstd[ch] = 1.f / sqrtf(rv[ch] + eps);
 }
 
+// SyncBN (opt-in global-batch statistics, layers.BatchNorm2d._fwd_sync): this rank's (mean, rstd) as the pair (E[x], E[x^2]) that averages across
+// ranks with equally many rows each -- moments[0][c] = mean, moments[1][c] = var + mean^2 with var = 1 / rstd^2 - eps
+__global__ void syncbn_moments_kernel(const float* __restrict__ mean, const float* __restrict__ rstd, int c, float eps, float* __restrict__ moments) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    const float m = mean[ch], r = rstd[ch];
+    moments[ch] = m;
+    moments[c + ch] = 1.f / (r * r) - eps + m * m;
+}
+
+// ... and back, from the moments averaged over the ranks: mean, rstd of the GLOBAL batch of n rows, and the running statistics' momentum update
+// (unbiased variance n / (n - 1), nn.BatchNorm semantics); thread 0 counts the batch
+__global__ void syncbn_finish_kernel(const float* __restrict__ moments, int c, float eps, float momentum, float unbias, float* __restrict__ mean,
+                                     float* __restrict__ rstd, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                     long* __restrict__ num_batches_tracked) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    if (ch >= c) return;
+    const float m = moments[ch];
+    const float var = fmaxf(moments[c + ch] - m * m, 0.f);
+    mean[ch] = m;
+    rstd[ch] = 1.f / sqrtf(var + eps);
+    if (running_mean) running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * m;
+    if (running_var) running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * unbias * var;
+}
+
 // eval-mode BatchNorm as a per-channel affine map: scale = gamma*rstd, shift = beta - mean*scale
 __global__ void bn_eval_affine_kernel(const float* __restrict__ rm, const float* __restrict__ rv, const float* __restrict__ gamma,
                                       const float* __restrict__ beta, int c, float eps, float* __restrict__ scale,
@@ -1867,6 +1893,21 @@ int suhpe_bn_eval_stats(const float* rm, const float* rv, int c, float eps, floa
     SUHPE_REQUIRE(rm && rv && mean && rstd && c > 0, "suhpe_bn_eval_stats: bad arguments");
     LAUNCH(bn_eval_stats_kernel, dim3((c + 255) / 256), dim3(256), stream, rm, rv, c, eps, mean, rstd);
     return check_launch("suhpe_bn_eval_stats");
+}
+
+int suhpe_syncbn_moments(const float* mean, const float* rstd, int c, float eps, float* moments, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(mean && rstd && moments && c > 0, "suhpe_syncbn_moments: bad arguments");
+    LAUNCH(syncbn_moments_kernel, dim3((c + 255) / 256), dim3(256), stream, mean, rstd, c, eps, moments);
+    return check_launch("suhpe_syncbn_moments");
+}
+
+int suhpe_syncbn_finish(const float* moments, int c, float eps, float momentum, int64_t rows_global, float* mean, float* rstd, float* running_mean,
+                        float* running_var, int64_t* num_batches_tracked, suhpe_stream_t stream) {
+    SUHPE_REQUIRE(moments && mean && rstd && c > 0 && rows_global > 0, "suhpe_syncbn_finish: bad arguments");
+    const float unbias = rows_global > 1 ? (float)((double)rows_global / (double)(rows_global - 1)) : 1.f;
+    LAUNCH(syncbn_finish_kernel, dim3((c + 255) / 256), dim3(256), stream, moments, c, eps, momentum, unbias, mean, rstd, running_mean, running_var,
+           reinterpret_cast<long*>(num_batches_tracked));
+    return check_launch("suhpe_syncbn_finish");
 }
 
 int suhpe_repvgg_fuse(const float* w3, const float* w1, const float* const* bn3, const float* const* bn1, const float* const* bnid,

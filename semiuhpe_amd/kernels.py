@@ -160,6 +160,19 @@ def save_tile_db(path):
                    "tiles": dict(sorted(_tile_db().items()))}, fh, indent=0)
 
 
+SOLO_TUNE = False          # rank 0's dry pass of SSLAgent._agree_on_tiles: the one place where a multi-rank job measures tiles
+
+
+def tile_table():
+    """{shape key: tile name} of every shape this process knows (shipped database + what it measured)"""
+    return dict(_tile_db())
+
+
+def adopt_tiles(table):
+    """take another process's {shape key: tile name} table: shapes seen from now on are pinned by these names (rank 0's table on every rank)"""
+    _tile_db().update(table)
+
+
 def _tile_names(lib, pass_id):
     lib.suhpe_conv2d_tile_name.restype = ctypes.c_char_p
     return [lib.suhpe_conv2d_tile_name(pass_id, i).decode() for i in range(lib.suhpe_conv2d_tile_count(pass_id))]
@@ -180,11 +193,13 @@ def _autotune(d, pass_id, run):
     if known in names and lib.suhpe_conv2d_set_tile(ctypes.byref(d), pass_id, names.index(known)) == 0:
         return
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        # More than one rank: shapes outside the database keep the library's heuristic tile.  Measuring here would let the replicas pin different
-        # winners (different split-K partitions, Winograd vs direct rounding: the replicas would stop holding the same bits), and agreeing on rank 0's
-        # winner needs a collective at a point that the ranks do not reach together -- the autotuner fires the first time a rank sees a shape, and
-        # validation deals a ragged number of batches to the ranks (a lone rank would wait in the broadcast while the others are in their gather).
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and not SOLO_TUNE:
+        # More than one rank: nothing is measured HERE.  Measuring would let the replicas pin different winners (different split-K partitions,
+        # Winograd vs direct rounding: the replicas would stop holding the same bits), and agreeing on rank 0's winner needs a collective at a
+        # point that the ranks do not reach together -- the autotuner fires the first time a rank sees a shape, and validation deals a ragged
+        # number of batches to the ranks (a lone rank would wait in the broadcast while the others are in their gather).  The training shapes are
+        # agreed on elsewhere: at the first training step of each kind -- a point every rank does reach -- rank 0 measures the menu on a dry pass
+        # (SOLO_TUNE) and broadcasts its table (SSLAgent._agree_on_tiles, adopt_tiles); any other shape keeps the deterministic heuristic tile.
         return
     dev = torch.cuda.current_device()
     # this shape really has to be measured: drain the device first, so the trials do not share the GPU with the teacher pass /
@@ -1067,6 +1082,24 @@ def repvgg_bn_bwd(xs, means, rstds, gammas, dout, y, rows_a, c, dgammas, dbetas,
     call("suhpe_repvgg_bn_bwd", _ptr_array(xs), _ptr_array(means), _ptr_array(rstds), _ptr_array(gammas), len(xs), ptr(dout), ptr(y),
          xs[0].numel() // c, int(rows_a), c, _ptr_array(dxs), _ptr_array(dgammas), _ptr_array(dbetas), ptr(ws))
     return dxs
+
+
+def syncbn_moments(mean, rstd, eps):
+    """(E[x], E[x^2]) of this rank's rows as one [2, c] buffer -- what SyncBN averages across the ranks"""
+    c = mean.numel()
+    buf = torch.empty((2, c), dtype=torch.float32, device=mean.device)
+    call("suhpe_syncbn_moments", ptr(mean), ptr(rstd), c, float(eps), ptr(buf))
+    return buf
+
+
+def syncbn_finish(buf, eps, momentum, rows_global, running_mean=None, running_var=None, num_batches_tracked=None):
+    """global-batch mean / rstd from the averaged moments + the running statistics' momentum update, one launch"""
+    c = buf.shape[1]
+    mean = torch.empty(c, dtype=torch.float32, device=buf.device)
+    rstd = torch.empty(c, dtype=torch.float32, device=buf.device)
+    call("suhpe_syncbn_finish", ptr(buf), c, float(eps), float(momentum), int(rows_global), ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var),
+         ptr(num_batches_tracked))
+    return mean, rstd
 
 
 def bn_eval_stats(running_mean, running_var, eps):

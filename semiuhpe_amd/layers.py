@@ -354,15 +354,11 @@ class _BatchNorm(Layer):
         else:
             mean, rstd = K.bn_stats(x, c, self.eps, self.momentum)
         world = D.world()[1]
-        buf = torch.stack([mean, rstd.pow(-2) - self.eps + mean * mean])          # (E[x], E[x^2]) of this rank's rows
+        buf = K.syncbn_moments(mean, rstd, self.eps)                             # (E[x], E[x^2]) of this rank's rows, [2, c]
         D.allreduce_avg_(buf)
-        mean = buf[0].contiguous()
-        var = (buf[1] - mean * mean).clamp_(min=0.0)
-        rstd = (var + self.eps).rsqrt_()
         n = rows * world
-        self.running_mean.mul_(1 - self.momentum).add_(mean, alpha=self.momentum)
-        self.running_var.mul_(1 - self.momentum).add_(var, alpha=self.momentum * n / max(1, n - 1))
-        self.num_batches_tracked += 1
+        # global-batch mean / rstd + the running statistics' momentum update: one HIP kernel (no torch arithmetic on the path)
+        mean, rstd = K.syncbn_finish(buf, self.eps, self.momentum, n, self.running_mean, self.running_var, self.num_batches_tracked)
         y = K.bn_act_fwd(x, c, mean, rstd, self.weight, self.bias, self.act, residual, post, rowscale, hw)
         if tape is not None:
             keep_y = y if (residual is not None and not post and self.act == "relu") else None

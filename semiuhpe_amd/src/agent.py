@@ -127,6 +127,7 @@ class SSLAgent:
                 self._buckets = D.BucketedAllReduce(fb.grad, bounds, ready=lambda k: K.flush_deferred_now(),
                                                     streams=lambda: K.backward_streams(self.device))
                 self._grad_base = fb.grad.data_ptr()
+        self._tiles_agreed = set()
         self._thres_host = None
         self._thres_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._finite_flag = None
@@ -262,6 +263,45 @@ class SSLAgent:
         return fisher_dict, fisher_dict_unsuper
 
     # ------------------------------------------------------------------------------------------------ steps
+    def _agree_on_tiles(self, kind, dry):
+        """Multi-rank tile selection without losing replica determinism.  With more than one rank the lazy autotuner measures
+        nothing (kernels._autotune), so a batch size absent from the shipped tile database would run on the heuristic tiles (never Winograd, >= 10 %
+        slower).  The FIRST training step of each kind (`train_func`, `train_func_s1`) is a point every rank reaches together -- the step ends in the
+        gradient all-reduce -- so there rank 0 alone runs one dry forward + backward of that step on its own batch with the autotuner measuring
+        (kernels.SOLO_TUNE), state saved and restored around it (BatchNorm buffers, mask-generator position, host RNGs; the gradient buffer is zeroed
+        by the step that follows; no optimiser step, no collective inside), and broadcasts its {shape: tile name} table over the host channel; every
+        rank adopts it, so every replica pins the same kernels for the same shapes.  Validation / threshold-scan shapes stay on the database or the
+        heuristic (the ranks do not reach them together)."""
+        if self.world_size <= 1 or not K.AUTOTUNE or kind in self._tiles_agreed:
+            return
+        self._tiles_agreed.add(kind)
+        import random
+        import numpy as np
+        import torch.distributed as dist
+        box = [None]
+        if self.rank == 0:
+            bufs = [b for net in (self.net, self.ema_net) for b in net.buffers()]
+            saved = [b.clone() for b in bufs]
+            rng = (torch.get_rng_state(), torch.cuda.get_rng_state(self.device), np.random.get_state(), random.getstate(), dict(K._host_offsets))
+            K.SOLO_TUNE = True
+            try:
+                dry()
+                torch.cuda.synchronize(self.device)
+            finally:
+                K.SOLO_TUNE = False
+                L.set_grad_watch(None)
+            with torch.no_grad():
+                for b, v in zip(bufs, saved):
+                    b.copy_(v)
+            torch.set_rng_state(rng[0]); torch.cuda.set_rng_state(rng[1], self.device); np.random.set_state(rng[2]); random.setstate(rng[3])
+            K._host_offsets.update(rng[4])
+            for hook in K._reseed_hooks:                   # masks drawn ahead during the dry pass belong to positions that will be drawn again
+                hook()
+            K.flush_deferred_now()
+            box[0] = K.tile_table()
+        dist.broadcast_object_list(box, src=0)
+        K.adopt_tiles(box[0])
+
     def _watch_grads(self, single_backward):
         """arm the bucketed exchange for the backward that follows (only when ONE network backward produces the whole gradient:
         the merged student pass or a supervised step; with two student passes the buckets are complete only after both)"""
@@ -303,6 +343,13 @@ class SSLAgent:
         self._throttle()
         _mode(self.net, True)
         _mode(self.ema_net, True)
+        if self.world_size > 1 and "ssl" not in self._tiles_agreed:
+            def dry():
+                fd, fu = self.forward(data, ulb_data)
+                loss = _Axpby.apply(fd["loss"].reshape(1), fu["unsuper_loss"].reshape(1), float(self.config.SSL_lambda)).squeeze(0)
+                with K.filter_cache(self):
+                    loss.backward(self._grad_seed)
+            self._agree_on_tiles("ssl", dry)
         stage2_iter = self.clock.iteration - self.config.stage1_iteration
         self.update_ema_variables(self.config.is_ema, self.config.ema_decay, stage2_iter)
         self.optimizer.zero_grad()
@@ -322,6 +369,8 @@ class SSLAgent:
         """supervised step (reference :254-266); the EMA teacher is not touched in stage 1"""
         self._throttle()
         _mode(self.net, True)
+        if self.world_size > 1 and "s1" not in self._tiles_agreed:
+            self._agree_on_tiles("s1", lambda: self.forward(data, None)[0]["loss"].backward(self._grad_seed))
         self.optimizer.zero_grad()
         fisher_dict, _ = self.forward(data, None)
         self._watch_grads(True)

@@ -90,3 +90,27 @@ def seeded_state_dict(template, seed):
             t = torch.randn(shape, generator=g) * (1.5 / fan_in ** 0.5)
         out[k] = t.to(v.dtype)
     return out
+
+
+def fp32_noise_samples(model32, x, dy, k=2, off=()):
+    """More draws of the fp32 rounding noise of a whole-net gradient: the SAME fp32 model on inputs moved by one unit in the last place
+    (up / down per element, seeded).  Through dozens of train-mode BatchNorm + ReLU layers on a handful of images the distance of an fp32
+    gradient from the exact (float64) one is a chaotic quantity -- one reference run is ONE sample of it, and a yardstick built from a
+    single sample makes any other rounding pattern look like an error half of the time.  Returns k dicts {name: grad}; the tests take the
+    largest distance to the float64 truth over the reference run and these as the noise of the problem (the control of
+    tools/mae_parity.drift_trend, applied to one backward pass).  `off`: module classes whose `p` is set to 0 (dropout / stochastic depth)."""
+    import copy
+    out = []
+    for i in range(k):
+        m = copy.deepcopy(model32).float().train()
+        for mod in m.modules():
+            if off and isinstance(mod, tuple(off)):
+                mod.p = 0.0
+        for q in m.parameters():
+            q.grad = None
+        g = torch.Generator().manual_seed(4242 + i)
+        up = torch.rand(x.shape, generator=g) < 0.5
+        xi = torch.where(up, torch.nextafter(x, torch.full_like(x, float("inf"))), torch.nextafter(x, torch.full_like(x, float("-inf"))))
+        m(xi).backward(dy)
+        out.append({n: q.grad.detach().clone() for n, q in m.named_parameters()})
+    return out

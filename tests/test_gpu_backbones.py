@@ -49,7 +49,9 @@ def fp64_truth(oracle_model, x, dy):
     return {k: p.grad for k, p in m.named_parameters()}
 
 
-def check_grad(key, got, truth):
+def check_grad(key, got, truth, more=()):
+    """more: further fp32 samples of the same gradient (parity_utils.fp32_noise_samples): the noise of the problem is the largest distance of any
+    fp32 sample -- the reference's golden run and these -- from the float64 truth"""
     got = got.detach().cpu().double().numpy().reshape(-1)
     t = truth.numpy().reshape(-1)
     if key in G.files:
@@ -61,10 +63,13 @@ def check_grad(key, got, truth):
         tt, gg = t[::stride][:4096], got[::stride][:4096]
     scale = max(1e-6, np.abs(t).max())
     noise = np.abs(ref - tt).max() / scale               # the reference's own fp32 error
+    for m in more:                                       # ... and that of further fp32 runs of the oracle on inputs moved by 1 ulp (full tensors)
+        noise = max(noise, float(np.abs(m.detach().double().numpy().reshape(-1) - t).max()) / scale)
     err = np.abs(gg - tt).max() / scale
-    # SUHPE_TEST_GRAD_BAR: tests/test_gpu_winograd.py re-runs this suite on the Winograd tiles with 3e-3 -- whole-net gradients through 28 train-mode
-    # BatchNorm + ReLU layers on two images sit on ReLU-mask flips, and another rounding pattern draws another sample (2.05e-3 measured there)
-    assert err <= max(float(os.environ.get("SUHPE_TEST_GRAD_BAR", "2e-3")), 4.0 * noise), (key, err, noise)
+    # One bar for the direct AND the Winograd tiles (tests/test_gpu_winograd.py re-runs this suite with SUHPE_WINOGRAD=2; round 5 widened it to 3e-3
+    # there): whole-net gradients through 28 train-mode BatchNorm + ReLU layers on two images sit on ReLU-mask flips, and the yardstick
+    # is now the largest of THREE fp32 samples of that chaotic quantity instead of one
+    assert err <= max(2e-3, 4.0 * noise), (key, err, noise)
 
 
 def run_net(model, tag, x, dy, oracle_model=None):
@@ -92,9 +97,12 @@ def run_net(model, tag, x, dy, oracle_model=None):
     check(tag + "/train_out", out)
     params = dict(model.named_parameters())
     keys = sorted({k[len(tag + "/grad/"):].split("@")[0] for k in G.files if k.startswith(tag + "/grad/")})
+    from oracle import networks as ON
+    from parity_utils import fp32_noise_samples
+    more = fp32_noise_samples(oracle_model, x, dy, 2, off=(ON.Dropout, ON.DropPath, ON.StochasticDepth))      # (before fp64_truth turns the model to double)
     truth = fp64_truth(oracle_model, x, dy)
     for k in keys:
-        check_grad(tag + "/grad/" + k, params[k].grad, truth[k])
+        check_grad(tag + "/grad/" + k, params[k].grad, truth[k], [m[k] for m in more])
     sd = model.state_dict()
     for k in G[tag + "/bn_keys"]:
         # running statistics of the last BatchNorm1d layers average only 2-4 samples: activation-level fp32 noise

@@ -98,12 +98,17 @@ def test_train_forward_backward_and_running_stats(models):
     y.backward(dy.cuda())
     assert rel_err(y, y_ref) < 2e-4
     g_ref, g_hip = dict(ref.named_parameters()), dict(hip.named_parameters())
+    from parity_utils import fp32_noise_samples
+    ref0 = copy.deepcopy(ref)
+    ref0.load_state_dict(before)                                  # (the samples start from the same state as the two runs above)
+    more = fp32_noise_samples(ref0, x, dy, 2, off=(ON.Dropout,))
     for n, t in truth.items():
         scale = max(1e-6, float(t.abs().max()))
-        noise = float((g_ref[n].grad.double() - t).abs().max()) / scale
+        # the noise of the problem = the largest distance of THREE fp32 oracle runs (the reference run + two on inputs moved by 1 ulp) from the float64
+        # truth; one bar for the direct and the Winograd tiles (round 5 allowed the Winograd second pass 9 x of a single sample: VERDICT r5 6c)
+        noise = max(float((g.double() - t).abs().max()) for g in [g_ref[n].grad] + [m[n] for m in more]) / scale
         err = float((g_hip[n].grad.detach().cpu().double() - t).abs().max()) / scale
-        # (SUHPE_TEST_NOISE_FACTOR: the Winograd second pass of tests/test_gpu_winograd.py allows 9 x -- the quantity is chaotic, see there)
-        assert err <= max(2e-3, float(os.environ.get("SUHPE_TEST_NOISE_FACTOR", "6.0")) * noise), (n, err, noise)
+        assert err <= max(2e-3, 6.0 * noise), (n, err, noise)
     for (n, b_ref), (_, b) in zip(ref.named_buffers(), hip.named_buffers()):
         if b_ref.dtype == torch.float32:
             # running statistics 50 train-mode layers deep: the fp32 CPU oracle's own reduction order (its thread count) moves them by ~1e-4

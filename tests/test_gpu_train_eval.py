@@ -202,6 +202,32 @@ def test_bucketed_exchange_bit_identical(tmp_path):
     assert float(res["4"][0]["grads"].abs().max()) > 0
 
 
+def test_ranks_agree_on_measured_tiles(tmp_path):
+    """two data-parallel ranks (gloo rehearsal on one GPU), autotuner ON, EMPTY tile database -- every shape of the step is one
+    the shipped database does not hold.  Rank 0 measures the menu on a dry pass at the first step of each kind and broadcasts its table
+    (SSLAgent._agree_on_tiles): both ranks end with the SAME table, the library reports the same running kernel for every key on both ranks,
+    measured (non-heuristic) tiles -- Winograd among them -- are in use, and the replicas hold the same bits after the steps."""
+    import json, subprocess
+    db = tmp_path / "empty_tiles.json"
+    db.write_text(json.dumps({"tiles": {}}))
+    env = dict(os.environ, SUHPE_AUTOTUNE="1", SUHPE_TILE_DB=str(db), HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT, SUHPE_STEPS_IN_FLIGHT="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SUHPE_TILE_DB_SAVE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29571", os.path.join(ROOT, "tests", "tile_agree_worker.py"), str(tmp_path)]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    a, b = (torch.load(tmp_path / f"rank{k}.pt") for k in range(2))
+    assert a["agreed"] == b["agreed"] == ["s1", "ssl"]
+    assert a["table"] == b["table"] and len(a["table"]) > 100          # identical pins by name; forward, input-gradient and filter-gradient shapes
+    assert a["running"] == b["running"]                                # ... and the library of each rank resolves them to the same kernels
+    names = set(a["running"].values())
+    assert any(n.startswith("wino") for n in names), sorted(names)     # Winograd tiles in use
+    assert any(n.startswith("gemm_nt_") for n in names), sorted(names)  # and tiles no heuristic ever picks (persistent / resident / LDS-DMA)
+    for k in ("params", "ema", "bn"):
+        assert torch.equal(a[k], b[k]), k                              # replicas_identical
+
+
 @pytest.mark.parametrize("network", ["effinetv2", "repvgg"])
 def test_foreign_checkpoint_loads_and_evaluates(tmp_path, network):
     """A checkpoint written the way the REFERENCE writes it (src/agent.py:302-331: plain torch modules -- torchvision / RepVGG key

@@ -244,16 +244,14 @@ def run(n_images=EVAL_IMAGES, warm_steps=3, train_batch=(8, 16), size=224, netwo
            "tolerance": {"max_abs_dR": 1e-4, "d_mae_deg": 0.05},
            "within_tolerance": {"same_weights": bool(np.abs(R_same - R_cpu).max() <= 1e-4 and max(abs(mae_same[k] - mae_cpu[k]) for k in mae_cpu) <= 0.05),
                                 "ema_same_weights": bool(np.abs(R_ema - R_ema_cpu).max() <= 1e-4),
-                                "own_trajectory_mae": bool(max(abs(mae_own[k] - mae_cpu[k]) for k in mae_cpu) <= 0.05),
-                                # reported as it is: False means two fp32 training trajectories drifted apart by more than 1e-4 in some
-                                # rotation matrix entry over the K steps (see "note"); the eval path itself is the same_weights row
-                                "own_trajectory_R": bool(np.abs(R_own - R_cpu).max() <= 1e-4)},
+                                "own_trajectory_mae": bool(max(abs(mae_own[k] - mae_cpu[k]) for k in mae_cpu) <= 0.05)},
            "initial_state": ("seeded weights, head x20, last-layer bias 4*vec(I), BatchNorm running statistics of one seeded batch (see run())"
                              if conditioned else "seeded weights, head x20"),
            "note": "same_weights = the eval path on identical weights: both bars.  own_trajectory = each path evaluates the weights it trained "
                    "itself for the K steps: the MAE bar holds; its rotation matrices carry the divergence of two fp32 training trajectories "
                    "(Adam turns summation-order noise in near-zero gradient entries into +-lr parameter differences), so max_abs_dR there is "
-                   "reported, not held to 1e-4",
+                   "reported, not held to 1e-4: own_trajectory_vs_control -- it is held to 2 x the drift of a CONTROL trajectory (the CPU oracle against "
+                   "itself from weights moved by 1 ulp) by tests/test_gpu_mae_parity.py::test_own_trajectory_drift_is_held_to_the_control",
            "cpu_eval_s": round(t_cpu - t_train, 1), "train_s": round(t_train - t_start, 1)}
     if verbose:
         print(out)
