@@ -236,6 +236,21 @@ int64_t suhpe_dwconv_dgrad_bnsums_workspace_bytes(const suhpe_conv_t* d);
 int suhpe_dwconv_dgrad_bnsums(const suhpe_conv_t* d, const float* dy, const float* w, float* dx, const float* bn_x, const float* mean,
                               const float* rstd, const float* gamma, const float* beta, int act, int seg_n, float* sums, float* dgamma,
                               float* dbeta, int accumulate, void* workspace, int64_t workspace_bytes, suhpe_stream_t stream);
+/* The depthwise conv's WHOLE backward in one launch (round 6; 3x3 / pad 1 / stride 1 on 14 x 14 or 7 x 7 maps: torchvision MBConv's depthwise
+ * Conv2dNormActivation, reached through /root/reference/src/networks.py:301-303): the input gradient dx and the producer BatchNorm's backward sums as
+ * suhpe_dwconv_dgrad_bnsums gives them, AND the filter gradient dw (what suhpe_dwconv_bnact_wgrad computes from act(BN(bn_x)): same BatchNorm, so no
+ * second parameter set), from ONE staged tile of the output gradient.  Section form (mid_y != NULL): `dy` is then dout = d loss / d (z s) of the
+ * SqueezeExcitation section and the conv's output gradient is formed while the tile is filled -- suhpe_se_bn_bwd_apply's arithmetic on (mid_y, dout,
+ * mid_s, mid_dpool, mid_chan, the depthwise BatchNorm's mean / rstd [sets][c], gamma, beta), never written to memory.  seg_n = samples of the first
+ * batch segment (0: one).  _ok: can this descriptor take the call (SUHPE_DW_BWD_FUSED=0: never).  Results equal the three-kernel path within fp32
+ * rounding (other summation order of the filter gradient; one sigmoid per element shared by z and act'). */
+int suhpe_dwconv_bwd_fused_ok(const suhpe_conv_t* d);
+int64_t suhpe_dwconv_bwd_fused_workspace_bytes(const suhpe_conv_t* d);
+int suhpe_dwconv_bwd_fused(const suhpe_conv_t* d, const float* dy, const float* w, float* dx, const float* bn_x, const float* mean, const float* rstd,
+                           const float* gamma, const float* beta, int act, int seg_n, float* sums, float* dgamma, float* dbeta, int accumulate,
+                           float* dw, int dw_accumulate, const float* mid_y, const float* mid_s, const float* mid_dpool, const float* mid_chan,
+                           const float* mid_mean, const float* mid_rstd, const float* mid_gamma, const float* mid_beta, int mid_act,
+                           int mid_train_stats, void* workspace, int64_t workspace_bytes, suhpe_stream_t stream);
 int suhpe_bn_act_bwd_apply_seg(const float* x, const float* dy, int64_t rows, int64_t rows_a, int c, const float* mean, const float* rstd,
                                const float* gamma, const float* beta, int act, const float* sums, float* dx, suhpe_stream_t stream);
 int64_t suhpe_dwconv_wgrad_workspace_bytes(const suhpe_conv_t* d);

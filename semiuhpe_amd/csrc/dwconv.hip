@@ -744,6 +744,258 @@ __global__ __launch_bounds__(256, 2) void dw3x3_wgrad_tile_kernel(const float* _
     }
 }
 
+// ---- the depthwise conv's WHOLE backward on the image tiles (round 6): input gradient + the producer BatchNorm's backward sums (what
+// dw3x3_tile_kernel<HW, false, false, true> does) AND the filter gradient from the same staged tile, optionally with the conv's OUTPUT gradient formed
+// while the tile is filled (DYF: the apply pass of the depthwise BatchNorm + SqueezeExcitation section, se_bn_bwd_apply_kernel's arithmetic, never
+// written).  torchvision MBConv (expand 1x1 -> BatchNorm_e -> SiLU -> depthwise 3x3 -> BatchNorm_d -> SiLU -> SE -> project), per block and step:
+//   before   se_bn_bwd_apply  reads y, dout          writes dy          (3 passes over the expanded tensor)
+//            dw wgrad         reads e0, dy                              (2)
+//            dw dgrad + sums  reads dy, e0           writes d           (3)        = 8 passes
+//   here     reads dout, y (DYF) or dy, and e0;      writes d                      = 4 passes (3 without DYF), two launches fewer
+// One LDS tile holds the output gradient dy of the group's image(s) with a zero ring, as in the input-gradient kernel.  Both gradients are sums over
+// the SAME 3 x 3 window of dy around an input position q:   d(q) = sum_ij dy(q + (i-1, j-1)) w[2-i][2-j]   and, with z = act(BN_e(e0)) the conv's
+// input,   dW[r][s] = sum_q z(q) dy(q - (r-1, s-1)) = sum_q z(q) win[2-r][2-s]   -- so the filter gradient needs z only at the window's CENTRE, and
+// e0(q) is already streamed there for the BatchNorm_e sums (xhat and act' come from it): ONE sigmoid per element serves z, act' and the sums.
+// DYF fill: dy = gamma_d rstd_d (g - m0 - xhat_d m1),  g = (dout s[n] + dpool[n] / hw) act'(xhat_d gamma_d + beta_d),  xhat_d = (y - mean_d) rstd_d,
+// (m0, m1) = the section's per-channel sums over the segment / rows (se_bn_bwd_combine_kernel's `chan`); the per-channel constants of both batch
+// segments sit in a small LDS table behind the tile and are read per pixel (a group of two 7 x 7 images may straddle the segment boundary).
+struct DwMid {
+    const float* y;          // the depthwise conv's raw output (N, HW, HW, C); NULL: `src` IS dy (no DYF)
+    const float* s;          // (N, C) excitation
+    const float* dpool;      // (N, C)
+    const float* chan;       // [sets][2 C]: (sum g, sum g xhat) per channel
+    const float* mean; const float* rstd; const float* gamma; const float* beta;      // BatchNorm_d: mean / rstd [sets][C]
+    int act, seg_n, train_stats;
+    float inv_rows_a, inv_rows_b, inv_hw;
+};
+template <int HW, bool DYF, int ACTC>
+__global__ __launch_bounds__(256, 2) void dw3x3_bwd_tile_kernel(const float* __restrict__ src, const float* __restrict__ w, float* __restrict__ dst, int N, int C,
+                                                                int ngroups, const DwBnb bnb, const DwMid mid, float* __restrict__ wpart) {
+    using T = DwTile<HW>;
+    constexpr int WP = T::wp, LPT = T::lpt;
+    extern __shared__ __attribute__((aligned(16))) float tile[];          // [imgs][HW+2][HW+2][64] + DYF: [2 sets][mean | rstd | m0 | m1][64]
+    float* ctab = tile + T::imgs * WP * WP * 64;
+    const int t = threadIdx.x, vc = t & 15, slot = t >> 4;
+    const int col0 = blockIdx.y * 16, c0 = (col0 + vc) * 4;
+    const bool cok = c0 < C;
+    const int cc = cok ? c0 : 0;
+    for (int i = t; i < T::imgs * WP * WP * 16; i += 256) reinterpret_cast<float4*>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (DYF && t < 128) {                                // thread (set, quantity, channel vector) fills one float4 of the table
+        const int set = t >> 6, qty = (t >> 4) & 3, v4 = t & 15;
+        const int ch0 = (col0 + v4) * 4;
+        const bool live = ch0 < C && (set == 0 || mid.seg_n > 0);
+        const float inv = set ? mid.inv_rows_b : mid.inv_rows_a;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        if (live) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int ch = ch0 + v;
+                o[v] = qty == 0 ? mid.mean[set * C + ch] : qty == 1 ? mid.rstd[set * C + ch]
+                     : (mid.train_stats ? mid.chan[set * 2 * C + 2 * ch + (qty - 2)] * inv : 0.f);
+            }
+        }
+        *reinterpret_cast<float4*>(&ctab[((set * 4 + qty) * 16 + v4) * 4]) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    float4 wv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {                        // flipped: the input gradient is a correlation with the rotated filter
+        const int kk = 8 - k;
+        wv[k] = cok ? make_float4(w[(int64_t)(c0 + 0) * 9 + kk], w[(int64_t)(c0 + 1) * 9 + kk], w[(int64_t)(c0 + 2) * 9 + kk], w[(int64_t)(c0 + 3) * 9 + kk])
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int bact = ACTC >= 0 ? ACTC : bnb.act;
+    const int mact = ACTC >= 0 ? ACTC : mid.act;
+    float b_mu[4], b_rs[4], b_ga[4], b_be[4], b_s0[4] = {0.f, 0.f, 0.f, 0.f}, b_s1[4] = {0.f, 0.f, 0.f, 0.f}, b_a0[4] = {0.f, 0.f, 0.f, 0.f},
+          b_a1[4] = {0.f, 0.f, 0.f, 0.f};
+    bool b_crossed = false;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        b_mu[v] = bnb.mean[cc + v]; b_rs[v] = bnb.rstd[cc + v];
+        b_ga[v] = bnb.gamma ? bnb.gamma[cc + v] : 1.f; b_be[v] = bnb.beta ? bnb.beta[cc + v] : 0.f;
+    }
+    float m_ga[4] = {1.f, 1.f, 1.f, 1.f}, m_be[4] = {0.f, 0.f, 0.f, 0.f};
+    if (DYF) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { m_ga[v] = mid.gamma ? mid.gamma[cc + v] : 1.f; m_be[v] = mid.beta ? mid.beta[cc + v] : 0.f; }
+    }
+    float4 accw[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) accw[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // The group's pixels are loaded and written to the tile in chunks of CHK per thread, every load of a chunk issued before the first use; nothing is
+    // prefetched across the window loop: with the nine filter-gradient accumulators beside the window and the filter, a group's worth of loads held
+    // in registers there spilled (256 VGPRs at two workgroups per CU) -- the second resident workgroup covers the load phase instead.
+    constexpr int CHK = DYF ? 5 : 7;
+    float4 sv[DYF ? T::imgs : 1], pv[DYF ? T::imgs : 1];
+    int g = blockIdx.x;
+    __syncthreads();
+    const int img = slot / HW, row = slot - img * HW;
+    const bool crow = slot < T::imgs * HW;
+    for (; g < ngroups; g += gridDim.x) {
+        const int64_t p0 = (int64_t)g * T::npix;
+        if (DYF) {
+#pragma unroll
+            for (int qi = 0; qi < T::imgs; ++qi) {
+                const int64_t n = (int64_t)g * T::imgs + qi;
+                const bool ok = cok && n < N;
+                sv[qi] = ok ? *reinterpret_cast<const float4*>(mid.s + n * C + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                pv[qi] = ok ? *reinterpret_cast<const float4*>(mid.dpool + n * C + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int k0 = 0; k0 < LPT; k0 += CHK) {
+            float4 pf[CHK], pg[DYF ? CHK : 1];
+#pragma unroll
+            for (int k = 0; k < CHK; ++k) {
+                const int q = slot + kTileSlots * (k0 + k);
+                const int64_t pix = p0 + q;
+                const bool ok = cok && k0 + k < LPT && q < T::npix && pix < (int64_t)N * HW * HW;
+                pf[k] = ok ? *reinterpret_cast<const float4*>(src + pix * C + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (DYF) pg[k] = ok ? *reinterpret_cast<const float4*>(mid.y + pix * C + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < CHK; ++k) {
+                const int q = slot + kTileSlots * (k0 + k);
+                if (k0 + k >= LPT || q >= T::npix) continue;
+                const int qi = q / (HW * HW), rem = q - qi * HW * HW, h = rem / HW, x = rem - h * HW;
+                float4 v = pf[k];
+                if (DYF) {
+                    const int64_t n = (int64_t)g * T::imgs + qi;
+                    const int set = (mid.seg_n > 0 && n >= mid.seg_n) ? 1 : 0;
+                    const float4 mu4 = *reinterpret_cast<const float4*>(&ctab[((set * 4 + 0) * 16 + vc) * 4]);
+                    const float4 rs4 = *reinterpret_cast<const float4*>(&ctab[((set * 4 + 1) * 16 + vc) * 4]);
+                    const float4 m04 = *reinterpret_cast<const float4*>(&ctab[((set * 4 + 2) * 16 + vc) * 4]);
+                    const float4 m14 = *reinterpret_cast<const float4*>(&ctab[((set * 4 + 3) * 16 + vc) * 4]);
+                    const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, rs[4] = {rs4.x, rs4.y, rs4.z, rs4.w};
+                    const float m0[4] = {m04.x, m04.y, m04.z, m04.w}, m1[4] = {m14.x, m14.y, m14.z, m14.w};
+                    const float dv[4] = {v.x, v.y, v.z, v.w}, yv[4] = {pg[k].x, pg[k].y, pg[k].z, pg[k].w};
+                    const float4 s4 = sv[T::imgs > 1 ? qi : 0], p4 = pv[T::imgs > 1 ? qi : 0];
+                    const float ss[4] = {s4.x, s4.y, s4.z, s4.w}, pp[4] = {p4.x, p4.y, p4.z, p4.w};
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xh = (yv[e] - mu[e]) * rs[e];
+                        float gq = (dv[e] * ss[e] + pp[e] * mid.inv_hw) * act_grad(xh * m_ga[e] + m_be[e], mact);
+                        gq = gq - m0[e] - xh * m1[e];
+                        o[e] = m_ga[e] * rs[e] * gq;
+                    }
+                    const bool ok = cok && n < N;
+                    v = ok ? make_float4(o[0], o[1], o[2], o[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                *reinterpret_cast<float4*>(&tile[((qi * WP + h + 1) * WP + x + 1) * 64 + vc * 4]) = v;
+            }
+        }
+        __syncthreads();
+        const int64_t n = (int64_t)g * T::imgs + img;
+        if (crow && cok && n < N) {
+            if (bnb.seg_n > 0 && !b_crossed && n >= bnb.seg_n) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    b_a0[v] = b_s0[v]; b_a1[v] = b_s1[v]; b_s0[v] = 0.f; b_s1[v] = 0.f;
+                    b_mu[v] = bnb.mean[C + c0 + v]; b_rs[v] = bnb.rstd[C + c0 + v];
+                }
+                b_crossed = true;
+            }
+            // the conv's raw input e0 at the window's centre, kTileAhead column steps ahead of its use
+            const float* bxp = bnb.x + ((n * HW + row) * HW) * C + c0;
+            float4 bq[kTileAhead];
+#pragma unroll
+            for (int d = 0; d < kTileAhead; ++d) bq[d] = *reinterpret_cast<const float4*>(bxp + (int64_t)(d < HW ? d : HW - 1) * C);
+            const float* base = &tile[((img * WP + row) * WP) * 64 + vc * 4];      // padded (row, column 0): the window's top-left corner
+            float4 a[3], b[3], c[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                a[r] = *reinterpret_cast<const float4*>(base + (r * WP + 0) * 64);
+                b[r] = *reinterpret_cast<const float4*>(base + (r * WP + 1) * 64);
+            }
+            float* out = dst + ((n * HW + row) * HW) * C + c0;
+#pragma unroll 1
+            for (int ow = 0; ow < HW; ++ow) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) c[r] = *reinterpret_cast<const float4*>(base + (r * WP + ow + 2) * 64);
+                const float4 bxc = bq[0];
+#pragma unroll
+                for (int d = 0; d + 1 < kTileAhead; ++d) bq[d] = bq[d + 1];
+                bq[kTileAhead - 1] = *reinterpret_cast<const float4*>(bxp + (int64_t)(ow + kTileAhead < HW ? ow + kTileAhead : HW - 1) * C);
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { fma4(acc, a[r], wv[r * 3]); fma4(acc, b[r], wv[r * 3 + 1]); fma4(acc, c[r], wv[r * 3 + 2]); }
+                *reinterpret_cast<float4*>(out + (int64_t)ow * C) = acc;
+                const float o[4] = {acc.x, acc.y, acc.z, acc.w}, xv[4] = {bxc.x, bxc.y, bxc.z, bxc.w};
+                float zc[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float xh = (xv[v] - b_mu[v]) * b_rs[v];
+                    const float u = xh * b_ga[v] + b_be[v];
+                    float ag;
+                    if (bact == SUHPE_ACT_SILU) {           // one sigmoid serves the conv's input z = u sigma(u) and act' = sigma (1 + u (1 - sigma))
+                        const float sg = fast_sigmoid(u);
+                        zc[v] = u * sg;
+                        ag = sg * (1.f + u * (1.f - sg));
+                    } else {
+                        zc[v] = act_apply(u, bact);
+                        ag = act_grad(u, bact);
+                    }
+                    const float gg = o[v] * ag;
+                    b_s0[v] += gg;
+                    b_s1[v] += gg * xh;
+                }
+                const float4 z4 = make_float4(zc[0], zc[1], zc[2], zc[3]);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { fma4(accw[r * 3], a[r], z4); fma4(accw[r * 3 + 1], b[r], z4); fma4(accw[r * 3 + 2], c[r], z4); }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { a[r] = b[r]; b[r] = c[r]; }
+            }
+        }
+        __syncthreads();
+    }
+    const bool active = crow && cok;
+    {
+        // BatchNorm_e sums: threads that share a channel vector, added in a fixed order; records [plane][blockIdx.x][C] float2 (bn_bwd_partial's format)
+        const bool two = bnb.seg_n > 0;
+        if (two && !b_crossed) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { b_a0[v] = b_s0[v]; b_a1[v] = b_s1[v]; b_s0[v] = 0.f; b_s1[v] = 0.f; }
+        }
+        float* scratch = tile;
+        for (int plane = 0; plane < (two ? 2 : 1); ++plane) {
+            const float* q0 = (two && plane == 0) ? b_a0 : b_s0;
+            const float* q1 = (two && plane == 0) ? b_a1 : b_s1;
+            __syncthreads();
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { scratch[t * 8 + v] = active ? q0[v] : 0.f; scratch[t * 8 + 4 + v] = active ? q1[v] : 0.f; }
+            __syncthreads();
+            if (t < 16 && (col0 + t) * 4 < C) {
+                float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int r = 0; r < kTileSlots; ++r) {
+                    const float* e = &scratch[(r * 16 + t) * 8];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) { a0[v] += e[v]; a1[v] += e[4 + v]; }
+                }
+                float2* rec = reinterpret_cast<float2*>(bnb.part) + ((int64_t)plane * gridDim.x + blockIdx.x) * C + (col0 + t) * 4;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) rec[v] = make_float2(a0[v], a1[v]);
+            }
+        }
+    }
+    // filter gradient: the 16 row slots of a channel vector, added in a fixed order; window position k = 3 i + j holds tap 8 - k
+    __syncthreads();
+    float* red = tile;                                   // [k][256][4]: 36 KB of the tile
+#pragma unroll
+    for (int k = 0; k < 9; ++k) *reinterpret_cast<float4*>(&red[(k * 256 + t) * 4]) = active ? accw[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    if (t < 16 && (col0 + t) * 4 < C) {
+        for (int k = 0; k < 9; ++k) {
+            float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int rr = 0; rr < kTileSlots; ++rr) {
+                const float4 v = *reinterpret_cast<const float4*>(&red[(k * 256 + rr * 16 + t) * 4]);
+                s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+            }
+            *reinterpret_cast<float4*>(&wpart[((int64_t)blockIdx.x * 9 + (8 - k)) * C + (col0 + t) * 4]) = s4;
+        }
+    }
+}
+
 // filter-gradient partials with the same sliding window: part[bx][tap][c]
 template <bool XF>
 __global__ __launch_bounds__(256) void dw3x3_wgrad_row_kernel(const float* __restrict__ x_, const float* __restrict__ dy, float* __restrict__ part,
@@ -1147,6 +1399,70 @@ int suhpe_dwconv_dgrad_bnsums(const suhpe_conv_t* d, const float* dy, const floa
     // finish: (sum g, sum g xhat) per channel and segment -> sums [c][2] / [2][c][2], dgamma / dbeta (nn_elem.hip's finalisers)
     launch_bn_bwd_finalize(part, seg_n > 0 ? gx : 0, seg_n > 0 ? 2 * gx : gx, d->cin, sums, dgamma, dbeta, accumulate, as_stream(stream));
     return check_launch("suhpe_dwconv_dgrad_bnsums");
+}
+
+// ---- the depthwise conv's whole backward in one launch (dw3x3_bwd_tile_kernel): 3x3 / pad 1 / stride 1 on 14 x 14 or 7 x 7 maps
+static void dw_bwd_tile_grid(const suhpe_conv_t* d, int hw, int* gx, int* ny, int* ngroups) {
+    const int imgs = kTileSlots / hw;
+    *ngroups = (d->n + imgs - 1) / imgs;
+    *ny = (d->cin / 4 + 15) / 16;
+    const int64_t slots = 256 * 2;                          // two resident workgroups per compute unit (register budget of the fused kernel)
+    const int64_t iters = ceil_div((int64_t)*ngroups * *ny, slots);
+    *gx = (int)ceil_div((int64_t)*ngroups, iters < 1 ? 1 : iters);
+}
+static const bool kDwBwdFused = !(getenv("SUHPE_DW_BWD_FUSED") && atoi(getenv("SUHPE_DW_BWD_FUSED")) == 0);
+int suhpe_dwconv_bwd_fused_ok(const suhpe_conv_t* d) {
+    return (kDwBwdFused && d && d->groups == d->cin && d->cin == d->cout && d->cin % 4 == 0 && dw_tile_hw(d)) ? 1 : 0;
+}
+int64_t suhpe_dwconv_bwd_fused_workspace_bytes(const suhpe_conv_t* d) {
+    if (!suhpe_dwconv_bwd_fused_ok(d)) return 0;
+    int gx, ny, ngroups;
+    dw_bwd_tile_grid(d, dw_tile_hw(d), &gx, &ny, &ngroups);
+    return ((int64_t)2 * gx * d->cin * 2 + (int64_t)gx * 9 * d->cin) * sizeof(float);
+}
+int suhpe_dwconv_bwd_fused(const suhpe_conv_t* d, const float* dy, const float* w, float* dx, const float* bn_x, const float* mean, const float* rstd,
+                           const float* gamma, const float* beta, int act, int seg_n, float* sums, float* dgamma, float* dbeta, int accumulate, float* dw,
+                           int dw_accumulate, const float* mid_y, const float* mid_s, const float* mid_dpool, const float* mid_chan, const float* mid_mean,
+                           const float* mid_rstd, const float* mid_gamma, const float* mid_beta, int mid_act, int mid_train_stats, void* workspace,
+                           int64_t workspace_bytes, suhpe_stream_t stream) {
+    int rc = dw_check(d, "suhpe_dwconv_bwd_fused");
+    if (rc) return rc;
+    SUHPE_REQUIRE(suhpe_dwconv_bwd_fused_ok(d), "suhpe_dwconv_bwd_fused: 3x3 / pad 1 / stride 1 depthwise convs on 14 x 14 or 7 x 7 maps only (see _ok)");
+    SUHPE_REQUIRE(dy && w && dx && bn_x && mean && rstd && sums && dw && workspace && seg_n >= 0 && seg_n < d->n, "suhpe_dwconv_bwd_fused: bad arguments");
+    SUHPE_REQUIRE(act >= SUHPE_ACT_NONE && act <= SUHPE_ACT_SIGMOID && mid_act >= SUHPE_ACT_NONE && mid_act <= SUHPE_ACT_SIGMOID, "suhpe_dwconv_bwd_fused: unknown activation");
+    SUHPE_REQUIRE(!mid_y || (mid_s && mid_dpool && mid_mean && mid_rstd && (mid_chan || !mid_train_stats)),
+                  "suhpe_dwconv_bwd_fused: the section form (mid_y) needs s, dpool, mean, rstd and, in train mode, the channel sums");
+    if (workspace_bytes < suhpe_dwconv_bwd_fused_workspace_bytes(d)) {
+        set_error("suhpe_dwconv_bwd_fused: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)suhpe_dwconv_bwd_fused_workspace_bytes(d));
+        return SUHPE_EWORKSPACE;
+    }
+    const int hw = dw_tile_hw(d);
+    int gx, ny, ngroups;
+    dw_bwd_tile_grid(d, hw, &gx, &ny, &ngroups);
+    float* part = static_cast<float*>(workspace);
+    float* wpart = part + (int64_t)2 * gx * d->cin * 2;
+    const DwBnb bnb{bn_x, mean, rstd, gamma, beta, act, seg_n, part};
+    const int64_t rows = (int64_t)d->n * hw * hw, rows_a = (int64_t)seg_n * hw * hw;
+    const DwMid mid{mid_y, mid_s, mid_dpool, mid_chan, mid_mean, mid_rstd, mid_gamma, mid_beta, mid_act, seg_n, mid_train_stats,
+                    1.0f / (float)(rows_a > 0 ? rows_a : rows), 1.0f / (float)(rows - rows_a), 1.0f / (float)(hw * hw)};
+    hipStream_t st = as_stream(stream);
+    auto go = [&](auto kern, int lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(kern, dim3(gx, ny), dim3(256), lds, st, dy, w, dx, d->n, d->cin, ngroups, bnb, mid, wpart);
+    };
+    const bool silu = act == SUHPE_ACT_SILU && (!mid_y || mid_act == SUHPE_ACT_SILU);
+    constexpr int kTab = 2 * 4 * 16 * 4 * (int)sizeof(float);
+    if (hw == 14) {
+        if (mid_y) { if (silu) go(dw3x3_bwd_tile_kernel<14, true, SUHPE_ACT_SILU>, DwTile<14>::lds_bytes + kTab); else go(dw3x3_bwd_tile_kernel<14, true, -1>, DwTile<14>::lds_bytes + kTab); }
+        else { if (silu) go(dw3x3_bwd_tile_kernel<14, false, SUHPE_ACT_SILU>, DwTile<14>::lds_bytes); else go(dw3x3_bwd_tile_kernel<14, false, -1>, DwTile<14>::lds_bytes); }
+    } else {
+        if (mid_y) { if (silu) go(dw3x3_bwd_tile_kernel<7, true, SUHPE_ACT_SILU>, DwTile<7>::lds_bytes + kTab); else go(dw3x3_bwd_tile_kernel<7, true, -1>, DwTile<7>::lds_bytes + kTab); }
+        else { if (silu) go(dw3x3_bwd_tile_kernel<7, false, SUHPE_ACT_SILU>, DwTile<7>::lds_bytes); else go(dw3x3_bwd_tile_kernel<7, false, -1>, DwTile<7>::lds_bytes); }
+    }
+    // finish: (sum g, sum g xhat) per channel and segment -> sums, dgamma / dbeta; filter-gradient records -> dw (fp64, fixed order)
+    launch_bn_bwd_finalize(part, seg_n > 0 ? gx : 0, seg_n > 0 ? 2 * gx : gx, d->cin, sums, dgamma, dbeta, accumulate, st);
+    hipLaunchKernelGGL(dw_wgrad_finalize, dim3((9 * d->cin + 63) / 64), dim3(256), 0, st, wpart, gx, 9, d->cin, dw, dw_accumulate);
+    return check_launch("suhpe_dwconv_bwd_fused");
 }
 
 int64_t suhpe_dwconv_wgrad_workspace_bytes(const suhpe_conv_t* d) {

@@ -365,6 +365,39 @@ def dwconv_dgrad_bnsums(dy, w, x_shape, stride, pad, bn_x, mean, rstd, gamma, be
     return dx, sums
 
 
+def dwconv_bwd_fused_ok(x_shape, w_shape, stride, pad):
+    """can the depthwise conv's whole backward (input gradient + producer BatchNorm sums + filter gradient) run as ONE launch for this shape?"""
+    d = conv_desc(x_shape, w_shape, stride, pad, x_shape[-1])
+    return _is_depthwise(d) and bool(_lib.load().suhpe_dwconv_bwd_fused_ok(ctypes.byref(d)))
+
+
+@_memop
+def dwconv_bwd_fused(dy, w, x_shape, stride, pad, bn_x, mean, rstd, gamma, beta, act, seg_n, dgamma, dbeta, dw, mid=None):
+    """suhpe_dwconv_bwd_fused: the depthwise conv's input gradient dx (= gradient of act(BN(bn_x))), that BatchNorm's backward sums and the conv's
+    filter gradient (accumulated into dw) from one staged tile of the output gradient.  mid = (y, s, dpool, chan, mean_d, rstd_d, gamma_d, beta_d,
+    act_d, train_stats): `dy` is then dout of the SqueezeExcitation section and the conv's output gradient is formed on the fly (se_bn_bwd_apply's
+    arithmetic, never stored).  -> (dx, sums [2c] or [2, 2c]); dgamma / dbeta / dw are accumulated into"""
+    _chk(dy, "dy"); _chk(bn_x, "bn_x")
+    d = conv_desc(x_shape, w.shape, stride, pad, x_shape[-1])
+    c = d.cin
+    two = seg_n > 0
+    assert mean.numel() == rstd.numel() == (2 if two else 1) * c and tuple(bn_x.shape) == tuple(x_shape) and tuple(dy.shape) == tuple(x_shape)
+    dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
+    sums = torch.empty(((2, 2 * c) if two else (2 * c,)), dtype=torch.float32, device=dy.device)
+    nbytes = _lib.load().suhpe_dwconv_bwd_fused_workspace_bytes(ctypes.byref(d))
+    ws = workspace("dw_bwd_fused", nbytes, dy.device)
+    if mid is not None:
+        y, s_, dp, chan, mean_d, rstd_d, gamma_d, beta_d, act_d, train_stats = mid
+        _chk(y, "y"); _chk(s_, "s"); _chk(dp, "dpool")
+        assert tuple(y.shape) == tuple(x_shape) and s_.numel() == dp.numel() == d.n * c and mean_d.numel() == rstd_d.numel() == (2 if two else 1) * c
+        margs = (ptr(y), ptr(s_), ptr(dp), ptr(chan), ptr(mean_d), ptr(rstd_d), ptr(gamma_d), ptr(beta_d), ACT[act_d], int(bool(train_stats)))
+    else:
+        margs = (None, None, None, None, None, None, None, None, 0, 0)
+    call("suhpe_dwconv_bwd_fused", ctypes.byref(d), ptr(dy), ptr(w), ptr(dx), ptr(bn_x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ACT[act],
+         int(seg_n) if two else 0, ptr(sums), ptr(dgamma), ptr(dbeta), 1, ptr(dw), 1, *margs, ptr(ws), nbytes)
+    return dx, sums
+
+
 @_memop
 def bn_act_bwd_apply_seg(x, dy, rows_a, c, mean, rstd, gamma, beta, act, sums):
     """the BatchNorm backward's apply pass with two batch segments, from sums [2, 2c] a producer reduced"""

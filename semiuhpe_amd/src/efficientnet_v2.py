@@ -63,16 +63,41 @@ def bn_sums_from_dw_ok(conv_d, tape):
         return False
     return K.dwconv_dgrad_bnsums_ok(top.shape, conv_d.weight.shape, conv_d.stride, conv_d.padding)
 
-def dw_dgrad_expand_bwd(conv_d, expand, dy, tape):
+# The depthwise conv's whole backward as ONE launch (suhpe_dwconv_bwd_fused, round 6): the filter gradient comes from the same staged tile of the
+# output gradient as the input gradient and the expand BatchNorm's sums, and -- inside the fused depthwise / SqueezeExcitation section -- that output
+# gradient is formed while the tile is filled, so se_bn_bwd_apply's pass and the separate filter-gradient kernel disappear (8 -> 4 passes over the
+# expanded tensor, two launches fewer per MBConv block).  SUHPE_DW_BWD_FUSED=0 (read by the library): the three-kernel path.
+def dw_bwd_fused_ok(conv_d, tape):
+    """the folded-expand form on a shape the fused kernel takes: the tape's top is (raw expand output, its BatchNorm as input transform) and the
+    entry below it that BatchNorm's train-mode record of the SAME tensor"""
+    top, rec = tape[-1], tape[-2]
+    return (isinstance(top, tuple) and len(top) == 2 and torch.is_tensor(top[0]) and top[1] is not None and top[1][0] == "bn" and rec[0] is top[0]
+            and K.dwconv_bwd_fused_ok(top[0].shape, conv_d.weight.shape, conv_d.stride, conv_d.padding))
+
+
+def dw_dgrad_expand_bwd(conv_d, expand, dy, tape, mid=None):
     """depthwise filter gradient; depthwise input gradient + the expand BatchNorm's (sum g, sum g xhat) from ONE kernel; that
-    BatchNorm's apply pass; the expand conv's backward"""
+    BatchNorm's apply pass; the expand conv's backward.  mid: see kernels.dwconv_bwd_fused (dy is then the section's dout)"""
     conv_e, bn_e = expand
+    fused = dw_bwd_fused_ok(conv_d, tape)
+    assert fused or mid is None
     a1, xf = tape.pop(), None
     if isinstance(a1, tuple):                            # folded: the filter gradient recomputes act(BN(a1)) while it stages a1
         a1, xf = a1
-    K.conv2d_wgrad(a1, dy, conv_d.weight.shape, conv_d.stride, conv_d.padding, conv_d.groups, out=grad_of(conv_d.weight), accumulate=True, xf=xf)
+    if not fused:
+        K.conv2d_wgrad(a1, dy, conv_d.weight.shape, conv_d.stride, conv_d.padding, conv_d.groups, out=grad_of(conv_d.weight), accumulate=True, xf=xf)
     x1, mean, rstd, _, _, _, hw = tape.pop()
     cexp = bn_e.num_features
+    if fused:
+        two = isinstance(mean, tuple)
+        (m2, r2), seg = (mean, rstd) if two else ((mean, rstd), 0)
+        d, sums = K.dwconv_bwd_fused(dy, conv_d.weight, a1.shape, conv_d.stride, conv_d.padding, x1, m2, r2, bn_e.weight, bn_e.bias, bn_e.act, seg,
+                                     grad_of(bn_e.weight), grad_of(bn_e.bias), grad_of(conv_d.weight), mid=mid)
+        if two:
+            dz = K.bn_act_bwd_apply_seg(x1, d, seg * hw, cexp, m2, r2, bn_e.weight, bn_e.bias, bn_e.act, sums)
+        else:
+            dz = K.bn_act_bwd_apply(x1, d, cexp, mean, rstd, bn_e.weight, bn_e.bias, bn_e.act, sums, x1.numel() // cexp)
+        return conv_e.bwd(dz, tape)
     if isinstance(mean, tuple):                          # two batch segments: ((mean[2, c], rstd[2, c]), samples of the first)
         (m2, r2), seg = mean, rstd
         d, sums = K.dwconv_dgrad_bnsums(dy, conv_d.weight, a1.shape, conv_d.stride, conv_d.padding, x1, m2, r2, bn_e.weight, bn_e.bias, bn_e.act,
@@ -275,6 +300,10 @@ class MBConv(_ResidualBlock):
         dp = K.se_mlp_bwd(sums[0], s, a1, p, se.fc1.weight, se.fc2.weight, grad_of(se.fc1.weight), grad_of(se.fc1.bias),
                           grad_of(se.fc2.weight), grad_of(se.fc2.bias))
         chan = K.se_bn_bwd_combine(sums, s, dp, rows_a // hw, hw, grad_of(bn_d.weight), grad_of(bn_d.bias), True)
+        if expand is not None and self._bn_sums_from_dw(conv_d, tape) and dw_bwd_fused_ok(conv_d, tape):
+            # the section's apply pass, the depthwise filter gradient and input gradient (+ the expand BatchNorm's sums) as one launch: dy is never stored
+            return dw_dgrad_expand_bwd(conv_d, expand, dout.contiguous(), tape,
+                                       mid=(y, s, dp, chan, mean, rstd, bn_d.weight, bn_d.bias, bn_d.act, train_stats))
         dy = K.se_bn_bwd_apply(y, dout, rows_a, c, mean, rstd, bn_d.weight, bn_d.bias, bn_d.act, s, dp, chan, train_stats, hw)
         if expand is not None and self._bn_sums_from_dw(conv_d, tape):
             return self._dw_dgrad_expand_bwd(conv_d, expand, dy, tape)

@@ -235,6 +235,24 @@ def test_depthwise_kernels_stay_inside_their_buffers(cfg):
     dw.check("dwconv_wgrad")
     ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double().cpu(), wt.double().cpu(), None, stride, 1, 1, c).permute(0, 2, 3, 1)
     assert float((y.payload.cpu().double() - ref.reshape(-1)).abs().max()) < 1e-4
+    # the whole backward in one launch (round 6): plain form and section form (the output gradient formed from (y, dout, s, dpool, chan) on the fly)
+    lib.suhpe_dwconv_bwd_fused_workspace_bytes.restype = ctypes.c_int64
+    if lib.suhpe_dwconv_bwd_fused_ok(dref):
+        fb = lib.suhpe_dwconv_bwd_fused_workspace_bytes(dref)
+        s_ = torch.rand(n, c, generator=gen).cuda()
+        dpool = torch.randn(n, c, generator=gen).cuda()
+        chan = torch.randn(2, 2 * c, generator=gen).cuda()
+        for section in (False, True):
+            dx2, sums, dgm, dbt, dw2, ws2 = Guarded(x.numel()), Guarded(2 * 2 * c), Guarded(c), Guarded(c), Guarded(wt.numel()), Guarded(max(1, fb // 4))
+            for t_ in (dgm, dbt, dw2):
+                t_.payload.zero_()
+            mid = (P(x), P(s_), P(dpool), P(chan), P(mean), P(rstd), P(gamma), P(beta), 3, 1) if section else (None,) * 8 + (0, 0)
+            _lib.call("suhpe_dwconv_bwd_fused", dref, P(dy), P(wt), dx2.ptr, P(x), P(mean), P(rstd), P(gamma), P(beta), 3, seg, sums.ptr, dgm.ptr, dbt.ptr, 1,
+                      dw2.ptr, 1, *mid, ws2.ptr, ctypes.c_int64(fb))
+            dx2.check(f"dwconv_bwd_fused dx section={section}"); sums.check("dwconv_bwd_fused sums"); dgm.check("dwconv_bwd_fused dgamma")
+            dbt.check("dwconv_bwd_fused dbeta"); dw2.check("dwconv_bwd_fused dw"); ws2.check("dwconv_bwd_fused workspace", fully_written=False)
+            if not section:
+                assert float((dx2.payload - dx.payload).abs().max()) < 1e-5
 
 
 # rows, c, hw (rows per sample): channel counts off the 4-wide vectors and the 64-column blocks, row counts off every block height

@@ -1179,6 +1179,61 @@ def test_depthwise_dgrad_reduces_producer_batchnorm_sums(K, n, h, c, seg, act):
         assert rel(s[:, 0], gg.sum(0)) < 2e-5 and rel(s[:, 1], (gg * xh).sum(0)) < 2e-5
 
 
+@pytest.mark.parametrize("n,h,c,seg,act,section", [(160, 14, 960, 32, "silu", True), (160, 7, 1536, 32, "silu", True), (9, 14, 192, None, "silu", True),
+                                                   (7, 7, 40, 3, "silu", True), (5, 7, 96, None, "relu", True), (12, 14, 512, 4, "silu", False),
+                                                   (11, 7, 264, 5, "gelu", False)])
+def test_depthwise_whole_backward_in_one_launch(K, n, h, c, seg, act, section):
+    """suhpe_dwconv_bwd_fused (round 6) against the three kernels it replaces: the depthwise BatchNorm + SqueezeExcitation section's apply pass
+    (se_bn_bwd_apply -> dy), the filter gradient of the conv whose input is act(BN_e(e0)) (dwconv_bnact_wgrad) and the input gradient with the
+    expand BatchNorm's backward sums (dwconv_dgrad_bnsums) -- one and two batch segments (the boundary inside a two-image group of 7 x 7 maps),
+    ragged batches, channel counts off the 64-channel chunks; section=False: dy given (the fused kernel's plain form).  Tolerances: the filter
+    gradient is summed in another order (workgroup records of other image groups), the conv's input z = act(BN_e(e0)) shares its sigmoid with act'."""
+    g = torch.Generator().manual_seed(23 + n + c)
+    hw, rows = h * h, n * h * h
+    e0 = (torch.randn(n, h, h, c, generator=g) * 1.5 + 0.3).cuda()                  # expand conv output = input of BatchNorm_e
+    y = (torch.randn(n, h, h, c, generator=g) * 0.8 - 0.1).cuda()                    # depthwise conv output = input of BatchNorm_d
+    dout = torch.randn(n, h, h, c, generator=g).cuda()
+    w = K.to_filter_layout((torch.randn(c, 1, 3, 3, generator=g) / 3).cuda())
+    ga_e, be_e = (torch.rand(c, generator=g) + 0.5).cuda(), (torch.randn(c, generator=g) * 0.2).cuda()
+    ga_d, be_d = (torch.rand(c, generator=g) + 0.5).cuda(), (torch.randn(c, generator=g) * 0.2).cuda()
+    s_ = torch.rand(n, c, generator=g).cuda()
+    dp = (torch.randn(n, c, generator=g) * 0.3).cuda()
+    assert K.dwconv_bwd_fused_ok(e0.shape, w.shape, 1, 1)
+    rows_a = (seg or 0) * hw
+    st = (lambda t: K.bn_stats_seg(t, rows_a, c, 1e-3, 0.1)) if seg else (lambda t: K.bn_stats(t, c, 1e-3, 0.1))
+    (mean_e, rstd_e), (mean_d, rstd_d) = st(e0), st(y)
+    if section:
+        sums5 = K.se_bn_bwd_reduce(y, dout, rows_a, c, mean_d, rstd_d, ga_d, be_d, act, hw)
+        chan = K.se_bn_bwd_combine(sums5, s_, dp, rows_a // hw, hw, torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda"), True)
+        dy = K.se_bn_bwd_apply(y, dout, rows_a, c, mean_d, rstd_d, ga_d, be_d, act, s_, dp, chan, True, hw)
+        mid = (y, s_, dp, chan, mean_d, rstd_d, ga_d, be_d, act, True)
+    else:
+        dy, mid = dout, None
+    # the three-kernel path
+    dw_ref = torch.full(tuple(w.shape), 0.125, device="cuda")
+    dw_ref = K.dwconv_bnact_wgrad(e0, mean_e, rstd_e, ga_e, be_e, act, dy, tuple(w.shape), 1, 1, out=dw_ref, accumulate=True, seg=seg)
+    dg_ref, db_ref = torch.full((c,), 0.5, device="cuda"), torch.full((c,), -0.25, device="cuda")
+    d_ref, sums_ref = K.dwconv_dgrad_bnsums(dy, w, e0.shape, 1, 1, e0, mean_e, rstd_e, ga_e, be_e, act, seg or 0, dg_ref, db_ref)
+    # one launch
+    dw_got = torch.full(tuple(w.shape), 0.125, device="cuda")
+    dg, db = torch.full((c,), 0.5, device="cuda"), torch.full((c,), -0.25, device="cuda")
+    d, sums = K.dwconv_bwd_fused(dout if section else dy, w, e0.shape, 1, 1, e0, mean_e, rstd_e, ga_e, be_e, act, seg or 0, dg, db, dw_got, mid=mid)
+    assert rel(d, d_ref.cpu()) < (2e-6 if section else 1e-7)         # (plain form: the same window sums on the same dy)
+    assert rel(sums, sums_ref.cpu()) < 2e-5
+    assert rel(dg, dg_ref.cpu()) < 2e-5 and rel(db, db_ref.cpu()) < 2e-5
+    assert rel(dw_got, dw_ref.cpu()) < 2e-5
+    # ... and the filter gradient against float64 (torch): dW[c][r][s] = sum dy(p) z(p + (r - 1, s - 1)), z = act(BN_e(e0))
+    m64 = mean_e.double().cpu().reshape(-1, c); r64 = rstd_e.double().cpu().reshape(-1, c)
+    xs = e0.double().cpu().reshape(rows, c)
+    parts = [(0, rows)] if not seg else [(0, rows_a), (rows_a, rows)]
+    u = torch.cat([((xs[lo:hi] - m64[i]) * r64[i]) * ga_e.double().cpu() + be_e.double().cpu() for i, (lo, hi) in enumerate(parts)])
+    z = {"silu": torch.nn.functional.silu, "relu": torch.relu, "gelu": lambda t: torch.nn.functional.gelu(t)}[act](u).reshape(n, h, h, c)
+    zp = torch.nn.functional.pad(z.permute(0, 3, 1, 2), (1, 1, 1, 1))
+    dy64 = dy.double().cpu().permute(0, 3, 1, 2)
+    want = torch.stack([torch.stack([(dy64 * zp[:, :, r:r + h, q:q + h]).sum((0, 2, 3)) for q in range(3)], -1) for r in range(3)], -2)    # [c][3][3]
+    assert rel(dw_got.reshape(c, 3, 3) - 0.125, want) < 2e-5
+
+
 def _db_entries(max_elems=160 * 112 * 112 * 96):
     import json, os
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "semiuhpe_amd", "tiles_mi355x.json")

@@ -65,3 +65,10 @@ for hw_side, c in ((14, 512), (14, 960), (7, 1536)):
         line("dwconv_dgrad_bnsums", timed(lambda: K.dwconv_dgrad_bnsums(dy, w, tuple(x.shape), 1, 1, x, m, r, gamma, beta, "silu", seg, dg, db), [x, dy]), 3, nb)
     line("dwconv_dgrad", timed(lambda: K.conv2d_dgrad(dy, w, tuple(x.shape), 1, 1, c), [dy]), 2, nb)
     line("dwconv_wgrad", timed(lambda: K.conv2d_wgrad(x, dy, tuple(w.shape), 1, 1, c), [x, dy]), 2, nb)
+    # round 6: the depthwise conv's whole backward as one launch against the kernels it replaces
+    e0 = torch.randn_like(x); dwg = torch.zeros_like(w)
+    line("dwconv_bnact_wgrad (replaced)", timed(lambda: K.dwconv_bnact_wgrad(e0, m, r, gamma, beta, "silu", dy, tuple(w.shape), 1, 1, out=dwg, accumulate=True, seg=seg or None), [e0, dy]), 2, nb)
+    if K.dwconv_bwd_fused_ok(tuple(x.shape), tuple(w.shape), 1, 1):
+        line("dwconv_bwd_fused (plain: dy given)", timed(lambda: K.dwconv_bwd_fused(dy, w, tuple(x.shape), 1, 1, e0, m, r, gamma, beta, "silu", seg, dg, db, dwg), [e0, dy]), 3, nb)
+        mid = (x, s, dpool, chan, m, r, gamma, beta, "silu", True)
+        line("dwconv_bwd_fused (section form)", timed(lambda: K.dwconv_bwd_fused(dy, w, tuple(x.shape), 1, 1, e0, m, r, gamma, beta, "silu", seg, dg, db, dwg, mid=mid), [e0, dy, x]), 4, nb)
