@@ -24,51 +24,30 @@ __global__ __launch_bounds__(kSeThreads) void se_mlp_fwd_kernel(const float* __r
     float* pl = sm;            // [c]
     float* hl = sm + c;        // [csq]
     const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    // Round 6: the kernel is a chain of dependent L2 round trips (pooled vector -> fc1 rows -> fc2 rows: 19.7 us for 0.3 MB of weights).  The WEIGHTS
-    // do not depend on anything computed here, so the first block of fc1 rows and of fc2 rows of every thread is requested before the first
-    // barrier: both matrix-vector products then start on operands that are already in registers.  Same arithmetic in the same order: same bits.
-    auto load_w1 = [&](int j0, int i0, float4 (&wv)[4][4]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * 256 < c ? i0 + u * 256 : c - 4;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) wv[u][q] = *reinterpret_cast<const float4*>(w1 + (int64_t)((j0 + q) < csq ? j0 + q : csq - 1) * c + i);
-        }
-    };
-    const int sub = t & 15, grp = t >> 4;                   // fc2: 64 row slots per pass
-    const bool okj = sub * 4 < csq;
-    const int jq = okj ? sub * 4 : csq - 4;
-    auto load_w2_half = [&](int r0, int half, float4 (&wv)[8]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int uu = half * 4 + u;
-            const int row = r0 + uu * 64 < c ? r0 + uu * 64 : c - 1;
-            wv[uu] = *reinterpret_cast<const float4*>(w2 + (int64_t)row * csq + jq);
-        }
-    };
-    auto load_w2 = [&](int r0, float4 (&wv)[8]) __attribute__((always_inline)) { load_w2_half(r0, 0, wv); load_w2_half(r0, 1, wv); };
-    // (the register file holds 128 values per thread at 1024 threads: the fc1 rows and HALF of the first fc2 block go out before the first barrier,
-    //  the other half as soon as the fc1 rows have been consumed -- still ahead of the wave reduction, the LDS hand-over and the second barrier)
-    float4 wv1_first[4][4], wv2_first[8];
-    const int j_first = wave * 4;
-    if (j_first < csq) load_w1(j_first, lane * 4, wv1_first);
-    load_w2_half(grp, 0, wv2_first);
     for (int i = t * 4; i < c; i += kSeThreads * 4) *reinterpret_cast<float4*>(pl + i) = *reinterpret_cast<const float4*>(p + (int64_t)n * c + i);
     __syncthreads();
     // fc1: a wavefront takes 4 squeeze outputs at a time (4 independent row streams); 16 waves cover 64 outputs in one round
-    auto fc1_block = [&](const float4 (&wv)[4][4], int i0, float (&acc)[4]) __attribute__((always_inline)) {
+    for (int j0 = wave * 4; j0 < csq; j0 += kSeWaves * 4) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i0 = lane * 4; i0 < c; i0 += 1024) {       // 16 independent 16-byte loads in flight (clamped, not branched)
+            float4 wv[4][4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const bool ok = i0 + u * 256 < c;
-            const float4 pv = *reinterpret_cast<const float4*>(pl + (ok ? i0 + u * 256 : 0));
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256 < c ? i0 + u * 256 : c - 4;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float d = wv[u][q].x * pv.x + wv[u][q].y * pv.y + wv[u][q].z * pv.z + wv[u][q].w * pv.w;
-                acc[q] += ok ? d : 0.f;
+                for (int q = 0; q < 4; ++q) wv[u][q] = *reinterpret_cast<const float4*>(w1 + (int64_t)(j0 + q) * c + i);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = i0 + u * 256 < c;
+                const float4 pv = *reinterpret_cast<const float4*>(pl + (ok ? i0 + u * 256 : 0));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float d = wv[u][q].x * pv.x + wv[u][q].y * pv.y + wv[u][q].z * pv.z + wv[u][q].w * pv.w;
+                    acc[q] += ok ? d : 0.f;
+                }
             }
         }
-    };
-    auto fc1_finish = [&](int j0, float (&acc)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q] = wave_sum(acc[q]);
         if (lane < 4) {
@@ -76,38 +55,24 @@ __global__ __launch_bounds__(kSeThreads) void se_mlp_fwd_kernel(const float* __r
             a1[(int64_t)n * csq + j0 + lane] = a;
             hl[j0 + lane] = silu_f(a);
         }
-    };
-    // (the first block is peeled: its rows were requested before the barrier and their registers are free again behind it)
-    if (j_first < csq) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        fc1_block(wv1_first, lane * 4, acc);
-        load_w2_half(grp, 1, wv2_first);
-        for (int i0 = lane * 4 + 1024; i0 < c; i0 += 1024) {       // 16 independent 16-byte loads in flight (clamped, not branched)
-            float4 wv[4][4];
-            load_w1(j_first, i0, wv);
-            fc1_block(wv, i0, acc);
-        }
-        fc1_finish(j_first, acc);
-    } else {
-        load_w2_half(grp, 1, wv2_first);
-    }
-    for (int j0 = j_first + kSeWaves * 4; j0 < csq; j0 += kSeWaves * 4) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int i0 = lane * 4; i0 < c; i0 += 1024) {
-            float4 wv[4][4];
-            load_w1(j0, i0, wv);
-            fc1_block(wv, i0, acc);
-        }
-        fc1_finish(j0, acc);
     }
     __syncthreads();
     // fc2: 16 lanes share one output channel: together they read its whole w2 row (<= 64 floats) as one coalesced 256-byte
     // request and reduce with four xor-shuffles (a lane-per-row layout fetches a full cache line per 16 useful bytes).
     // Out-of-range rows / columns read a clamped address and are dropped afterwards: no branch around the loads.
     {
+        const int sub = t & 15, grp = t >> 4;               // 64 row slots per pass
+        const bool okj = sub * 4 < csq;
+        const int jq = okj ? sub * 4 : csq - 4;
         float4 hv = *reinterpret_cast<const float4*>(hl + jq);
         if (!okj) hv = make_float4(0.f, 0.f, 0.f, 0.f);
-        auto fc2_block = [&](const float4 (&wv)[8], int r0) __attribute__((always_inline)) {
+        for (int r0 = grp; r0 < c; r0 += 64 * 8) {
+            float4 wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = r0 + u * 64 < c ? r0 + u * 64 : c - 1;
+                wv[u] = *reinterpret_cast<const float4*>(w2 + (int64_t)row * csq + jq);
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 float d = wv[u].x * hv.x + wv[u].y * hv.y + wv[u].z * hv.z + wv[u].w * hv.w;
@@ -118,12 +83,6 @@ __global__ __launch_bounds__(kSeThreads) void se_mlp_fwd_kernel(const float* __r
                 const int row = r0 + u * 64;
                 if (sub == 0 && row < c) s[(int64_t)n * c + row] = 1.f / (1.f + expf(-(d + b2[row])));
             }
-        };
-        if (grp < c) fc2_block(wv2_first, grp);             // requested before the first barrier
-        for (int r0 = grp + 64 * 8; r0 < c; r0 += 64 * 8) {
-            float4 wv[8];
-            load_w2(r0, wv);
-            fc2_block(wv, r0);
         }
     }
 }
@@ -138,32 +97,6 @@ __global__ __launch_bounds__(kSeThreads) void se_mlp_bwd_kernel(const float* __r
     float* red = sm + c;                     // [kSeWaves][kMaxSq] partial dh
     float* dl = red + kSeWaves * kMaxSq;     // da1 [kMaxSq]
     const int n = blockIdx.x, t = threadIdx.x;
-    // (round 6, as in the forward kernel: the first block of w2 / w1 values of every thread is requested before the first barrier -- the weights do
-    //  not depend on anything computed here; same arithmetic, same order, same bits)
-    const int j = t & 63, q = t >> 6;
-    const int jj = j < csq ? j : csq - 1;
-    const int cq = (c + kSeWaves - 1) / kSeWaves, c0 = q * cq, c1 = (c0 + cq < c) ? c0 + cq : c;
-    auto load_w2 = [&](int base, float (&wv)[32]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int u = 0; u < 32; ++u) {
-            const int cc = base + u < c1 ? base + u : (c1 > 0 ? c1 - 1 : 0);
-            wv[u] = w2[(int64_t)cc * csq + jj];
-        }
-    };
-    int ccl[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) { const int cc = t + kSeThreads * k; ccl[k] = cc < c ? cc : c - 1; }
-    auto load_w1 = [&](int j0, float (&wv)[2][16]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int jx = j0 + u < csq ? j0 + u : csq - 1;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) wv[k][u] = w1[(int64_t)jx * c + ccl[k]];
-        }
-    };
-    float w2_first[32], w1_first[2][16];
-    if (c0 < c1) load_w2(c0, w2_first);
-    load_w1(0, w1_first);
     for (int cc = t; cc < c; cc += kSeThreads) {
         const float sv = s[(int64_t)n * c + cc];
         const float g = ds[(int64_t)n * c + cc] * sv * (1.f - sv);
@@ -174,14 +107,16 @@ __global__ __launch_bounds__(kSeThreads) void se_mlp_bwd_kernel(const float* __r
     // dh[j] = sum_c w2[c][j] * da2[c]: lane = j, wavefront = one sixteenth of the channels; rows of w2 are read coalesced
     // across j.  Loads go to a register block first (32 in flight), clamped instead of branched.
     {
+        const int j = t & 63, q = t >> 6;
+        const int jj = j < csq ? j : csq - 1;
+        const int cq = (c + kSeWaves - 1) / kSeWaves, c0 = q * cq, c1 = (c0 + cq < c) ? c0 + cq : c;
         float acc0 = 0.f, acc1 = 0.f;
         for (int base = c0; base < c1; base += 32) {
             float wv[32];
-            if (base == c0) {
 #pragma unroll
-                for (int u = 0; u < 32; ++u) wv[u] = w2_first[u];
-            } else {
-                load_w2(base, wv);
+            for (int u = 0; u < 32; ++u) {
+                const int cc = base + u < c1 ? base + u : c1 - 1;
+                wv[u] = w2[(int64_t)cc * csq + jj];
             }
 #pragma unroll
             for (int u = 0; u < 32; u += 2) {
@@ -204,15 +139,16 @@ __global__ __launch_bounds__(kSeThreads) void se_mlp_bwd_kernel(const float* __r
     }
     __syncthreads();
     float acc[2] = {0.f, 0.f};
+    int ccl[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { const int cc = t + kSeThreads * k; ccl[k] = cc < c ? cc : c - 1; }
     for (int j0 = 0; j0 < csq; j0 += 16) {          // 32 independent loads in flight per thread
         float wv[2][16];
-        if (j0 == 0) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
+        for (int u = 0; u < 16; ++u) {
+            const int j = j0 + u < csq ? j0 + u : csq - 1;
 #pragma unroll
-                for (int k = 0; k < 2; ++k) wv[k][u] = w1_first[k][u];
-        } else {
-            load_w1(j0, wv);
+            for (int k = 0; k < 2; ++k) wv[k][u] = w1[(int64_t)j * c + ccl[k]];
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
