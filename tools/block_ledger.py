@@ -71,7 +71,7 @@ def main():
         for i in rng:
             fb, wb, us = 2 * f[i][3] / 1e6, w[i][3] / 1e6, f[i][4]
             tf += fb; tw += wb; tt += us
-            print(f"{f[i][1][:58]:58s} {us:7.1f} {fb:9.1f} {wb:9.1f} {(fb + wb) / E:9.2f} {(fb + wb) / us / 1e6 * 1e6 / 1e6:6.2f}")
+            print(f"{f[i][1][:58]:58s} {us:7.1f} {fb:9.1f} {wb:9.1f} {(fb + wb) / E:9.2f} {(fb + wb) / us:6.2f}")
         print(f"{'sum':58s} {tt:7.1f} {tf:9.1f} {tw:9.1f} {(tf + tw) / E:9.2f}")
     ideal_f = (C + E) + (E + E) + (E + C)                   # expand in / out, depthwise in / out, project in / out
     print(f"\nideal-fusion count (tools/count_work.py: every conv input and output once): forward {ideal_f:.0f} MB = {ideal_f / E:.2f} E-passes, "
