@@ -775,6 +775,7 @@ __global__ __launch_bounds__(256, 2) void dw3x3_bwd_tile_kernel(const float* __r
     constexpr int WP = T::wp, LPT = T::lpt;
     extern __shared__ __attribute__((aligned(16))) float tile[];          // [imgs][HW+2][HW+2][64] + DYF: [2 sets][mean | rstd | m0 | m1][64]
     float* ctab = tile + T::imgs * WP * WP * 64;
+    float* wtab = ctab + 2 * 4 * 64;                       // the flipped filter [9][64 channels]: read per window step (the LDS is 3 % busy; 36 registers are not free)
     const int t = threadIdx.x, vc = t & 15, slot = t >> 4;
     const int col0 = blockIdx.y * 16, c0 = (col0 + vc) * 4;
     const bool cok = c0 < C;
@@ -796,12 +797,12 @@ __global__ __launch_bounds__(256, 2) void dw3x3_bwd_tile_kernel(const float* __r
         }
         *reinterpret_cast<float4*>(&ctab[((set * 4 + qty) * 16 + v4) * 4]) = make_float4(o[0], o[1], o[2], o[3]);
     }
-    float4 wv[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {                        // flipped: the input gradient is a correlation with the rotated filter
-        const int kk = 8 - k;
-        wv[k] = cok ? make_float4(w[(int64_t)(c0 + 0) * 9 + kk], w[(int64_t)(c0 + 1) * 9 + kk], w[(int64_t)(c0 + 2) * 9 + kk], w[(int64_t)(c0 + 3) * 9 + kk])
-                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < 9 * 16) {                                    // flipped: the input gradient is a correlation with the rotated filter
+        const int kq = t >> 4, v4 = t & 15, ch0 = (col0 + v4) * 4, kk = 8 - kq;
+        const bool okw = ch0 < C;
+        *reinterpret_cast<float4*>(&wtab[(kq * 16 + v4) * 4]) =
+            okw ? make_float4(w[(int64_t)(ch0 + 0) * 9 + kk], w[(int64_t)(ch0 + 1) * 9 + kk], w[(int64_t)(ch0 + 2) * 9 + kk], w[(int64_t)(ch0 + 3) * 9 + kk])
+                : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int bact = ACTC >= 0 ? ACTC : bnb.act;
     const int mact = ACTC >= 0 ? ACTC : mid.act;
@@ -825,7 +826,7 @@ __global__ __launch_bounds__(256, 2) void dw3x3_bwd_tile_kernel(const float* __r
     // The group's pixels are loaded and written to the tile in chunks of CHK per thread, every load of a chunk issued before the first use; nothing is
     // prefetched across the window loop: with the nine filter-gradient accumulators beside the window and the filter, a group's worth of loads held
     // in registers there spilled (256 VGPRs at two workgroups per CU) -- the second resident workgroup covers the load phase instead.
-    constexpr int CHK = DYF ? 5 : 7;
+    constexpr int CHK = 7;
     float4 sv[DYF ? T::imgs : 1], pv[DYF ? T::imgs : 1];
     int g = blockIdx.x;
     __syncthreads();
@@ -919,7 +920,12 @@ __global__ __launch_bounds__(256, 2) void dw3x3_bwd_tile_kernel(const float* __r
                 bq[kTileAhead - 1] = *reinterpret_cast<const float4*>(bxp + (int64_t)(ow + kTileAhead < HW ? ow + kTileAhead : HW - 1) * C);
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int r = 0; r < 3; ++r) { fma4(acc, a[r], wv[r * 3]); fma4(acc, b[r], wv[r * 3 + 1]); fma4(acc, c[r], wv[r * 3 + 2]); }
+                for (int r = 0; r < 3; ++r) {
+                    const float4 w0 = *reinterpret_cast<const float4*>(&wtab[((r * 3 + 0) * 16 + vc) * 4]);
+                    const float4 w1 = *reinterpret_cast<const float4*>(&wtab[((r * 3 + 1) * 16 + vc) * 4]);
+                    const float4 w2 = *reinterpret_cast<const float4*>(&wtab[((r * 3 + 2) * 16 + vc) * 4]);
+                    fma4(acc, a[r], w0); fma4(acc, b[r], w1); fma4(acc, c[r], w2);
+                }
                 *reinterpret_cast<float4*>(out + (int64_t)ow * C) = acc;
                 const float o[4] = {acc.x, acc.y, acc.z, acc.w}, xv[4] = {bxc.x, bxc.y, bxc.z, bxc.w};
                 float zc[4];
@@ -1451,13 +1457,13 @@ int suhpe_dwconv_bwd_fused(const suhpe_conv_t* d, const float* dy, const float* 
         hipLaunchKernelGGL(kern, dim3(gx, ny), dim3(256), lds, st, dy, w, dx, d->n, d->cin, ngroups, bnb, mid, wpart);
     };
     const bool silu = act == SUHPE_ACT_SILU && (!mid_y || mid_act == SUHPE_ACT_SILU);
-    constexpr int kTab = 2 * 4 * 16 * 4 * (int)sizeof(float);
+    constexpr int kTab = (2 * 4 * 16 * 4 + 9 * 64) * (int)sizeof(float);      // BatchNorm_d constants of both segments + the flipped filter
     if (hw == 14) {
         if (mid_y) { if (silu) go(dw3x3_bwd_tile_kernel<14, true, SUHPE_ACT_SILU>, DwTile<14>::lds_bytes + kTab); else go(dw3x3_bwd_tile_kernel<14, true, -1>, DwTile<14>::lds_bytes + kTab); }
-        else { if (silu) go(dw3x3_bwd_tile_kernel<14, false, SUHPE_ACT_SILU>, DwTile<14>::lds_bytes); else go(dw3x3_bwd_tile_kernel<14, false, -1>, DwTile<14>::lds_bytes); }
+        else { if (silu) go(dw3x3_bwd_tile_kernel<14, false, SUHPE_ACT_SILU>, DwTile<14>::lds_bytes + kTab); else go(dw3x3_bwd_tile_kernel<14, false, -1>, DwTile<14>::lds_bytes + kTab); }
     } else {
         if (mid_y) { if (silu) go(dw3x3_bwd_tile_kernel<7, true, SUHPE_ACT_SILU>, DwTile<7>::lds_bytes + kTab); else go(dw3x3_bwd_tile_kernel<7, true, -1>, DwTile<7>::lds_bytes + kTab); }
-        else { if (silu) go(dw3x3_bwd_tile_kernel<7, false, SUHPE_ACT_SILU>, DwTile<7>::lds_bytes); else go(dw3x3_bwd_tile_kernel<7, false, -1>, DwTile<7>::lds_bytes); }
+        else { if (silu) go(dw3x3_bwd_tile_kernel<7, false, SUHPE_ACT_SILU>, DwTile<7>::lds_bytes + kTab); else go(dw3x3_bwd_tile_kernel<7, false, -1>, DwTile<7>::lds_bytes + kTab); }
     }
     // finish: (sum g, sum g xhat) per channel and segment -> sums, dgamma / dbeta; filter-gradient records -> dw (fp64, fixed order)
     launch_bn_bwd_finalize(part, seg_n > 0 ? gx : 0, seg_n > 0 ? 2 * gx : gx, d->cin, sums, dgamma, dbeta, accumulate, st);

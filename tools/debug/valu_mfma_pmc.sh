@@ -3,7 +3,10 @@
 # MFMA cycles + ~4.5 cycles per other vector instruction): two rocprofv3 --pmc passes per kernel (SQ activity / instruction counts), the last launch of each.
 #   bash tools/debug/valu_mfma_pmc.sh        (from the repo root through gpurun; writes gpurun_out/r05_wino_bench.txt and gpurun_out/r05_valu_mfma_pmc.txt)
 # Do NOT add TA_* counters: that group hung rocprofv3 on this pool.
-R=$GRAFT_REPO_ROOT; cd $R
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd "$R" || exit 1
+mkdir -p gpurun_out
 python tools/wino_bench.py all 2>&1 | grep -v amdgpu.ids > gpurun_out/r05_wino_bench.txt
 cd /tmp && export TMPDIR=/tmp PYTHONPATH=$R
 groups=(
@@ -21,6 +24,8 @@ f=glob.glob('/tmp/pm/**/*counter_collection.csv',recursive=True)
 if not f:
     print("  (no counter file)"); raise SystemExit
 rows=[r for r in csv.DictReader(open(f[0])) if os.environ['PAT'] in r['Kernel_Name']]
+if not rows:
+    print('  (no matching kernel)'); raise SystemExit
 last=max(int(r['Dispatch_Id']) for r in rows)
 rr=[r for r in rows if int(r['Dispatch_Id'])==last]
 dur=int(rr[0]['End_Timestamp'])-int(rr[0]['Start_Timestamp'])

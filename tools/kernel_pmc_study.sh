@@ -18,6 +18,8 @@ f=glob.glob('/tmp/pm/**/*counter_collection.csv',recursive=True)
 if not f:
     print("  (no counter file)"); print(open('/tmp/pm.log').read()[-600:]); raise SystemExit
 rows=[r for r in csv.DictReader(open(f[0])) if os.environ['KERN'] in r['Kernel_Name']]
+if not rows:
+    print('  (no matching kernel)'); raise SystemExit
 last=max(int(r['Dispatch_Id']) for r in rows)
 rr=[r for r in rows if int(r['Dispatch_Id'])==last]
 dur=int(rr[0]['End_Timestamp'])-int(rr[0]['Start_Timestamp'])
