@@ -19,12 +19,20 @@ w = (torch.randn(c, 1, 3, 3, device="cuda") * 0.2).contiguous(memory_format=torc
 dg, db, dwg = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda"), torch.zeros_like(w)
 chan = torch.randn(2, 2 * c, device="cuda") * 0.01
 flush = torch.zeros(1 << 27, dtype=torch.float32, device="cuda")
-for _ in range(4):
+ts = []
+for _ in range(7):
     flush.sum()
+    e0.copy_(e0 * 1.0)                   # (the producer has just written the operand: the step's cache state)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(400000)
+    ev0.record()
     if form == "fwd":
         K.dwconv_bnact_fwd(e0, m, r, gamma, beta, "silu", w, 1, 1, seg=seg or None, stats=True)
     else:
         mid = (x, s, dpool, chan, m, r, gamma, beta, "silu", True) if form == "section" else None
         K.dwconv_bwd_fused(dy, w, tuple(x.shape), 1, 1, e0, m, r, gamma, beta, "silu", seg, dg, db, dwg, mid=mid)
-torch.cuda.synchronize()
-print("done")
+    ev1.record()
+    torch.cuda.synchronize()
+    ts.append(ev0.elapsed_time(ev1) * 1e3)
+ts.sort()
+print(f"{form} {n} x {hw}x{hw} x {c}: median {ts[len(ts) // 2]:.1f} us (min {ts[0]:.1f})")
