@@ -173,6 +173,16 @@ def adopt_tiles(table):
     _tile_db().update(table)
 
 
+def share_tiles_from_rank0():
+    """every rank adopts rank 0's {shape: tile name} table (one object broadcast over the torch.distributed group: the host channel); a COLLECTIVE --
+    call it where every rank passes (SSLAgent._agree_on_tiles: the first training step of each kind)"""
+    import torch.distributed as dist
+    box = [tile_table() if dist.get_rank() == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    adopt_tiles(box[0])
+    return box[0]
+
+
 def _tile_names(lib, pass_id):
     lib.suhpe_conv2d_tile_name.restype = ctypes.c_char_p
     return [lib.suhpe_conv2d_tile_name(pass_id, i).decode() for i in range(lib.suhpe_conv2d_tile_count(pass_id))]

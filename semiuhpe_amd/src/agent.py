@@ -277,8 +277,6 @@ class SSLAgent:
         self._tiles_agreed.add(kind)
         import random
         import numpy as np
-        import torch.distributed as dist
-        box = [None]
         if self.rank == 0:
             bufs = [b for net in (self.net, self.ema_net) for b in net.buffers()]
             saved = [b.clone() for b in bufs]
@@ -298,9 +296,7 @@ class SSLAgent:
             for hook in K._reseed_hooks:                   # masks drawn ahead during the dry pass belong to positions that will be drawn again
                 hook()
             K.flush_deferred_now()
-            box[0] = K.tile_table()
-        dist.broadcast_object_list(box, src=0)
-        K.adopt_tiles(box[0])
+        K.share_tiles_from_rank0()
 
     def _watch_grads(self, single_backward):
         """arm the bucketed exchange for the backward that follows (only when ONE network backward produces the whole gradient:

@@ -123,3 +123,46 @@ def test_bucket_boundaries_follow_network_units():
     assert b[0] == 0 and b[-1] == 200
     assert set(b[1:-1]) <= {10, 20, 60, 100, 180}               # never inside features.1.0 (40) nor inside layers.1 (140)
     assert bucket_boundaries(names, offs, 200, 1) == [0, 200]
+
+
+def _tile_worker(rank, world, port, out):
+    """rank 0 holds a table of measured winners; after the broadcast every rank pins the SAME tile by name the first time it meets the shape --
+    without running a single trial launch (host logic of the library: no GPU needed)"""
+    import ctypes
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from semiuhpe_amd import _lib, kernels as K
+    from semiuhpe_amd.src import distributed as D
+    D.init_from_env("gloo")
+    K._TILE_DB = {}                                              # an empty database: every shape is "absent from tiles_mi355x.json"
+    lib = _lib.load()
+    lib.suhpe_conv2d_kernel_name.restype = ctypes.c_char_p
+    d3 = K.conv_desc((5, 28, 28, 64), (256, 64, 3, 3), 1, 1, 1)               # 3x3 / stride 1 on an even map: Winograd-eligible
+    d1 = K.conv_desc((5, 14, 14, 160), (960, 160, 1, 1), 1, 0, 1)             # pointwise, K % 32 == 0: LDS-DMA-eligible
+    key = lambda d, p: ",".join(str(v) for v in (p, d.n, d.h, d.w, d.cin, d.cout, d.r, d.s, d.stride, d.pad, d.groups))
+    if rank == 0:                                                 # what rank 0's dry pass would have measured
+        K._TILE_DB.update({key(d3, 0): "wino_nt_kernel<64,64>", key(d3, 2): "wino_wgrad_kernel<64,64>", key(d1, 0): "gemm_nt_dma<128,128>",
+                           key(d1, 1): "gemm_nt_persistent<128,64,32,32>"})
+    before = lib.suhpe_conv2d_kernel_name(ctypes.byref(d3), 0).decode()
+    table = K.share_tiles_from_rank0()
+    ran = []
+    K._tuned.clear()
+    for d, p in ((d3, 0), (d3, 2), (d1, 0), (d1, 1)):
+        K._autotune(d, p, lambda: ran.append(1))                  # world 2: measures nothing; a known shape is pinned by name
+    names = [lib.suhpe_conv2d_kernel_name(ctypes.byref(d), p).decode() for d, p in ((d3, 0), (d3, 2), (d1, 0), (d1, 1))]
+    out[rank] = dict(table=dict(table), names=names, ran=len(ran), before=before)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_pin_rank0s_measured_tiles():
+    """kernels.share_tiles_from_rank0 / adopt_tiles (SSLAgent._agree_on_tiles' collective half): identical tables and identical
+    pins on both ranks, tiles no heuristic ever picks among them, no trial launch on either rank"""
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_tile_worker, args=(world, port, out), nprocs=world, join=True)
+    r0, r1 = out[0], out[1]
+    assert r0["table"] == r1["table"] and len(r0["table"]) == 4
+    assert r0["names"] == r1["names"] == ["wino_nt_kernel<64,64>", "wino_wgrad_kernel<64,64>", "gemm_nt_dma<128,128>", "gemm_nt_persistent<128,64,32,32>"]
+    assert r0["ran"] == r1["ran"] == 0
+    assert not r1["before"].startswith("wino")                    # (unpinned, the heuristic keeps the direct tile)
