@@ -119,3 +119,23 @@ def test_last_kernel_name_is_exported_and_empty_before_any_launch():
     code = "from semiuhpe_amd import _lib\nassert _lib.load().suhpe_last_kernel_name() == b''\nprint('ok')\n"
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PYTHONPATH=root), capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr
+
+
+def test_pinned_tile_without_an_instantiation_is_an_error_on_every_entry_point():
+    """the narrow LDS-DMA tile writes 32-row statistics records that no other tile writes, so a call it cannot take (a bias)
+    with statistics asked for must come back as SUHPE_EINVAL -- from suhpe_conv2d_fwd_wino too, which used to return SUHPE_OK with y and the records
+    unwritten.  Decided on the host before anything is launched: no GPU needed (the pointers are never dereferenced)."""
+    from semiuhpe_amd import _lib
+    lib = _lib.load()
+    names = [lib.suhpe_conv2d_tile_name(0, i).decode() for i in range(lib.suhpe_conv2d_tile_count(0))]
+    d = _lib.ConvDesc(4, 56, 56, 192, 56, 56, 48, 1, 1, 1, 0, 1)               # FusedMBConv's project conv: 192 -> 48, pointwise
+    P = ctypes.c_void_p(1 << 20)                                               # 16-byte aligned, never read
+    assert lib.suhpe_conv2d_set_tile(ctypes.byref(d), 0, names.index("gemm_nt_dma<256,64>")) == 0
+    try:
+        assert lib.suhpe_conv2d_fwd_stats_tile_rows(ctypes.byref(d)) == 32
+        rc = lib.suhpe_conv2d_fwd_wino(ctypes.byref(d), P, P, None, P, P, P, None, ctypes.c_int64(0), None)      # bias AND statistics
+        assert rc == -1, rc
+        msg = lib.suhpe_last_error()
+        assert b"suhpe_conv2d_fwd_wino" in msg and b"no instantiation" in msg, msg
+    finally:
+        assert lib.suhpe_conv2d_set_tile(ctypes.byref(d), 0, -1) == 0

@@ -229,3 +229,36 @@ def test_winograd_results_do_not_depend_on_memory_latency(K):
             del big
         finally:
             _pin(K, d, names, False)
+
+
+def test_last_kernel_name_reports_what_really_ran(K):
+    """suhpe_conv2d_kernel_name predicts the kernel from the descriptor alone; run-time facts send a call elsewhere: a bias on a shape of the
+    register-resident Winograd form runs wino_nt_kernel's narrow form instead (launch_wino_small declines a bias).  suhpe_last_kernel_name -- what
+    kernels._Prof records, bench.py's per-kernel roofline and tools/pmc_traffic's name join -- must say so."""
+    from semiuhpe_amd import _lib
+    lib = _lib.load()
+    names = _names()
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(6, 16, 16, 24, generator=gen).cuda()
+    wg = K.to_filter_layout((torch.randn(24, 24, 3, 3, generator=gen) / 15).cuda())
+    bias = torch.randn(24, generator=gen).cuda()
+    d = K.conv_desc(x.shape, wg.shape, 1, 1, 1)
+    _pin(K, d, names, True)
+    try:
+        predicted = lib.suhpe_conv2d_kernel_name(ctypes.byref(d), 0).decode()
+        assert predicted == "wino_small_kernel"
+        y0 = K.conv2d_fwd(x, wg, None, 1, 1, 1)
+        assert lib.suhpe_last_kernel_name().decode() == "wino_small_kernel"
+        y1 = K.conv2d_fwd(x, wg, bias, 1, 1, 1)
+        assert lib.suhpe_last_kernel_name().decode() == "wino_nt_kernel<64,64>"          # the fallback the descriptor cannot see
+        assert rel(y1 - bias.view(1, 1, 1, -1), y0) < 2e-6
+        K.PROFILE = []
+        try:
+            K.conv2d_fwd(x, wg, bias, 1, 1, 1)
+            assert [r[0] for r in K.PROFILE] == ["wino_nt_kernel<64,64>"]                # ... and the live profile keys on it
+        finally:
+            K.PROFILE = None
+    finally:
+        _pin(K, d, names, False)
+    K.conv2d_fwd(x, wg, None, 1, 1, 1)
+    assert lib.suhpe_last_kernel_name().decode().startswith(("igemm_nt", "gemm_nt"))     # unpinned: a direct tile
