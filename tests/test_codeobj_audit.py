@@ -82,3 +82,10 @@ def test_hand_pipelined_kernels_of_the_built_library_have_no_scratch():
         assert len(hit) >= least, (pat, sorted(hit))
         for k, v in hit.items():
             assert v["scratch"] == 0 and v["vgpr_spill"] == 0, (k, v)
+    # round 6: the fused depthwise backward sits at the 256-register cap of two workgroups per CU by design (filter in LDS, fill in chunks of 7
+    # pixels, nothing prefetched across the window loop); the instantiations the training step runs -- SiLU at compile time, both map sizes, both forms --
+    # must stay free of scratch (every spilling variant measured slower: DESIGN.md section 3)
+    fused = {k: v for k, v in ks.items() if "dw3x3_bwd_tile_kernel" in k and k.rstrip("E").endswith(("Li3E", "Li3EE")) or ("dw3x3_bwd_tile_kernel" in k and "ELi3EEEv" in k)}
+    assert len(fused) == 4, sorted(k for k in ks if "dw3x3_bwd_tile_kernel" in k)
+    for k, v in fused.items():
+        assert v["scratch"] == 0 and v["vgpr_spill"] == 0, (k, v)
